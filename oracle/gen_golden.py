@@ -1,0 +1,344 @@
+"""Golden-vector generator — runs ONLY in the build container, where /root/reference exists.
+
+Imports the reference's own Python (lxrt/modeling.py, lxrt/optimization.py, lxrt/tokenization.py,
+lxrt/entry.py) unmodified, with empty stand-in modules for the absent `boto3`/`botocore` packages that
+lxrt/file_utils.py:16-18 imports for S3 downloads only, fills it with the deterministic
+weights of rgqa_amd/synth.py, runs it on deterministic inputs and writes small .npz/.json fixtures into
+tests/golden/.  The fixtures are data (inputs are regenerated from names; outputs are stored); no
+reference source text is written anywhere.
+
+    python oracle/gen_golden.py            # regenerates every fixture
+"""
+import json
+import os
+import random
+import sys
+import textwrap
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/src"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from rgqa_amd import synth  # noqa: E402
+
+
+def import_reference():
+    for n in ("boto3", "botocore", "botocore.exceptions"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["botocore.exceptions"].ClientError = type("ClientError", (Exception,), {})
+    sys.path.insert(0, REF)
+    import lxrt.modeling as M
+    import lxrt.optimization as OPT
+    import lxrt.tokenization as TOK
+    import lxrt.entry as ENT
+    return M, OPT, TOK, ENT
+
+
+def build_reference(M, cfgd):
+    """Reference GQAModel built as tasks/gqa_model.py:17-28 does, minus the network download
+    (SURVEY.md §8 C3 (i))."""
+    M.VISUAL_CONFIG.l_layers = cfgd["l_layers"]
+    M.VISUAL_CONFIG.x_layers = cfgd["x_layers"]
+    M.VISUAL_CONFIG.r_layers = cfgd["r_layers"]
+    M.VISUAL_CONFIG.set_visual_dims(cfgd["feat_dim"], cfgd["pos_dim"])
+    bc = M.BertConfig(cfgd["vocab_size"], hidden_size=cfgd["hidden"], num_attention_heads=cfgd["heads"],
+                      intermediate_size=cfgd["inter"], max_position_embeddings=cfgd["max_pos"],
+                      type_vocab_size=cfgd["type_vocab"])
+    enc = M.LXRTFeatureExtraction(bc, mode="x")
+    H = cfgd["hidden"]
+    head = torch.nn.Sequential(torch.nn.Linear(H, 2 * H), M.GeLU(), M.BertLayerNorm(2 * H, eps=1e-12),
+                               torch.nn.Linear(2 * H, cfgd["num_answers"]))
+
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lxrt_encoder = torch.nn.Module()
+            self.lxrt_encoder.model = enc
+            self.logit_fc = head
+
+        def forward(self, feat, pos, ids, seg, mask):
+            x = self.lxrt_encoder.model(ids, seg, mask, visual_feats=(feat, pos), visual_attention_mask=None)
+            return self.logit_fc(x), x
+
+    m = Wrap()
+    sd = m.state_dict()
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    return m
+
+
+def sample_idx(name, numel, k=64):
+    k = min(k, numel)
+    return (synth.hash_u32("gradsample." + name, k) % np.uint64(numel)).astype(np.int64)
+
+
+SMALL = dict(vocab_size=64, hidden=64, heads=4, inter=128, max_pos=32, type_vocab=2, l_layers=2, x_layers=2,
+             r_layers=2, feat_dim=32, pos_dim=4, num_answers=11)
+FULL = dict(vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9,
+            x_layers=5, r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842)
+
+
+def small_batch(T):
+    b = synth.synth_batch(3, T, O=6, F=32, NA=11, vocab=64, seed=77 + T, uq_frac=0.34, min_len=2)
+    b["input_ids"][1, 1:] = 0          # a 1-token question: only [CLS] survives as a real token
+    b["input_ids"][1, 0] = 2
+    b["input_mask"] = (b["input_ids"] != 0).astype(np.int64)
+    return b
+
+
+def full_batch(T):
+    b = synth.synth_batch(4, T, seed=4242 + T)
+    ids = b["input_ids"]
+    ids[0, :] = 0
+    ids[0, 0], ids[0, 1] = 101, 102   # shortest question: [CLS][SEP]
+    full = 1000 + (synth.hash_u32("fullrow%d" % T, T) % np.uint64(29000)).astype(np.int64)
+    ids[3, :] = full
+    ids[3, 0], ids[3, T - 1] = 101, 102  # max-length question, no padding
+    b["input_mask"] = (ids != 0).astype(np.int64)
+    return b
+
+
+def run_reference(m, b, train_grads=True, want_dfeats=False):
+    t = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
+    m.eval()  # dropout off: parity runs are eval-mode (SURVEY.md §7 hard parts)
+    feats = t["feats"].clone().requires_grad_(want_dfeats)
+    boxes = t["boxes"].clone().requires_grad_(want_dfeats)
+    for p in m.parameters():
+        p.grad = None
+    logit, pooled = m(feats, boxes, t["input_ids"], t["segment_ids"], t["input_mask"])
+    loss = torch.nn.BCEWithLogitsLoss()(logit, t["target"]) * logit.size(1)  # tasks/gqa_conf.py:197-198
+    out = dict(logits=logit.detach().numpy(), pooled=pooled.detach().numpy(), loss=np.float32(loss.item()))
+    if train_grads:
+        loss.backward()
+        out["_grads"] = {k: (p.grad.detach().numpy() if p.grad is not None else None)
+                         for k, p in m.named_parameters()}
+        if want_dfeats:
+            out["dfeats"] = feats.grad.numpy()
+            out["dboxes"] = boxes.grad.numpy()
+    return out
+
+
+def trace_reference(M, m, b):
+    """Layer-by-layer activations via forward hooks on the reference's own modules."""
+    tr = {}
+    enc = m.lxrt_encoder.model.bert.encoder
+    hooks = []
+
+    def grab(name, idx=None):
+        def fn(mod, inp, out):
+            if idx is None:
+                tr[name] = out.detach().numpy().copy()
+            else:
+                for suffix, o in zip(idx, out):
+                    tr[name + suffix] = o.detach().numpy().copy()
+        return fn
+    hooks.append(m.lxrt_encoder.model.bert.embeddings.register_forward_hook(grab("embed_lang")))
+    hooks.append(enc.visn_fc.register_forward_hook(grab("embed_visn")))
+    for i, l in enumerate(enc.layer):
+        hooks.append(l.register_forward_hook(grab("l%d" % i)))
+    for i, l in enumerate(enc.r_layers):
+        hooks.append(l.register_forward_hook(grab("r%d" % i)))
+    for i, l in enumerate(enc.x_layers):
+        hooks.append(l.register_forward_hook(grab("x%d" % i, ("_lang", "_visn"))))
+    t = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
+    m.eval()
+    with torch.no_grad():
+        m(t["feats"], t["boxes"], t["input_ids"], t["segment_ids"], t["input_mask"])
+    for h in hooks:
+        h.remove()
+    return tr
+
+
+def gen_small(M):
+    m = build_reference(M, SMALL)
+    for T in (5, 8):
+        b = small_batch(T)
+        out = run_reference(m, b, True, True)
+        tr = trace_reference(M, m, b)
+        z = {"logits": out["logits"], "pooled": out["pooled"], "loss": out["loss"],
+             "dfeats": out["dfeats"], "dboxes": out["dboxes"], "input_ids": b["input_ids"]}
+        for k, v in tr.items():
+            z["act." + k] = v
+        dead = []
+        for k, g in out["_grads"].items():
+            if g is None:
+                dead.append(k)
+            else:
+                z["grad." + k] = g
+        z["dead"] = np.array(dead)
+        np.savez_compressed(os.path.join(OUT, "g1_small_T%d.npz" % T), **z)
+        print("g1 T=%d loss=%.6f dead=%d" % (T, out["loss"], len(dead)))
+
+
+def gen_full(M):
+    m = build_reference(M, FULL)
+    for T in (20, 30):
+        b = full_batch(T)
+        out = run_reference(m, b, True, False)
+        tr = trace_reference(M, m, b)
+        z = {"logits": out["logits"], "pooled": out["pooled"], "loss": out["loss"],
+             "input_ids": b["input_ids"]}
+        z["act_names"] = np.array(sorted(tr))
+        z["act_l2"] = np.array([np.sqrt((tr[k].astype(np.float64) ** 2).sum()) for k in sorted(tr)])
+        z["act_first"] = np.stack([tr[k].reshape(-1)[:16] for k in sorted(tr)])
+        names, vals, dead, sq = [], [], [], 0.0
+        for k, g in out["_grads"].items():
+            if g is None:
+                dead.append(k)
+                continue
+            sq += float((g.astype(np.float64) ** 2).sum())
+            names.append(k)
+            vals.append(g.reshape(-1)[sample_idx(k, g.size)])
+        z["grad_names"] = np.array(names)
+        z["grad_samples"] = np.concatenate(vals).astype(np.float32)
+        z["grad_counts"] = np.array([len(v) for v in vals])
+        z["grad_norm"] = np.float64(np.sqrt(sq))
+        z["dead"] = np.array(dead)
+        np.savez_compressed(os.path.join(OUT, "g2_full_T%d.npz" % T), **z)
+        print("g2 T=%d loss=%.6f gnorm=%.6f dead=%d" % (T, out["loss"], z["grad_norm"], len(dead)))
+
+
+def gen_adam(OPT):
+    """G3: three BertAdam steps incl. a grad=None param, t_total=10, warmup=0.1 (optimization.py:101-180)."""
+    shapes = {"a": (7, 5), "b": (13,), "c": (3, 4, 2), "d": (1,), "e": (6,)}
+    ps = {k: torch.nn.Parameter(torch.from_numpy(synth.uniform("adam.p." + k, s, -1, 1))) for k, s in shapes.items()}
+    opt = OPT.BertAdam(list(ps.values()), lr=1e-2, warmup=0.1, t_total=10)
+    z = {}
+    for step in range(3):
+        for k, p in ps.items():
+            if k == "e" or (k == "d" and step == 0):
+                p.grad = None
+            else:
+                p.grad = torch.from_numpy(synth.uniform("adam.g%d.%s" % (step, k), shapes[k], -2, 2))
+        opt.step()
+        for k, p in ps.items():
+            z["p%d.%s" % (step, k)] = p.detach().numpy().copy()
+    for k, p in ps.items():
+        st = opt.state[p]
+        if len(st):
+            z["m." + k] = st["next_m"].numpy().copy()
+            z["v." + k] = st["next_v"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g3_bertadam.npz"), **z)
+    print("g3 ok")
+
+
+VOCAB_WORDS = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "the", "is", "what", "color", "of", "a", "an",
+               "on", "in", "to", "left", "right", "man", "woman", "dog", "cat", "table", "?", ",", ".", "'",
+               "s", "##s", "##ing", "##ed", "who", "wear", "hold", "sit", "stand", "red", "blue", "green",
+               "are", "there", "any", "or", "and", "side", "which", "kind", "animal", "furniture", "do",
+               "you", "see", "both", "that", "this", "it", "made", "wood", "##en", "un", "##aff", "##able",
+               "cafe", "-", "t", "shirt", "1", "2", "##0", "photo", "not", "bottle", "##neck", "near",
+               "behind", "front", "top", "bottom", "whe", "##re", "x"]
+
+SENTENCES = [
+    "What color is the dog?", "Is the man to the left of the woman?", "who is holding the bottle",
+    "Are there any cats or dogs on the table?", "  What   is the  woman wearing ?  ", "unaffable",
+    "Is this a café table, or not?", "what's on the left side", "Which kind of animal is sitting?",
+    "Do you see both a man and a woman?", "Is it made of wood?", "the wooden table", "t-shirt",
+    "Is the man's shirt red, blue or green", "zzzz qqqq", "", "?", "What is 20", "THE DOG IS STANDING",
+    "Is the bottleneck near the bottle?", "what\tis\nthis", "Where is the cat", "a" * 101, "xray",
+    "Is there a dog in front of the table behind the man on the right side of the photo to the left of"
+    " the woman holding the red bottle near the top of the table and the cat",
+    "é è ü", "what is the [MASK] of the dog", "[CLS] dog [SEP]", "dogs cats tables", "seeing holding standing",
+    "who's that?", "is,it.a-dog", "one 1 two 2", "What kind of furniture is this?", "Is the woman standing or sitting",
+    "the man the woman the dog the cat", "blue", "Which side is the green bottle on, the left or the right?",
+    "shirts", "Whe re",
+]
+
+
+def gen_tokenizer(TOK, ENT):
+    vpath = os.path.join(OUT, "g4_vocab.txt")
+    with open(vpath, "w", encoding="utf-8") as f:
+        f.write("\n".join(VOCAB_WORDS) + "\n")
+    tok = TOK.BertTokenizer(vpath, do_lower_case=True)
+    res = {"sentences": SENTENCES}
+    for T in (20, 30):
+        feats = ENT.convert_sents_to_features(SENTENCES, T, tok)
+        res["T%d" % T] = dict(input_ids=[f.input_ids for f in feats], input_mask=[f.input_mask for f in feats],
+                              segment_ids=[f.segment_ids for f in feats])
+    with open(os.path.join(OUT, "g4_tokenizer.json"), "w", encoding="utf-8") as f:
+        json.dump(res, f, ensure_ascii=False)
+    print("g4 ok")
+
+
+def gen_mixup():
+    """G5: executes the reference's own RoI-mixup statements (tasks/gqa_mixup_vis.py:134-181) read from the
+    reference file at run time, with seeded `random` / `np.random` and a stub dataset; records the RNG draws
+    (partner, prop, index set) next to the outputs."""
+    path = os.path.join(REF, "tasks", "gqa_mixup_vis.py")
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if "elif args.mixup_mode.startswith('mixup')" in l)
+    end = next(i for i, l in enumerate(lines) if i > start and "sent = sent + sent" in l)
+    body = textwrap.dedent("\n".join(lines[start + 1:end + 1]))
+    B, O, Fd, NA = 6, 36, 8, 5
+    z = {}
+    for mode in ("mixup_v1", "mixup_v2", "mixup_v3"):
+        feats = torch.from_numpy(synth.uniform("mix.f", (B, O, Fd), 0, 1))
+        boxes = torch.from_numpy(synth.uniform("mix.b", (B, O, 4), 0, 1))
+        target = torch.from_numpy(synth.uniform("mix.t", (B, NA), 0, 1))
+        ques_id = ["q%d" % i for i in range(B)]
+        img = {"q0": "A", "q1": "B", "q2": "A", "q3": "C", "q4": "D", "q5": "B"}
+
+        class DS:
+            id2datum = {q: {"img_id": img[q]} for q in ques_id}
+        draws = {"partner": [], "prop": [], "idx": []}
+        real_choice, real_beta, real_shuffle = random.choice, np.random.beta, np.random.shuffle
+        pending = {}
+
+        def choice(seq):
+            r = real_choice(seq)
+            pending["last"] = seq.index(r)
+            return r
+
+        def beta(a, b):
+            draws["partner"].append(pending["last"])
+            p = real_beta(a, b)
+            draws["prop"].append(p)
+            return p
+
+        def shuffle(arr):
+            real_shuffle(arr)
+            draws["idx"].append(arr.copy())
+        random.seed(9595)
+        np.random.seed(9595)
+        ns = dict(args=types.SimpleNamespace(mixup_mode=mode, mixup_alpha=1.0, mixup_beta=5.0), dset=DS,
+                  ques_id=ques_id, feats=feats, boxes=boxes, target=target, sent=["s"] * B, torch=torch,
+                  np=types.SimpleNamespace(random=types.SimpleNamespace(beta=beta, shuffle=shuffle), arange=np.arange),
+                  random=types.SimpleNamespace(choice=choice))
+        exec(body, ns)
+        z[mode + ".feats"] = ns["feats"].numpy()
+        z[mode + ".boxes"] = ns["boxes"].numpy()
+        z[mode + ".target"] = ns["target"].numpy()
+        z[mode + ".partner"] = np.array(draws["partner"])
+        z[mode + ".prop"] = np.array(draws["prop"], dtype=np.float64)
+        z[mode + ".perm"] = np.stack(draws["idx"])
+        assert len(ns["sent"]) == 2 * B
+    np.savez_compressed(os.path.join(OUT, "g5_mixup.npz"), **z)
+    print("g5 ok")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    M, OPT, TOK, ENT = import_reference()
+    which = sys.argv[1:] or ["small", "full", "adam", "tok", "mixup"]
+    if "small" in which:
+        gen_small(M)
+    if "adam" in which:
+        gen_adam(OPT)
+    if "tok" in which:
+        gen_tokenizer(TOK, ENT)
+    if "mixup" in which:
+        gen_mixup()
+    if "full" in which:
+        gen_full(M)
+
+
+if __name__ == "__main__":
+    main()
