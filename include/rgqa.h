@@ -1,0 +1,114 @@
+/* rgqa.h — C ABI of librgqa_hip.so (MI355X / gfx950).
+ *
+ * The reference (chihhuiho/RGQA) has no FFI or operator registry: its boundary for this path is a pair of
+ * Python classes.  This library is what the Python mirror of those classes
+ * (rgqa_amd/lxrt/entry.py, rgqa_amd/tasks/gqa_model.py) binds through ctypes.  Each entry point names the
+ * reference code it replaces (paths relative to the reference's src/).
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every function returns 0 on success or a
+ * negative RGQA_ERR_* code and never throws; rgqa_last_error_string() describes the last failure on the
+ * calling thread; nothing here allocates or frees caller memory — parameter arenas and the workspace are
+ * caller-owned device buffers; all work is enqueued on the given hipStream_t (passed as void*) and is
+ * stream-ordered.  Device pointers unless stated otherwise.
+ */
+#ifndef RGQA_H
+#define RGQA_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGQA_PRECISION_F32 0   /* exact-f32 operands: logits within 1e-3 of the reference CPU path */
+#define RGQA_PRECISION_BF16 1  /* bf16 MFMA operands, f32 accumulate / statistics: throughput path */
+
+typedef struct rgqa_config {
+    int32_t vocab_size, hidden, heads, inter, max_pos, type_vocab; /* BertConfig, lxrt/modeling.py:172-258 */
+    int32_t l_layers, x_layers, r_layers;                         /* VISUAL_CONFIG, lxrt/entry.py:74-77   */
+    int32_t feat_dim, pos_dim;                                    /* VisualConfig, lxrt/modeling.py:141-169 */
+    int32_t num_answers;                                          /* tasks/gqa_model.py:15,26 */
+    int32_t precision;                                            /* RGQA_PRECISION_* */
+    float ln_eps;                                                 /* 1e-12 everywhere in the reference */
+    float hidden_dropout, attn_dropout;                           /* 0.1 / 0.1, lxrt/modeling.py:182-183 */
+} rgqa_config;
+
+typedef struct rgqa_engine rgqa_engine;
+
+const char* rgqa_last_error_string(void);
+int rgqa_version(void);
+
+/* ---- engine: replaces GQAModel.__init__/forward (tasks/gqa_model.py:14-43), LXRTEncoder.forward after
+ * tokenisation (lxrt/entry.py:113-120) and everything below it in lxrt/modeling.py. */
+int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out);
+void rgqa_engine_destroy(rgqa_engine* e);
+/* flat-arena layout: number of f32 elements, number of tensors, and per-tensor (state_dict key, offset, shape) */
+int rgqa_engine_arena_elems(const rgqa_engine* e, size_t* out);
+int rgqa_engine_num_params(const rgqa_engine* e, int* out);
+int rgqa_engine_param_info(const rgqa_engine* e, int index, char* name, size_t name_cap, size_t* offset,
+                           int64_t shape[2], int* ndim, int* flags /* bit0 linear weight, bit1 dead in mode 'x' */);
+/* element range [begin,end) of the parameters that never receive gradients in mode 'x' */
+int rgqa_engine_dead_range(const rgqa_engine* e, size_t* begin, size_t* end);
+int rgqa_engine_workspace_bytes(rgqa_engine* e, int B, int T, int O, size_t* out);
+/* params / grads: f32 arenas of arena_elems; params_lp / params_lp_t: bf16 arenas of arena_elems (may be null in
+ * f32 precision); workspace: ws_bytes of scratch.  Must be called again when B, T or O change. */
+int rgqa_engine_bind(rgqa_engine* e, float* params, float* grads, void* params_lp, void* params_lp_t,
+                     void* workspace, size_t ws_bytes, int B, int T, int O);
+/* refresh the low-precision weight copies from the f32 master arena (after load_state_dict / external updates) */
+int rgqa_engine_sync_weights(rgqa_engine* e, void* stream);
+/* forward: feats [B,O,feat_dim] f32, boxes [B,O,pos_dim] f32, ids/seg/mask [B,T] i64 (seg may be null = zeros)
+ * -> pooled [B,hidden] f32 (may be null), logits [B,num_answers] f32 with row stride ld_logits. train != 0
+ * applies dropout (counter-based, keyed by seed) and keeps what backward needs. */
+int rgqa_engine_forward(rgqa_engine* e, const float* feats, const float* boxes, const int64_t* input_ids,
+                        const int64_t* segment_ids, const int64_t* input_mask, float* pooled, float* logits,
+                        int ld_logits, int train, uint64_t seed, void* stream);
+/* BCE-with-logits x NA loss (tasks/gqa_conf.py:197-198) + full backward (loss.backward(), :200) into the grad arena.
+ * grad_scale multiplies dL/dlogits (1 for a plain step). accumulate = 0 overwrites the gradient arena. */
+int rgqa_engine_loss_backward(rgqa_engine* e, const float* target, int ld_target, float* loss_out, float grad_scale,
+                              int accumulate, void* stream);
+/* backward from a caller-supplied dL/dlogits [B,num_answers] f32 (autograd integration) */
+int rgqa_engine_backward(rgqa_engine* e, const float* dlogits, int ld, int accumulate, void* stream);
+/* backward from dL/dpooled [B,hidden] f32: LXRTEncoder used under a caller-owned head (tasks/vqa_model.py, nlvr2_model.py) */
+int rgqa_engine_backward_pooled(rgqa_engine* e, const float* dpooled, int ld, int accumulate, void* stream);
+/* debug / parity: copy a saved activation ("embed_lang", "embed_visn", "l3", "r1", "x2_lang", "x2_visn", "pooled") as f32 */
+int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, size_t cap_elems, void* stream);
+
+/* ---- optimizer: replaces nn.utils.clip_grad_norm_(params, max_norm) (tasks/gqa_conf.py:201) followed by
+ * BertAdam.step (lxrt/optimization.py:101-180) over arena ranges. */
+int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws /* >= 1024 f32 */, float* sumsq_out,
+                    int accumulate, void* stream);
+int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp /* bf16 copy or null */, size_t n,
+                       float lr_t, float b1, float b2, float eps, float weight_decay,
+                       const float* sumsq /* device scalar or null */, float max_norm, float grad_prescale, void* stream);
+
+/* ---- batch construction: replaces the host loop of RoI-mixup (tasks/gqa_mixup_vis.py:134-181).
+ * feats [2B,O,F] / boxes [2B,O,4] with rows [0,B) filled; partner [B] i32; take_pos [B,O] u8 (1 = RoI taken from
+ * the positive sample). Writes rows [B,2B). */
+int rgqa_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uint8_t* take_pos, int B, int O,
+                      int F, int mode_v3, void* stream);
+/* target[B+j,:] = target[j,:] * prop[j]   (mixup_v1 / v3 soft targets, gqa_mixup_vis.py:170-171) */
+int rgqa_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, void* stream);
+
+/* ---- stand-alone operators (unit parity tests; the engine calls the same kernels internally) ------------- */
+/* C[M,N] = A[M,K] W[N,K]^T + bias, epilogue 0 none / 1 gelu / 2 tanh; dtype 0 f32, 1 bf16 (A, W, C all dtype) */
+int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
+                   int ldc, int epilogue, int dtype, void* stream);
+/* C[M,N] f32 = A[K,M]^T B[K,N]   (wgrad form); dtype of A and B */
+int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      int dtype, void* stream);
+int rgqa_op_layernorm(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int M, int N, float eps, int dtype, void* stream);
+int rgqa_op_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                          void* dx, float* dgamma, float* dbeta, float* ws /* 512*3*N f32 */, int M, int N, int dtype,
+                          void* stream);
+/* fused attention core on a packed QKV buffer [B*L, 3*nh*dh] (self-attention), impl 0 generic / 1 MFMA (bf16 only) */
+int rgqa_op_attention(const void* qkv, const float* mask /* [B,L] additive or null */, void* out, float* lse, int B,
+                      int nh, int L, int dh, int dtype, int impl, void* stream);
+int rgqa_op_attention_bwd(const void* qkv, const float* mask, const float* lse, const void* dout, void* dqkv, int B,
+                          int nh, int L, int dh, int dtype, int impl, void* stream);
+int rgqa_op_bce(const float* logits, const float* target, float* loss, float* dlogits, int B, int NA, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,79 @@
+"""ctypes binding of librgqa_hip.so (include/rgqa.h). There is no CPU fallback: a missing library is an error."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librgqa_hip.so")
+
+PREC_F32, PREC_BF16 = 0, 1
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab_size", "hidden", "heads", "inter", "max_pos", "type_vocab", "l_layers",
+                                         "x_layers", "r_layers", "feat_dim", "pos_dim", "num_answers", "precision")] + \
+               [("ln_eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float)]
+
+
+_vp, _sz, _i, _f, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_uint64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/rgqa.h
+SIGNATURES = {
+    "rgqa_version": [],
+    "rgqa_engine_create": [C.POINTER(Config), C.POINTER(_vp)],
+    "rgqa_engine_destroy": [_vp],
+    "rgqa_engine_arena_elems": [_vp, C.POINTER(_sz)],
+    "rgqa_engine_num_params": [_vp, C.POINTER(_i)],
+    "rgqa_engine_param_info": [_vp, _i, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(C.c_int64), C.POINTER(_i), C.POINTER(_i)],
+    "rgqa_engine_dead_range": [_vp, C.POINTER(_sz), C.POINTER(_sz)],
+    "rgqa_engine_workspace_bytes": [_vp, _i, _i, _i, C.POINTER(_sz)],
+    "rgqa_engine_bind": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i],
+    "rgqa_engine_sync_weights": [_vp, _vp],
+    "rgqa_engine_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _vp],
+    "rgqa_engine_loss_backward": [_vp, _vp, _i, _vp, _f, _i, _vp],
+    "rgqa_engine_backward": [_vp, _vp, _i, _i, _vp],
+    "rgqa_engine_backward_pooled": [_vp, _vp, _i, _vp],
+    "rgqa_engine_get_activation": [_vp, C.c_char_p, _vp, _sz, _vp],
+    "rgqa_grad_sumsq": [_vp, _sz, _vp, _vp, _i, _vp],
+    "rgqa_bertadam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _f, _f, _vp],
+    "rgqa_mixup_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "rgqa_scale_rows": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "rgqa_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rgqa_op_matmul_tn": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rgqa_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "rgqa_op_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "rgqa_op_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "rgqa_op_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "rgqa_op_bce": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "rgqa_last_error_string": [],
+}
+_RESTYPES = {"rgqa_last_error_string": C.c_char_p, "rgqa_engine_destroy": None}
+
+_lib = None
+
+
+def load():
+    """Loads the library (once). Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("rgqa_amd: %s not found. Build it with `python -m rgqa_amd.build` "
+                           "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header / library mismatch
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().rgqa_last_error_string()
+        raise RuntimeError("rgqa: %s (code %d)" % (msg.decode("utf-8", "replace") if msg else "unknown error", rc))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

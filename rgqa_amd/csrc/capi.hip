@@ -1,0 +1,155 @@
+// extern "C" surface of librgqa_hip.so (declared in include/rgqa.h).
+#include "engine.h"
+#include <string.h>
+#include <new>
+
+struct rgqa_engine { EngineBase* impl; };
+
+#define S(x) reinterpret_cast<hipStream_t>(x)
+#define NEED(e) do { if ((e) == nullptr || (e)->impl == nullptr) { rgqa_set_error("null engine handle"); return RGQA_ERR_ARG; } } while (0)
+
+extern "C" {
+
+int rgqa_version(void) { return 100; }
+
+int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out) {
+    RGQA_REQUIRE(cfg != nullptr && out != nullptr, "engine_create: null argument");
+    RGQA_REQUIRE(cfg->hidden > 0 && cfg->heads > 0 && cfg->hidden % cfg->heads == 0,
+                 "The hidden size (%d) is not a multiple of the number of attention heads (%d)", cfg->hidden, cfg->heads);  // modeling.py:298-301
+    RGQA_REQUIRE(cfg->hidden % 64 == 0 && cfg->hidden <= 1024, "engine_create: hidden (%d) must be a multiple of 64 and <= 1024", cfg->hidden);
+    RGQA_REQUIRE(cfg->hidden / cfg->heads <= 64, "engine_create: head size %d > 64 unsupported", cfg->hidden / cfg->heads);
+    RGQA_REQUIRE(cfg->inter % 8 == 0 && cfg->feat_dim % 8 == 0, "engine_create: intermediate (%d) and feature (%d) sizes must be multiples of 8", cfg->inter, cfg->feat_dim);
+    RGQA_REQUIRE(cfg->pos_dim >= 1 && cfg->pos_dim <= 4, "engine_create: pos_dim %d unsupported", cfg->pos_dim);
+    RGQA_REQUIRE(cfg->vocab_size > 0 && cfg->max_pos > 0 && cfg->type_vocab > 0 && cfg->num_answers > 0, "engine_create: empty table");
+    RGQA_REQUIRE(cfg->l_layers >= 0 && cfg->x_layers >= 0 && cfg->r_layers >= 0, "engine_create: negative layer count");
+    RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16, "engine_create: unknown precision %d", cfg->precision);
+    RGQA_REQUIRE(cfg->hidden_dropout >= 0.f && cfg->hidden_dropout < 1.f && cfg->attn_dropout >= 0.f && cfg->attn_dropout < 1.f, "engine_create: dropout out of range");
+    rgqa_engine* e = new (std::nothrow) rgqa_engine;
+    if (!e) { rgqa_set_error("engine_create: out of host memory"); return RGQA_ERR_STATE; }
+    e->impl = make_engine(*cfg);
+    *out = e;
+    return RGQA_OK;
+}
+void rgqa_engine_destroy(rgqa_engine* e) { if (e) { delete e->impl; delete e; } }
+
+int rgqa_engine_arena_elems(const rgqa_engine* e, size_t* out) { NEED(e); *out = e->impl->arena_elems; return RGQA_OK; }
+int rgqa_engine_num_params(const rgqa_engine* e, int* out) { NEED(e); *out = (int)e->impl->params.size(); return RGQA_OK; }
+int rgqa_engine_param_info(const rgqa_engine* e, int index, char* name, size_t name_cap, size_t* offset, int64_t shape[2], int* ndim, int* flags) {
+    NEED(e);
+    RGQA_REQUIRE(index >= 0 && index < (int)e->impl->params.size(), "param_info: index %d out of range", index);
+    const ParamInfo& p = e->impl->params[index];
+    RGQA_REQUIRE(name_cap > p.name.size(), "param_info: name buffer too small");
+    strcpy(name, p.name.c_str());
+    *offset = p.offset; shape[0] = p.shape[0]; shape[1] = p.shape[1]; *ndim = p.ndim;
+    *flags = (p.is_linear_weight ? 1 : 0) | (p.dead_in_x_mode ? 2 : 0);
+    return RGQA_OK;
+}
+int rgqa_engine_dead_range(const rgqa_engine* e, size_t* b, size_t* en) { NEED(e); *b = e->impl->dead_begin; *en = e->impl->dead_end; return RGQA_OK; }
+int rgqa_engine_workspace_bytes(rgqa_engine* e, int B, int T, int O, size_t* out) {
+    NEED(e);
+    RGQA_REQUIRE(B > 0 && T > 0 && O > 0, "workspace_bytes: bad shape");
+    *out = e->impl->workspace_bytes(B, T, O);
+    return RGQA_OK;
+}
+int rgqa_engine_bind(rgqa_engine* e, float* params, float* grads, void* plp, void* plpt, void* ws, size_t ws_bytes, int B, int T, int O) {
+    NEED(e);
+    return e->impl->bind(params, grads, plp, plpt, ws, ws_bytes, B, T, O);
+}
+int rgqa_engine_sync_weights(rgqa_engine* e, void* stream) { NEED(e); return e->impl->sync_weights(S(stream)); }
+int rgqa_engine_forward(rgqa_engine* e, const float* feats, const float* boxes, const int64_t* ids, const int64_t* seg, const int64_t* mask,
+                        float* pooled, float* logits, int ld_logits, int train, uint64_t seed, void* stream) {
+    NEED(e);
+    return e->impl->forward(feats, boxes, ids, seg, mask, pooled, logits, ld_logits, train, seed, S(stream));
+}
+int rgqa_engine_loss_backward(rgqa_engine* e, const float* target, int ldt, float* loss_out, float grad_scale, int accumulate, void* stream) {
+    NEED(e);
+    RGQA_REQUIRE(target != nullptr, "loss_backward: null target");
+    return e->impl->loss_backward(target, ldt, loss_out, grad_scale, accumulate, S(stream));
+}
+int rgqa_engine_backward(rgqa_engine* e, const float* dlogits, int ld, int accumulate, void* stream) {
+    NEED(e);
+    return e->impl->backward(dlogits, ld, accumulate, S(stream));
+}
+int rgqa_engine_backward_pooled(rgqa_engine* e, const float* dpooled, int ld, int accumulate, void* stream) {
+    NEED(e);
+    return e->impl->backward_pooled(dpooled, ld, accumulate, S(stream));
+}
+int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, size_t cap, void* stream) {
+    NEED(e);
+    RGQA_REQUIRE(name && out, "get_activation: null argument");
+    return e->impl->get_activation(name, out, cap, S(stream));
+}
+
+int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws, float* sumsq_out, int accumulate, void* stream) {
+    RGQA_REQUIRE(grads && partial_ws && sumsq_out, "grad_sumsq: null argument");
+    return k_sumsq(grads, n, partial_ws, sumsq_out, accumulate, S(stream));
+}
+int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp, size_t n, float lr_t, float b1, float b2, float eps, float wd,
+                       const float* sumsq, float max_norm, float grad_prescale, void* stream) {
+    RGQA_REQUIRE(p && g && m && v, "bertadam_step: null argument");
+    AdamArgs a; a.p = p; a.g = g; a.m = m; a.v = v; a.p_lp = p_lp; a.n = n; a.lr_t = lr_t; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;
+    a.sumsq = sumsq; a.max_norm = max_norm; a.grad_prescale = grad_prescale;
+    return k_bertadam(a, S(stream));
+}
+int rgqa_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uint8_t* take_pos, int B, int O, int F, int mode_v3, void* stream) {
+    RGQA_REQUIRE(feats && boxes && partner && take_pos, "mixup_gather: null argument");
+    return k_mixup_gather(feats, boxes, partner, take_pos, B, O, F, mode_v3, S(stream));
+}
+int rgqa_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, void* stream) {
+    RGQA_REQUIRE(target && prop, "scale_rows: null argument");
+    return k_scale_rows(target, prop, B, NA, ld, row0, S(stream));
+}
+
+// ---------------------------------------------------------------------------- stand-alone operators
+int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc, int epilogue, int dtype, void* stream) {
+    GemmGroup g; memset(&g, 0, sizeof g);
+    g.count = 1; g.drop = make_drop(0.f, 0, 0);
+    GemmProblem& p = g.p[0];
+    p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.epi = epilogue;
+    RGQA_REQUIRE(epilogue >= 0 && epilogue <= 2, "op_linear: epilogue must be 0..2");
+    return dtype == 1 ? launch_gemm_nt_bf16(g, 0, S(stream)) : launch_gemm_f32(g, 0, 0, S(stream));
+}
+int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {
+    GemmGroup g; memset(&g, 0, sizeof g);
+    g.count = 1; g.drop = make_drop(0.f, 0, 0);
+    GemmProblem& p = g.p[0];
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.epi = EPI_BIAS;
+    return dtype == 1 ? launch_gemm_tn_bf16(g, 1, S(stream)) : launch_gemm_f32(g, 1, 1, S(stream));
+}
+int rgqa_op_layernorm(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int N, float eps, int dtype, void* stream) {
+    if (dtype == 1) return k_ln_fwd<bf16_t>((const bf16_t*)x, N, gamma, beta, (bf16_t*)y, N, mean, rstd, M, N, eps, S(stream));
+    return k_ln_fwd<float>((const float*)x, N, gamma, beta, (float*)y, N, mean, rstd, M, N, eps, S(stream));
+}
+int rgqa_op_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                          float* ws, int M, int N, int dtype, void* stream) {
+    const DropCfg nd = make_drop(0.f, 0, 0);
+    if (dtype == 1) return k_ln_bwd<bf16_t>((const bf16_t*)dy, N, (const bf16_t*)x, N, gamma, mean, rstd, (bf16_t*)dx, nullptr, N, ws, dgamma, dbeta, nullptr, 0, M, N, nd, nd, 1.f, S(stream));
+    return k_ln_bwd<float>((const float*)dy, N, (const float*)x, N, gamma, mean, rstd, (float*)dx, nullptr, N, ws, dgamma, dbeta, nullptr, 0, M, N, nd, nd, 1.f, S(stream));
+}
+static void fill_attn(AttnArgs& a, const void* qkv, const float* mask, int B, int nh, int L, int dh, size_t esz) {
+    memset(&a, 0, sizeof a);
+    const int H = nh * dh;
+    a.q = qkv; a.k = (const char*)qkv + (size_t)H * esz; a.v = (const char*)qkv + (size_t)2 * H * esz;
+    a.ldq = a.ldk = a.ldv = 3 * H; a.mask = mask; a.B = B; a.nh = nh; a.Lq = a.Lk = L; a.dh = dh;
+    a.scale = 1.0f / sqrtf((float)dh); a.drop = make_drop(0.f, 0, 0);
+}
+int rgqa_op_attention(const void* qkv, const float* mask, void* out, float* lse, int B, int nh, int L, int dh, int dtype, int impl, void* stream) {
+    AttnArgs a; fill_attn(a, qkv, mask, B, nh, L, dh, dtype == 1 ? 2 : 4);
+    a.out = out; a.ldo = nh * dh; a.lse = lse;
+    if (dtype == 1) return impl == 1 ? k_attn_fwd_mfma(a, S(stream)) : k_attn_fwd_ref<bf16_t>(a, S(stream));
+    return k_attn_fwd_ref<float>(a, S(stream));
+}
+int rgqa_op_attention_bwd(const void* qkv, const float* mask, const float* lse, const void* dout, void* dqkv, int B, int nh, int L, int dh, int dtype, int impl, void* stream) {
+    const size_t esz = dtype == 1 ? 2 : 4;
+    AttnArgs a; fill_attn(a, qkv, mask, B, nh, L, dh, esz);
+    const int H = nh * dh;
+    a.lse = const_cast<float*>(lse); a.dout = dout; a.lddo = H;
+    a.dq = dqkv; a.dk = (char*)dqkv + (size_t)H * esz; a.dv = (char*)dqkv + (size_t)2 * H * esz; a.lddq = a.lddk = a.lddv = 3 * H;
+    if (dtype == 1) return impl == 1 ? k_attn_bwd_mfma(a, S(stream)) : k_attn_bwd_ref<bf16_t>(a, S(stream));
+    return k_attn_bwd_ref<float>(a, S(stream));
+}
+int rgqa_op_bce(const float* logits, const float* target, float* loss, float* dlogits, int B, int NA, void* stream) {
+    return k_bce_fwd_bwd(logits, NA, target, NA, loss, dlogits, NA, B, NA, NA, 1.0f, S(stream));
+}
+
+}  // extern "C"

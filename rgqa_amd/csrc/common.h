@@ -1,0 +1,98 @@
+// Shared device/host helpers for the rgqa HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define RGQA_OK 0
+#define RGQA_ERR_ARG (-1)
+#define RGQA_ERR_HIP (-2)
+#define RGQA_ERR_STATE (-3)
+#define RGQA_ERR_WORKSPACE (-4)
+
+void rgqa_set_error(const char* fmt, ...);
+int rgqa_check_hip(hipError_t e, const char* what);
+#define RGQA_HIP(x) do { int _r = rgqa_check_hip((x), #x); if (_r) return _r; } while (0)
+#define RGQA_LAUNCH_CHECK(name) do { int _r = rgqa_check_hip(hipGetLastError(), name); if (_r) return _r; } while (0)
+#define RGQA_REQUIRE(cond, ...) do { if (!(cond)) { rgqa_set_error(__VA_ARGS__); return RGQA_ERR_ARG; } } while (0)
+
+// ---------------------------------------------------------------- scalar conversions
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// 4 consecutive elements, 8-/16-byte aligned
+__device__ __forceinline__ void load4(const float* p, float v[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+__device__ __forceinline__ void store4(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
+    bf16x4 t; t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = t;
+}
+
+// ---------------------------------------------------------------- wave (64-lane) reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- math
+// exact-erf GeLU, as the reference's gelu() (lxrt/modeling.py:112-118)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx gelu = Phi(x) + x*phi(x)
+__device__ __forceinline__ float dgelu_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// keep(seed, stream, idx): one 32-bit hash word per element; the same (seed, stream, idx) is re-derived in
+// the backward pass so no mask is stored.  `stream` separates the dropout sites of one step.
+__device__ __forceinline__ uint32_t rng_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u + seed_lo;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    x += seed_hi;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    return x;
+}
+struct DropCfg {
+    uint32_t seed_lo, seed_hi;  // seed_hi carries the site id
+    uint32_t thresh;            // drop when hash < thresh  (thresh = p * 2^32); 0 = no dropout
+    float scale;                // 1/(1-p)
+};
+__device__ __forceinline__ float drop_apply(const DropCfg& d, uint32_t idx, float v) {
+    if (d.thresh == 0u) return v;
+    return rng_hash(d.seed_lo, d.seed_hi, idx) < d.thresh ? 0.0f : v * d.scale;
+}
+static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
+    DropCfg d;
+    d.seed_lo = (uint32_t)seed;
+    d.seed_hi = (uint32_t)(seed >> 32) ^ (site * 0x632BE5ABu + 0x7F4A7C15u);
+    if (p <= 0.f) { d.thresh = 0u; d.scale = 1.f; }
+    else { double t = (double)p * 4294967296.0; d.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t; d.scale = 1.0f / (1.0f - p); }
+    return d;
+}
+__host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,61 @@
+// LXMERT-GQA encoder engine: owns the parameter layout of the flat arenas, the workspace plan and the
+// launch sequence of the whole forward / backward pass (reference path: tasks/gqa_model.py:30-43 ->
+// lxrt/entry.py:109-120 -> lxrt/modeling.py:845-886, 546-566).  One engine per process / GPU.
+#pragma once
+#include <string>
+#include <vector>
+#include "kernels.h"
+#include "../../include/rgqa.h"
+
+struct ParamInfo {
+    std::string name;   // state_dict key of GQAModel (tasks/gqa_model.py)
+    size_t offset;      // element offset in the flat f32 arena
+    int ndim;
+    long shape[2];
+    int is_linear_weight;  // has a transposed low-precision copy
+    int dead_in_x_mode;    // never receives a gradient when mode == 'x' 
+};
+
+struct Lin { size_t w, b; int out, in, ldt; };     // ldt: leading dim of the transposed copy (round_up(out, 64))
+struct LNp { size_t w, b; int n; };
+struct AttP { Lin qkv, o; LNp ln; };
+struct FfnP { Lin up, down; LNp ln; };
+
+enum StageKind { ST_ATT_SELF = 0, ST_ATT_CROSS = 1, ST_FFN = 2 };
+
+struct SegBuf {        // per (stage, modality) activation pointers; byte pointers typed at use
+    void* x_in; void* y;
+    void* qkv; void* ctx; void* z; void* hpre; void* h;
+    float* lse; float* mean; float* rstd;
+};
+
+struct Stage {
+    int kind;
+    int active[2];             // [lang, visn]
+    const AttP* att[2];        // self: per modality; cross: both point at the shared module
+    const FfnP* ffn[2];
+    SegBuf sb[2];
+    uint32_t site;
+    int last_dead;             // 1: visn side is the dead branch of the final x-layer
+};
+
+class EngineBase {
+public:
+    virtual ~EngineBase() {}
+    rgqa_config cfg;
+    std::vector<ParamInfo> params;
+    size_t arena_elems = 0;
+    size_t dead_begin = 0, dead_end = 0;   // element range of the final x-layer's visn_* parameters
+    std::string err;
+    virtual size_t workspace_bytes(int B, int T, int O) = 0;
+    virtual int bind(float* p, float* g, void* plp, void* plpt, void* ws, size_t ws_bytes, int B, int T, int O) = 0;
+    virtual int sync_weights(hipStream_t s) = 0;
+    virtual int forward(const float* feats, const float* boxes, const int64_t* ids, const int64_t* seg, const int64_t* mask,
+                        float* pooled_out, float* logits_out, int ld_logits, int train, uint64_t seed, hipStream_t s) = 0;
+    virtual int loss_backward(const float* target, int ldt, float* loss_out, float grad_scale, int accumulate, hipStream_t s) = 0;
+    virtual int backward(const float* dlogits, int ldd, int accumulate, hipStream_t s) = 0;
+    virtual int backward_pooled(const float* dpooled, int ld, int accumulate, hipStream_t s) = 0;
+    virtual int get_activation(const char* name, float* out, size_t cap_elems, hipStream_t s) = 0;
+};
+
+EngineBase* make_engine(const rgqa_config& cfg);

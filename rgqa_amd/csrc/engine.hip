@@ -1,0 +1,700 @@
+// Engine implementation: parameter table, workspace plan, forward and backward launch sequences.
+#include "engine.h"
+#include <string.h>
+#include <stdio.h>
+
+static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ============================================================================ parameter table
+struct ModelParams {
+    size_t word, pos, type; LNp emb_ln;
+    Lin visn_fc; LNp visn_ln; Lin box_fc; LNp box_ln;
+    std::vector<AttP> l_att, r_att; std::vector<FfnP> l_ffn, r_ffn;
+    std::vector<AttP> x_cross, x_latt, x_vatt; std::vector<FfnP> x_lffn, x_vffn;
+    Lin pooler, head0; LNp head_ln; Lin head3;
+};
+
+struct TableBuilder {
+    std::vector<ParamInfo>& out;
+    size_t cur = 0;
+    bool dead = false;
+    explicit TableBuilder(std::vector<ParamInfo>& o) : out(o) {}
+    size_t add(const std::string& name, long d0, long d1, int ndim, size_t reserve, int is_w) {
+        cur = rup(cur, 64);
+        ParamInfo p; p.name = name; p.offset = cur; p.ndim = ndim; p.shape[0] = d0; p.shape[1] = d1;
+        p.is_linear_weight = is_w; p.dead_in_x_mode = dead ? 1 : 0;
+        out.push_back(p);
+        size_t n = (size_t)d0 * (ndim == 2 ? (size_t)d1 : 1);
+        size_t off = cur;
+        cur += n > reserve ? n : reserve;
+        return off;
+    }
+    Lin lin(const std::string& name, int o, int i) {
+        Lin l; l.out = o; l.in = i; l.ldt = (int)rup(o, 64);
+        l.w = add(name + ".weight", o, i, 2, (size_t)i * l.ldt, 1);
+        l.b = add(name + ".bias", o, 0, 1, rup(o, 64), 0);
+        return l;
+    }
+    LNp ln(const std::string& name, int n) {
+        LNp l; l.n = n;
+        l.w = add(name + ".weight", n, 0, 1, 0, 0);
+        l.b = add(name + ".bias", n, 0, 1, 0, 0);
+        return l;
+    }
+    // query/key/value stay separate state_dict tensors but sit back-to-back: one fused [3H,H] projection
+    AttP att(const std::string& self_name, const std::string& out_name, int H) {
+        AttP a;
+        a.qkv.out = 3 * H; a.qkv.in = H; a.qkv.ldt = 3 * H;
+        a.qkv.w = add(self_name + ".query.weight", H, H, 2, 0, 2);
+        add(self_name + ".key.weight", H, H, 2, 0, 2);
+        add(self_name + ".value.weight", H, H, 2, 0, 2);
+        a.qkv.b = add(self_name + ".query.bias", H, 0, 1, 0, 0);
+        add(self_name + ".key.bias", H, 0, 1, 0, 0);
+        add(self_name + ".value.bias", H, 0, 1, 0, 0);
+        a.o = lin(out_name + ".dense", H, H);
+        a.ln = ln(out_name + ".LayerNorm", H);
+        return a;
+    }
+    FfnP ffn(const std::string& inter, const std::string& outp, int H, int I) {
+        FfnP f;
+        f.up = lin(inter + ".dense", I, H);
+        f.down = lin(outp + ".dense", H, I);
+        f.ln = ln(outp + ".LayerNorm", H);
+        return f;
+    }
+};
+
+static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, ModelParams& mp, size_t& total, size_t& dead_b, size_t& dead_e) {
+    TableBuilder tb(tab);
+    const int H = c.hidden, I = c.inter;
+    const std::string pre = "lxrt_encoder.model.bert.";
+    mp.word = tb.add(pre + "embeddings.word_embeddings.weight", c.vocab_size, H, 2, 0, 0);
+    mp.pos = tb.add(pre + "embeddings.position_embeddings.weight", c.max_pos, H, 2, 0, 0);
+    mp.type = tb.add(pre + "embeddings.token_type_embeddings.weight", c.type_vocab, H, 2, 0, 0);
+    mp.emb_ln = tb.ln(pre + "embeddings.LayerNorm", H);
+    const std::string enc = pre + "encoder.";
+    mp.visn_fc = tb.lin(enc + "visn_fc.visn_fc", H, c.feat_dim);
+    mp.visn_ln = tb.ln(enc + "visn_fc.visn_layer_norm", H);
+    mp.box_fc = tb.lin(enc + "visn_fc.box_fc", H, c.pos_dim);
+    mp.box_ln = tb.ln(enc + "visn_fc.box_layer_norm", H);
+    char buf[64];
+    for (int i = 0; i < c.l_layers; ++i) {
+        snprintf(buf, sizeof buf, "layer.%d", i);
+        std::string n = enc + buf;
+        mp.l_att.push_back(tb.att(n + ".attention.self", n + ".attention.output", H));
+        mp.l_ffn.push_back(tb.ffn(n + ".intermediate", n + ".output", H, I));
+    }
+    for (int i = 0; i < c.r_layers; ++i) {
+        snprintf(buf, sizeof buf, "r_layers.%d", i);
+        std::string n = enc + buf;
+        mp.r_att.push_back(tb.att(n + ".attention.self", n + ".attention.output", H));
+        mp.r_ffn.push_back(tb.ffn(n + ".intermediate", n + ".output", H, I));
+    }
+    dead_b = dead_e = 0;
+    for (int i = 0; i < c.x_layers; ++i) {
+        snprintf(buf, sizeof buf, "x_layers.%d", i);
+        std::string n = enc + buf;
+        mp.x_cross.push_back(tb.att(n + ".visual_attention.att", n + ".visual_attention.output", H));
+        mp.x_latt.push_back(tb.att(n + ".lang_self_att.self", n + ".lang_self_att.output", H));
+        mp.x_lffn.push_back(tb.ffn(n + ".lang_inter", n + ".lang_output", H, I));
+        const bool last = (i == c.x_layers - 1);
+        if (last) { tb.cur = rup(tb.cur, 64); dead_b = tb.cur; tb.dead = true; }
+        mp.x_vatt.push_back(tb.att(n + ".visn_self_att.self", n + ".visn_self_att.output", H));
+        mp.x_vffn.push_back(tb.ffn(n + ".visn_inter", n + ".visn_output", H, I));
+        if (last) { tb.cur = rup(tb.cur, 64); dead_e = tb.cur; tb.dead = false; }
+    }
+    mp.pooler = tb.lin(pre + "pooler.dense", H, H);
+    mp.head0 = tb.lin("logit_fc.0", 2 * H, H);
+    mp.head_ln = tb.ln("logit_fc.2", 2 * H);
+    mp.head3 = tb.lin("logit_fc.3", c.num_answers, 2 * H);
+    total = rup(tb.cur, 64);
+}
+
+// ============================================================================ engine
+template <typename T>
+class Engine : public EngineBase {
+public:
+    static constexpr bool LP = !std::is_same<T, float>::value;
+    ModelParams mp;
+    std::vector<Stage> stages;
+    // bound memory
+    float* P = nullptr; float* G = nullptr; T* Pb = nullptr; T* PbT = nullptr;
+    char* ws = nullptr; size_t ws_bytes_ = 0, ws_used = 0;
+    int B = 0, Tn = 0, O = 0, Rl = 0, Rv = 0, R = 0, NAp = 0;
+    bool dry = false;
+    // inputs of the last forward (caller-owned, must stay alive until backward returns)
+    const float* in_feats = nullptr; const float* in_boxes = nullptr; const int64_t* in_ids = nullptr; const int64_t* in_seg = nullptr;
+    int last_train = 0; uint64_t last_seed = 0; bool have_fwd = false;
+    // workspace pieces
+    float* maskf = nullptr;
+    T *emb_out = nullptr, *emb_z = nullptr; float *emb_mean = nullptr, *emb_rstd = nullptr;
+    T *zf = nullptr, *visn_out = nullptr; float* visn_stats = nullptr;
+    T *pooled = nullptr, *h1pre = nullptr, *h1 = nullptr, *h2 = nullptr; float *hd_mean = nullptr, *hd_rstd = nullptr;
+    float* logits = nullptr; T* dlogits = nullptr; float* loss_dev = nullptr;
+    T *gA = nullptr, *gB = nullptr, *gz = nullptr, *gzd = nullptr, *gctx = nullptr, *gqkv = nullptr, *gh = nullptr;
+    T *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
+    float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
+    void* lang_final = nullptr;
+    std::vector<TransDesc> tdesc_host;
+
+    explicit Engine(const rgqa_config& c) {
+        cfg = c;
+        build_params(cfg, params, mp, arena_elems, dead_begin, dead_end);
+        build_transpose_table();
+    }
+
+    void build_transpose_table() {
+        // every [out,in] linear weight gets a transposed low-precision copy at the same arena offset
+        auto add = [&](const Lin& l) {
+            TransDesc d; d.src_off = (long)l.w; d.dst_off = (long)l.w; d.N = l.out; d.K = l.in; d.ld_dst = l.ldt; d.tile_start = tdesc_tiles;
+            tdesc_tiles += cdiv(l.ldt, 32) * cdiv(l.in, 32);
+            tdesc_host.push_back(d);
+        };
+        add(mp.visn_fc);
+        auto addatt = [&](const AttP& a) { add(a.qkv); add(a.o); };
+        auto addffn = [&](const FfnP& f) { add(f.up); add(f.down); };
+        for (auto& a : mp.l_att) addatt(a);
+        for (auto& f : mp.l_ffn) addffn(f);
+        for (auto& a : mp.r_att) addatt(a);
+        for (auto& f : mp.r_ffn) addffn(f);
+        for (auto& a : mp.x_cross) addatt(a);
+        for (auto& a : mp.x_latt) addatt(a);
+        for (auto& a : mp.x_vatt) addatt(a);
+        for (auto& f : mp.x_lffn) addffn(f);
+        for (auto& f : mp.x_vffn) addffn(f);
+        add(mp.pooler); add(mp.head0); add(mp.head3);
+        n_tdesc = (int)tdesc_host.size();
+    }
+
+    // ------------------------------------------------------------------ workspace plan
+    template <typename U> U* take(size_t n) {
+        size_t bytes = rup(n * sizeof(U), 256);
+        U* p = dry ? nullptr : reinterpret_cast<U*>(ws + ws_used);
+        ws_used += bytes;
+        return p;
+    }
+    static void* rows(void* base, size_t row, size_t width) { return base ? (void*)((T*)base + row * width) : nullptr; }
+
+    void plan(int B_, int T_, int O_) {
+        B = B_; Tn = T_; O = O_; Rl = B * Tn; Rv = B * O; R = Rl + Rv;
+        NAp = (int)rup(cfg.num_answers, 64);
+        const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads;
+        ws_used = 0;
+        stages.clear();
+        maskf = take<float>(Rl);
+        emb_out = take<T>((size_t)R * H); emb_z = take<T>((size_t)Rl * H); emb_mean = take<float>(Rl); emb_rstd = take<float>(Rl);
+        zf = take<T>((size_t)Rv * H); visn_stats = take<float>((size_t)Rv * 4);
+        visn_out = emb_out ? emb_out + (size_t)Rl * H : nullptr;   // [lang; visn] contiguous
+        void* cur[2] = {emb_out, visn_out};
+        uint32_t site = 16;
+        auto new_stage = [&](int kind, bool al, bool av) -> Stage& {
+            Stage st; memset(&st, 0, sizeof st);
+            st.kind = kind; st.active[0] = al; st.active[1] = av; st.site = site; site += 8;
+            T* y = take<T>((size_t)R * H);
+            T* z = take<T>((size_t)R * H);
+            float* mean = take<float>(R); float* rstd = take<float>(R);
+            T *qkv = nullptr, *ctx = nullptr, *hpre = nullptr, *h = nullptr; float* lse = nullptr;
+            if (kind == ST_FFN) { hpre = take<T>((size_t)R * I); h = take<T>((size_t)R * I); }
+            else { qkv = take<T>((size_t)R * 3 * H); ctx = take<T>((size_t)R * H); lse = take<float>((size_t)B * nh * (Tn + O)); }
+            for (int m = 0; m < 2; ++m) {
+                const size_t r0 = m == 0 ? 0 : Rl;
+                SegBuf& s = st.sb[m];
+                s.x_in = cur[m];
+                s.y = rows(y, r0, H); s.z = rows(z, r0, H);
+                s.mean = mean ? mean + r0 : nullptr; s.rstd = rstd ? rstd + r0 : nullptr;
+                s.qkv = rows(qkv, r0, 3 * H); s.ctx = rows(ctx, r0, H);
+                s.hpre = rows(hpre, r0, I); s.h = rows(h, r0, I);
+                s.lse = lse ? lse + (m == 0 ? 0 : (size_t)B * nh * Tn) : nullptr;
+                if (st.active[m]) cur[m] = s.y;
+            }
+            stages.push_back(st);
+            return stages.back();
+        };
+        const int nlr = cfg.l_layers > cfg.r_layers ? cfg.l_layers : cfg.r_layers;
+        for (int i = 0; i < nlr; ++i) {
+            const bool al = i < cfg.l_layers, av = i < cfg.r_layers;
+            Stage& a = new_stage(ST_ATT_SELF, al, av);
+            if (al) a.att[0] = &mp.l_att[i];
+            if (av) a.att[1] = &mp.r_att[i];
+            Stage& f = new_stage(ST_FFN, al, av);
+            if (al) f.ffn[0] = &mp.l_ffn[i];
+            if (av) f.ffn[1] = &mp.r_ffn[i];
+        }
+        // the cross-modality layers need [lang; visn] contiguous: copy-free when both chains end in one stage,
+        // otherwise the engine gathers them into x0 (one row copy of the shorter chain's output)
+        x0_needed = (cfg.x_layers > 0) && (cfg.l_layers != cfg.r_layers);
+        if (x0_needed) {
+            x0 = take<T>((size_t)R * H);
+            x0_src[0] = cur[0]; x0_src[1] = cur[1];
+            cur[0] = x0; cur[1] = rows(x0, Rl, H);
+        }
+        for (int i = 0; i < cfg.x_layers; ++i) {
+            const bool last = (i == cfg.x_layers - 1);
+            Stage& c = new_stage(ST_ATT_CROSS, true, !last);
+            c.att[0] = c.att[1] = &mp.x_cross[i]; c.last_dead = last;
+            Stage& a = new_stage(ST_ATT_SELF, true, !last);
+            a.att[0] = &mp.x_latt[i]; a.att[1] = &mp.x_vatt[i]; a.last_dead = last;
+            Stage& f = new_stage(ST_FFN, true, !last);
+            f.ffn[0] = &mp.x_lffn[i]; f.ffn[1] = &mp.x_vffn[i]; f.last_dead = last;
+        }
+        lang_final = cur[0];
+        visn_final = cur[1];
+        pooled = take<T>((size_t)B * H); h1pre = take<T>((size_t)B * 2 * H); h1 = take<T>((size_t)B * 2 * H); h2 = take<T>((size_t)B * 2 * H);
+        hd_mean = take<float>(B); hd_rstd = take<float>(B);
+        logits = take<float>((size_t)B * NAp); dlogits = take<T>((size_t)B * NAp); loss_dev = take<float>(64);
+        gA = take<T>((size_t)R * H); gB = take<T>((size_t)R * H); gz = take<T>((size_t)R * H); gzd = take<T>((size_t)R * H);
+        gctx = take<T>((size_t)R * H); gqkv = take<T>((size_t)R * 3 * H); gh = take<T>((size_t)R * I);
+        gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
+        size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
+        part = take<float>((size_t)512 * 10 * pw);
+        tdesc = take<TransDesc>(n_tdesc + 1);
+    }
+    bool x0_needed = false; T* x0 = nullptr; void* x0_src[2] = {nullptr, nullptr}; void* visn_final = nullptr;
+
+    size_t workspace_bytes(int B_, int T_, int O_) override {
+        dry = true;
+        plan(B_, T_, O_);
+        dry = false;
+        return ws_used + 256;
+    }
+
+    int bind(float* p, float* g, void* plp, void* plpt, void* w, size_t wb, int B_, int T_, int O_) override {
+        RGQA_REQUIRE(p != nullptr && w != nullptr, "bind: null parameter arena or workspace");
+        RGQA_REQUIRE(B_ > 0 && T_ > 0 && O_ > 0 && T_ <= 64 && O_ <= 64, "bind: B=%d T=%d O=%d unsupported (T, O <= 64)", B_, T_, O_);
+        RGQA_REQUIRE(T_ <= cfg.max_pos, "bind: T=%d exceeds max_position_embeddings=%d", T_, cfg.max_pos);
+        if (LP) RGQA_REQUIRE(plp != nullptr && plpt != nullptr, "bind: bf16 precision needs the low-precision arenas");
+        RGQA_REQUIRE(((uintptr_t)p % 256) == 0 && ((uintptr_t)w % 256) == 0, "bind: arenas must be 256-byte aligned");
+        size_t need = workspace_bytes(B_, T_, O_);
+        if (wb < need) { rgqa_set_error("bind: workspace too small (%zu < %zu bytes)", wb, need); return RGQA_ERR_WORKSPACE; }
+        P = p; G = g; Pb = (T*)plp; PbT = (T*)plpt; ws = (char*)w; ws_bytes_ = wb;
+        plan(B_, T_, O_);
+        have_fwd = false;
+        tdesc_uploaded = false;
+        return RGQA_OK;
+    }
+    bool tdesc_uploaded = false;
+
+    int sync_weights(hipStream_t s) override {
+        RGQA_REQUIRE(P != nullptr, "sync_weights: engine not bound");
+        if (!LP) return RGQA_OK;
+        if (!tdesc_uploaded) {
+            RGQA_HIP(hipMemcpyAsync(tdesc, tdesc_host.data(), sizeof(TransDesc) * n_tdesc, hipMemcpyHostToDevice, s));
+            tdesc_uploaded = true;
+        }
+        int r = k_cast_bf16(P, Pb, arena_elems, s);
+        if (r) return r;
+        return k_cast_transpose(P, PbT, tdesc, n_tdesc, tdesc_tiles, s);
+    }
+
+    // ------------------------------------------------------------------ GEMM helpers
+    DropCfg drop_base(float p) const { return make_drop(last_train ? p : 0.f, last_seed, 0); }
+    DropCfg drop_site(float p, uint32_t site) const { DropCfg d = drop_base(p); d.seed_hi ^= site; return d; }
+
+    struct GG { GemmGroup g; };
+    static void gg_init(GemmGroup& g) { memset(&g, 0, sizeof g); }
+    // y[rows, out_cols] = x[rows, in] @ W[row0.., :]^T (+bias) ; FWD
+    void add_fwd(GemmGroup& g, const void* x, int ldx, const Lin& l, int wrow0, int wrows, void* y, int ldy, int M, int epi, const void* aux, int ldaux, void* c2, uint32_t site, bool bias = true) {
+        GemmProblem& p = g.p[g.count++];
+        memset(&p, 0, sizeof p);
+        p.A = x; p.lda = ldx; p.M = M; p.N = wrows; p.K = l.in; p.C = y; p.ldc = ldy; p.C2 = c2;
+        p.B = LP ? (const void*)(Pb + l.w + (size_t)wrow0 * l.in) : (const void*)(P + l.w + (size_t)wrow0 * l.in);
+        p.ldb = l.in;
+        p.bias = bias ? P + l.b + wrow0 : nullptr;
+        p.aux = aux; p.ldaux = ldaux; p.epi = epi; p.drop_site = site;
+    }
+    // dx[rows, in] = dy[rows, cols] @ W[wrow0 : wrow0+cols, :]      ; DGRAD
+    void add_dgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, void* dx, int lddx, int M, int epi, const void* aux, int ldaux) {
+        GemmProblem& p = g.p[g.count++];
+        memset(&p, 0, sizeof p);
+        p.A = dy; p.lda = lddy; p.M = M; p.N = l.in; p.C = dx; p.ldc = lddx;
+        if (LP) { p.B = PbT + l.w + wrow0; p.ldb = l.ldt; p.K = (wrow0 + wrows == l.out) ? (int)rup(wrows, 8) : wrows; if (p.K > l.ldt - wrow0) p.K = l.ldt - wrow0; }
+        else { p.B = P + l.w + (size_t)wrow0 * l.in; p.ldb = l.in; p.K = wrows; }
+        p.aux = aux; p.ldaux = ldaux; p.epi = epi;
+    }
+    // dW[wrow0 : wrow0+cols, :] (+)= dy[rows, cols]^T @ x[rows, in]   ; WGRAD
+    void add_wgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, const void* x, int ldx, int M, int accumulate) {
+        GemmProblem& p = g.p[g.count++];
+        memset(&p, 0, sizeof p);
+        p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.K = M; p.M = wrows; p.N = l.in;
+        p.C = G + l.w + (size_t)wrow0 * l.in; p.ldc = l.in; p.epi = accumulate ? EPI_ACCUM : EPI_BIAS;
+    }
+    int run_fwd(GemmGroup& g, hipStream_t s, int out_f32 = 0, int a_f32 = 0) {
+        if (g.count == 0) return RGQA_OK;
+        g.a_f32 = a_f32;
+        return LP ? launch_gemm_nt_bf16(g, out_f32, s) : launch_gemm_f32(g, 0, 0, s);
+    }
+    int run_dgrad(GemmGroup& g, hipStream_t s) {
+        if (g.count == 0) return RGQA_OK;
+        return LP ? launch_gemm_nt_bf16(g, 0, s) : launch_gemm_f32(g, 0, 1, s);
+    }
+    int run_wgrad(GemmGroup& g, hipStream_t s, int b_f32 = 0) {
+        if (g.count == 0) return RGQA_OK;
+        g.a_f32 = b_f32;
+        return LP ? launch_gemm_tn_bf16(g, 1, s) : launch_gemm_f32(g, 1, 1, s);
+    }
+    int attn_fwd(const AttnArgs& a, hipStream_t s) { return attn_fwd_dispatch(a, s); }
+    int attn_fwd_dispatch(const AttnArgs& a, hipStream_t s);
+    int attn_bwd_dispatch(const AttnArgs& a, hipStream_t s);
+
+#define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
+
+    int seg_rows(int m) const { return m == 0 ? Rl : Rv; }
+    int seg_len(int m) const { return m == 0 ? Tn : O; }
+
+    // ------------------------------------------------------------------ forward
+    int forward(const float* feats, const float* boxes, const int64_t* ids, const int64_t* seg, const int64_t* mask,
+                float* pooled_out, float* logits_out, int ld_logits, int train, uint64_t seed, hipStream_t s) override {
+        RGQA_REQUIRE(P != nullptr && ws != nullptr, "forward: engine not bound");
+        RGQA_REQUIRE(feats && boxes && ids && mask, "forward: null input");
+        const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh;
+        in_feats = feats; in_boxes = boxes; in_ids = ids; in_seg = seg; last_train = train; last_seed = seed;
+        const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
+        CK(k_make_mask(mask, maskf, Rl, s));
+        CK(k_embed_fwd<T>(ids, seg, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z, emb_mean, emb_rstd,
+                          B, Tn, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
+        {   // VisualFeatEncoder: GEMM on the raw f32 features (converted to bf16 while staging), then the fused LN/LN/avg tail
+            GemmGroup g; gg_init(g);
+            add_fwd(g, feats, cfg.feat_dim, mp.visn_fc, 0, H, zf, H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
+            CK(run_fwd(g, s, 0, LP ? 1 : 0));
+            CK(k_visn_combine_fwd<T>(zf, H, boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.visn_ln.b, P + mp.box_ln.w, P + mp.box_ln.b,
+                                     visn_out, H, visn_stats, Rv, H, cfg.pos_dim, cfg.ln_eps, drop_site(pd, 2), s));
+        }
+        bool gathered = false;
+        for (size_t si = 0; si < stages.size(); ++si) {
+            Stage& st = stages[si];
+            if (st.kind == ST_ATT_CROSS && x0_needed && !gathered) {
+                CK(rgqa_check_hip(hipMemcpyAsync(x0, x0_src[0], (size_t)Rl * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather lang"));
+                CK(rgqa_check_hip(hipMemcpyAsync(x0 + (size_t)Rl * H, x0_src[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather visn"));
+                gathered = true;
+            }
+            if (st.kind == ST_FFN) {
+                GemmGroup g; gg_init(g);
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    add_fwd(g, st.sb[m].x_in, H, st.ffn[m]->up, 0, I, st.sb[m].h, I, seg_rows(m), EPI_GELU, nullptr, 0, st.sb[m].hpre, 0);
+                CK(run_fwd(g, s));
+                gg_init(g); g.drop = drop_base(pd);
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    add_fwd(g, st.sb[m].h, I, st.ffn[m]->down, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
+                CK(run_fwd(g, s));
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    CK(k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.ffn[m]->ln.w, P + st.ffn[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
+                continue;
+            }
+            // ---- attention stages
+            const bool cross = st.kind == ST_ATT_CROSS;
+            {
+                GemmGroup g; gg_init(g);
+                if (cross) {
+                    const AttP& ap = *st.att[0];
+                    if (st.active[1]) add_fwd(g, st.sb[0].x_in, H, ap.qkv, 0, 3 * H, st.sb[0].qkv, 3 * H, R, EPI_BIAS, nullptr, 0, nullptr, 0);
+                    else {   // final x-layer: only lang queries and visn keys/values are live
+                        add_fwd(g, st.sb[0].x_in, H, ap.qkv, 0, H, st.sb[0].qkv, 3 * H, Rl, EPI_BIAS, nullptr, 0, nullptr, 0);
+                        add_fwd(g, st.sb[1].x_in, H, ap.qkv, H, 2 * H, (T*)st.sb[1].qkv + H, 3 * H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
+                    }
+                } else {
+                    for (int m = 0; m < 2; ++m) if (st.active[m])
+                        add_fwd(g, st.sb[m].x_in, H, st.att[m]->qkv, 0, 3 * H, st.sb[m].qkv, 3 * H, seg_rows(m), EPI_BIAS, nullptr, 0, nullptr, 0);
+                }
+                CK(run_fwd(g, s));
+            }
+            for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                const int km = cross ? 1 - m : m;    // modality that provides keys / values
+                AttnArgs a; memset(&a, 0, sizeof a);
+                a.q = st.sb[m].qkv; a.ldq = 3 * H;
+                a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
+                a.out = st.sb[m].ctx; a.ldo = H;
+                a.mask = km == 0 ? maskf : nullptr;      // only language keys carry a padding mask (entry.py:119)
+                a.lse = st.sb[m].lse;
+                a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
+                a.scale = 1.0f / sqrtf((float)dh);
+                a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
+                CK(attn_fwd_dispatch(a, s));
+            }
+            {
+                GemmGroup g; gg_init(g); g.drop = drop_base(pd);
+                if (cross && st.active[1]) {
+                    add_fwd(g, st.sb[0].ctx, H, st.att[0]->o, 0, H, st.sb[0].z, H, R, EPI_RESID_DROP, st.sb[0].x_in, H, nullptr, st.site + 1);
+                } else {
+                    for (int m = 0; m < 2; ++m) if (st.active[m])
+                        add_fwd(g, st.sb[m].ctx, H, st.att[m]->o, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
+                }
+                CK(run_fwd(g, s));
+            }
+            if (cross && st.active[1]) {
+                CK(k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
+            } else {
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    CK(k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.att[m]->ln.w, P + st.att[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
+            }
+        }
+        // ---- BertPooler (modeling.py:575-581) + answer head (gqa_model.py:22-27)
+        {
+            GemmGroup g; gg_init(g);
+            add_fwd(g, lang_final, Tn * H, mp.pooler, 0, H, pooled, H, B, EPI_TANH, nullptr, 0, nullptr, 0);
+            CK(run_fwd(g, s));
+            gg_init(g);
+            add_fwd(g, pooled, H, mp.head0, 0, 2 * H, h1, 2 * H, B, EPI_GELU, nullptr, 0, h1pre, 0);
+            CK(run_fwd(g, s));
+            CK(k_ln_fwd<T>(h1, 2 * H, P + mp.head_ln.w, P + mp.head_ln.b, h2, 2 * H, hd_mean, hd_rstd, B, 2 * H, cfg.ln_eps, s));
+            gg_init(g);
+            add_fwd(g, h2, 2 * H, mp.head3, 0, cfg.num_answers, logits, NAp, B, EPI_BIAS, nullptr, 0, nullptr, 0);
+            CK(run_fwd(g, s, 1));
+        }
+        if (pooled_out) CK(k_to_f32<T>(pooled, H, pooled_out, H, B, H, s));
+        if (logits_out) CK(k_fill_rows<float>(logits_out, ld_logits, logits, NAp, B, cfg.num_answers, s));
+        have_fwd = true;
+        return RGQA_OK;
+    }
+
+    // ------------------------------------------------------------------ backward
+    int loss_backward(const float* target, int ldt, float* loss_out, float grad_scale, int accumulate, hipStream_t s) override {
+        RGQA_REQUIRE(have_fwd, "loss_backward: no forward pass recorded");
+        RGQA_REQUIRE(G != nullptr, "loss_backward: no gradient arena bound");
+        // BCE on the f32 logits; dlogits written as f32 into `logits`' sibling then cast+padded to T
+        float* dl32 = part;   // scratch [B, NAp] f32
+        CK(k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, cfg.num_answers, NAp, grad_scale, s));
+        if (loss_out) CK(rgqa_check_hip(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s), "loss copy"));
+        CK(k_cast_pad<T>(dl32, NAp, dlogits, NAp, B, NAp, 1.0f, s));
+        return backward_impl(accumulate, s);
+    }
+    int backward(const float* dl, int ldd, int accumulate, hipStream_t s) override {
+        RGQA_REQUIRE(have_fwd, "backward: no forward pass recorded");
+        RGQA_REQUIRE(G != nullptr && dl != nullptr, "backward: null gradient arena / dlogits");
+        CK(k_cast_pad<T>(dl, ldd, dlogits, NAp, B, cfg.num_answers, 1.0f, s));
+        return backward_impl(accumulate, s);
+    }
+
+    int colsum_bias(const void* dy, int ld, const Lin& l, int col0, int cols, int M, int accumulate, hipStream_t s) {
+        return k_colsum<T>((const T*)dy + col0, ld, part, G + l.b + col0, accumulate, M, cols, s);
+    }
+
+    int backward_impl(int accumulate, hipStream_t s) {
+        const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh, NA = cfg.num_answers;
+        const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
+        const DropCfg nodrop = make_drop(0.f, 0, 0);
+        if (!accumulate) {
+            // tables written by atomics and parameters that receive no gradient must start from zero
+            CK(rgqa_check_hip(hipMemsetAsync(G + mp.word, 0, sizeof(float) * (mp.emb_ln.w - mp.word), s), "zero embedding grads"));
+            if (dead_end > dead_begin) CK(rgqa_check_hip(hipMemsetAsync(G + dead_begin, 0, sizeof(float) * (dead_end - dead_begin), s), "zero dead grads"));
+        }
+        GemmGroup g;
+        // ---- head
+        // padded columns of dlogits are exact zeros and the bias slot reserves round_up(NA, 64) elements
+        CK(colsum_bias(dlogits, NAp, mp.head3, 0, NAp, B, accumulate, s));
+        gg_init(g); add_wgrad(g, dlogits, NAp, mp.head3, 0, NA, h2, 2 * H, B, accumulate); CK(run_wgrad(g, s));
+        gg_init(g); add_dgrad(g, dlogits, NAp, mp.head3, 0, NA, gp1, 2 * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
+        CK(k_ln_bwd<T>(gp1, 2 * H, h1, 2 * H, P + mp.head_ln.w, hd_mean, hd_rstd, gp2, nullptr, 2 * H, part, G + mp.head_ln.w, G + mp.head_ln.b, nullptr,
+                       accumulate, B, 2 * H, nodrop, nodrop, 1.0f, s));
+        CK(k_dgelu_mul<T>(gp2, h1pre, gp3, (size_t)B * 2 * H, s));
+        CK(colsum_bias(gp3, 2 * H, mp.head0, 0, 2 * H, B, accumulate, s));
+        gg_init(g); add_wgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, pooled, H, B, accumulate); CK(run_wgrad(g, s));
+        gg_init(g); add_dgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, gp1, H, B, EPI_DTANH, pooled, H); CK(run_dgrad(g, s));   // gp1[B,H] = d(pooler pre-tanh)
+        return backward_encoder(accumulate, s);
+    }
+
+    // encoder-only autograd entry: dL/dpooled supplied by the caller (LXRTEncoder used under a foreign head)
+    int backward_pooled(const float* dpooled, int ld, int accumulate, hipStream_t s) override {
+        RGQA_REQUIRE(have_fwd, "backward_pooled: no forward pass recorded");
+        RGQA_REQUIRE(G != nullptr && dpooled != nullptr, "backward_pooled: null gradient arena / dpooled");
+        const int H = cfg.hidden;
+        if (!accumulate) {
+            CK(rgqa_check_hip(hipMemsetAsync(G + mp.word, 0, sizeof(float) * (mp.emb_ln.w - mp.word), s), "zero embedding grads"));
+            if (dead_end > dead_begin) CK(rgqa_check_hip(hipMemsetAsync(G + dead_begin, 0, sizeof(float) * (dead_end - dead_begin), s), "zero dead grads"));
+            CK(rgqa_check_hip(hipMemsetAsync(G + mp.head0.w, 0, sizeof(float) * (arena_elems - mp.head0.w), s), "zero head grads"));
+        }
+        CK(k_cast_pad<T>(dpooled, ld, gp2, H, B, H, 1.0f, s));
+        CK(k_dtanh_mul<T>(gp2, pooled, gp1, (size_t)B * H, s));
+        return backward_encoder(accumulate, s);
+    }
+
+    int backward_encoder(int accumulate, hipStream_t s) {
+        const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh;
+        const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
+        const DropCfg nodrop = make_drop(0.f, 0, 0);
+        GemmGroup g;
+        CK(colsum_bias(gp1, H, mp.pooler, 0, H, B, accumulate, s));
+        gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, lang_final, Tn * H, B, accumulate); CK(run_wgrad(g, s));
+        // gradient w.r.t. the final hidden states: zero except the [CLS] rows of lang
+        T* dy = gA; T* dx = gB;
+        CK(rgqa_check_hip(hipMemsetAsync(dy, 0, (size_t)R * H * sizeof(T), s), "zero dy"));
+        gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, dy, Tn * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
+
+        // ---- encoder stages in reverse
+        for (int si = (int)stages.size() - 1; si >= 0; --si) {
+            Stage& st = stages[si];
+            const bool cross = st.kind == ST_ATT_CROSS;
+            const bool shared_all = cross && st.active[1];
+            auto rowp = [&](T* base, int m, int width) { return base + (size_t)(m == 0 ? 0 : Rl) * width; };
+            if (st.kind == ST_FFN) {
+                for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                    const FfnP& f = *st.ffn[m];
+                    DropCfg d = drop_site(pd, st.site + m * 4 + 1);
+                    CK(k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s));
+                }
+                T* gzm = drop_base(pd).thresh ? gzd : gz;
+                gg_init(g);
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    add_dgrad(g, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, rowp(gh, m, I), I, seg_rows(m), EPI_DGELU, st.sb[m].hpre, I);
+                CK(run_dgrad(g, s));
+                gg_init(g);
+                for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                    add_wgrad(g, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, st.sb[m].h, I, seg_rows(m), accumulate);
+                    add_wgrad(g, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, st.sb[m].x_in, H, seg_rows(m), accumulate);
+                }
+                CK(run_wgrad(g, s));
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    CK(colsum_bias(rowp(gh, m, I), I, st.ffn[m]->up, 0, I, seg_rows(m), accumulate, s));
+                gg_init(g);
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    add_dgrad(g, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, rowp(dx, m, H), H, seg_rows(m), EPI_ADD, rowp(gz, m, H), H);
+                CK(run_dgrad(g, s));
+                // inactive modality: its gradient passes through untouched
+                for (int m = 0; m < 2; ++m) if (!st.active[m] && !st.last_dead)
+                    CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
+                T* t = dy; dy = dx; dx = t;
+                continue;
+            }
+            // ---- attention stage backward
+            T* gzm = drop_base(pd).thresh ? gzd : gz;
+            if (shared_all) {
+                const AttP& ap = *st.att[0];
+                DropCfg d = drop_site(pd, st.site + 1);
+                CK(k_ln_bwd<T>(dy, H, (T*)st.sb[0].z, H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
+                               G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, R, H, d, nodrop, 1.0f, s));
+                gg_init(g); add_dgrad(g, gzm, H, ap.o, 0, H, gctx, H, R, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
+            } else {
+                for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                    const AttP& ap = *st.att[m];
+                    DropCfg d = drop_site(pd, st.site + m * 4 + 1);
+                    CK(k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s));
+                }
+                gg_init(g);
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    add_dgrad(g, rowp(gzm, m, H), H, st.att[m]->o, 0, H, rowp(gctx, m, H), H, seg_rows(m), EPI_BIAS, nullptr, 0);
+                CK(run_dgrad(g, s));
+            }
+            // attention core backward -> gqkv (packed like the forward qkv buffer)
+            if (cross && !st.active[1]) {
+                // dead visn-query direction: lang rows get no dk/dv, visn rows get no dq
+                CK(rgqa_check_hip(hipMemsetAsync(gqkv, 0, (size_t)R * 3 * H * sizeof(T), s), "zero dqkv"));
+            }
+            for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                const int km = cross ? 1 - m : m;
+                AttnArgs a; memset(&a, 0, sizeof a);
+                a.q = st.sb[m].qkv; a.ldq = 3 * H;
+                a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
+                a.mask = km == 0 ? maskf : nullptr;
+                a.lse = st.sb[m].lse;
+                a.dout = rowp(gctx, m, H); a.lddo = H;
+                a.dq = rowp(gqkv, m, 3 * H); a.dk = rowp(gqkv, km, 3 * H) + H; a.dv = rowp(gqkv, km, 3 * H) + 2 * H;
+                a.lddq = a.lddk = a.lddv = 3 * H;
+                a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
+                a.scale = 1.0f / sqrtf((float)dh);
+                a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
+                CK(attn_bwd_dispatch(a, s));
+            }
+            // weight / bias gradients
+            gg_init(g);
+            if (shared_all) {
+                const AttP& ap = *st.att[0];
+                add_wgrad(g, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, R, accumulate);
+                add_wgrad(g, gqkv, 3 * H, ap.qkv, 0, 3 * H, st.sb[0].x_in, H, R, accumulate);
+                CK(run_wgrad(g, s));
+                CK(colsum_bias(gqkv, 3 * H, ap.qkv, 0, 3 * H, R, accumulate, s));
+            } else if (cross) {
+                const AttP& ap = *st.att[0];
+                add_wgrad(g, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, Rl, accumulate);
+                add_wgrad(g, gqkv, 3 * H, ap.qkv, 0, H, st.sb[0].x_in, H, Rl, accumulate);
+                add_wgrad(g, rowp(gqkv, 1, 3 * H) + H, 3 * H, ap.qkv, H, 2 * H, st.sb[1].x_in, H, Rv, accumulate);
+                CK(run_wgrad(g, s));
+                CK(colsum_bias(gqkv, 3 * H, ap.qkv, 0, H, Rl, accumulate, s));
+                CK(colsum_bias(rowp(gqkv, 1, 3 * H), 3 * H, ap.qkv, H, 2 * H, Rv, accumulate, s));
+            } else {
+                for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                    add_wgrad(g, rowp(gzm, m, H), H, st.att[m]->o, 0, H, st.sb[m].ctx, H, seg_rows(m), accumulate);
+                    add_wgrad(g, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, st.sb[m].x_in, H, seg_rows(m), accumulate);
+                }
+                CK(run_wgrad(g, s));
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    CK(colsum_bias(rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, seg_rows(m), accumulate, s));
+            }
+            // input gradient: dx = dqkv @ Wqkv + dz (residual path)
+            gg_init(g);
+            if (shared_all) {
+                add_dgrad(g, gqkv, 3 * H, st.att[0]->qkv, 0, 3 * H, dx, H, R, EPI_ADD, gz, H);
+            } else if (cross) {
+                add_dgrad(g, gqkv, 3 * H, st.att[0]->qkv, 0, H, dx, H, Rl, EPI_ADD, gz, H);
+                add_dgrad(g, rowp(gqkv, 1, 3 * H) + H, 3 * H, st.att[0]->qkv, H, 2 * H, rowp(dx, 1, H), H, Rv, EPI_BIAS, nullptr, 0);
+            } else {
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    add_dgrad(g, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, rowp(dx, m, H), H, seg_rows(m), EPI_ADD, rowp(gz, m, H), H);
+            }
+            CK(run_dgrad(g, s));
+            if (!cross) {
+                for (int m = 0; m < 2; ++m) if (!st.active[m] && !st.last_dead)
+                    CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
+            }
+            T* t = dy; dy = dx; dx = t;
+        }
+        // ---- embeddings: dropout -> LN backward -> scatter-add into the three tables
+        {
+            DropCfg din = drop_site(pd, 1);
+            CK(k_ln_bwd<T>(dy, H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
+                           nodrop, din, 1.0f, s));
+            CK(k_embed_scatter<T>(gz, in_ids, in_seg, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, s));
+        }
+        // ---- visual embedding
+        {
+            T* dyv = dy + (size_t)Rl * H;
+            T* dzf = gz + (size_t)Rl * H;
+            CK(k_visn_combine_bwd<T>(dyv, H, zf, H, in_boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.box_ln.w, visn_stats, dzf, H, part,
+                                     G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.visn_fc.b, G + mp.box_fc.w, G + mp.box_fc.b,
+                                     accumulate, Rv, H, cfg.pos_dim, drop_site(pd, 2), s));
+            gg_init(g);
+            add_wgrad(g, dzf, H, mp.visn_fc, 0, H, in_feats, cfg.feat_dim, Rv, accumulate);
+            CK(run_wgrad(g, s, LP ? 1 : 0));
+        }
+        return RGQA_OK;
+    }
+
+    int get_activation(const char* name, float* out, size_t cap, hipStream_t s) override {
+        RGQA_REQUIRE(have_fwd, "get_activation: no forward pass recorded");
+        const int H = cfg.hidden;
+        const void* src = nullptr; size_t n = 0;
+        std::string nm(name);
+        auto stage_out = [&](int idx, int m) { src = stages[idx].sb[m].y; n = (size_t)seg_rows(m) * H; };
+        const int nlr = cfg.l_layers > cfg.r_layers ? cfg.l_layers : cfg.r_layers;
+        int i = -1;
+        if (nm == "embed_lang") { src = emb_out; n = (size_t)Rl * H; }
+        else if (nm == "embed_visn") { src = visn_out; n = (size_t)Rv * H; }
+        else if (nm == "pooled") { src = pooled; n = (size_t)B * H; }
+        else if (sscanf(name, "l%d", &i) == 1 && nm[0] == 'l' && i >= 0 && i < cfg.l_layers) stage_out(2 * i + 1, 0);
+        else if (sscanf(name, "r%d", &i) == 1 && nm[0] == 'r' && i >= 0 && i < cfg.r_layers) stage_out(2 * i + 1, 1);
+        else if (sscanf(name, "x%d_", &i) == 1 && nm[0] == 'x' && i >= 0 && i < cfg.x_layers) {
+            const bool visn = nm.find("_visn") != std::string::npos;
+            RGQA_REQUIRE(!(visn && i == cfg.x_layers - 1), "get_activation: %s is the dead branch in mode 'x' and is not computed", name);
+            stage_out(2 * nlr + 3 * i + 2, visn ? 1 : 0);
+        }
+        RGQA_REQUIRE(src != nullptr, "get_activation: unknown activation '%s'", name);
+        RGQA_REQUIRE(cap >= n, "get_activation: buffer too small (%zu < %zu)", cap, n);
+        return k_to_f32<T>((const T*)src, H, out, H, (int)(n / H), H, s);
+    }
+};
+
+template <> int Engine<float>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) { return k_attn_fwd_ref<float>(a, s); }
+template <> int Engine<float>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) { return k_attn_bwd_ref<float>(a, s); }
+template <> int Engine<bf16_t>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) {
+    if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_fwd_mfma(a, s);
+    return k_attn_fwd_ref<bf16_t>(a, s);
+}
+template <> int Engine<bf16_t>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) {
+    if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_bwd_mfma(a, s);
+    return k_attn_bwd_ref<bf16_t>(a, s);
+}
+
+EngineBase* make_engine(const rgqa_config& cfg) {
+    if (cfg.precision == RGQA_PRECISION_BF16) return new Engine<bf16_t>(cfg);
+    return new Engine<float>(cfg);
+}

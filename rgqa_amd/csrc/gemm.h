@@ -1,0 +1,106 @@
+// Grouped GEMM descriptors + the shared epilogue (used by the bf16 MFMA kernels and the f32 kernel).
+#pragma once
+#include "common.h"
+
+enum GemmEpi {
+    EPI_BIAS = 0,        // C = acc + bias
+    EPI_GELU = 1,        // pre = acc + bias; C2 = pre (if C2); C = gelu(pre)            (BertIntermediate)
+    EPI_TANH = 2,        // C = tanh(acc + bias)                                        (BertPooler)
+    EPI_RESID_DROP = 3,  // C = dropout(acc + bias) + aux                               (BertAttOutput / BertOutput, pre-LN)
+    EPI_DGELU = 4,       // C = acc * gelu'(aux)                                        (dgrad through GeLU)
+    EPI_ADD = 5,         // C = acc + aux                                               (dgrad + residual-path gradient)
+    EPI_ACCUM = 6,       // C += acc  (C must be f32)                                   (wgrad accumulate)
+    EPI_DTANH = 7,       // C = acc * (1 - aux^2)                                       (dgrad through the pooler's tanh)
+};
+
+// One problem: C[M,N] = op(A)[M,K] * op(B)[K,N] (+ epilogue).  Layout depends on the kernel:
+//   NT kernel: A [M,K] row-major (lda), B = W [N,K] row-major (ldb)        -> x @ W^T
+//   TN kernel: A = P [K,M] row-major (lda), B = Q [K,N] row-major (ldb)    -> P^T @ Q   (wgrad: dW[n,k] = dY^T X)
+struct GemmProblem {
+    const void* A;
+    const void* B;
+    void* C;
+    void* C2;           // optional second output (pre-activation), same type / ld as C
+    const float* bias;  // [N] or null
+    const void* aux;    // [M,N] residual or pre-activation, act type
+    int M, N, K;
+    int lda, ldb, ldc, ldaux;
+    int tile_start;     // first linear tile id of this problem in the grouped launch
+    int tiles_n;        // number of tiles along N
+    uint32_t drop_site; // mixed into the dropout stream for EPI_RESID_DROP
+    int epi;            // GemmEpi
+};
+
+#define GEMM_MAX_PROBLEMS 6
+struct GemmGroup {
+    int count;
+    int total_tiles;
+    int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
+    DropCfg drop;
+    GemmProblem p[GEMM_MAX_PROBLEMS];
+};
+
+// Epilogue on 4 consecutive columns n0..n0+3 of row m. OutT = float or bf16_t; AuxT = act type.
+template <typename OutT, typename AuxT>
+__device__ __forceinline__ void gemm_epilogue4(const GemmProblem& P, const DropCfg& drop, int m, int n0, float v[4]) {
+    const int epi = P.epi;
+    if (m >= P.M || n0 >= P.N) return;
+    const int nvalid = (P.N - n0) >= 4 ? 4 : (P.N - n0);
+    if (P.bias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < nvalid) v[i] += P.bias[n0 + i];
+    }
+    OutT* crow = reinterpret_cast<OutT*>(P.C) + (size_t)m * P.ldc + n0;
+    float pre[4] = {v[0], v[1], v[2], v[3]};
+    if (epi == EPI_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gelu_f(pre[i]);
+    } else if (epi == EPI_TANH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = tanhf(pre[i]);
+    } else if (epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_DTANH) {
+        const AuxT* arow = reinterpret_cast<const AuxT*>(P.aux) + (size_t)m * P.ldaux + n0;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid == 4) load4(arow, a);
+        else for (int i = 0; i < nvalid; ++i) a[i] = to_f32(arow[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (epi == EPI_RESID_DROP) {
+                uint32_t idx = (uint32_t)m * (uint32_t)P.N + (uint32_t)(n0 + i);
+                DropCfg d = drop; d.seed_hi ^= P.drop_site;
+                v[i] = drop_apply(d, idx, v[i]) + a[i];
+            } else if (epi == EPI_DGELU) {
+                v[i] = v[i] * dgelu_f(a[i]);
+            } else if (epi == EPI_DTANH) {
+                v[i] = v[i] * (1.0f - a[i] * a[i]);
+            } else {
+                v[i] = v[i] + a[i];
+            }
+        }
+    } else if (epi == EPI_ACCUM) {
+        float* c = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + n0;
+        if (nvalid == 4) {
+            float o[4]; load4(c, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += v[i];
+            store4(c, o);
+        } else for (int i = 0; i < nvalid; ++i) c[i] += v[i];
+        return;
+    }
+    if (nvalid == 4) {
+        store4(crow, v);
+        if (epi == EPI_GELU && P.C2 != nullptr) store4(reinterpret_cast<OutT*>(P.C2) + (size_t)m * P.ldc + n0, pre);
+    } else {
+        for (int i = 0; i < nvalid; ++i) {
+            crow[i] = from_f32<OutT>(v[i]);
+            if (epi == EPI_GELU && P.C2 != nullptr) (reinterpret_cast<OutT*>(P.C2) + (size_t)m * P.ldc + n0)[i] = from_f32<OutT>(pre[i]);
+        }
+    }
+}
+
+// host launchers (gemm_mfma.hip / gemm_f32.hip). out_f32: C is float (else bf16). All return RGQA_* codes.
+int launch_gemm_nt_bf16(GemmGroup& g, int out_f32, hipStream_t s);
+int launch_gemm_tn_bf16(GemmGroup& g, int out_f32, hipStream_t s);
+// f32 generic: A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; everything f32.
+int launch_gemm_f32(GemmGroup& g, int trans_a, int trans_b, hipStream_t s);
+void gemm_group_finalize(GemmGroup& g, int bm, int bn);

@@ -1,0 +1,94 @@
+// Internal kernel launchers (host side). Every function enqueues work on `s` and returns an RGQA_* code;
+// none allocates, frees or synchronises.  T = float (parity mode) or bf16_t (throughput mode).
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+// ---- norm.hip
+#define FIN_MAXQ 10
+struct FinOut { float* p[FIN_MAXQ]; int stride[FIN_MAXQ]; };
+int k_colsum_finalize(const float* part, int nblk, int nq, int N, const FinOut& fo, int accumulate, hipStream_t s);
+template <typename T>
+int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s);
+int ln_bwd_blocks(int M);
+// part: workspace of ln_bwd_blocks(M)*3*N floats (or null: no column sums). dzd may be null.
+template <typename T>
+int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, const float* mean, const float* rstd, T* dz, T* dzd, int lddz,
+             float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s);
+// out[n] (+)= sum_m x[m][n]; part: workspace of 256*N floats
+template <typename T>
+int k_colsum(const T* x, int ldx, float* part, float* out, int accumulate, int M, int N, hipStream_t s);
+
+// ---- attn.hip
+struct AttnArgs {
+    const void* q; const void* k; const void* v;  // element (row 0, head 0, dim 0) of each operand
+    int ldq, ldk, ldv;                             // row strides in elements
+    void* out; int ldo;                            // fwd: context [B*Lq, nh*dh]
+    const float* mask;                             // additive key mask [B, Lk] (0 / -10000) or null
+    float* lse;                                    // [B, nh, Lq] log-sum-exp of the masked, scaled scores
+    // backward only
+    const void* dout; int lddo;
+    void* dq; void* dk; void* dv; int lddq, lddk, lddv;
+    int B, nh, Lq, Lk, dh;
+    float scale;
+    DropCfg drop;                                  // attention-probability dropout (reference modeling.py:341)
+    uint32_t drop_site;
+};
+template <typename T> int k_attn_fwd_ref(const AttnArgs& a, hipStream_t s);
+template <typename T> int k_attn_bwd_ref(const AttnArgs& a, hipStream_t s);
+int k_attn_fwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
+int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
+
+// ---- embed.hip
+// lang[b*T+t] = dropout(LN(word[ids] + pos[t] + type[seg]))      (reference BertEmbeddings, modeling.py:278-292)
+template <typename T>
+int k_embed_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+                T* out, int ldo, T* zsave, float* mean, float* rstd, int B, int Tn, int H, int vocab, int type_vocab, float eps, DropCfg drop, hipStream_t s);
+// de [B*T, H] f32 (gradient w.r.t. the pre-LN embedding sum) scattered into the three tables; row 0 of each
+// table gets no gradient (padding_idx=0, modeling.py:269-271)
+template <typename T>
+int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, float* dword, float* dpos, float* dtype, int B, int Tn, int H, hipStream_t s);
+// additive key mask (1 - m) * -10000 from the 0/1 int64 attention mask (modeling.py:857-865)
+int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s);
+
+// ---- visn.hip
+// out = dropout((LN(zf) + LN(boxes Wb^T + bb)) / 2)            (reference VisualFeatEncoder, modeling.py:507-517)
+template <typename T>
+int k_visn_combine_fwd(const T* zf, int ldz, const float* boxes, const float* Wb, const float* bb, const float* g1, const float* b1, const float* g2,
+                       const float* b2, T* out, int ldo, float* stats /*[M,4]: mean1,rstd1,mean2,rstd2*/, int M, int H, int pos_dim, float eps, DropCfg drop, hipStream_t s);
+// backward of the above: dzf (gradient entering visn_fc's output) + all small parameter gradients
+template <typename T>
+int k_visn_combine_bwd(const T* dout, int lddo, const T* zf, int ldz, const float* boxes, const float* Wb, const float* bb, const float* g1, const float* g2,
+                       const float* stats, T* dzf, int lddz, float* part, float* dg1, float* db1, float* dg2, float* db2, float* dbias_fc,
+                       float* dWb, float* dbb, int accumulate, int M, int H, int pos_dim, DropCfg drop, hipStream_t s);
+
+// ---- loss.hip
+// loss = mean_b sum_n BCEWithLogits(z, t)  (= BCEWithLogitsLoss() * NA, gqa_conf.py:197-198); dz = (sigmoid(z)-t)/B * grad_scale
+int k_bce_fwd_bwd(const float* logits, int ldl, const float* target, int ldt, float* loss_out, float* dlogits, int lddl, int B, int NA, int NAp, float grad_scale, hipStream_t s);
+
+// ---- optim.hip
+int k_sumsq(const float* g, size_t n, float* partial /*>=1024 floats*/, float* out_sumsq, int accumulate_into_out, hipStream_t s);
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    void* p_lp;            // optional bf16 copy at the same element offsets (null in f32 mode)
+    size_t n;
+    float lr_t, b1, b2, eps, wd;
+    const float* sumsq;    // device scalar: sum of squared grads (for clip); null = no clipping
+    float max_norm;
+    float grad_prescale;   // multiplies g before everything (1/world_size for DP sum-reduce), 1 otherwise
+};
+int k_bertadam(const AdamArgs& a, hipStream_t s);
+// dst_t[k][n] = (bf16) src[n][k] for each listed [N,K] matrix; desc on device: {src_off, dst_off, N, K, tile_start}
+struct TransDesc { long src_off, dst_off; int N, K, ld_dst, tile_start; };
+int k_cast_transpose(const float* src, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s);
+int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+
+// ---- misc.hip
+// RoI-mixup gather (gqa_mixup_vis.py:134-181): rows [B,2B) of feats/boxes built from partner + positive rows
+int k_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uint8_t* take_pos /*[B,O]*/, int B, int O, int F, int mode_v3, hipStream_t s);
+int k_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, hipStream_t s);
+template <typename T> int k_fill_rows(T* dst, int ld, const T* src, int lds, int rows, int cols, hipStream_t s);
+template <typename T> int k_cast_pad(const float* src, int lds, T* dst, int ldd, int rows, int cols, float scale, hipStream_t s);
+template <typename T> int k_to_f32(const T* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
+template <typename T> int k_dgelu_mul(const T* dy, const T* pre, T* out, size_t n, hipStream_t s);
+template <typename T> int k_dtanh_mul(const T* dy, const T* y, T* out, size_t n, hipStream_t s);

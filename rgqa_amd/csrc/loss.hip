@@ -1,0 +1,33 @@
+// Fused BCE-with-logits loss forward + backward (reference tasks/gqa_conf.py:197-198):
+//   loss = BCEWithLogitsLoss()(z, t) * NA = (1/B) * sum_{b,n} [max(z,0) - z t + log1p(exp(-|z|))]
+//   dz   = (sigmoid(z) - t) / B
+#include "kernels.h"
+
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ z, int ldl, const float* __restrict__ t, int ldt, float* __restrict__ loss,
+                                                  float* __restrict__ dz, int lddl, int B, int NA, int NAp, float inv_b, float gscale) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float acc = 0.f;
+    for (int n = threadIdx.x; n < NAp; n += 256) {
+        float g = 0.f;
+        if (n < NA) {
+            const float x = z[(size_t)b * ldl + n], y = t[(size_t)b * ldt + n];
+            acc += fmaxf(x, 0.f) - x * y + log1pf(__expf(-fabsf(x)));
+            const float sg = 1.f / (1.f + __expf(-x));
+            g = (sg - y) * inv_b * gscale;
+        }
+        if (dz) dz[(size_t)b * lddl + n] = g;   // padded columns get exact zeros (they feed K-padded GEMMs)
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_b);
+}
+
+int k_bce_fwd_bwd(const float* logits, int ldl, const float* target, int ldt, float* loss_out, float* dlogits, int lddl, int B, int NA, int NAp, float grad_scale, hipStream_t s) {
+    RGQA_REQUIRE(B > 0 && NA > 0 && NAp >= NA, "bce: bad shape");
+    if (loss_out) RGQA_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), s));
+    hipLaunchKernelGGL(bce_kernel, dim3(B), dim3(256), 0, s, logits, ldl, target, ldt, loss_out, dlogits, lddl, B, NA, NAp, 1.0f / (float)B, grad_scale);
+    RGQA_LAUNCH_CHECK("bce_kernel");
+    return RGQA_OK;
+}

@@ -1,0 +1,121 @@
+// RoI-mixup device gather (reference tasks/gqa_mixup_vis.py:134-181) and small utilities.
+#include "kernels.h"
+
+// rows [B,2B) of feats [2B,O,F] / boxes [2B,O,4]: RoI o of sample j comes from the positive sample j when
+// take_pos[j][o], else from the partner sample (zeros for feats in mixup_v3). One block per (j, o): an
+// 8 KB row copy for F=2048, HBM-bound.
+__global__ __launch_bounds__(256) void mixup_gather_kernel(float* __restrict__ feats, float* __restrict__ boxes, const int32_t* __restrict__ partner,
+                                                           const uint8_t* __restrict__ take_pos, int B, int O, int F, int v3) {
+    const int j = blockIdx.x / O, o = blockIdx.x % O;
+    const bool pos = take_pos[(size_t)j * O + o] != 0;
+    const int srcb = pos ? j : partner[j];
+    const float* sf = feats + ((size_t)srcb * O + o) * F;
+    float* df = feats + ((size_t)(B + j) * O + o) * F;
+    const bool zero = v3 && !pos;
+    for (int c = threadIdx.x; c < (F >> 2); c += 256) {
+        float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4*>(sf)[c];
+        reinterpret_cast<float4*>(df)[c] = v;
+    }
+    if (threadIdx.x < 4) boxes[((size_t)(B + j) * O + o) * 4 + threadIdx.x] = boxes[((size_t)srcb * O + o) * 4 + threadIdx.x];
+}
+int k_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uint8_t* take_pos, int B, int O, int F, int mode_v3, hipStream_t s) {
+    RGQA_REQUIRE(F % 4 == 0 && B > 0 && O > 0, "mixup_gather: bad shape");
+    hipLaunchKernelGGL(mixup_gather_kernel, dim3(B * O), dim3(256), 0, s, feats, boxes, partner, take_pos, B, O, F, mode_v3);
+    RGQA_LAUNCH_CHECK("mixup_gather_kernel");
+    return RGQA_OK;
+}
+
+// target[row0 + j][:] = target[j][:] * prop[j]
+__global__ void scale_rows_kernel(float* __restrict__ target, const float* __restrict__ prop, int NA, int ld, int row0) {
+    const int j = blockIdx.x;
+    const float p = prop[j];
+    for (int n = threadIdx.x; n < NA; n += blockDim.x) target[(size_t)(row0 + j) * ld + n] = target[(size_t)j * ld + n] * p;
+}
+int k_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, hipStream_t s) {
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(B), dim3(256), 0, s, target, prop, NA, ld, row0);
+    RGQA_LAUNCH_CHECK("scale_rows_kernel");
+    return RGQA_OK;
+}
+
+template <typename T>
+__global__ void fill_rows_kernel(T* __restrict__ dst, int ld, const T* __restrict__ src, int lds, int rows, int cols) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(size_t)r * ld + c] = src[(size_t)r * lds + c];
+}
+template <typename T>
+int k_fill_rows(T* dst, int ld, const T* src, int lds, int rows, int cols, hipStream_t s) {
+    if (rows <= 0) return RGQA_OK;
+    hipLaunchKernelGGL(fill_rows_kernel<T>, dim3(rows), dim3(256), 0, s, dst, ld, src, lds, rows, cols);
+    RGQA_LAUNCH_CHECK("fill_rows_kernel");
+    return RGQA_OK;
+}
+template int k_fill_rows<float>(float*, int, const float*, int, int, int, hipStream_t);
+template int k_fill_rows<bf16_t>(bf16_t*, int, const bf16_t*, int, int, int, hipStream_t);
+
+// dst[r][c] = (T) src[r][c] for c < cols, 0 for cols <= c < ldd  (pads K-side buffers with exact zeros)
+template <typename T>
+__global__ void cast_pad_kernel(const float* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int cols, float scale) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < ldd; c += blockDim.x) dst[(size_t)r * ldd + c] = from_f32<T>(c < cols ? src[(size_t)r * lds + c] * scale : 0.f);
+}
+template <typename T>
+int k_cast_pad(const float* src, int lds, T* dst, int ldd, int rows, int cols, float scale, hipStream_t s) {
+    if (rows <= 0) return RGQA_OK;
+    hipLaunchKernelGGL(cast_pad_kernel<T>, dim3(rows), dim3(256), 0, s, src, lds, dst, ldd, cols, scale);
+    RGQA_LAUNCH_CHECK("cast_pad_kernel");
+    return RGQA_OK;
+}
+template int k_cast_pad<float>(const float*, int, float*, int, int, int, float, hipStream_t);
+template int k_cast_pad<bf16_t>(const float*, int, bf16_t*, int, int, int, float, hipStream_t);
+
+// dst f32 [rows, cols] = src T
+template <typename T>
+__global__ void to_f32_kernel(const T* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int cols) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(size_t)r * ldd + c] = to_f32(src[(size_t)r * lds + c]);
+}
+template <typename T>
+int k_to_f32(const T* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s) {
+    if (rows <= 0) return RGQA_OK;
+    hipLaunchKernelGGL(to_f32_kernel<T>, dim3(rows), dim3(256), 0, s, src, lds, dst, ldd, cols);
+    RGQA_LAUNCH_CHECK("to_f32_kernel");
+    return RGQA_OK;
+}
+template int k_to_f32<float>(const float*, int, float*, int, int, int, hipStream_t);
+template int k_to_f32<bf16_t>(const bf16_t*, int, float*, int, int, int, hipStream_t);
+
+// y = dy * gelu'(pre)   (head backward, where no GEMM sits between LN-bwd and the GeLU)
+template <typename T>
+__global__ void dgelu_mul_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = from_f32<T>(to_f32(dy[i]) * dgelu_f(to_f32(pre[i])));
+}
+template <typename T>
+int k_dgelu_mul(const T* dy, const T* pre, T* out, size_t n, hipStream_t s) {
+    if (n == 0) return RGQA_OK;
+    int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(dgelu_mul_kernel<T>, dim3(nb), dim3(256), 0, s, dy, pre, out, n);
+    RGQA_LAUNCH_CHECK("dgelu_mul_kernel");
+    return RGQA_OK;
+}
+template int k_dgelu_mul<float>(const float*, const float*, float*, size_t, hipStream_t);
+template int k_dgelu_mul<bf16_t>(const bf16_t*, const bf16_t*, bf16_t*, size_t, hipStream_t);
+
+// out = dy * (1 - y^2)   (backward through tanh given its output)
+template <typename T>
+__global__ void dtanh_mul_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float t = to_f32(y[i]);
+        out[i] = from_f32<T>(to_f32(dy[i]) * (1.0f - t * t));
+    }
+}
+template <typename T>
+int k_dtanh_mul(const T* dy, const T* y, T* out, size_t n, hipStream_t s) {
+    if (n == 0) return RGQA_OK;
+    int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(dtanh_mul_kernel<T>, dim3(nb), dim3(256), 0, s, dy, y, out, n);
+    RGQA_LAUNCH_CHECK("dtanh_mul_kernel");
+    return RGQA_OK;
+}
+template int k_dtanh_mul<float>(const float*, const float*, float*, size_t, hipStream_t);
+template int k_dtanh_mul<bf16_t>(const bf16_t*, const bf16_t*, bf16_t*, size_t, hipStream_t);

@@ -1,0 +1,132 @@
+// Fused global-norm clip + BertAdam (reference nn.utils.clip_grad_norm_(.., 5.) at tasks/gqa_conf.py:201 and
+// BertAdam.step at lxrt/optimization.py:101-180) over a flat f32 parameter arena, plus the bf16 re-cast of
+// the updated weights.  HBM-bound: 4 f32 reads + 3 f32 writes (+1 bf16 write) per parameter.
+#include "kernels.h"
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const size_t nv = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(g)[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[(nv << 2) + threadIdx.x]; acc += v * v; }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out, int accumulate) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { float v = (float)(red[0] + red[1] + red[2] + red[3]); *out = accumulate ? *out + v : v; }
+}
+
+int k_sumsq(const float* g, size_t n, float* partial, float* out_sumsq, int accumulate_into_out, hipStream_t s) {
+    RGQA_REQUIRE(((uintptr_t)g % 16) == 0, "sumsq: 16-byte alignment required");
+    int nblk = (int)((n / 4 + 255) / 256);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, s, g, n, partial);
+    RGQA_LAUNCH_CHECK("sumsq_kernel");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, out_sumsq, accumulate_into_out);
+    RGQA_LAUNCH_CHECK("sumsq_final_kernel");
+    return RGQA_OK;
+}
+
+__global__ __launch_bounds__(256) void bertadam_kernel(const AdamArgs a) {
+    // clip coefficient exactly as torch's clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied when < 1
+    float coef = a.grad_prescale;
+    if (a.sumsq) {
+        const float norm = sqrtf(*a.sumsq) * a.grad_prescale;
+        const float c = a.max_norm / (norm + 1e-6f);
+        if (c < 1.f) coef *= c;
+    }
+    const size_t nv = a.n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        float p[4], g[4], m[4], v[4];
+        load4(a.p + i * 4, p); load4(a.g + i * 4, g); load4(a.m + i * 4, m); load4(a.v + i * 4, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gg = g[j] * coef;
+            m[j] = m[j] * a.b1 + (1.f - a.b1) * gg;              // optimization.py:142
+            v[j] = v[j] * a.b2 + (1.f - a.b2) * gg * gg;         // :143
+            float u = m[j] / (sqrtf(v[j]) + a.eps);              // :144 (no bias correction, :175-178)
+            u += a.wd * p[j];                                    // :153-154 (every parameter)
+            p[j] -= a.lr_t * u;                                  // :170-171
+        }
+        store4(a.p + i * 4, p); store4(a.m + i * 4, m); store4(a.v + i * 4, v);
+        if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + i * 4, p);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const size_t i = (nv << 2) + threadIdx.x;
+        const float gg = a.g[i] * coef;
+        float m = a.m[i] * a.b1 + (1.f - a.b1) * gg, v = a.v[i] * a.b2 + (1.f - a.b2) * gg * gg;
+        float u = m / (sqrtf(v) + a.eps) + a.wd * a.p[i];
+        a.p[i] -= a.lr_t * u; a.m[i] = m; a.v[i] = v;
+        if (a.p_lp) reinterpret_cast<bf16_t*>(a.p_lp)[i] = (bf16_t)a.p[i];
+    }
+}
+
+int k_bertadam(const AdamArgs& a, hipStream_t s) {
+    if (a.n == 0) return RGQA_OK;
+    RGQA_REQUIRE(((uintptr_t)a.p % 16) == 0 && ((uintptr_t)a.g % 16) == 0 && ((uintptr_t)a.m % 16) == 0 && ((uintptr_t)a.v % 16) == 0, "bertadam: 16-byte alignment required");
+    size_t nb = (a.n / 4 + 255) / 256;
+    int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
+    hipLaunchKernelGGL(bertadam_kernel, dim3(nblk), dim3(256), 0, s, a);
+    RGQA_LAUNCH_CHECK("bertadam_kernel");
+    return RGQA_OK;
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+    const size_t nv = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        float v[4];
+        load4(src + i * 4, v);
+        store4(dst + i * 4, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(nv << 2) + threadIdx.x] = (bf16_t)src[(nv << 2) + threadIdx.x];
+}
+int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
+    if (n == 0) return RGQA_OK;
+    size_t nb = (n / 4 + 255) / 256;
+    int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblk), dim3(256), 0, s, src, reinterpret_cast<bf16_t*>(dst), n);
+    RGQA_LAUNCH_CHECK("cast_bf16_kernel");
+    return RGQA_OK;
+}
+
+// Batched cast + transpose of every linear weight: dst[k][n] = bf16(src[n][k]); 32x32 tiles through LDS.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = ndesc - 1;
+    const int t = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (desc[mid].tile_start <= t) lo = mid; else hi = mid - 1; }
+    const TransDesc d = desc[lo];
+    const int lt = t - d.tile_start, tk = cdiv(d.K, 32);
+    const int n0 = (lt / tk) * 32, k0 = (lt % tk) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + ty + r * 8, k = k0 + tx;
+        tile[ty + r * 8][tx] = (n < d.N && k < d.K) ? src[d.src_off + (size_t)n * d.K + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + ty + r * 8, n = n0 + tx;
+        if (k < d.K && n < d.ld_dst) dst[d.dst_off + (size_t)k * d.ld_dst + n] = (bf16_t)tile[tx][ty + r * 8];
+    }
+}
+int k_cast_transpose(const float* src, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s) {
+    if (ndesc <= 0 || total_tiles <= 0) return RGQA_OK;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(total_tiles), dim3(256), 0, s, src, reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc);
+    RGQA_LAUNCH_CHECK("cast_transpose_kernel");
+    return RGQA_OK;
+}

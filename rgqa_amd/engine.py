@@ -1,0 +1,190 @@
+"""Python handle on the C++/HIP engine (include/rgqa.h): flat parameter arenas, workspace, forward / backward.
+
+torch is plumbing only here: it owns device memory (arenas, workspace, I/O tensors) and the HIP stream.
+Every tensor operation of the hot path happens inside librgqa_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Config, check, ptr, PREC_BF16, PREC_F32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ParamSpec:
+    __slots__ = ("name", "offset", "shape", "linear", "dead")
+
+    def __init__(self, name, offset, shape, flags):
+        self.name, self.offset, self.shape = name, offset, tuple(shape)
+        self.linear, self.dead = bool(flags & 1), bool(flags & 2)
+
+    @property
+    def numel(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
+
+
+class Engine:
+    """One engine = one model replica on one GPU."""
+
+    def __init__(self, vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9,
+                 x_layers=5, r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842, precision="bf16",
+                 ln_eps=1e-12, hidden_dropout=0.1, attn_dropout=0.1):
+        self.lib = _lib.load()
+        self.precision = precision
+        prec = {"bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
+        self.cfg = Config(vocab_size, hidden, heads, inter, max_pos, type_vocab, l_layers, x_layers, r_layers, feat_dim,
+                          pos_dim, num_answers, prec, ln_eps, hidden_dropout, attn_dropout)
+        h = C.c_void_p()
+        check(self.lib.rgqa_engine_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        n = C.c_size_t()
+        check(self.lib.rgqa_engine_arena_elems(self.h, C.byref(n)))
+        self.arena_elems = n.value
+        cnt = C.c_int()
+        check(self.lib.rgqa_engine_num_params(self.h, C.byref(cnt)))
+        self.specs = []
+        buf = C.create_string_buffer(256)
+        off, shape, nd, fl = C.c_size_t(), (C.c_int64 * 2)(), C.c_int(), C.c_int()
+        for i in range(cnt.value):
+            check(self.lib.rgqa_engine_param_info(self.h, i, buf, 256, C.byref(off), shape, C.byref(nd), C.byref(fl)))
+            self.specs.append(ParamSpec(buf.value.decode(), off.value, [shape[k] for k in range(nd.value)], fl.value))
+        b, e = C.c_size_t(), C.c_size_t()
+        check(self.lib.rgqa_engine_dead_range(self.h, C.byref(b), C.byref(e)))
+        self.dead_range = (b.value, e.value)
+        self.device = None
+        self.params = self.grads = self.params_lp = self.params_lp_t = self.workspace = None
+        self.adam_m = self.adam_v = None
+        self.shape = None
+        self._io = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.rgqa_engine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ memory
+    def allocate(self, device):
+        """Allocates the parameter / gradient arenas on `device` (a CUDA==HIP device)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("rgqa_amd runs on an MI355X (torch device 'cuda'); got %s. There is no CPU path." % device)
+        self.device = device
+        n = self.arena_elems
+        self.params = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=device)
+        if self.precision == "bf16":
+            self.params_lp = torch.zeros(n, dtype=torch.bfloat16, device=device)
+            self.params_lp_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        self.shape = None
+        return self
+
+    def view(self, arena, spec):
+        return arena[spec.offset:spec.offset + spec.numel].view(spec.shape)
+
+    def ensure_shape(self, B, T, O):
+        if self.shape == (B, T, O):
+            return
+        need = C.c_size_t()
+        check(self.lib.rgqa_engine_workspace_bytes(self.h, B, T, O, C.byref(need)))
+        if self.workspace is None or self.workspace.numel() < need.value:
+            self.workspace = None
+            self.workspace = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        check(self.lib.rgqa_engine_bind(self.h, ptr(self.params), ptr(self.grads), ptr(self.params_lp), ptr(self.params_lp_t),
+                                        ptr(self.workspace), self.workspace.numel(), B, T, O))
+        self.shape = (B, T, O)
+        na, H = self.cfg.num_answers, self.cfg.hidden
+        self._io = dict(logits=torch.empty(B, na, dtype=torch.float32, device=self.device),
+                        pooled=torch.empty(B, H, dtype=torch.float32, device=self.device),
+                        loss=torch.zeros(1, dtype=torch.float32, device=self.device))
+
+    def sync_weights(self):
+        """Refreshes the bf16 weight copies (direct + transposed) from the f32 master arena."""
+        if self.shape is None:
+            raise RuntimeError("sync_weights before the first ensure_shape/bind")
+        check(self.lib.rgqa_engine_sync_weights(self.h, _stream()))
+
+    # ------------------------------------------------------------------ compute
+    def forward(self, feats, boxes, input_ids, input_mask, segment_ids=None, train=False, seed=0):
+        """feats [B,O,F] f32, boxes [B,O,4] f32, ids/mask/(segment) [B,T] i64, all on the engine's device and
+        contiguous. Returns (logits [B,NA] f32, pooled [B,H] f32) — engine-owned buffers, overwritten by the next call."""
+        B, O, F = feats.shape
+        T = input_ids.shape[1]
+        if F != self.cfg.feat_dim or boxes.shape != (B, O, self.cfg.pos_dim) or input_mask.shape != (B, T):
+            raise ValueError("bad input shapes: feats %s boxes %s ids %s mask %s" % (tuple(feats.shape), tuple(boxes.shape),
+                                                                                     tuple(input_ids.shape), tuple(input_mask.shape)))
+        for t, dt in ((feats, torch.float32), (boxes, torch.float32), (input_ids, torch.int64), (input_mask, torch.int64)):
+            if t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("inputs must be contiguous %s tensors on %s" % (dt, self.device))
+        if segment_ids is not None and (segment_ids.dtype != torch.int64 or not segment_ids.is_contiguous()):
+            raise ValueError("segment_ids must be a contiguous int64 tensor")
+        self.ensure_shape(B, T, O)
+        self._keep = (feats, boxes, input_ids, input_mask, segment_ids)   # backward reads them again
+        lg, pl = self._io["logits"], self._io["pooled"]
+        check(self.lib.rgqa_engine_forward(self.h, ptr(feats), ptr(boxes), ptr(input_ids), ptr(segment_ids), ptr(input_mask),
+                                           ptr(pl), ptr(lg), lg.stride(0), 1 if train else 0, C.c_uint64(seed), _stream()))
+        return lg, pl
+
+    def loss_backward(self, target, grad_scale=1.0, accumulate=False):
+        """BCE x NA loss on the last forward's logits + backward into the gradient arena. Returns the loss (device scalar)."""
+        if target.dtype != torch.float32 or target.stride(1) != 1:
+            raise ValueError("target must be f32 with unit inner stride")
+        check(self.lib.rgqa_engine_loss_backward(self.h, ptr(target), target.stride(0), ptr(self._io["loss"]), grad_scale,
+                                                 1 if accumulate else 0, _stream()))
+        return self._io["loss"]
+
+    def backward(self, dlogits, accumulate=False):
+        dlogits = dlogits.contiguous().float()
+        check(self.lib.rgqa_engine_backward(self.h, ptr(dlogits), dlogits.stride(0), 1 if accumulate else 0, _stream()))
+
+    def backward_pooled(self, dpooled, accumulate=False):
+        dpooled = dpooled.contiguous().float()
+        check(self.lib.rgqa_engine_backward_pooled(self.h, ptr(dpooled), dpooled.stride(0), 1 if accumulate else 0, _stream()))
+
+    def activation(self, name, rows, cols=None):
+        out = torch.empty(rows, cols or self.cfg.hidden, dtype=torch.float32, device=self.device)
+        check(self.lib.rgqa_engine_get_activation(self.h, name.encode(), ptr(out), out.numel(), _stream()))
+        return out
+
+    # ------------------------------------------------------------------ optimizer (fused clip + BertAdam over the arena)
+    def live_ranges(self):
+        b, e = self.dead_range
+        n = self.arena_elems
+        return [(0, b), (e, n)] if e > b else [(0, n)]
+
+    def adam_step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, grad_prescale=1.0, clip=True):
+        """clip_grad_norm_(params, max_norm) + BertAdam.step over every parameter that receives a gradient
+        (gqa_conf.py:201-202); then refreshes the bf16 weight copies."""
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+            self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._sq_ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
+        s = _stream()
+        rngs = self.live_ranges()
+        if clip:
+            for i, (a, b) in enumerate(rngs):
+                check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
+        for a, b in rngs:
+            check(self.lib.rgqa_bertadam_step(ptr(self.params[a:b]), ptr(self.grads[a:b]), ptr(self.adam_m[a:b]), ptr(self.adam_v[a:b]),
+                                              None, b - a, lr_t, b1, b2, eps, weight_decay, ptr(self._sumsq) if clip else None,
+                                              max_norm, grad_prescale, s))
+        if self.precision == "bf16":
+            self.sync_weights()
+
+    def grad_norm(self):
+        self.adam_m if self.adam_m is not None else None
+        tot = torch.zeros(1, dtype=torch.float32, device=self.device)
+        ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
+        for i, (a, b) in enumerate(self.live_ranges()):
+            check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(ws), ptr(tot), 1 if i else 0, _stream()))
+        return tot.sqrt()

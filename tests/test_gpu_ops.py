@@ -1,0 +1,243 @@
+"""Per-kernel parity on a real MI355X, through the C ABI (include/rgqa.h).  Floating-point kernels are compared
+with a plain PyTorch fp32 evaluation of the same op on the same (bf16-rounded, where applicable) inputs."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rgqa_amd import _lib
+    return _lib.load()
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def ck(rc):
+    from rgqa_amd._lib import check
+    check(rc)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (5120, 768, 768), (256, 1842, 1536), (77, 2304, 768)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_linear_bf16(lib, M, N, K, epi):
+    A = rnd(M, K, seed=1).bfloat16()
+    W = rnd(N, K, seed=2, scale=0.05).bfloat16()
+    b = rnd(N, seed=3)
+    ldc = (N + 63) // 64 * 64
+    Cc = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device="cuda")
+    ck(lib.rgqa_op_linear(P(A), P(W), P(b), P(Cc), M, N, K, K, K, ldc, epi, 1, S()))
+    ref = A.float() @ W.float().t() + b
+    ref = [ref, torch.nn.functional.gelu(ref), torch.tanh(ref)][epi]
+    got = Cc[:, :N].float()
+    tol = 2e-2 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) < tol
+    # relative Frobenius error at bf16 output rounding level
+    assert float((got - ref).norm() / ref.norm()) < 4e-3
+    if ldc > N:
+        assert float((Cc[:, N:].float() - 7.0).abs().max()) == 0.0   # padding untouched
+
+
+def test_linear_bf16_exact_integers(lib):
+    # asymmetric small-integer operands: every product and sum is exact in bf16/f32 -> bit-exact layout check
+    M, N, K = 192, 160, 128
+    A = ((torch.arange(M * K).reshape(M, K) * 7 + 3) % 5 - 2).float().cuda().bfloat16()
+    W = ((torch.arange(N * K).reshape(N, K) * 11 + 1) % 7 - 3).float().cuda().bfloat16()
+    Cc = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    Cb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ck(lib.rgqa_op_linear(P(A), P(W), None, P(Cb), M, N, K, K, K, N, 0, 1, S()))
+    ref = A.float() @ W.float().t()
+    assert torch.equal(Cb.float(), ref.bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (100, 72, 50), (512, 768, 768)])
+def test_linear_f32(lib, M, N, K):
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+    ldc = (N + 3) // 4 * 4
+    Cc = torch.zeros(M, ldc, device="cuda")
+    ck(lib.rgqa_op_linear(P(A), P(W), P(b), P(Cc), M, N, K, K, K, ldc, 0, 0, S()))
+    ref = (A.double() @ W.double().t() + b.double()).float()
+    np.testing.assert_allclose(Cc[:, :N].cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (768, 768, 1000), (200, 72, 100), (2304, 768, 5120)])
+def test_matmul_tn_bf16(lib, M, N, K):
+    A = rnd(K, M, seed=4).bfloat16()   # [K, M]
+    Bm = rnd(K, N, seed=5).bfloat16()  # [K, N]
+    lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    Ap = torch.zeros(K, lda, dtype=torch.bfloat16, device="cuda"); Ap[:, :M] = A
+    Bp = torch.zeros(K, ldb, dtype=torch.bfloat16, device="cuda"); Bp[:, :N] = Bm
+    ldc = (N + 3) // 4 * 4
+    Cc = torch.zeros(M, ldc, device="cuda")
+    ck(lib.rgqa_op_matmul_tn(P(Ap), P(Bp), P(Cc), M, N, K, lda, ldb, ldc, 1, S()))
+    ref = A.float().t() @ Bm.float()
+    got = Cc[:, :N]
+    assert float((got - ref).norm() / ref.norm()) < 1e-3
+    assert float((got - ref).abs().max()) < 1e-2 * math.sqrt(K)
+
+
+def test_matmul_tn_exact_integers(lib):
+    M, N, K = 144, 208, 192
+    A = ((torch.arange(K * M).reshape(K, M) * 5 + 1) % 7 - 3).float().cuda().bfloat16()
+    Bm = ((torch.arange(K * N).reshape(K, N) * 3 + 2) % 5 - 2).float().cuda().bfloat16()
+    Cc = torch.zeros(M, N, device="cuda")
+    ck(lib.rgqa_op_matmul_tn(P(A), P(Bm), P(Cc), M, N, K, M, N, N, 1, S()))
+    assert torch.equal(Cc, A.float().t() @ Bm.float())
+
+
+def test_matmul_tn_f32(lib):
+    M, N, K = 70, 52, 33
+    A, Bm = rnd(K, M, seed=1), rnd(K, N, seed=2)
+    Cc = torch.zeros(M, N, device="cuda")
+    ck(lib.rgqa_op_matmul_tn(P(A), P(Bm), P(Cc), M, N, K, M, N, N, 0, S()))
+    np.testing.assert_allclose(Cc.cpu().numpy(), (A.double().t() @ Bm.double()).float().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("M,N", [(7, 64), (1000, 768), (256, 1536), (33, 128)])
+def test_layernorm_fwd_bwd(lib, dtype, M, N):
+    td = torch.bfloat16 if dtype else torch.float32
+    x = rnd(M, N, seed=1, scale=2.0).to(td)
+    g, b = 1 + 0.1 * rnd(N, seed=2), 0.1 * rnd(N, seed=3)
+    dy = rnd(M, N, seed=4).to(td)
+    y = torch.empty_like(x); mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
+    ck(lib.rgqa_op_layernorm(P(x), P(g), P(b), P(y), P(mean), P(rstd), M, N, 1e-12, dtype, S()))
+    xr = x.float().requires_grad_(True); gr = g.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (N,), gr, br, 1e-12)
+    yr.backward(dy.float())
+    tol = 3e-2 if dtype else 2e-5
+    np.testing.assert_allclose(y.float().cpu().numpy(), yr.detach().cpu().numpy(), rtol=tol, atol=tol)
+    dx = torch.empty_like(x); dg = torch.empty(N, device="cuda"); db = torch.empty(N, device="cuda")
+    ws = torch.empty(512 * 3 * N, device="cuda")
+    ck(lib.rgqa_op_layernorm_bwd(P(dy), P(x), P(g), P(mean), P(rstd), P(dx), P(dg), P(db), P(ws), M, N, dtype, S()))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.cpu().numpy(), rtol=1e-3, atol=1e-3 * math.sqrt(M))
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.cpu().numpy(), rtol=1e-3, atol=1e-3 * math.sqrt(M))
+
+
+def attn_ref(qkv, mask, B, nh, L, dh):
+    H = nh * dh
+    x = qkv.float().view(B, L, 3, nh, dh)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    if mask is not None:
+        s = s + mask.view(B, 1, 1, L)
+    p = torch.softmax(s, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * L, H), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype,impl", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("B,nh,L,dh", [(3, 4, 5, 16), (2, 12, 36, 64), (4, 12, 20, 64), (2, 12, 30, 64), (1, 2, 64, 64)])
+def test_attention_fwd_bwd(lib, dtype, impl, B, nh, L, dh):
+    if impl == 1 and dh != 64:
+        pytest.skip("MFMA attention is specialised for head size 64")
+    td = torch.bfloat16 if dtype else torch.float32
+    H = nh * dh
+    qkv = rnd(B * L, 3 * H, seed=7).to(td)
+    lens = torch.tensor([max(1, L - 3 * i) for i in range(B)])
+    mask = ((torch.arange(L)[None, :] >= lens[:, None]).float() * -10000.0).cuda()
+    dout = rnd(B * L, H, seed=8).to(td)
+    out = torch.empty(B * L, H, dtype=td, device="cuda"); lse = torch.empty(B, nh, L, device="cuda")
+    ck(lib.rgqa_op_attention(P(qkv), P(mask), P(out), P(lse), B, nh, L, dh, dtype, impl, S()))
+    qr = qkv.float().requires_grad_(True)
+    oref, lref = attn_ref(qr, mask, B, nh, L, dh)
+    oref.backward(dout.float())
+    tol = 2e-2 if dtype else 2e-5
+    np.testing.assert_allclose(out.float().cpu().numpy(), oref.detach().cpu().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(lse.cpu().numpy(), lref.detach().cpu().numpy(), rtol=1e-3 if dtype else 1e-5, atol=1e-2 if dtype else 1e-4)
+    dqkv = torch.empty_like(qkv)
+    ck(lib.rgqa_op_attention_bwd(P(qkv), P(mask), P(lse), P(dout), P(dqkv), B, nh, L, dh, dtype, impl, S()))
+    ref = qr.grad
+    if dtype:
+        assert float((dqkv.float() - ref).norm() / ref.norm()) < 2e-2
+    else:
+        np.testing.assert_allclose(dqkv.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_bce(lib):
+    B, NA = 5, 1842
+    z, t = rnd(B, NA, seed=1, scale=2.0), (rnd(B, NA, seed=2) > 1.5).float()
+    t[2] = 0
+    loss = torch.zeros(1, device="cuda"); dz = torch.empty(B, NA, device="cuda")
+    ck(lib.rgqa_op_bce(P(z), P(t), P(loss), P(dz), B, NA, S()))
+    zr = z.clone().requires_grad_(True)
+    lr = torch.nn.functional.binary_cross_entropy_with_logits(zr, t) * NA
+    lr.backward()
+    np.testing.assert_allclose(loss.item(), lr.item(), rtol=1e-5)
+    np.testing.assert_allclose(dz.cpu().numpy(), zr.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_bertadam_and_clip_vs_oracle(lib, golden_dir):
+    from oracle import lxmert_ref as R
+    n = 100003
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=3.0)
+    p = p0.clone(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    sq = torch.zeros(1, device="cuda"); ws = torch.zeros(2048, device="cuda")
+    pc = p0.cpu().clone(); opt = R.BertAdamRef([pc], lr=1e-3, warmup=0.1, t_total=100)
+    for step in range(3):
+        gs = g * (step + 1)
+        ck(lib.rgqa_grad_sumsq(P(gs), n, P(ws), P(sq), 0, S()))
+        np.testing.assert_allclose(sq.sqrt().item(), gs.double().norm().item(), rtol=1e-5)
+        lr_t = 1e-3 * R.warmup_linear(step / 100, 0.1)
+        ck(lib.rgqa_bertadam_step(P(p), P(gs), P(m), P(v), None, n, lr_t, 0.9, 0.999, 1e-6, 0.01, P(sq), 5.0, 1.0, S()))
+        gc = gs.cpu().clone()
+        R.clip_grad_norm([gc], 5.0)
+        opt.step([gc])
+        np.testing.assert_allclose(p.cpu().numpy(), pc.numpy(), rtol=2e-5, atol=1e-7)
+    # golden G3 (reference BertAdam, no clipping) through the same kernel
+    gd = np.load(os.path.join(golden_dir, "g3_bertadam.npz"))
+    from rgqa_amd import synth
+    shapes = {"a": (7, 5), "b": (13,), "c": (3, 4, 2), "d": (1,)}
+    for k, shp in shapes.items():
+        n = int(np.prod(shp))
+        npad = (n + 3) // 4 * 4
+        pp = torch.zeros(npad, device="cuda"); pp[:n] = torch.from_numpy(synth.uniform("adam.p." + k, shp, -1, 1)).reshape(-1).cuda()
+        mm = torch.zeros(npad, device="cuda"); vv = torch.zeros(npad, device="cuda")
+        st = 0
+        for step in range(3):
+            if k == "d" and step == 0:
+                continue
+            gg = torch.zeros(npad, device="cuda"); gg[:n] = torch.from_numpy(synth.uniform("adam.g%d.%s" % (step, k), shp, -2, 2)).reshape(-1).cuda()
+            lr_t = 1e-2 * R.warmup_linear(st / 10, 0.1)
+            ck(lib.rgqa_bertadam_step(P(pp), P(gg), P(mm), P(vv), None, n, lr_t, 0.9, 0.999, 1e-6, 0.01, None, 0.0, 1.0, S()))
+            st += 1
+            np.testing.assert_allclose(pp[:n].cpu().numpy(), gd["p%d.%s" % (step, k)].reshape(-1), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("mode", ["mixup_v1", "mixup_v3"])
+def test_mixup_gather_vs_golden(lib, golden_dir, mode):
+    from rgqa_amd import synth
+    g = np.load(os.path.join(golden_dir, "g5_mixup.npz"))
+    B, O, Fd, NA = 6, 36, 8, 5
+    feats = torch.zeros(2 * B, O, Fd, device="cuda"); feats[:B] = torch.from_numpy(synth.uniform("mix.f", (B, O, Fd), 0, 1)).cuda()
+    boxes = torch.zeros(2 * B, O, 4, device="cuda"); boxes[:B] = torch.from_numpy(synth.uniform("mix.b", (B, O, 4), 0, 1)).cuda()
+    target = torch.zeros(2 * B, NA, device="cuda"); target[:B] = torch.from_numpy(synth.uniform("mix.t", (B, NA), 0, 1)).cuda()
+    prop = g[mode + ".prop"]
+    take = np.zeros((B, O), dtype=np.uint8)
+    for j in range(B):
+        take[j, g[mode + ".perm"][j][: int(prop[j] * O)]] = 1
+    partner = torch.from_numpy(g[mode + ".partner"].astype(np.int32)).cuda()
+    takeg = torch.from_numpy(take).cuda()
+    propg = torch.from_numpy(prop.astype(np.float32)).cuda()
+    ck(lib.rgqa_mixup_gather(P(feats), P(boxes), P(partner), P(takeg), B, O, Fd, 1 if mode == "mixup_v3" else 0, S()))
+    ck(lib.rgqa_scale_rows(P(target), P(propg), B, NA, NA, B, S()))
+    assert np.array_equal(feats.cpu().numpy(), g[mode + ".feats"])
+    assert np.array_equal(boxes.cpu().numpy(), g[mode + ".boxes"])
+    np.testing.assert_allclose(target.cpu().numpy(), g[mode + ".target"], rtol=1e-6)
