@@ -78,6 +78,8 @@ class Engine:
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("rgqa_amd runs on an MI355X (torch device 'cuda'); got %s. There is no CPU path." % device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         n = self.arena_elems
         self.params = torch.zeros(n, dtype=torch.float32, device=device)

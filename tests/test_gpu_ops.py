@@ -218,7 +218,7 @@ def test_bertadam_and_clip_vs_oracle(lib, golden_dir):
             lr_t = 1e-2 * R.warmup_linear(st / 10, 0.1)
             ck(lib.rgqa_bertadam_step(P(pp), P(gg), P(mm), P(vv), None, n, lr_t, 0.9, 0.999, 1e-6, 0.01, None, 0.0, 1.0, S()))
             st += 1
-            np.testing.assert_allclose(pp[:n].cpu().numpy(), gd["p%d.%s" % (step, k)].reshape(-1), rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(pp[:n].cpu().numpy(), gd["p%d.%s" % (step, k)].reshape(-1), rtol=1e-4, atol=2e-6)
 
 
 @pytest.mark.parametrize("mode", ["mixup_v1", "mixup_v3"])
