@@ -1,0 +1,184 @@
+"""Headline benchmark: QA-pairs/sec of one LXMERT-GQA train step (BASELINE.json), B=256 per GPU, T=20, O=36,
+bf16 MFMA operands / f32 accumulate, synthetic inputs already resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = forward (train mode, dropout 0.1) + BCE x NA loss + backward + [RCCL gradient all-reduce] +
+clip_grad_norm_(5.) + BertAdam + bf16 weight re-cast: everything tasks/gqa_conf.py:174-202 does per batch.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_BWD_GFLOP = {20: 30.3388, 30: 37.0403}   # per QA pair, SURVEY.md §8 D3
+PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16, MI355X_MICROARCH.md
+FULL = dict(vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9, x_layers=5,
+            r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842)
+
+
+def warmup_linear(x, warmup):
+    return x / warmup if x < warmup else max((x - 1.0) / (warmup - 1.0), 0.0)
+
+
+def init_params(e, seed):
+    """random-init weights of the reference architecture (init_bert_weights: N(0, 0.02), LN = 1/0, bias = 0)."""
+    g = torch.Generator(device=e.device).manual_seed(seed)
+    e.params.normal_(0.0, 0.02, generator=g)
+    for sp in e.specs:
+        v = e.view(e.params, sp)
+        if len(sp.shape) == 1:
+            v.fill_(1.0 if ("LayerNorm.weight" in sp.name or "layer_norm.weight" in sp.name or sp.name == "logit_fc.2.weight") else 0.0)
+
+
+def cpu_baseline(T, sample_b, iters):
+    """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this box's host cores."""
+    from oracle import lxmert_ref as R
+    from rgqa_amd import synth
+    cfg = R.RefConfig(**FULL)
+    torch.manual_seed(0)
+    P = {}
+    for k, shp in R.param_shapes(cfg).items():
+        t = torch.randn(shp) * 0.02 if len(shp) > 1 else (torch.ones(shp) if "LayerNorm.weight" in k or "layer_norm.weight" in k else torch.zeros(shp))
+        P[k] = t.requires_grad_(True)
+    b = synth.synth_batch(sample_b, T, seed=99)
+    batch = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
+    opt = R.BertAdamRef(list(P.values()), lr=1e-5, warmup=0.1, t_total=1000)
+    R.train_step(P, cfg, batch, opt)
+    ts = []
+    for _ in range(iters):
+        t0 = time.time()
+        R.train_step(P, cfg, batch, opt)
+        ts.append(time.time() - t0)
+    t = float(np.median(ts))
+    return dict(value=sample_b / t, unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample="full train step (fwd+BCE+bwd+clip+BertAdam), B=%d T=%d, fp32, %d timed iters, median %.2fs" % (sample_b, T, iters, t))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="QA pairs per GPU per step")
+    ap.add_argument("--seq", type=int, default=20)
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda unavailable); there is no CPU path")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from rgqa_amd.engine import Engine
+    from rgqa_amd import synth
+    from rgqa_amd.parallel import GradAllReduce
+
+    B, T, O = args.batch, args.seq, 36
+    e = Engine(precision=args.precision, **FULL).allocate("cuda")
+    init_params(e, seed=0)       # identical replica on every rank
+    b = synth.synth_batch(B, T, seed=1234 + rank)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    comm = GradAllReduce(e, dist) if world > 1 else None
+    t_total = 10000
+    state = dict(step=0)
+
+    def step():
+        i = state["step"]
+        e.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=True, seed=4321 + rank + 1000003 * i)
+        e.loss_backward(dev["target"])
+        if comm is not None:
+            comm.all_reduce()
+        e.adam_step(1e-5 * warmup_linear(i / t_total, 0.1), max_norm=5.0, grad_prescale=1.0 / world)
+        state["step"] = i + 1
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    # live roofline of the dominant kernel (the bf16 MFMA NT GEMM): HIP events around every launch, on the launch stream
+    roof = None
+    prof = None
+    if rank == 0:
+        e.profile(True)
+        for _ in range(args.profile_steps):
+            step()
+        prof = e.profile_read()
+        e.profile(False)
+        nt = prof["gemm_nt"]
+        if nt["launches"]:
+            per_launch_flops = nt["flops"] / nt["launches"]
+            avg_ms = nt["ms"] / nt["launches"]
+            ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                        traffic=None, kernel="gemm_nt_kernel", launches_per_step=nt["launches"] // args.profile_steps,
+                        avg_launch_us=round(avg_ms * 1e3, 2), gflop_per_launch=round(per_launch_flops / 1e9, 3))
+    if dist is not None:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(T, args.cpu_sample, 2)
+
+    if rank == 0:
+        step_tflops = value * FWD_BWD_GFLOP.get(T, FWD_BWD_GFLOP[20]) / 1e3
+        out = {
+            "metric": "QA-pairs/sec (train step) LXMERT-GQA B=256", "value": round(value, 1), "unit": "QA-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "LXMERT-GQA RP finetune train step (fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768",
+                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "rois": O, "feat_dim": 2048,
+                       "num_answers": 1842, "parallelism": "dp%d" % world, "dropout": 0.1},
+            "step_model_tflops_per_gpu": round(step_tflops / world, 1),
+            "step_frac_of_bf16_peak": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if prof is not None:
+            out["kernel_ms_per_step"] = {k: round(v["ms"] / args.profile_steps, 3) for k, v in prof.items() if v["launches"]}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

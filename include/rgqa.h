@@ -73,6 +73,12 @@ int rgqa_engine_backward_pooled(rgqa_engine* e, const float* dpooled, int ld, in
 /* debug / parity: copy a saved activation ("embed_lang", "embed_visn", "l3", "r1", "x2_lang", "x2_visn", "pooled") as f32 */
 int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, size_t cap_elems, void* stream);
 
+/* measurement: time every GEMM / attention launch with HIP events on the launch stream. profile_read synchronises
+ * on the recorded events; categories: 0 gemm NT (fwd + dgrad), 1 gemm TN (wgrad), 2 attention fwd, 3 attention bwd,
+ * 4 layernorm, 5 other. flops / bytes are algorithmic (2*M*N*K; operand + result bytes). */
+int rgqa_engine_profile(rgqa_engine* e, int enable);
+int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* bytes, int64_t* launches, int ncat);
+
 /* ---- optimizer: replaces nn.utils.clip_grad_norm_(params, max_norm) (tasks/gqa_conf.py:201) followed by
  * BertAdam.step (lxrt/optimization.py:101-180) over arena ranges. */
 int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws /* >= 1024 f32 */, float* sumsq_out,

@@ -419,3 +419,20 @@ def sents_to_features(sents, max_seq_length, vocab):
         masks.append([1] * len(row) + [0] * pad)
         segs.append([0] * max_seq_length)
     return ids, masks, segs
+
+
+# --------------------------------------------------------------------------- whole train step (CPU baseline)
+def train_step(P, cfg, batch, opt, max_norm=5.0):
+    """One reference train step in eval-free form (tasks/gqa_conf.py:174-202): forward, BCE x NA, backward,
+    clip_grad_norm_(5.), BertAdam.step.  P: {key: leaf tensor requiring grad}; opt: BertAdamRef over list(P.values()).
+    Dropout is not applied (the timing difference is negligible on CPU). Returns the loss value."""
+    for p in P.values():
+        p.grad = None
+    logits, _ = gqa_forward(P, cfg, batch["feats"], batch["boxes"], batch["input_ids"], batch["input_mask"], batch.get("segment_ids"))
+    loss = bce_loss(logits, batch["target"])
+    loss.backward()
+    grads = [p.grad for p in P.values()]
+    clip_grad_norm(grads, max_norm)
+    with torch.no_grad():
+        opt.step(grads)
+    return float(loss.detach())

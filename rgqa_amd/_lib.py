@@ -33,6 +33,8 @@ SIGNATURES = {
     "rgqa_engine_backward": [_vp, _vp, _i, _i, _vp],
     "rgqa_engine_backward_pooled": [_vp, _vp, _i, _vp],
     "rgqa_engine_get_activation": [_vp, C.c_char_p, _vp, _sz, _vp],
+    "rgqa_engine_profile": [_vp, _i],
+    "rgqa_engine_profile_read": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _i],
     "rgqa_grad_sumsq": [_vp, _sz, _vp, _vp, _i, _vp],
     "rgqa_bertadam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _f, _f, _vp],
     "rgqa_mixup_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -56,6 +58,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime already resident when our library is
+    # mapped, otherwise the process ends up with two runtimes and torch's device pointers / streams mean nothing to ours
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("rgqa_amd: %s not found. Build it with `python -m rgqa_amd.build` "
                            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)

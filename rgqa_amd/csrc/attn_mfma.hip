@@ -1,4 +1,347 @@
-// MFMA attention core (bf16) — placeholder wiring; replaced by the tiled MFMA kernels.
+// MFMA attention core for gfx950 (bf16 operands, f32 softmax), head size 64, Lq, Lk <= 64.
+// Reference semantics: BertAttention.forward, lxrt/modeling.py:326-346.
+//
+// One 64-lane wave (= one workgroup) per (sample, head).  Scores are produced TRANSPOSED,
+//   S^T[key][query] = K Q^T   via v_mfma_f32_16x16x32_bf16(a = K fragment, b = Q fragment)
+// so that each lane owns ONE query column and 4 keys per 16-key tile: the softmax reduction is lane-local plus
+// two xor-shuffles (lane groups 16/32), and the probability tile is, without any data movement, the B operand of
+//   ctx^T[d][query] = V^T P^T
+// whose A operand (V transposed) comes from a row-major LDS image of V through ds_read_b64_tr_b16.
+// K and Q fragments are loaded straight from HBM/L2 (16 B per lane, rows are 128-B head slices).
+// Nothing of size [Lq,Lk] ever leaves registers.
+//
+// Backward recomputes P from the saved log-sum-exp, in both orientations (lane = query for dQ; lane = key for
+// dK / dV), so every gradient is again a chain of MFMAs fed from accumulators: 5 products as in flash-style
+// backward, no atomics, each output element written exactly once.
 #include "kernels.h"
-int k_attn_fwd_mfma(const AttnArgs& a, hipStream_t s) { return k_attn_fwd_ref<bf16_t>(a, s); }
-int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s) { return k_attn_bwd_ref<bf16_t>(a, s); }
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#define ROWB 144  // LDS row pitch in bytes for a [rows][64] bf16 image (128 + 16: spreads 8 consecutive rows over banks)
+
+__device__ __forceinline__ bf16x8 ldfrag(const bf16_t* base, int row, int nrows, int ld, int s, int g) {
+    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row >= nrows) return z;
+    return *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + s * 32 + g * 8);
+}
+// stage a [nrows][64] bf16 matrix (row stride ld) into an LDS image of `trows` rows (zero padded)
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* src, int nrows, int trows, int ld, int lane) {
+    for (int c = lane; c < trows * 8; c += 64) {
+        const int row = c >> 3, ch = c & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < nrows) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
+        *reinterpret_cast<uint4*>(lds + row * ROWB + ch * 16) = v;
+    }
+}
+// transposed fragment: element jj = tile[ (jj<4 ? r0a : r0b) + 4*g + (jj&3) ][ c0 + (lane&15) ]
+__device__ __forceinline__ bf16x8 trfrag(const unsigned char* tile, int r0a, int r0b, bool has_b, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const unsigned char* a1 = tile + (r0a + 4 * g + q) * ROWB + (c0 + 4 * p) * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
+    bf16x4 hi = {0, 0, 0, 0};
+    if (has_b) {
+        const unsigned char* a2 = tile + (r0b + 4 * g + q) * ROWB + (c0 + 4 * p) * 2;
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a2);
+    }
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+    r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
+    r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
+    return r;
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// ============================================================================ forward
+template <int NQT, int NKT>
+__global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char vs[NKT * 16 * ROWB];
+    const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const int Lq = a.Lq, Lk = a.Lk;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * Lq * a.ldq + h * 64;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * Lk * a.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (size_t)b * Lk * a.ldv + h * 64;
+    stage_tile(vs, V, Lk, NKT * 16, a.ldv, lane);
+
+    bf16x8 qf[NQT][2];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[qt][s] = ldfrag(Q, qt * 16 + fr, Lq, a.ldq, s, g);
+    f32x4 acc[NKT][NQT];
+    float mk[NKT][4];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        bf16x8 kf0 = ldfrag(K, kt * 16 + fr, Lk, a.ldk, 0, g), kf1 = ldfrag(K, kt * 16 + fr, Lk, a.ldk, 1, g);
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            c = MFMA(kf0, qf[qt][0], c);
+            c = MFMA(kf1, qf[qt][1], c);
+            acc[kt][qt] = c;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * Lk + key] : 0.f) : -INFINITY;
+        }
+    }
+    DropCfg dc = a.drop; dc.seed_hi ^= a.drop_site;
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        const int q = qt * 16 + fr;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float s = acc[kt][qt][r] * a.scale + mk[kt][r]; acc[kt][qt][r] = s; m = fmaxf(m, s); }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float p = __expf(acc[kt][qt][r] - m); acc[kt][qt][r] = p; sum += p; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        if (g == 0 && q < Lq && a.lse) a.lse[((size_t)b * a.nh + h) * Lq + q] = m + __logf(sum);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t idx = (uint32_t)(((b * a.nh + h) * Lq + q) * Lk + kt * 16 + 4 * g + r);
+                acc[kt][qt][r] = drop_apply(dc, idx, acc[kt][qt][r] * inv);
+            }
+    }
+    // ctx^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * Lq * a.ldo + h * 64;
+    constexpr int NKS = (NKT + 1) / 2;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        bf16x8 va[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) va[ks] = trfrag(vs, 2 * ks * 16, (2 * ks + 1) * 16, 2 * ks + 1 < NKT, dt * 16, lane);
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                bf16x8 pb = pack8(acc[2 * ks][qt], (2 * ks + 1 < NKT) ? acc[(2 * ks + 1 < NKT) ? 2 * ks + 1 : 0][qt] : zero4);
+                o = MFMA(va[ks], pb, o);
+            }
+            const int q = qt * 16 + fr;
+            if (q < Lq) {
+                float v[4] = {o[0], o[1], o[2], o[3]};
+                store4(O + (size_t)q * a.ldo + dt * 16 + 4 * g, v);
+            }
+        }
+    }
+}
+
+// ============================================================================ backward
+template <int NQT, int NKT>
+__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char ks_[NKT * 16 * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char qs_[NQT * 16 * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char os_[NQT * 16 * ROWB];
+    __shared__ __attribute__((aligned(16))) float delta_s[NQT * 16];
+    const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const int Lq = a.Lq, Lk = a.Lk;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * Lq * a.ldq + h * 64;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * Lk * a.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (size_t)b * Lk * a.ldv + h * 64;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + (size_t)b * Lq * a.lddo + h * 64;
+    const float* lse = a.lse + ((size_t)b * a.nh + h) * Lq;
+    stage_tile(ks_, K, Lk, NKT * 16, a.ldk, lane);
+    stage_tile(qs_, Q, Lq, NQT * 16, a.ldq, lane);
+    stage_tile(os_, dO, Lq, NQT * 16, a.lddo, lane);
+    DropCfg dc = a.drop; dc.seed_hi ^= a.drop_site;
+    const uint32_t idx0 = (uint32_t)((b * a.nh + h) * Lq) * (uint32_t)Lk;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NKS = (NKT + 1) / 2, NQS = (NQT + 1) / 2;
+
+    // ---------------- pass T: lane = query, registers = keys  ->  delta[q], dQ
+    {
+        bf16x8 kf[NKT][2], vf[NKT][2];
+        float mk[NKT][4];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { kf[kt][s] = ldfrag(K, kt * 16 + fr, Lk, a.ldk, s, g); vf[kt][s] = ldfrag(V, kt * 16 + fr, Lk, a.ldv, s, g); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * Lk + key] : 0.f) : -INFINITY;
+            }
+        }
+        bf16_t* dQ = reinterpret_cast<bf16_t*>(a.dq) + (size_t)b * Lq * a.lddq + h * 64;
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            const int q = qt * 16 + fr;
+            const bf16x8 qf0 = ldfrag(Q, q, Lq, a.ldq, 0, g), qf1 = ldfrag(Q, q, Lq, a.ldq, 1, g);
+            const bf16x8 of0 = ldfrag(dO, q, Lq, a.lddo, 0, g), of1 = ldfrag(dO, q, Lq, a.lddo, 1, g);
+            const float lq = q < Lq ? lse[q] : 0.f;
+            f32x4 pp[NKT], dpp[NKT];
+            float delta = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
+                s4 = MFMA(kf[kt][0], qf0, s4); s4 = MFMA(kf[kt][1], qf1, s4);
+                dp4 = MFMA(vf[kt][0], of0, dp4); dp4 = MFMA(vf[kt][1], of1, dp4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = q < Lq ? __expf(s4[r] * a.scale + mk[kt][r] - lq) : 0.f;
+                    const float keep = drop_apply(dc, idx0 + (uint32_t)(q * Lk + kt * 16 + 4 * g + r), 1.0f);
+                    const float dp = dp4[r] * keep;
+                    delta += p * dp;
+                    s4[r] = p; dp4[r] = dp;
+                }
+                pp[kt] = s4; dpp[kt] = dp4;
+            }
+            delta += __shfl_xor(delta, 16, 64);
+            delta += __shfl_xor(delta, 32, 64);
+            if (g == 0) delta_s[qt * 16 + fr] = delta;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pp[kt][r] = pp[kt][r] * (dpp[kt][r] - delta) * a.scale;   // dS^T
+            // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const bf16x8 ka = trfrag(ks_, 2 * ks * 16, (2 * ks + 1) * 16, 2 * ks + 1 < NKT, dt * 16, lane);
+                    const bf16x8 db = pack8(pp[2 * ks], (2 * ks + 1 < NKT) ? pp[(2 * ks + 1 < NKT) ? 2 * ks + 1 : 0] : zero4);
+                    o = MFMA(ka, db, o);
+                }
+                if (q < Lq) {
+                    float v[4] = {o[0], o[1], o[2], o[3]};
+                    store4(dQ + (size_t)q * a.lddq + dt * 16 + 4 * g, v);
+                }
+            }
+        }
+    }
+    __syncthreads();   // single-wave workgroup: orders the delta_s writes before the reads below
+    // ---------------- pass N: lane = key, registers = queries  ->  dK, dV
+    {
+        bf16x8 qf[NQT][2], of[NQT][2];
+        float lq[NQT][4], dl[NQT][4];
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { qf[qt][s] = ldfrag(Q, qt * 16 + fr, Lq, a.ldq, s, g); of[qt][s] = ldfrag(dO, qt * 16 + fr, Lq, a.lddo, s, g); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qt * 16 + 4 * g + r;
+                lq[qt][r] = q < Lq ? lse[q] : 0.f;
+                dl[qt][r] = delta_s[q];
+            }
+        }
+        bf16_t* dK = reinterpret_cast<bf16_t*>(a.dk) + (size_t)b * Lk * a.lddk + h * 64;
+        bf16_t* dV = reinterpret_cast<bf16_t*>(a.dv) + (size_t)b * Lk * a.lddv + h * 64;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const int key = kt * 16 + fr;
+            const bf16x8 kf0 = ldfrag(K, key, Lk, a.ldk, 0, g), kf1 = ldfrag(K, key, Lk, a.ldk, 1, g);
+            const bf16x8 vf0 = ldfrag(V, key, Lk, a.ldv, 0, g), vf1 = ldfrag(V, key, Lk, a.ldv, 1, g);
+            const float mkk = key < Lk ? (a.mask ? a.mask[(size_t)b * Lk + key] : 0.f) : -INFINITY;
+            f32x4 dsn[NQT], pdn[NQT];
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
+                s4 = MFMA(qf[qt][0], kf0, s4); s4 = MFMA(qf[qt][1], kf1, s4);      // S[q][key]: lane = key, regs = queries
+                dp4 = MFMA(of[qt][0], vf0, dp4); dp4 = MFMA(of[qt][1], vf1, dp4);  // dP[q][key]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qt * 16 + 4 * g + r;
+                    const float p = q < Lq ? __expf(s4[r] * a.scale + mkk - lq[qt][r]) : 0.f;
+                    const float keep = drop_apply(dc, idx0 + (uint32_t)(q * Lk + key), 1.0f);
+                    dsn[qt][r] = p * (dp4[r] * keep - dl[qt][r]) * a.scale;
+                    pdn[qt][r] = p * keep;
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 ok = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int qs = 0; qs < NQS; ++qs) {
+                    const bool two = 2 * qs + 1 < NQT;
+                    const bf16x8 qa = trfrag(qs_, 2 * qs * 16, (2 * qs + 1) * 16, two, dt * 16, lane);
+                    const bf16x8 oa = trfrag(os_, 2 * qs * 16, (2 * qs + 1) * 16, two, dt * 16, lane);
+                    const bf16x8 dsb = pack8(dsn[2 * qs], two ? dsn[two ? 2 * qs + 1 : 0] : zero4);
+                    const bf16x8 pdb = pack8(pdn[2 * qs], two ? pdn[two ? 2 * qs + 1 : 0] : zero4);
+                    ok = MFMA(qa, dsb, ok);   // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+                    ov = MFMA(oa, pdb, ov);   // dV^T[d][key] = sum_q dO^T[d][q] Pd[q][key]
+                }
+                if (key < Lk) {
+                    float v1[4] = {ok[0], ok[1], ok[2], ok[3]}, v2[4] = {ov[0], ov[1], ov[2], ov[3]};
+                    store4(dK + (size_t)key * a.lddk + dt * 16 + 4 * g, v1);
+                    store4(dV + (size_t)key * a.lddv + dt * 16 + 4 * g, v2);
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================ host side
+static int mfma_check(const AttnArgs& a, bool bwd) {
+    RGQA_REQUIRE(a.dh == 64, "mfma attention: head size must be 64 (got %d)", a.dh);
+    RGQA_REQUIRE(a.B > 0 && a.nh > 0 && a.Lq > 0 && a.Lk > 0 && a.Lq <= 64 && a.Lk <= 64, "mfma attention: Lq/Lk must be in 1..64 (got %d %d)", a.Lq, a.Lk);
+    RGQA_REQUIRE(a.q && a.k && a.v && (a.ldq % 8) == 0 && (a.ldk % 8) == 0 && (a.ldv % 8) == 0, "mfma attention: null operand or row stride not a multiple of 8");
+    RGQA_REQUIRE(((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0, "mfma attention: operands must be 16-byte aligned");
+    if (bwd) {
+        RGQA_REQUIRE(a.dout && a.dq && a.dk && a.dv && a.lse, "mfma attention bwd: null operand");
+        RGQA_REQUIRE((a.lddo % 8) == 0 && (a.lddq % 4) == 0 && (a.lddk % 4) == 0 && (a.lddv % 4) == 0, "mfma attention bwd: bad row strides");
+    } else {
+        RGQA_REQUIRE(a.out && (a.ldo % 4) == 0, "mfma attention: null output / bad stride");
+    }
+    return RGQA_OK;
+}
+
+#define DISPATCH_TILES(KERNEL, nqt, nkt)                                                                          \
+    switch ((nqt) * 8 + (nkt)) {                                                                                  \
+        case 1 * 8 + 1: hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(64), 0, s, a); break;                        \
+        case 1 * 8 + 2: hipLaunchKernelGGL((KERNEL<1, 2>), grid, dim3(64), 0, s, a); break;                        \
+        case 1 * 8 + 3: hipLaunchKernelGGL((KERNEL<1, 3>), grid, dim3(64), 0, s, a); break;                        \
+        case 1 * 8 + 4: hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(64), 0, s, a); break;                        \
+        case 2 * 8 + 1: hipLaunchKernelGGL((KERNEL<2, 1>), grid, dim3(64), 0, s, a); break;                        \
+        case 2 * 8 + 2: hipLaunchKernelGGL((KERNEL<2, 2>), grid, dim3(64), 0, s, a); break;                        \
+        case 2 * 8 + 3: hipLaunchKernelGGL((KERNEL<2, 3>), grid, dim3(64), 0, s, a); break;                        \
+        case 2 * 8 + 4: hipLaunchKernelGGL((KERNEL<2, 4>), grid, dim3(64), 0, s, a); break;                        \
+        case 3 * 8 + 1: hipLaunchKernelGGL((KERNEL<3, 1>), grid, dim3(64), 0, s, a); break;                        \
+        case 3 * 8 + 2: hipLaunchKernelGGL((KERNEL<3, 2>), grid, dim3(64), 0, s, a); break;                        \
+        case 3 * 8 + 3: hipLaunchKernelGGL((KERNEL<3, 3>), grid, dim3(64), 0, s, a); break;                        \
+        case 3 * 8 + 4: hipLaunchKernelGGL((KERNEL<3, 4>), grid, dim3(64), 0, s, a); break;                        \
+        case 4 * 8 + 1: hipLaunchKernelGGL((KERNEL<4, 1>), grid, dim3(64), 0, s, a); break;                        \
+        case 4 * 8 + 2: hipLaunchKernelGGL((KERNEL<4, 2>), grid, dim3(64), 0, s, a); break;                        \
+        case 4 * 8 + 3: hipLaunchKernelGGL((KERNEL<4, 3>), grid, dim3(64), 0, s, a); break;                        \
+        default: hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(64), 0, s, a); break;                               \
+    }
+
+int k_attn_fwd_mfma(const AttnArgs& a, hipStream_t s) {
+    int r = mfma_check(a, false);
+    if (r) return r;
+    const int nqt = cdiv(a.Lq, 16), nkt = cdiv(a.Lk, 16);
+    dim3 grid(a.B * a.nh);
+    DISPATCH_TILES(attn_fwd_mfma_kernel, nqt, nkt)
+    RGQA_LAUNCH_CHECK("attn_fwd_mfma_kernel");
+    return RGQA_OK;
+}
+
+int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s) {
+    int r = mfma_check(a, true);
+    if (r) return r;
+    const int nqt = cdiv(a.Lq, 16), nkt = cdiv(a.Lk, 16);
+    dim3 grid(a.B * a.nh);
+    DISPATCH_TILES(attn_bwd_mfma_kernel, nqt, nkt)
+    RGQA_LAUNCH_CHECK("attn_bwd_mfma_kernel");
+    return RGQA_OK;
+}

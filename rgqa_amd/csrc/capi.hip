@@ -80,6 +80,14 @@ int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, siz
     return e->impl->get_activation(name, out, cap, S(stream));
 }
 
+int rgqa_engine_profile(rgqa_engine* e, int enable) { NEED(e); e->impl->profiling = enable != 0; return RGQA_OK; }
+int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* bytes, int64_t* launches, int ncat) {
+    NEED(e);
+    RGQA_REQUIRE(ncat >= PC_COUNT, "profile_read: need room for %d categories", PC_COUNT);
+    ProfSummary ps; e->impl->prof_collect(ps);
+    for (int i = 0; i < PC_COUNT; ++i) { ms[i] = ps.ms[i]; flops[i] = ps.flops[i]; bytes[i] = ps.bytes[i]; launches[i] = ps.launches[i]; }
+    return RGQA_OK;
+}
 int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws, float* sumsq_out, int accumulate, void* stream) {
     RGQA_REQUIRE(grads && partial_ws && sumsq_out, "grad_sumsq: null argument");
     return k_sumsq(grads, n, partial_ws, sumsq_out, accumulate, S(stream));

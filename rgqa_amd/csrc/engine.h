@@ -4,6 +4,7 @@
 #pragma once
 #include <string>
 #include <vector>
+#include <string.h>
 #include "kernels.h"
 #include "../../include/rgqa.h"
 
@@ -39,9 +40,38 @@ struct Stage {
     int last_dead;             // 1: visn side is the dead branch of the final x-layer
 };
 
+// Optional per-launch timing with HIP events on the launch stream (bench.py's live roofline figures).
+enum ProfCat { PC_GEMM_NT = 0, PC_GEMM_TN = 1, PC_ATTN_FWD = 2, PC_ATTN_BWD = 3, PC_LN = 4, PC_OTHER = 5, PC_COUNT = 6 };
+struct ProfRec { hipEvent_t a, b; int cat; double flops, bytes; };
+struct ProfSummary { double ms[PC_COUNT]; double flops[PC_COUNT]; double bytes[PC_COUNT]; long launches[PC_COUNT]; };
+
 class EngineBase {
 public:
     virtual ~EngineBase() {}
+    bool profiling = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    size_t prof_used = 0;
+    hipEvent_t prof_event() {
+        if (prof_used == prof_pool.size()) { hipEvent_t e; hipEventCreate(&e); prof_pool.push_back(e); }
+        return prof_pool[prof_used++];
+    }
+    void prof_begin(int cat, double flops, double bytes, hipStream_t s) {
+        if (!profiling) return;
+        ProfRec r; r.a = prof_event(); r.b = prof_event(); r.cat = cat; r.flops = flops; r.bytes = bytes;
+        hipEventRecord(r.a, s);
+        prof_recs.push_back(r);
+    }
+    void prof_end(hipStream_t s) { if (profiling) hipEventRecord(prof_recs.back().b, s); }
+    // host-synchronising: call after the stream has been synchronised
+    void prof_collect(ProfSummary& out) {
+        memset(&out, 0, sizeof out);
+        for (auto& r : prof_recs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { out.ms[r.cat] += ms; out.flops[r.cat] += r.flops; out.bytes[r.cat] += r.bytes; out.launches[r.cat]++; }
+        }
+        prof_recs.clear(); prof_used = 0;
+    }
     rgqa_config cfg;
     std::vector<ParamInfo> params;
     size_t arena_elems = 0;

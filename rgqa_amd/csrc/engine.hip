@@ -318,19 +318,39 @@ public:
         p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.K = M; p.M = wrows; p.N = l.in;
         p.C = G + l.w + (size_t)wrow0 * l.in; p.ldc = l.in; p.epi = accumulate ? EPI_ACCUM : EPI_BIAS;
     }
+    void gemm_work(const GemmGroup& g, double& flops, double& bytes) const {
+        flops = 0; bytes = 0;
+        for (int i = 0; i < g.count; ++i) {
+            const GemmProblem& p = g.p[i];
+            flops += 2.0 * p.M * p.N * p.K;
+            bytes += sizeof(T) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+        }
+    }
     int run_fwd(GemmGroup& g, hipStream_t s, int out_f32 = 0, int a_f32 = 0) {
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = a_f32;
-        return LP ? launch_gemm_nt_bf16(g, out_f32, s) : launch_gemm_f32(g, 0, 0, s);
+        double f, b; gemm_work(g, f, b);
+        prof_begin(PC_GEMM_NT, f, b, s);
+        int r = LP ? launch_gemm_nt_bf16(g, out_f32, s) : launch_gemm_f32(g, 0, 0, s);
+        prof_end(s);
+        return r;
     }
     int run_dgrad(GemmGroup& g, hipStream_t s) {
         if (g.count == 0) return RGQA_OK;
-        return LP ? launch_gemm_nt_bf16(g, 0, s) : launch_gemm_f32(g, 0, 1, s);
+        double f, b; gemm_work(g, f, b);
+        prof_begin(PC_GEMM_NT, f, b, s);
+        int r = LP ? launch_gemm_nt_bf16(g, 0, s) : launch_gemm_f32(g, 0, 1, s);
+        prof_end(s);
+        return r;
     }
     int run_wgrad(GemmGroup& g, hipStream_t s, int b_f32 = 0) {
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = b_f32;
-        return LP ? launch_gemm_tn_bf16(g, 1, s) : launch_gemm_f32(g, 1, 1, s);
+        double f, b; gemm_work(g, f, b);
+        prof_begin(PC_GEMM_TN, f, b, s);
+        int r = LP ? launch_gemm_tn_bf16(g, 1, s) : launch_gemm_f32(g, 1, 1, s);
+        prof_end(s);
+        return r;
     }
     int attn_fwd(const AttnArgs& a, hipStream_t s) { return attn_fwd_dispatch(a, s); }
     int attn_fwd_dispatch(const AttnArgs& a, hipStream_t s);
@@ -408,7 +428,10 @@ public:
                 a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
                 a.scale = 1.0f / sqrtf((float)dh);
                 a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
-                CK(attn_fwd_dispatch(a, s));
+                prof_begin(PC_ATTN_FWD, 4.0 * B * nh * a.Lq * a.Lk * dh, sizeof(T) * (double)B * nh * dh * (2.0 * a.Lq + 2.0 * a.Lk), s);
+                int ra = attn_fwd_dispatch(a, s);
+                prof_end(s);
+                CK(ra);
             }
             {
                 GemmGroup g; gg_init(g); g.drop = drop_base(pd);
@@ -593,7 +616,10 @@ public:
                 a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
                 a.scale = 1.0f / sqrtf((float)dh);
                 a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
-                CK(attn_bwd_dispatch(a, s));
+                prof_begin(PC_ATTN_BWD, 10.0 * B * nh * a.Lq * a.Lk * dh, sizeof(T) * (double)B * nh * dh * (4.0 * a.Lq + 4.0 * a.Lk), s);
+                int ra = attn_bwd_dispatch(a, s);
+                prof_end(s);
+                CK(ra);
             }
             // weight / bias gradients
             gg_init(g);

@@ -133,21 +133,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     }
 }
 
-// out[q][n*stride] (+)= sum_blk part[blk][q][n] for q < nq (null output pointers are skipped)
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int nq, int N, FinOut fo, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+// out[q][n*stride] (+)= sum_blk part[blk][q][n] for q < nq (null output pointers are skipped).
+// Block = 16 columns x 16 partial groups: every thread sums nblk/16 partials (fixed order -> bit-reproducible),
+// then the 16 group sums are folded in a fixed order through LDS.
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int nq, int N, FinOut fo, int accumulate) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + c;
     const int q = blockIdx.y;
-    if (n >= N) return;
     float* o = fo.p[q];
     if (o == nullptr) return;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[((size_t)b * nq + q) * N + n];
-    o += (size_t)n * fo.stride[q];
-    *o = accumulate ? *o + s : s;
+    if (n < N)
+        for (int b = grp; b < nblk; b += 16) s += part[((size_t)b * nq + q) * N + n];
+    red[grp][c] = s;
+    __syncthreads();
+    if (grp == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][c];
+        o += (size_t)n * fo.stride[q];
+        *o = accumulate ? *o + t : t;
+    }
 }
 
 int k_colsum_finalize(const float* part, int nblk, int nq, int N, const FinOut& fo, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(N, 256), nq), dim3(256), 0, s, part, nblk, nq, N, fo, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(N, 16), nq), dim3(256), 0, s, part, nblk, nq, N, fo, accumulate);
     RGQA_LAUNCH_CHECK("colsum_finalize_kernel");
     return RGQA_OK;
 }

@@ -157,6 +157,19 @@ class Engine:
         check(self.lib.rgqa_engine_get_activation(self.h, name.encode(), ptr(out), out.numel(), _stream()))
         return out
 
+    PROFILE_CATS = ("gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "layernorm", "other")
+
+    def profile(self, enable):
+        check(self.lib.rgqa_engine_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        """{category: dict(ms, flops, bytes, launches)} accumulated since the last read (synchronises)."""
+        n = len(self.PROFILE_CATS)
+        ms, fl, by, ln = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+        torch.cuda.synchronize()
+        check(self.lib.rgqa_engine_profile_read(self.h, ms, fl, by, ln, n))
+        return {c: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=ln[i]) for i, c in enumerate(self.PROFILE_CATS)}
+
     # ------------------------------------------------------------------ optimizer (fused clip + BertAdam over the arena)
     def live_ranges(self):
         b, e = self.dead_range
