@@ -37,6 +37,8 @@ typedef struct rgqa_engine rgqa_engine;
 
 const char* rgqa_last_error_string(void);
 int rgqa_version(void);
+/* debug / A-B knobs (key 0: 1 forces the 128x128 GEMM kernel everywhere) */
+int rgqa_debug_set(int key, int value);
 
 /* ---- engine: replaces GQAModel.__init__/forward (tasks/gqa_model.py:14-43), LXRTEncoder.forward after
  * tokenisation (lxrt/entry.py:113-120) and everything below it in lxrt/modeling.py. */

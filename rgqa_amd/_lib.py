@@ -19,6 +19,7 @@ _vp, _sz, _i, _f, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_uint64
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/rgqa.h
 SIGNATURES = {
     "rgqa_version": [],
+    "rgqa_debug_set": [_i, _i],
     "rgqa_engine_create": [C.POINTER(Config), C.POINTER(_vp)],
     "rgqa_engine_destroy": [_vp],
     "rgqa_engine_arena_elems": [_vp, C.POINTER(_sz)],

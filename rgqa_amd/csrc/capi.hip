@@ -12,6 +12,16 @@ extern "C" {
 
 int rgqa_version(void) { return 100; }
 
+extern int g_rgqa_force_gemm128;
+extern int g_rgqa_force_mt;
+// debug / A-B knobs: key 0 = force the 128x128 GEMM kernel; key 1 = force the LDS-DMA kernel's MT (0 = auto)
+int rgqa_debug_set(int key, int value) {
+    if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
+    if (key == 1) { g_rgqa_force_mt = value; return RGQA_OK; }
+    rgqa_set_error("debug_set: unknown key %d", key);
+    return RGQA_ERR_ARG;
+}
+
 int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out) {
     RGQA_REQUIRE(cfg != nullptr && out != nullptr, "engine_create: null argument");
     RGQA_REQUIRE(cfg->hidden > 0 && cfg->heads > 0 && cfg->hidden % cfg->heads == 0,

@@ -42,8 +42,7 @@ struct GemmGroup {
 
 // Epilogue on 4 consecutive columns n0..n0+3 of row m. OutT = float or bf16_t; AuxT = act type.
 template <typename OutT, typename AuxT>
-__device__ __forceinline__ void gemm_epilogue4(const GemmProblem& P, const DropCfg& drop, int m, int n0, float v[4]) {
-    const int epi = P.epi;
+__device__ __forceinline__ void gemm_epilogue4_e(const GemmProblem& P, const int epi, const DropCfg& drop, int m, int n0, float v[4]) {
     if (m >= P.M || n0 >= P.N) return;
     const int nvalid = (P.N - n0) >= 4 ? 4 : (P.N - n0);
     if (P.bias != nullptr) {
@@ -87,6 +86,94 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmProblem& P, const DropC
         } else for (int i = 0; i < nvalid; ++i) c[i] += v[i];
         return;
     }
+    if (nvalid == 4) {
+        store4(crow, v);
+        if (epi == EPI_GELU && P.C2 != nullptr) store4(reinterpret_cast<OutT*>(P.C2) + (size_t)m * P.ldc + n0, pre);
+    } else {
+        for (int i = 0; i < nvalid; ++i) {
+            crow[i] = from_f32<OutT>(v[i]);
+            if (epi == EPI_GELU && P.C2 != nullptr) (reinterpret_cast<OutT*>(P.C2) + (size_t)m * P.ldc + n0)[i] = from_f32<OutT>(pre[i]);
+        }
+    }
+}
+
+template <typename OutT, typename AuxT>
+__device__ __forceinline__ void gemm_epilogue4(const GemmProblem& P, const DropCfg& drop, int m, int n0, float v[4]) {
+    gemm_epilogue4_e<OutT, AuxT>(P, P.epi, drop, m, n0, v);
+}
+
+// ---- two-phase epilogue for the MFMA kernels: all bias / aux operands of a lane are fetched up front (one exposed
+// memory round trip) instead of one dependent load per 4 outputs (loads cannot be hoisted over the stores in between).
+struct Aux4 { float a[4]; };
+
+__device__ __forceinline__ bool epi_needs_aux(int epi) { return epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_DTANH; }
+
+__device__ __forceinline__ void epi_fetch_bias(const GemmProblem& P, int n0, float b[4]) {
+    b[0] = b[1] = b[2] = b[3] = 0.f;
+    if (P.bias == nullptr || n0 >= P.N) return;
+    if (n0 + 3 < P.N) load4(P.bias + n0, b);
+    else for (int i = 0; i < P.N - n0; ++i) b[i] = P.bias[n0 + i];
+}
+
+// raw (packed) aux fetch: 4 consecutive AuxT elements as a uint2 (bf16) — converted at use
+template <typename AuxT> struct AuxRaw;
+template <> struct AuxRaw<bf16_t> { uint2 r; };
+template <> struct AuxRaw<float> { float4 r; };
+
+__device__ __forceinline__ void epi_fetch_aux(const GemmProblem& P, int epi, int m, int n0, AuxRaw<bf16_t>& out) {
+    out.r = make_uint2(0u, 0u);
+    if (!epi_needs_aux(epi) || m >= P.M || n0 >= P.N) return;
+    const bf16_t* arow = reinterpret_cast<const bf16_t*>(P.aux) + (size_t)m * P.ldaux + n0;
+    if (n0 + 3 < P.N) out.r = *reinterpret_cast<const uint2*>(arow);
+    else {
+        bf16x4 t = {0, 0, 0, 0};
+        for (int i = 0; i < P.N - n0; ++i) t[i] = arow[i];
+        out.r = *reinterpret_cast<uint2*>(&t);
+    }
+}
+__device__ __forceinline__ void aux_unpack(const AuxRaw<bf16_t>& in, float a[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(&in.r);
+    a[0] = (float)t[0]; a[1] = (float)t[1]; a[2] = (float)t[2]; a[3] = (float)t[3];
+}
+
+// finish: v = acc (4 consecutive columns of row m); bias and aux already in registers
+template <typename OutT>
+__device__ __forceinline__ void epi_finish(const GemmProblem& P, const int epi, const DropCfg& drop, int m, int n0, const float b[4], const float a[4], float v[4]) {
+    if (m >= P.M || n0 >= P.N) return;
+    const int nvalid = (P.N - n0) >= 4 ? 4 : (P.N - n0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += b[i];
+    float pre[4] = {v[0], v[1], v[2], v[3]};
+    if (epi == EPI_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gelu_f(pre[i]);
+    } else if (epi == EPI_TANH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = tanhf(pre[i]);
+    } else if (epi == EPI_RESID_DROP) {
+        DropCfg d = drop; d.seed_hi ^= P.drop_site;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = drop_apply(d, (uint32_t)m * (uint32_t)P.N + (uint32_t)(n0 + i), v[i]) + a[i];
+    } else if (epi == EPI_DGELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] * dgelu_f(a[i]);
+    } else if (epi == EPI_DTANH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] * (1.0f - a[i] * a[i]);
+    } else if (epi == EPI_ADD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] + a[i];
+    } else if (epi == EPI_ACCUM) {
+        float* c = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + n0;
+        if (nvalid == 4) {
+            float o[4]; load4(c, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += v[i];
+            store4(c, o);
+        } else for (int i = 0; i < nvalid; ++i) c[i] += v[i];
+        return;
+    }
+    OutT* crow = reinterpret_cast<OutT*>(P.C) + (size_t)m * P.ldc + n0;
     if (nvalid == 4) {
         store4(crow, v);
         if (epi == EPI_GELU && P.C2 != nullptr) store4(reinterpret_cast<OutT*>(P.C2) + (size_t)m * P.ldc + n0, pre);

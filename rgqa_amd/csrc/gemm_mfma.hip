@@ -8,6 +8,7 @@
 // MFMA roles are swapped (a = weight-side fragment, b = activation-side fragment) so that each lane ends
 // up with 4 consecutive output COLUMNS of one output row: wide (8/16 B) epilogue loads and stores.
 #include "gemm.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -115,13 +116,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const GemmGroup g) {
         __syncthreads();
     }
     // epilogue: lane holds row m = ..+fr, columns n = ..+4*fq+{0..3}
+    {
+        const int epi = P.epi;
+        float bias_r[4][4];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+        for (int tn = 0; tn < 4; ++tn) epi_fetch_bias(P, n0 + wn * 64 + tn * 16 + 4 * fq, bias_r[tn]);
+        AuxRaw<bf16_t> aux_r[4][4];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-            gemm_epilogue4<OutT, bf16_t>(P, g.drop, m0 + wm * 64 + tm * 16 + fr, n0 + wn * 64 + tn * 16 + 4 * fq, v);
-        }
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) epi_fetch_aux(P, epi, m0 + wm * 64 + tm * 16 + fr, n0 + wn * 64 + tn * 16 + 4 * fq, aux_r[tm][tn]);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
+                float a4[4];
+                aux_unpack(aux_r[tm][tn], a4);
+                epi_finish<OutT>(P, epi, g.drop, m0 + wm * 64 + tm * 16 + fr, n0 + wn * 64 + tn * 16 + 4 * fq, bias_r[tn], a4, v);
+            }
+    }
 }
 
 // ============================================================================ TN
@@ -212,13 +226,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const GemmGroup g) {
         __syncthreads();
     }
     const int fr = lane & 15, fq = lane >> 4;
+    {
+        const int epi = P.epi;
+        float bias_r[4][4];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+        for (int tn = 0; tn < 4; ++tn) epi_fetch_bias(P, n0 + wn * 64 + tn * 16 + 4 * fq, bias_r[tn]);
+        AuxRaw<bf16_t> aux_r[4][4];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-            gemm_epilogue4<OutT, bf16_t>(P, g.drop, m0 + wm * 64 + tm * 16 + fr, n0 + wn * 64 + tn * 16 + 4 * fq, v);
-        }
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) epi_fetch_aux(P, epi, m0 + wm * 64 + tm * 16 + fr, n0 + wn * 64 + tn * 16 + 4 * fq, aux_r[tm][tn]);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
+                float a4[4];
+                aux_unpack(aux_r[tm][tn], a4);
+                epi_finish<OutT>(P, epi, g.drop, m0 + wm * 64 + tm * 16 + fr, n0 + wn * 64 + tn * 16 + 4 * fq, bias_r[tn], a4, v);
+            }
+    }
 }
 
 // ============================================================================ host side
@@ -247,9 +274,14 @@ static int check_group(const GemmGroup& g, bool tn) {
     return RGQA_OK;
 }
 
+int g_rgqa_force_gemm128 = 0;
+bool gemm_nt256_eligible(const GemmGroup& g, int out_f32);
+int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s);
+
 int launch_gemm_nt_bf16(GemmGroup& g, int out_f32, hipStream_t s) {
     int r = check_group(g, false);
     if (r) return r;
+    if (!g_rgqa_force_gemm128 && gemm_nt256_eligible(g, out_f32)) return launch_gemm_nt256_bf16(g, s);
     gemm_group_finalize(g, BM, BN);
     dim3 grid(g.total_tiles), block(NTHREADS);
     if (g.a_f32) {

@@ -35,7 +35,8 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).cuda()
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (5120, 768, 768), (256, 1842, 1536), (77, 2304, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (5120, 768, 768), (256, 1842, 1536), (77, 2304, 768),
+                                   (14336, 768, 768), (4000, 2304, 768), (2000, 3072, 3072), (9216, 700, 128)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_linear_bf16(lib, M, N, K, epi):
     A = rnd(M, K, seed=1).bfloat16()
