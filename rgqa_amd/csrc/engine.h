@@ -38,6 +38,8 @@ struct Stage {
     SegBuf sb[2];
     uint32_t site;
     int last_dead;             // 1: visn side is the dead branch of the final x-layer
+    int slot;                  // stage index within its layer (selects the per-stage gradient buffers)
+    int layer_first;           // 1: first stage of a layer in forward order (deferred wgrads are launched after it in backward)
 };
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's live roofline figures).

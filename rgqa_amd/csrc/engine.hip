@@ -131,7 +131,9 @@ public:
     T *zf = nullptr, *visn_out = nullptr; float* visn_stats = nullptr;
     T *pooled = nullptr, *h1pre = nullptr, *h1 = nullptr, *h2 = nullptr; float *hd_mean = nullptr, *hd_rstd = nullptr;
     float* logits = nullptr; T* dlogits = nullptr; float* loss_dev = nullptr;
-    T *gA = nullptr, *gB = nullptr, *gz = nullptr, *gzd = nullptr, *gctx = nullptr, *gqkv = nullptr, *gh = nullptr;
+    T *gA = nullptr, *gB = nullptr, *gctx = nullptr;
+    T *gz_s[3] = {nullptr, nullptr, nullptr}, *gzd_s[3] = {nullptr, nullptr, nullptr}, *gqkv_s[3] = {nullptr, nullptr, nullptr}, *gh_s[3] = {nullptr, nullptr, nullptr};
+    T* gemb = nullptr;
     T *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
     void* lang_final = nullptr;
@@ -216,9 +218,11 @@ public:
             Stage& a = new_stage(ST_ATT_SELF, al, av);
             if (al) a.att[0] = &mp.l_att[i];
             if (av) a.att[1] = &mp.r_att[i];
+            a.slot = 0; a.layer_first = 1;
             Stage& f = new_stage(ST_FFN, al, av);
             if (al) f.ffn[0] = &mp.l_ffn[i];
             if (av) f.ffn[1] = &mp.r_ffn[i];
+            f.slot = 1; f.layer_first = 0;
         }
         // the cross-modality layers need [lang; visn] contiguous: copy-free when both chains end in one stage,
         // otherwise the engine gathers them into x0 (one row copy of the shorter chain's output)
@@ -231,19 +235,24 @@ public:
         for (int i = 0; i < cfg.x_layers; ++i) {
             const bool last = (i == cfg.x_layers - 1);
             Stage& c = new_stage(ST_ATT_CROSS, true, !last);
-            c.att[0] = c.att[1] = &mp.x_cross[i]; c.last_dead = last;
+            c.att[0] = c.att[1] = &mp.x_cross[i]; c.last_dead = last; c.slot = 0; c.layer_first = 1;
             Stage& a = new_stage(ST_ATT_SELF, true, !last);
-            a.att[0] = &mp.x_latt[i]; a.att[1] = &mp.x_vatt[i]; a.last_dead = last;
+            a.att[0] = &mp.x_latt[i]; a.att[1] = &mp.x_vatt[i]; a.last_dead = last; a.slot = 1; a.layer_first = 0;
             Stage& f = new_stage(ST_FFN, true, !last);
-            f.ffn[0] = &mp.x_lffn[i]; f.ffn[1] = &mp.x_vffn[i]; f.last_dead = last;
+            f.ffn[0] = &mp.x_lffn[i]; f.ffn[1] = &mp.x_vffn[i]; f.last_dead = last; f.slot = 2; f.layer_first = 0;
         }
         lang_final = cur[0];
         visn_final = cur[1];
         pooled = take<T>((size_t)B * H); h1pre = take<T>((size_t)B * 2 * H); h1 = take<T>((size_t)B * 2 * H); h2 = take<T>((size_t)B * 2 * H);
         hd_mean = take<float>(B); hd_rstd = take<float>(B);
         logits = take<float>((size_t)B * NAp); dlogits = take<T>((size_t)B * NAp); loss_dev = take<float>(64);
-        gA = take<T>((size_t)R * H); gB = take<T>((size_t)R * H); gz = take<T>((size_t)R * H); gzd = take<T>((size_t)R * H);
-        gctx = take<T>((size_t)R * H); gqkv = take<T>((size_t)R * 3 * H); gh = take<T>((size_t)R * I);
+        gA = take<T>((size_t)R * H); gB = take<T>((size_t)R * H); gctx = take<T>((size_t)R * H); gemb = take<T>((size_t)R * H);
+        // one set of per-stage gradient buffers per stage slot of a layer: the weight-gradient GEMMs of a whole layer are
+        // deferred into ONE grouped launch (432-504 tiles: fills the 256 CUs), so their operands must outlive the stage
+        for (int k = 0; k < 3; ++k) {
+            gz_s[k] = take<T>((size_t)R * H); gzd_s[k] = take<T>((size_t)R * H);
+            gqkv_s[k] = take<T>((size_t)R * 3 * H); gh_s[k] = take<T>((size_t)R * I);
+        }
         gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
@@ -542,9 +551,11 @@ public:
         CK(rgqa_check_hip(hipMemsetAsync(dy, 0, (size_t)R * H * sizeof(T), s), "zero dy"));
         gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, dy, Tn * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
 
-        // ---- encoder stages in reverse
+        // ---- encoder stages in reverse; weight-gradient GEMMs are collected per layer and launched once
+        GemmGroup wg; gg_init(wg);
         for (int si = (int)stages.size() - 1; si >= 0; --si) {
             Stage& st = stages[si];
+            T* gz = gz_s[st.slot]; T* gzd = gzd_s[st.slot]; T* gqkv = gqkv_s[st.slot]; T* gh = gh_s[st.slot];
             const bool cross = st.kind == ST_ATT_CROSS;
             const bool shared_all = cross && st.active[1];
             auto rowp = [&](T* base, int m, int width) { return base + (size_t)(m == 0 ? 0 : Rl) * width; };
@@ -560,12 +571,10 @@ public:
                 for (int m = 0; m < 2; ++m) if (st.active[m])
                     add_dgrad(g, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, rowp(gh, m, I), I, seg_rows(m), EPI_DGELU, st.sb[m].hpre, I);
                 CK(run_dgrad(g, s));
-                gg_init(g);
                 for (int m = 0; m < 2; ++m) if (st.active[m]) {
-                    add_wgrad(g, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, st.sb[m].h, I, seg_rows(m), accumulate);
-                    add_wgrad(g, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, st.sb[m].x_in, H, seg_rows(m), accumulate);
+                    add_wgrad(wg, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, st.sb[m].h, I, seg_rows(m), accumulate);
+                    add_wgrad(wg, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, st.sb[m].x_in, H, seg_rows(m), accumulate);
                 }
-                CK(run_wgrad(g, s));
                 for (int m = 0; m < 2; ++m) if (st.active[m])
                     CK(colsum_bias(rowp(gh, m, I), I, st.ffn[m]->up, 0, I, seg_rows(m), accumulate, s));
                 gg_init(g);
@@ -576,6 +585,7 @@ public:
                 for (int m = 0; m < 2; ++m) if (!st.active[m] && !st.last_dead)
                     CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
                 T* t = dy; dy = dx; dx = t;
+                if (st.layer_first) { CK(run_wgrad(wg, s)); gg_init(wg); }
                 continue;
             }
             // ---- attention stage backward
@@ -621,28 +631,24 @@ public:
                 prof_end(s);
                 CK(ra);
             }
-            // weight / bias gradients
-            gg_init(g);
+            // weight / bias gradients (GEMMs deferred to the end of the layer)
             if (shared_all) {
                 const AttP& ap = *st.att[0];
-                add_wgrad(g, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, R, accumulate);
-                add_wgrad(g, gqkv, 3 * H, ap.qkv, 0, 3 * H, st.sb[0].x_in, H, R, accumulate);
-                CK(run_wgrad(g, s));
+                add_wgrad(wg, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, R, accumulate);
+                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, 3 * H, st.sb[0].x_in, H, R, accumulate);
                 CK(colsum_bias(gqkv, 3 * H, ap.qkv, 0, 3 * H, R, accumulate, s));
             } else if (cross) {
                 const AttP& ap = *st.att[0];
-                add_wgrad(g, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, Rl, accumulate);
-                add_wgrad(g, gqkv, 3 * H, ap.qkv, 0, H, st.sb[0].x_in, H, Rl, accumulate);
-                add_wgrad(g, rowp(gqkv, 1, 3 * H) + H, 3 * H, ap.qkv, H, 2 * H, st.sb[1].x_in, H, Rv, accumulate);
-                CK(run_wgrad(g, s));
+                add_wgrad(wg, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, Rl, accumulate);
+                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, H, st.sb[0].x_in, H, Rl, accumulate);
+                add_wgrad(wg, rowp(gqkv, 1, 3 * H) + H, 3 * H, ap.qkv, H, 2 * H, st.sb[1].x_in, H, Rv, accumulate);
                 CK(colsum_bias(gqkv, 3 * H, ap.qkv, 0, H, Rl, accumulate, s));
                 CK(colsum_bias(rowp(gqkv, 1, 3 * H), 3 * H, ap.qkv, H, 2 * H, Rv, accumulate, s));
             } else {
                 for (int m = 0; m < 2; ++m) if (st.active[m]) {
-                    add_wgrad(g, rowp(gzm, m, H), H, st.att[m]->o, 0, H, st.sb[m].ctx, H, seg_rows(m), accumulate);
-                    add_wgrad(g, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, st.sb[m].x_in, H, seg_rows(m), accumulate);
+                    add_wgrad(wg, rowp(gzm, m, H), H, st.att[m]->o, 0, H, st.sb[m].ctx, H, seg_rows(m), accumulate);
+                    add_wgrad(wg, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, st.sb[m].x_in, H, seg_rows(m), accumulate);
                 }
-                CK(run_wgrad(g, s));
                 for (int m = 0; m < 2; ++m) if (st.active[m])
                     CK(colsum_bias(rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, seg_rows(m), accumulate, s));
             }
@@ -663,7 +669,10 @@ public:
                     CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
             }
             T* t = dy; dy = dx; dx = t;
+            if (st.layer_first) { CK(run_wgrad(wg, s)); gg_init(wg); }
         }
+        CK(run_wgrad(wg, s));
+        T* gz = gemb;
         // ---- embeddings: dropout -> LN backward -> scatter-add into the three tables
         {
             DropCfg din = drop_site(pd, 1);

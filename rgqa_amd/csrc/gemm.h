@@ -31,7 +31,7 @@ struct GemmProblem {
     int epi;            // GemmEpi
 };
 
-#define GEMM_MAX_PROBLEMS 6
+#define GEMM_MAX_PROBLEMS 12
 struct GemmGroup {
     int count;
     int total_tiles;
@@ -106,7 +106,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmProblem& P, const DropC
 // memory round trip) instead of one dependent load per 4 outputs (loads cannot be hoisted over the stores in between).
 struct Aux4 { float a[4]; };
 
-__device__ __forceinline__ bool epi_needs_aux(int epi) { return epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_DTANH; }
+__host__ __device__ __forceinline__ bool epi_needs_aux(int epi) { return epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_DTANH; }
 
 __device__ __forceinline__ void epi_fetch_bias(const GemmProblem& P, int n0, float b[4]) {
     b[0] = b[1] = b[2] = b[3] = 0.f;

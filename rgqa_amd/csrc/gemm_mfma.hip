@@ -295,9 +295,13 @@ int launch_gemm_nt_bf16(GemmGroup& g, int out_f32, hipStream_t s) {
     return RGQA_OK;
 }
 
+bool gemm_tn_dma_eligible(const GemmGroup& g);
+int launch_gemm_tn_dma_bf16(GemmGroup& g, hipStream_t s);
+
 int launch_gemm_tn_bf16(GemmGroup& g, int out_f32, hipStream_t s) {
     int r = check_group(g, true);
     if (r) return r;
+    if (!g_rgqa_force_gemm128 && out_f32 && gemm_tn_dma_eligible(g)) return launch_gemm_tn_dma_bf16(g, s);
     gemm_group_finalize(g, BM, BN);
     dim3 grid(g.total_tiles), block(NTHREADS);
     if (g.a_f32) {  // for TN the f32 flag applies to the B operand (the raw f32 RoI features in visn_fc's wgrad)

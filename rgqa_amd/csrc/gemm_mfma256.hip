@@ -98,25 +98,79 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
         }
         __syncthreads();   // vmcnt(0): this wave's LDS-DMA for stage st^1 has landed; barrier: everyone is done with stage st
     }
-    // epilogue: every bias / aux operand of this lane is fetched before the first store
-    float bias_r[4][4];
+    // ---- epilogue. The accumulators are transposed through a wave-private LDS region (the operand stages are dead
+    // after the last barrier) so that every global access is a full 128-B line: 8 lanes x 16 B per output row,
+    // instead of 16 rows x 32 B per store straight out of the MFMA layout (which ran HBM writes at ~1.5-2.4 TB/s).
+    {
+        constexpr int TP = MT >= 4 ? MT / 2 : MT;          // m-tiles (16 rows) per pass; TP*4 KiB of f32 per wave
+        unsigned char* wl = lds + wave * (TP * 4096);
+        const int ecol = (lane & 7) * 8, erow = lane >> 3;
+        const int nb = n0 + wn * 64 + ecol;                 // first of this lane's 8 output columns
+        float bias8[8];
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) epi_fetch_bias(P, n0 + wn * 64 + tn * 16 + 4 * fq, bias_r[tn]);
-    AuxRaw<bf16_t> aux_r[MT][4];
+        for (int j = 0; j < 8; ++j) bias8[j] = (P.bias != nullptr && nb + j < N) ? P.bias[nb + j] : 0.f;
+        const bool full8 = nb + 8 <= N;
+        DropCfg dcf = g.drop; dcf.seed_hi ^= P.drop_site;
 #pragma unroll
-    for (int tm = 0; tm < MT; ++tm)
+        for (int pass = 0; pass < MT / TP; ++pass) {
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-            epi_fetch_aux(P, EPI, m0 + wm * (16 * MT) + tm * 16 + fr, n0 + wn * 64 + tn * 16 + 4 * fq, aux_r[tm][tn]);
+            for (int t = 0; t < TP; ++t)
 #pragma unroll
-    for (int tm = 0; tm < MT; ++tm)
+                for (int tn = 0; tn < 4; ++tn) {
+                    const int r = t * 16 + fr, c = tn * 4 + fq;
+                    *reinterpret_cast<f32x4*>(wl + r * 256 + ((c ^ (r & 15)) << 4)) = acc[pass * TP + t][tn];
+                }
+            // prefetch this pass's aux rows (residual / pre-activation), coalesced
+            uint4 auxv[2 * TP];
+            if (EPI == EPI_RESID_DROP || EPI == EPI_DGELU || EPI == EPI_ADD) {
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-            float a4[4];
-            aux_unpack(aux_r[tm][tn], a4);
-            epi_finish<OutT>(P, EPI, g.drop, m0 + wm * (16 * MT) + tm * 16 + fr, n0 + wn * 64 + tn * 16 + 4 * fq, bias_r[tn], a4, v);
+                for (int it = 0; it < 2 * TP; ++it) {
+                    const int m = m0 + wm * (16 * MT) + pass * TP * 16 + it * 8 + erow;
+                    auxv[it] = make_uint4(0, 0, 0, 0);
+                    if (m < M && nb < N) {
+                        const bf16_t* ap = reinterpret_cast<const bf16_t*>(P.aux) + (size_t)m * P.ldaux + nb;
+                        if (full8) auxv[it] = *reinterpret_cast<const uint4*>(ap);
+                        else { bf16x8 t8 = {0, 0, 0, 0, 0, 0, 0, 0}; for (int j = 0; j < N - nb; ++j) t8[j] = ap[j]; auxv[it] = *reinterpret_cast<uint4*>(&t8); }
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 2 * TP; ++it) {
+                const int r = it * 8 + erow;
+                const int m = m0 + wm * (16 * MT) + pass * TP * 16 + r;
+                const int c0 = (lane & 7) * 2;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((c0 ^ (r & 15)) << 4));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((c0 + 1) ^ (r & 15)) << 4));
+                if (m >= M || nb >= N) continue;
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                float pre[8];
+                const bf16x8 ax = *reinterpret_cast<const bf16x8*>(&auxv[it]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = v[j] + bias8[j];
+                    pre[j] = x;
+                    if (EPI == EPI_GELU) x = gelu_f(x);
+                    else if (EPI == EPI_RESID_DROP) x = drop_apply(dcf, (uint32_t)m * (uint32_t)N + (uint32_t)(nb + j), x) + (float)ax[j];
+                    else if (EPI == EPI_DGELU) x = x * dgelu_f((float)ax[j]);
+                    else if (EPI == EPI_ADD) x = x + (float)ax[j];
+                    v[j] = x;
+                }
+                bf16x8 o, op;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o[j] = (bf16_t)v[j]; op[j] = (bf16_t)pre[j]; }
+                bf16_t* cp = reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + nb;
+                if (full8) {
+                    *reinterpret_cast<bf16x8*>(cp) = o;
+                    if (EPI == EPI_GELU && P.C2 != nullptr) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(P.C2) + (size_t)m * P.ldc + nb) = op;
+                } else {
+                    for (int j = 0; j < N - nb; ++j) {
+                        cp[j] = o[j];
+                        if (EPI == EPI_GELU && P.C2 != nullptr) (reinterpret_cast<bf16_t*>(P.C2) + (size_t)m * P.ldc + nb)[j] = op[j];
+                    }
+                }
+            }
         }
+    }
 }
 
 // Tile height per launch: the MT in {8,6,4,2} (TM = 256/192/128/64) that minimises rounds-over-256-CUs x per-tile cost.
@@ -142,7 +196,8 @@ bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
     if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD)) return false;
     for (int i = 0; i < g.count; ++i) {
         const GemmProblem& p = g.p[i];
-        if (p.epi != epi || p.K % TK != 0 || p.K < TK) return false;
+        if (p.epi != epi || p.K % TK != 0 || p.K < TK || (p.ldc % 8) != 0) return false;
+        if (epi_needs_aux(epi) && (p.ldaux % 8) != 0) return false;
     }
     long tiles = 0;
     pick_mt(g, tiles);
@@ -185,4 +240,161 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
         case EPI_DGELU: return launch256_mt<EPI_DGELU>(g, mt, s);
         default: return launch256_mt<EPI_ADD>(g, mt, s);
     }
+}
+
+// ============================================================================ TN (wgrad) with LDS-DMA
+//   C[M,N] (f32) (+)= A[K,M]^T * B[K,N],  K % 64 == 0:  dW[n,k] = sum_rows dY[row,n] X[row,k]
+// 128 x 256 output tile, 8 waves (2 x 4, 64x64 each), 2 stages x (A 64x128 + B 64x256) bf16 = 96 KiB.
+// Both operands are row-major over the CONTRACTION index, so the LDS images are natural row-major copies filled
+// by LDS-DMA and the MFMA fragments are fetched with ds_read_b64_tr_b16.  32-byte granules of a row are XOR-
+// swizzled with f(row) = (row&3) | ((row>>3)&1)<<2 so that the 8 (row, 32 B) pieces a half-wave touches per
+// transposed read land on 8 distinct bank groups.  Tiles are launched longest-contraction-first so the hardware
+// dispatcher balances the unequal (lang / visn / shared) problems of one launch over the 256 CUs.
+#define WM 128
+#define WN 256
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+__device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <int PITCH>
+__device__ __forceinline__ bf16x8 tr_frag_dma(const unsigned char* tile, int r0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row = r0 + 8 * g + q;
+    const int ch = (c0 >> 3) + (p >> 1);
+    const int sw = tn_f(row) << 1;      // identical for row and row + 4
+    const unsigned char* a1 = tile + row * PITCH + ((ch ^ sw) << 4) + 8 * (p & 1);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(a1));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(a1 + 4 * PITCH));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int ACCUM>
+__global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int A_BYTES = TK * WM * 2, B_BYTES = TK * WN * 2, STAGE = A_BYTES + B_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tile = blockIdx.x, pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+        if (i < g.count && tile >= g.p[i].tile_start) pi = i;
+    const GemmProblem& P = g.p[pi];
+    const int local = tile - P.tile_start;
+    const int m0 = (local / P.tiles_n) * WM, n0 = (local % P.tiles_n) * WN;
+    const int nkt = P.K / TK;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(P.B);
+
+    // per-lane DMA sources (row within the K-step, column chunk after un-swizzling); columns clamped in-bounds
+    const bf16_t* asrc[2];
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 4 + (lane >> 4);
+        int col = m0 + (((lane & 15) ^ (tn_f(row) << 1)) << 3);
+        if (col > P.lda - 8) col = P.lda - 8;
+        asrc[i] = A + (size_t)row * P.lda + col;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 2 + (lane >> 5);
+        int col = n0 + (((lane & 31) ^ (tn_f(row) << 1)) << 3);
+        if (col > P.ldb - 8) col = P.ldb - 8;
+        bsrc[i] = B + (size_t)row * P.ldb + col;
+    }
+    auto issue = [&](int stage, int kt) {
+        unsigned char* base = lds + stage * STAGE;
+        const size_t ao = (size_t)kt * TK * P.lda, bo = (size_t)kt * TK * P.ldb;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + ao), (lds_void*)(base + (wave * 2 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + bo), (lds_void*)(base + A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < nkt) issue(st ^ 1, kt + 1);
+        const unsigned char* a = lds + st * STAGE;
+        const unsigned char* b = a + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 xa[4], xb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xa[t] = tr_frag_dma<WM * 2>(a, s * 32, wm * 64 + t * 16, lane);
+                xb[t] = tr_frag_dma<WN * 2>(b, s * 32, wn * 64 + t * 16, lane);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[tn], xa[tm], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+    float* Cc = reinterpret_cast<float*>(P.C);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + wm * 64 + tm * 16 + fr;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wn * 64 + tn * 16 + 4 * fq;
+            if (m < P.M && n < P.N) {
+                float* c = Cc + (size_t)m * P.ldc + n;
+                float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
+                if (n + 3 < P.N) {
+                    if (ACCUM) { float o[4]; load4(c, o); v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+                    store4(c, v);
+                } else {
+                    for (int i = 0; i < P.N - n; ++i) c[i] = ACCUM ? c[i] + v[i] : v[i];
+                }
+            }
+        }
+    }
+}
+
+bool gemm_tn_dma_eligible(const GemmGroup& g) {
+    if (g.a_f32) return false;
+    const int epi = g.p[0].epi;
+    if (epi != EPI_BIAS && epi != EPI_ACCUM) return false;
+    long tiles = 0;
+    for (int i = 0; i < g.count; ++i) {
+        const GemmProblem& p = g.p[i];
+        if (p.epi != epi || p.bias != nullptr || p.K % TK != 0 || p.K < TK || p.lda < WM || p.ldb < WN) return false;
+        tiles += (long)cdiv(p.M, WM) * cdiv(p.N, WN);
+    }
+    return tiles >= 48;
+}
+
+int launch_gemm_tn_dma_bf16(GemmGroup& g, hipStream_t s) {
+    // longest contraction first: block ids are dispatched in order, so the dispatcher does LPT balancing
+    for (int i = 1; i < g.count; ++i)
+        for (int j = i; j > 0 && g.p[j].K > g.p[j - 1].K; --j) { GemmProblem t = g.p[j]; g.p[j] = g.p[j - 1]; g.p[j - 1] = t; }
+    gemm_group_finalize(g, WM, WN);
+    constexpr int LDS_BYTES = 2 * (TK * WM * 2 + TK * WN * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    if (g.p[0].epi == EPI_ACCUM) hipLaunchKernelGGL((gemm_tn_dma_kernel<1>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_BYTES, s, g);
+    else hipLaunchKernelGGL((gemm_tn_dma_kernel<0>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_BYTES, s, g);
+    RGQA_LAUNCH_CHECK("gemm_tn_dma_kernel");
+    return RGQA_OK;
 }

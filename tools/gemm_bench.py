@@ -44,12 +44,16 @@ def tn(M, N, K):
     A = torch.randn(K, M, device="cuda").bfloat16()
     B = torch.randn(K, N, device="cuda").bfloat16()
     Cc = torch.empty(M, N, device="cuda")
-    t = timeit(lambda: _lib.check(lib.rgqa_op_matmul_tn(P(A), P(B), P(Cc), M, N, K, M, N, N, 1, S())))
-    print("TN  M=%6d N=%5d K=%5d       : %7.1f TF" % (M, N, K, 2.0 * M * N * K / t / 1e12), flush=True)
+    run = lambda: _lib.check(lib.rgqa_op_matmul_tn(P(A), P(B), P(Cc), M, N, K, M, N, N, 1, S()))
+    lib.rgqa_debug_set(0, 1)
+    t0 = timeit(run)
+    lib.rgqa_debug_set(0, 0)
+    t = timeit(run)
+    print("TN  M=%6d N=%5d K=%5d       : 128sq %7.1f TF   dma %7.1f TF" % (M, N, K, 2.0 * M * N * K / t0 / 1e12, 2.0 * M * N * K / t / 1e12), flush=True)
 
 
-if __name__ == "__main__":
-    for M in (14336, 9216, 5120):
+if __name__ == "__main__" and "--ksweep" not in sys.argv:
+    for M in (() if "--tn" in sys.argv else (14336, 9216, 5120)):
         for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072)):
             nt(M, N, K)
     nt(8192, 8192, 8192)
@@ -58,3 +62,21 @@ if __name__ == "__main__":
         for K in (14336, 5120):
             tn(M, N, K)
     tn(4096, 4096, 4096)
+
+
+def ksweep(M=14336, N=2304):
+    print("K sweep, M=%d N=%d (auto tile): time_us" % (M, N))
+    for K in (64, 128, 256, 512, 768, 1536, 3072, 6144):
+        A = torch.randn(M, K, device="cuda").bfloat16()
+        W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+        Cc = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        for mt in (8, 6, 2):
+            lib.rgqa_debug_set(1, mt)
+            t = timeit(lambda: _lib.check(lib.rgqa_op_linear(P(A), P(W), None, P(Cc), M, N, K, K, K, N, 0, 1, S())), iters=30)
+            print("  K=%5d MT%d: %8.1f us  %7.1f TF" % (K, mt, t * 1e6, 2.0 * M * N * K / t / 1e12), flush=True)
+    lib.rgqa_debug_set(1, 0)
+
+
+if "--ksweep" in sys.argv:
+    ksweep()
+    ksweep(14336, 768)
