@@ -1,0 +1,117 @@
+"""Mirror of the reference's lxrt/entry.py (27-152): `LXRTEncoder(args, max_seq_length, mode='x')`,
+`convert_sents_to_features`, `set_visual_config`, `InputFeatures` — same names, arguments and error behaviour,
+with the nn.Module underneath replaced by the HIP engine."""
+import os
+
+import torch
+import torch.nn as nn
+
+from .tokenization import BertTokenizer
+from .modeling import LXRTFeatureExtraction as VisualBertForLXRFeature, VISUAL_CONFIG
+
+
+class InputFeatures(object):
+    """A single set of features of data."""
+
+    def __init__(self, input_ids, input_mask, segment_ids):
+        self.input_ids = input_ids
+        self.input_mask = input_mask
+        self.segment_ids = segment_ids
+
+
+def convert_sents_to_features(sents, max_seq_length, tokenizer):
+    """Tokenise, truncate to max_seq_length-2, add [CLS]/[SEP], zero-pad; mask 1/0; segment all 0 (reference :36-71)."""
+    features = []
+    for sent in sents:
+        tokens_a = tokenizer.tokenize(sent.strip())
+        if len(tokens_a) > max_seq_length - 2:
+            tokens_a = tokens_a[:(max_seq_length - 2)]
+        tokens = ["[CLS]"] + tokens_a + ["[SEP]"]
+        input_ids = tokenizer.convert_tokens_to_ids(tokens)
+        n = len(input_ids)
+        pad = max_seq_length - n
+        input_mask = [1] * n + [0] * pad
+        segment_ids = [0] * max_seq_length
+        input_ids = input_ids + [0] * pad
+        assert len(input_ids) == max_seq_length
+        assert len(input_mask) == max_seq_length
+        assert len(segment_ids) == max_seq_length
+        features.append(InputFeatures(input_ids=input_ids, input_mask=input_mask, segment_ids=segment_ids))
+    return features
+
+
+def set_visual_config(args):
+    VISUAL_CONFIG.l_layers = args.llayers
+    VISUAL_CONFIG.x_layers = args.xlayers
+    VISUAL_CONFIG.r_layers = args.rlayers
+
+
+class LXRTEncoder(nn.Module):
+    def __init__(self, args, max_seq_length, mode='x'):
+        super().__init__()
+        self.max_seq_length = max_seq_length
+        set_visual_config(args)
+        self.tokenizer = BertTokenizer.from_pretrained("bert-base-uncased", do_lower_case=True)
+        self.model = VisualBertForLXRFeature.from_pretrained("bert-base-uncased", mode=mode)
+        self.model.load_pending_bert()
+        if getattr(args, "from_scratch", False):
+            print("initializing all the weights")
+            self.model.apply(self.model.init_bert_weights)
+        self._id_cache = {}
+
+    def multi_gpu(self):
+        """The reference wraps the inner model in single-process nn.DataParallel (:102-103). Here data parallelism is
+        one process per GPU with RCCL gradient all-reduce (rgqa_amd.parallel, launched with torch.distributed.run); in a
+        single process this is a no-op."""
+        return None
+
+    @property
+    def dim(self):
+        return self.model.config.hidden_size   # 768 for bert-base, the only size the reference ever builds (:105-107)
+
+    def _tokenize(self, sents, device):
+        if self.tokenizer is None:
+            raise RuntimeError("LXRTEncoder has no tokenizer: the BERT vocabulary was not found (set RGQA_BERT_VOCAB)")
+        T = self.max_seq_length
+        rows_i, rows_m = [], []
+        for s in sents:
+            hit = self._id_cache.get(s)
+            if hit is None:
+                f = convert_sents_to_features([s], T, self.tokenizer)[0]
+                hit = (f.input_ids, f.input_mask)
+                if len(self._id_cache) < 2000000:
+                    self._id_cache[s] = hit
+            rows_i.append(hit[0])
+            rows_m.append(hit[1])
+        ids = torch.tensor(rows_i, dtype=torch.long)
+        mask = torch.tensor(rows_m, dtype=torch.long)
+        seg = torch.zeros_like(ids)
+        return ids.to(device, non_blocking=True), seg.to(device, non_blocking=True), mask.to(device, non_blocking=True)
+
+    def forward(self, sents, feats, visual_attention_mask=None):
+        input_ids, segment_ids, input_mask = self._tokenize(sents, feats[0].device)
+        return self.model(input_ids, segment_ids, input_mask, visual_feats=feats, visual_attention_mask=visual_attention_mask)
+
+    def forward_with_head(self, sents, feats):
+        input_ids, segment_ids, input_mask = self._tokenize(sents, feats[0].device)
+        return self.model.forward_with_head(input_ids, segment_ids, input_mask, feats)
+
+    def save(self, path):
+        torch.save(self.model.state_dict(), os.path.join("%s_LXRT.pth" % path))
+
+    def load(self, path):
+        print("Load LXMERT pre-trained model from %s" % path)
+        state_dict = torch.load("%s_LXRT.pth" % path, map_location="cpu")
+        state_dict = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        load_keys = set(state_dict.keys())
+        model_keys = set(self.model.state_dict().keys())
+        print()
+        print("Weights in loaded but not in model:")
+        for key in sorted(load_keys.difference(model_keys)):
+            print(key)
+        print()
+        print("Weights in model but not in loaded:")
+        for key in sorted(model_keys.difference(load_keys)):
+            print(key)
+        print()
+        self.model.load_state_dict(state_dict, strict=False)

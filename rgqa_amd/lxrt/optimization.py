@@ -1,0 +1,162 @@
+"""Mirror of the reference's lxrt/optimization.py (BertAdam + warmup schedules, :20-180) on the fused HIP kernel.
+
+Same constructor, defaults, `get_lr()` and `step()` semantics: no bias correction, eps outside the sqrt, decoupled
+weight decay added to the update of EVERY parameter, learning rate from the per-parameter step counter read before it
+is incremented, parameters whose grad is None skipped.  Gradient clipping stays outside (the reference calls
+`nn.utils.clip_grad_norm_` before `step()`, tasks/gqa_conf.py:201).  Parameters that are adjacent views of a flat
+arena (rgqa_amd models) are updated by one kernel launch per contiguous run instead of one per tensor."""
+import ctypes as C
+import logging
+import math
+
+import torch
+from torch.optim import Optimizer
+from torch.optim.optimizer import required
+
+from .. import _lib
+
+logger = logging.getLogger(__name__)
+
+
+def warmup_cosine(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return 0.5 * (1.0 + math.cos(math.pi * x))
+
+
+def warmup_constant(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return 1.0
+
+
+def warmup_linear(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return max((x - 1.) / (warmup - 1.), 0)
+
+
+SCHEDULES = {'warmup_cosine': warmup_cosine, 'warmup_constant': warmup_constant, 'warmup_linear': warmup_linear}
+
+
+class BertAdam(Optimizer):
+    def __init__(self, params, lr=required, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999, e=1e-6,
+                 weight_decay=0.01, max_grad_norm=1.0):
+        if lr is not required and lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if schedule not in SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
+        if not 0.0 <= warmup < 1.0 and not warmup == -1:
+            raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
+        if not 0.0 <= b1 < 1.0:
+            raise ValueError("Invalid b1 parameter: {} - should be in [0.0, 1.0[".format(b1))
+        if not 0.0 <= b2 < 1.0:
+            raise ValueError("Invalid b2 parameter: {} - should be in [0.0, 1.0[".format(b2))
+        if not e >= 0.0:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(e))
+        defaults = dict(lr=lr, schedule=schedule, warmup=warmup, t_total=t_total, b1=b1, b2=b2, e=e,
+                        weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        super(BertAdam, self).__init__(params, defaults)
+        self._runs = {}
+
+    def get_lr(self):
+        lr = []
+        for group in self.param_groups:
+            for p in group['params']:
+                state = self.state[p]
+                if len(state) == 0:
+                    return [0]
+                if group['t_total'] != -1:
+                    lr_scheduled = group['lr'] * SCHEDULES[group['schedule']](state['step'] / group['t_total'], group['warmup'])
+                else:
+                    lr_scheduled = group['lr']
+                lr.append(lr_scheduled)
+        return lr
+
+    # a run = maximal sequence of parameters whose data AND grads are equally spaced neighbours in two flat buffers.
+    # Parameters are visited in ADDRESS order and only alignment padding (< 64 elements) may separate neighbours, so a
+    # run never spans another tensor (registration order differs from arena order; parameters without gradients sit
+    # between live ones).
+    def _build_runs(self, gi, plist):
+        runs, cur = [], None
+        for p in sorted(plist, key=lambda q: q.data_ptr()):
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.grad.dtype == torch.float32):
+                raise RuntimeError("BertAdam (rgqa_amd): parameters and gradients must be contiguous f32 tensors on the MI355X; "
+                                   "there is no CPU path")
+            st = self.state[p]
+            if cur is not None:
+                gap_p = p.data_ptr() - cur["p_end"]
+                gap_g = p.grad.data_ptr() - cur["g_end"]
+                if 0 <= gap_p == gap_g <= 252 and st.get("step", 0) == cur["step"] and p.device == cur["dev"] and ("next_m" in st) == cur["has_state"]:
+                    cur["params"].append(p)
+                    cur["p_end"] = p.data_ptr() + 4 * p.numel()
+                    cur["g_end"] = p.grad.data_ptr() + 4 * p.numel()
+                    continue
+            cur = dict(params=[p], p0=p.data_ptr(), g0=p.grad.data_ptr(), p_end=p.data_ptr() + 4 * p.numel(),
+                       g_end=p.grad.data_ptr() + 4 * p.numel(), step=st.get("step", 0), dev=p.device, has_state="next_m" in st)
+            runs.append(cur)
+        for r in runs:
+            n = (r["p_end"] - r["p0"]) // 4
+            r["n"] = n
+            if not r["has_state"]:
+                r["m"] = torch.zeros(n, dtype=torch.float32, device=r["dev"])
+                r["v"] = torch.zeros(n, dtype=torch.float32, device=r["dev"])
+                for p in r["params"]:
+                    off = (p.data_ptr() - r["p0"]) // 4
+                    st = self.state[p]
+                    st["step"] = 0
+                    st["next_m"] = r["m"][off:off + p.numel()].view_as(p)
+                    st["next_v"] = r["v"][off:off + p.numel()].view_as(p)
+            else:   # state restored from a checkpoint or created earlier per tensor: one launch per tensor
+                r["m"] = r["v"] = None
+        return runs
+
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            loss = closure()
+        lib = _lib.load()
+        stream = None
+        warned_for_t_total = False
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group['params'] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                if p.grad.is_sparse:
+                    raise RuntimeError('Adam does not support sparse gradients, please consider SparseAdam instead')
+            sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+            cached = self._runs.get(gi)
+            if cached is None or cached[0] != sig:
+                cached = (sig, self._build_runs(gi, plist))
+                self._runs[gi] = cached
+            if stream is None:
+                stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for r in cached[1]:
+                step = self.state[r["params"][0]]["step"]
+                if group['t_total'] != -1:
+                    progress = step / group['t_total']
+                    lr_scheduled = group['lr'] * SCHEDULES[group['schedule']](progress, group['warmup'])
+                    if group['schedule'] == "warmup_linear" and progress > 1. and not warned_for_t_total:
+                        logger.warning("Training beyond specified 't_total' steps with schedule '{}'. Learning rate set to {}. "
+                                       "Please set 't_total' of {} correctly.".format(group['schedule'], lr_scheduled, self.__class__.__name__))
+                        warned_for_t_total = True
+                else:
+                    lr_scheduled = group['lr']
+                if r["m"] is not None:
+                    _lib.check(lib.rgqa_bertadam_step(C.c_void_p(r["p0"]), C.c_void_p(r["g0"]), _lib.ptr(r["m"]), _lib.ptr(r["v"]), None,
+                                                      r["n"], lr_scheduled, group['b1'], group['b2'], group['e'], group['weight_decay'],
+                                                      None, 0.0, 1.0, stream))
+                else:
+                    for p in r["params"]:
+                        st = self.state[p]
+                        _lib.check(lib.rgqa_bertadam_step(_lib.ptr(p.data), _lib.ptr(p.grad), _lib.ptr(st["next_m"]), _lib.ptr(st["next_v"]),
+                                                          None, p.numel(), lr_scheduled, group['b1'], group['b2'], group['e'],
+                                                          group['weight_decay'], None, 0.0, 1.0, stream))
+                for p in r["params"]:
+                    self.state[p]["step"] += 1
+                # the kernel wrote through raw pointers: bump one version counter per run so that owners of derived data
+                # (the engine's bf16 weight copies) notice the change, as they would after any in-place torch op
+                p0 = r["params"][0]
+                torch._C._autograd._unsafe_set_version_counter((p0,), (p0._version + 1,))
+        return loss

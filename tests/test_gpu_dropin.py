@@ -1,0 +1,201 @@
+"""The drop-in Python surface (tasks.gqa_model.GQAModel, lxrt.entry.LXRTEncoder, lxrt.optimization.BertAdam) driven the
+way the reference's trainer drives it (tasks/gqa_conf.py:150-202), checked against the oracle on a real MI355X."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(vocab_size=80, hidden=128, heads=2, inter=256, max_pos=64, type_vocab=2, l_layers=2, x_layers=2, r_layers=1,
+           feat_dim=64, pos_dim=4, num_answers=17)
+SENTS = ["What color is the dog?", "Is the man to the left of the woman?", "who is holding the bottle", "unaffable", "?",
+         "Is there a dog in front of the table behind the man on the right side of the photo to the left of the woman holding the red bottle"]
+
+
+@pytest.fixture()
+def env(golden_dir, monkeypatch):
+    monkeypatch.setenv("RGQA_BERT_VOCAB", os.path.join(golden_dir, "g4_vocab.txt"))
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    import rgqa_amd.lxrt.modeling as M
+    monkeypatch.setattr(M.VISUAL_CONFIG, "visual_feat_dim", CFG["feat_dim"])
+    monkeypatch.setattr(M.LXRTFeatureExtraction, "from_pretrained", classmethod(
+        lambda cls, name, **kw: cls(M.BertConfig(CFG["vocab_size"], hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"],
+                                                 intermediate_size=CFG["inter"], max_position_embeddings=CFG["max_pos"],
+                                                 hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), **kw)))
+    yield M
+    sys.path.remove(os.path.join(ROOT, "dropin"))
+
+
+def build(precision, T=20):
+    from tasks.gqa_model import GQAModel
+    from rgqa_amd import synth
+    os.environ["RGQA_PRECISION"] = precision
+    args = types.SimpleNamespace(llayers=CFG["l_layers"], xlayers=CFG["x_layers"], rlayers=CFG["r_layers"], from_scratch=False)
+    m = GQAModel(CFG["num_answers"], max_seq_length=T, model_args=args)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})     # on the host, BEFORE .cuda(), as gqa_conf.py:97-110 does
+    return m.cuda(), filled
+
+
+def oracle(filled, feats, boxes, ids, mask, target):
+    from oracle import lxmert_ref as R
+    cfg = R.RefConfig(**CFG)
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in filled.items()}
+    lg, pooled = R.gqa_forward(P, cfg, feats, boxes, ids, mask)
+    loss = R.bce_loss(lg, target)
+    loss.backward()
+    return lg.detach(), pooled.detach(), loss.item(), P
+
+
+def batch(T=20):
+    from rgqa_amd import synth
+    B = len(SENTS)
+    b = synth.synth_batch(B, T, O=7, F=CFG["feat_dim"], NA=CFG["num_answers"], vocab=CFG["vocab_size"], seed=21)
+    return torch.from_numpy(b["feats"]), torch.from_numpy(b["boxes"]), torch.from_numpy(b["target"])
+
+
+def test_gqa_model_train_steps_match_oracle(env, golden_dir):
+    """zero_grad -> model(feats, boxes, sent) -> BCE*NA -> backward -> clip_grad_norm_(5.) -> BertAdam.step, three times
+    (f32 precision), against the oracle's functional model + BertAdamRef on identical weights and inputs."""
+    from oracle import lxmert_ref as R
+    from lxrt.optimization import BertAdam
+    T = 20
+    m, filled = build("f32", T)
+    feats, boxes, target = batch(T)
+    vocab = {w.rstrip("\n"): i for i, w in enumerate(open(os.path.join(golden_dir, "g4_vocab.txt"), encoding="utf-8"))}
+    ids, mask, _ = R.sents_to_features(SENTS, T, vocab)
+    ids, mask = torch.tensor(ids), torch.tensor(mask)
+    optim = BertAdam(list(m.parameters()), lr=1e-3, warmup=0.1, t_total=20)
+    Pref = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in filled.items()}
+    ref_opt = R.BertAdamRef(list(Pref.values()), lr=1e-3, warmup=0.1, t_total=20)
+    cfg = R.RefConfig(**CFG)
+    bce = torch.nn.BCEWithLogitsLoss()
+    m.eval()    # parity runs use dropout off (the reference's dropout stream cannot be reproduced); grads still flow
+    for step in range(3):
+        optim.zero_grad()
+        logit = m(feats.cuda(), boxes.cuda(), SENTS)
+        assert logit.dim() == 2 and logit.shape == (len(SENTS), CFG["num_answers"])
+        loss = bce(logit, target.cuda()) * logit.size(1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.)
+        optim.step()
+        batch_ref = dict(feats=feats, boxes=boxes, input_ids=ids, input_mask=mask, target=target)
+        loss_ref = R.train_step(Pref, cfg, batch_ref, ref_opt)
+        assert abs(loss.item() - loss_ref) < 1e-3 * max(1.0, abs(loss_ref)), (step, loss.item(), loss_ref)
+    sd = m.state_dict()
+    dead = 0
+    for k, p in Pref.items():
+        got = sd[k].cpu()
+        if ".x_layers.1.visn_" in k:       # never receive gradients in mode 'x': untouched by the optimizer in both
+            dead += 1
+            assert torch.equal(got, torch.from_numpy(filled[k])), k
+            continue
+        np.testing.assert_allclose(got.numpy(), p.detach().numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
+    assert dead == 16
+    named = dict(m.named_parameters())
+    assert all(named[k].grad is None for k in named if ".x_layers.1.visn_" in k)
+
+
+def test_gqa_model_bf16_forward_and_grads(env, golden_dir):
+    m, filled = build("bf16", 30)
+    from oracle import lxmert_ref as R
+    feats, boxes, target = batch(30)
+    vocab = {w.rstrip("\n"): i for i, w in enumerate(open(os.path.join(golden_dir, "g4_vocab.txt"), encoding="utf-8"))}
+    ids, mask, _ = R.sents_to_features(SENTS, 30, vocab)
+    lg_r, _, loss_r, Pr = oracle(filled, feats, boxes, torch.tensor(ids), torch.tensor(mask), target)
+    m.eval()
+    with torch.no_grad():
+        lg0 = m(feats.cuda(), boxes.cuda(), SENTS)
+    assert not lg0.requires_grad and float((lg0.cpu() - lg_r).abs().max()) < 6e-2
+    lg = m(feats.cuda(), boxes.cuda(), SENTS)
+    assert lg.requires_grad and torch.equal(lg, lg0)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(lg, target.cuda()) * lg.size(1)
+    loss.backward()
+    w = "lxrt_encoder.model.bert.encoder.x_layers.0.visual_attention.att.query.weight"
+    g = dict(m.named_parameters())[w].grad.cpu()
+    assert float((g - Pr[w].grad).norm() / Pr[w].grad.norm()) < 8e-2
+    # gradient accumulation: a second backward without zero_grad doubles the gradient
+    lg2 = m(feats.cuda(), boxes.cuda(), SENTS)
+    (torch.nn.functional.binary_cross_entropy_with_logits(lg2, target.cuda()) * lg2.size(1)).backward()
+    g2 = dict(m.named_parameters())[w].grad.cpu()
+    assert float((g2 - 2 * g).norm() / g.norm()) < 1e-2
+
+
+def test_encoder_alone_under_a_foreign_head(env):
+    """LXRTEncoder used the way tasks/vqa_model.py / nlvr2_model.py use it: pooled output feeds a caller-owned torch head;
+    gradients flow back through rgqa_engine_backward_pooled."""
+    from lxrt.entry import LXRTEncoder
+    from rgqa_amd import synth
+    from oracle import lxmert_ref as R
+    os.environ["RGQA_PRECISION"] = "f32"
+    args = types.SimpleNamespace(llayers=CFG["l_layers"], xlayers=CFG["x_layers"], rlayers=CFG["r_layers"], from_scratch=False)
+    enc = LXRTEncoder(args, max_seq_length=20)
+    filled = synth.fill_state_dict({"lxrt_encoder.model." + k: tuple(v.shape) for k, v in enc.model.state_dict().items()})
+    enc.model.load_state_dict({k[len("lxrt_encoder.model."):]: torch.from_numpy(v) for k, v in filled.items()})
+    enc = enc.cuda().eval()
+    head = torch.nn.Linear(CFG["hidden"], 5).cuda()
+    feats, boxes, _ = batch(20)
+    x = enc(SENTS, (feats.cuda(), boxes.cuda()))
+    assert x.shape == (len(SENTS), CFG["hidden"]) and x.requires_grad
+    (head(x) ** 2).sum().backward()
+    assert head.weight.grad is not None
+    # oracle: same encoder, same head
+    cfg = R.RefConfig(**CFG)
+    full = dict(filled)
+    for k, shp in R.param_shapes(cfg).items():
+        if k.startswith("logit_fc."):
+            full[k] = np.zeros(shp, dtype=np.float32)
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in full.items()}
+    vocab = enc.tokenizer.vocab
+    ids, mask, _ = R.sents_to_features(SENTS, 20, vocab)
+    _, _, pooled = R.encoder_forward(P, cfg, torch.tensor(ids), torch.zeros(len(SENTS), 20, dtype=torch.long), torch.tensor(mask), feats, boxes)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), pooled.detach().numpy(), rtol=0, atol=2e-5)
+    hw, hb = head.weight.detach().cpu(), head.bias.detach().cpu()
+    ((pooled @ hw.t() + hb) ** 2).sum().backward()
+    w = "lxrt_encoder.model.bert.encoder.layer.0.attention.self.value.weight"
+    got = dict(enc.model.named_parameters())[w[len("lxrt_encoder.model."):]].grad.cpu()
+    np.testing.assert_allclose(got.numpy(), P[w].grad.numpy(), rtol=2e-3, atol=1e-6 + 2e-4 * float(P[w].grad.abs().max()))
+    # save / load round trip (entry.py:122-152)
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rgqa_gpu_test")
+    enc.save(path)
+    before = {k: v.clone() for k, v in enc.model.state_dict().items()}
+    with torch.no_grad():
+        for p in enc.model.parameters():
+            p.add_(1.0)
+    enc.load(path)
+    after = enc.model.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    x2 = enc(SENTS, (feats.cuda(), boxes.cuda()))
+    assert torch.allclose(x2, x)            # bf16/f32 weight copies were refreshed after the in-place load
+    os.remove(path + "_LXRT.pth")
+
+
+def test_train_mode_runs_and_is_seeded(env):
+    """model.train(): dropout 0.1 active (reference BertConfig defaults); different forward calls draw different masks."""
+    import rgqa_amd.lxrt.modeling as M
+    from tasks.gqa_model import GQAModel
+    os.environ["RGQA_PRECISION"] = "bf16"
+    args = types.SimpleNamespace(llayers=2, xlayers=2, rlayers=1, from_scratch=True)
+    M.LXRTFeatureExtraction.from_pretrained = classmethod(
+        lambda cls, name, **kw: cls(M.BertConfig(CFG["vocab_size"], hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"],
+                                                 intermediate_size=CFG["inter"], max_position_embeddings=CFG["max_pos"]), **kw))
+    m = GQAModel(CFG["num_answers"], max_seq_length=20, model_args=args).cuda()
+    feats, boxes, target = batch(20)
+    m.train()
+    a = m(feats.cuda(), boxes.cuda(), SENTS)
+    b = m(feats.cuda(), boxes.cuda(), SENTS)
+    assert not torch.equal(a, b)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(b, target.cuda()) * b.size(1)
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    with pytest.raises(RuntimeError, match="newer forward"):
+        a.sum().backward()
+    m.eval()
+    c = m(feats.cuda(), boxes.cuda(), SENTS)
+    d = m(feats.cuda(), boxes.cuda(), SENTS)
+    assert torch.equal(c, d)

@@ -1,0 +1,190 @@
+"""CPU-only checks: host logic of the drop-in layer, the C-ABI surface, argument validation, and the N>1 gradient
+exchange over gloo (world_size 2).  No compute call is made on the HIP library here."""
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rgqa_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "rgqa.h")).read()
+    declared = set(re.findall(r"\b(rgqa_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib, name), "include/rgqa.h declares %s but librgqa_hip.so does not export it" % name
+        assert name in _lib.SIGNATURES, "no ctypes signature for %s" % name
+    assert lib.rgqa_version() >= 100
+
+
+def test_engine_layout_matches_reference_state_dict_contract():
+    """Engine parameter table == the reference's GQAModel state_dict keys/shapes, full 9/5/5 config;
+    fused-QKV contiguity and 64-element alignment hold; the dead range is exactly x_layers.4.visn_*."""
+    from oracle import lxmert_ref as R
+    from rgqa_amd.engine import Engine
+    e = Engine(precision="bf16")
+    ref = R.param_shapes(R.RefConfig())
+    got = {sp.name: sp.shape for sp in e.specs}
+    assert set(got) == set(ref)
+    assert all(tuple(ref[k]) == tuple(got[k]) for k in ref)
+    assert len(got) == 449 + 6
+    by = {sp.name: sp for sp in e.specs}
+    for sp in e.specs:
+        assert sp.offset % 64 == 0
+        if sp.name.endswith("query.weight"):
+            k, v = by[sp.name.replace("query", "key")], by[sp.name.replace("query", "value")]
+            assert k.offset == sp.offset + sp.numel and v.offset == k.offset + k.numel
+    dead = [sp for sp in e.specs if sp.dead]
+    assert len(dead) == 16 and all(".x_layers.4.visn_" in sp.name for sp in dead)
+    assert sum(sp.numel for sp in dead) == 7087872
+    b, en = e.dead_range
+    assert all(b <= sp.offset and sp.offset + sp.numel <= en for sp in dead)
+    assert sum(sp.numel for sp in e.specs if not sp.dead) == 204864306     # parameters with gradients
+
+
+def test_engine_create_rejects_bad_configs():
+    from rgqa_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="not a multiple of the number of attention"):
+        Engine(hidden=768, heads=7)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        Engine(hidden=96, heads=2)
+    with pytest.raises(RuntimeError):
+        Engine(hidden_dropout=1.5)
+    e = Engine()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        e.allocate("cpu")
+
+
+def test_tokenizer_and_features_match_reference_vectors(golden_dir):
+    from rgqa_amd.lxrt.tokenization import BertTokenizer
+    from rgqa_amd.lxrt.entry import convert_sents_to_features
+    g = json.load(open(os.path.join(golden_dir, "g4_tokenizer.json"), encoding="utf-8"))
+    tok = BertTokenizer(os.path.join(golden_dir, "g4_vocab.txt"), do_lower_case=True)
+    for T in (20, 30):
+        for _ in range(2):   # second pass is served by the per-string cache
+            feats = convert_sents_to_features(g["sentences"], T, tok)
+            assert [f.input_ids for f in feats] == g["T%d" % T]["input_ids"]
+            assert [f.input_mask for f in feats] == g["T%d" % T]["input_mask"]
+            assert [f.segment_ids for f in feats] == g["T%d" % T]["segment_ids"]
+    assert tok.tokenize("unaffable") == ["un", "##aff", "##able"]
+    assert tok.convert_ids_to_tokens(tok.convert_tokens_to_ids(["[CLS]", "dog", "[SEP]"])) == ["[CLS]", "dog", "[SEP]"]
+    with pytest.raises(ValueError):
+        BertTokenizer("/nonexistent/vocab.txt")
+    assert BertTokenizer.from_pretrained("/nonexistent-dir-xyz") is None      # reference returns None on a failed fetch
+
+
+def test_bertadam_validation_and_schedules():
+    from rgqa_amd.lxrt.optimization import BertAdam, warmup_linear, warmup_constant, warmup_cosine
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    for kw in (dict(lr=-1.0), dict(lr=1e-3, schedule="nope"), dict(lr=1e-3, warmup=1.5), dict(lr=1e-3, b1=1.0), dict(lr=1e-3, b2=-0.1), dict(lr=1e-3, e=-1.0)):
+        with pytest.raises(ValueError):
+            BertAdam(p, **kw)
+    assert warmup_linear(0.05, 0.1) == pytest.approx(0.5)
+    assert warmup_linear(0.1, 0.1) == pytest.approx(1.0)
+    assert warmup_linear(0.55, 0.1) == pytest.approx(0.5)
+    assert warmup_linear(1.2, 0.1) == 0
+    assert warmup_constant(0.5, 0.1) == 1.0 and warmup_cosine(0.05, 0.1) == pytest.approx(0.5)
+    opt = BertAdam(p, lr=1e-3, warmup=0.1, t_total=10)
+    assert opt.get_lr() == [0]
+    p[0].grad = torch.ones(3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        opt.step()
+
+
+def test_dropin_model_surface(golden_dir, monkeypatch):
+    """tasks.gqa_model.GQAModel / lxrt.entry.LXRTEncoder import under the reference's module names, carry the reference's
+    state_dict keys, and refuse to compute without a GPU."""
+    monkeypatch.setenv("RGQA_BERT_VOCAB", os.path.join(golden_dir, "g4_vocab.txt"))
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        from tasks.gqa_model import GQAModel, GQAModel_maha, MAX_GQA_LENGTH
+        from lxrt.entry import LXRTEncoder, convert_sents_to_features  # noqa: F401
+        from lxrt.modeling import BertLayerNorm, GeLU, VISUAL_CONFIG, BertConfig  # noqa: F401
+        from lxrt.optimization import BertAdam  # noqa: F401
+        import rgqa_amd.lxrt.modeling as M
+    finally:
+        sys.path.pop(0)
+    assert MAX_GQA_LENGTH == 30
+    monkeypatch.setattr(M.VISUAL_CONFIG, "visual_feat_dim", 64)
+    monkeypatch.setattr(M.LXRTFeatureExtraction, "from_pretrained", classmethod(
+        lambda cls, name, **kw: cls(M.BertConfig(80, hidden_size=128, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64), **kw)))
+    args = types.SimpleNamespace(llayers=2, xlayers=2, rlayers=1, from_scratch=True)
+    m = GQAModel(17, model_args=args)
+    from oracle import lxmert_ref as R
+    ref = R.param_shapes(R.RefConfig(vocab_size=80, hidden=128, heads=2, inter=256, max_pos=64, l_layers=2, x_layers=2, r_layers=1, feat_dim=64, num_answers=17))
+    sd = m.state_dict()
+    assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    assert isinstance(m.logit_fc[2], BertLayerNorm) and m.logit_fc[2].eps == 1e-12 and isinstance(m.logit_fc[1], GeLU)
+    assert m.lxrt_encoder.dim == 128 and m.lxrt_encoder.max_seq_length == 30
+    # init_bert_weights semantics: LN = 1/0, Linear bias = 0, weights ~ N(0, 0.02)
+    w = sd["lxrt_encoder.model.bert.encoder.layer.0.attention.self.query.weight"]
+    assert abs(float(w.std()) - 0.02) < 2e-3 and float(sd["logit_fc.2.weight"].min()) == 1.0 and float(sd["logit_fc.0.bias"].abs().max()) == 0.0
+    # state_dict round trip + `module.` prefix stripping of LXRTEncoder.load (entry.py:126-152)
+    enc_sd = {"module." + k: v.clone() + 1 for k, v in m.lxrt_encoder.model.state_dict().items()}
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rgqa_host_test")
+    torch.save(enc_sd, path + "_LXRT.pth")
+    m.lxrt_encoder.load(path)
+    assert torch.allclose(m.state_dict()["lxrt_encoder.model.bert.pooler.dense.bias"], enc_sd["module.bert.pooler.dense.bias"])
+    os.remove(path + "_LXRT.pth")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(2, 36, 64), torch.zeros(2, 36, 4), ["what is this", "is it red?"])
+    with pytest.raises(NotImplementedError):
+        M.LXRTFeatureExtraction(M.BertConfig(80, hidden_size=128, num_attention_heads=2, intermediate_size=256), mode="lxr")
+    with pytest.raises(ValueError):
+        M.BertConfig(3.5)
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from rgqa_amd.parallel import GradAllReduce
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    n = 1000
+    eng = types.SimpleNamespace(grads=torch.arange(n, dtype=torch.float32) * (rank + 1), live_ranges=lambda: [(0, 300), (364, n)])
+    GradAllReduce(eng, dist, bucket_mb=1).all_reduce()
+    q.put((rank, eng.grads.clone()))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2():
+    """DP exchange on CPU/gloo, world_size 2: live ranges are summed across ranks, the dead range is left alone."""
+    import torch.multiprocessing as mp
+    from rgqa_amd.parallel import bucket_ranges
+    assert bucket_ranges([(0, 10), (20, 25)], 4) == [(0, 4), (4, 8), (8, 10), (20, 24), (24, 25)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    base = torch.arange(1000, dtype=torch.float32)
+    for r in range(2):
+        g = res[r]
+        assert torch.equal(g[:300], base[:300] * 3) and torch.equal(g[364:], base[364:] * 3)
+        assert torch.equal(g[300:364], base[300:364] * (r + 1))
+
+
+def test_synth_batch_contract():
+    from rgqa_amd import synth
+    b = synth.synth_batch(8, 20, seed=1)
+    assert b["feats"].shape == (8, 36, 2048) and b["feats"].min() >= 0 and b["boxes"].shape == (8, 36, 4)
+    assert (b["boxes"][..., 0] <= b["boxes"][..., 2]).all() and (b["boxes"][..., 1] <= b["boxes"][..., 3]).all()
+    ids, m = b["input_ids"], b["input_mask"]
+    assert (ids[:, 0] == 101).all() and ((ids != 0) == (m == 1)).all()
+    for r in range(8):
+        L = int(m[r].sum())
+        assert ids[r, L - 1] == 102 and 5 <= L <= 20
+    assert set(np.unique(b["target"])) <= {0.0, 1.0} and (b["target"].sum(1) <= 1).all()
+    b2 = synth.synth_batch(8, 20, seed=1)
+    assert all(np.array_equal(b[k], b2[k]) for k in b)
