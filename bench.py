@@ -46,6 +46,11 @@ def cpu_baseline(T, sample_b, iters):
     from oracle import lxmert_ref as R
     from rgqa_amd import synth
     cfg = R.RefConfig(**FULL)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))     # the box's CPU share for one GPU
     torch.manual_seed(0)
     P = {}
     for k, shp in R.param_shapes(cfg).items():
@@ -74,7 +79,7 @@ def main():
     ap.add_argument("--seq", type=int, default=20)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--profile-steps", type=int, default=3)
     args = ap.parse_args()
 
@@ -151,7 +156,7 @@ def main():
             avg_ms = nt["ms"] / nt["launches"]
             ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=None, kernel="gemm_nt_kernel", launches_per_step=nt["launches"] // args.profile_steps,
+                        traffic=None, kernel="gemm_nt (gemm_nt256_kernel<EPI,MT> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
                         avg_launch_us=round(avg_ms * 1e3, 2), gflop_per_launch=round(per_launch_flops / 1e9, 3))
     if dist is not None:
         dist.barrier()
