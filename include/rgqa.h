@@ -58,6 +58,8 @@ int rgqa_engine_bind(rgqa_engine* e, float* params, float* grads, void* params_l
                      void* workspace, size_t ws_bytes, int B, int T, int O);
 /* refresh the low-precision weight copies from the f32 master arena (after load_state_dict / external updates) */
 int rgqa_engine_sync_weights(rgqa_engine* e, void* stream);
+/* same, but only the transposed copies: for use after rgqa_bertadam_step was given p_lp and already wrote the direct copy */
+int rgqa_engine_sync_transposed(rgqa_engine* e, void* stream);
 /* forward: feats [B,O,feat_dim] f32, boxes [B,O,pos_dim] f32, ids/seg/mask [B,T] i64 (seg may be null = zeros)
  * -> pooled [B,hidden] f32 (may be null), logits [B,num_answers] f32 with row stride ld_logits. train != 0
  * applies dropout (counter-based, keyed by seed) and keeps what backward needs. */

@@ -29,6 +29,7 @@ SIGNATURES = {
     "rgqa_engine_workspace_bytes": [_vp, _i, _i, _i, C.POINTER(_sz)],
     "rgqa_engine_bind": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i],
     "rgqa_engine_sync_weights": [_vp, _vp],
+    "rgqa_engine_sync_transposed": [_vp, _vp],
     "rgqa_engine_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _vp],
     "rgqa_engine_loss_backward": [_vp, _vp, _i, _vp, _f, _i, _vp],
     "rgqa_engine_backward": [_vp, _vp, _i, _i, _vp],

@@ -66,6 +66,7 @@ int rgqa_engine_bind(rgqa_engine* e, float* params, float* grads, void* plp, voi
     return e->impl->bind(params, grads, plp, plpt, ws, ws_bytes, B, T, O);
 }
 int rgqa_engine_sync_weights(rgqa_engine* e, void* stream) { NEED(e); return e->impl->sync_weights(S(stream)); }
+int rgqa_engine_sync_transposed(rgqa_engine* e, void* stream) { NEED(e); return e->impl->sync_transposed(S(stream)); }
 int rgqa_engine_forward(rgqa_engine* e, const float* feats, const float* boxes, const int64_t* ids, const int64_t* seg, const int64_t* mask,
                         float* pooled, float* logits, int ld_logits, int train, uint64_t seed, void* stream) {
     NEED(e);

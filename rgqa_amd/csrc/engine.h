@@ -82,6 +82,7 @@ public:
     virtual size_t workspace_bytes(int B, int T, int O) = 0;
     virtual int bind(float* p, float* g, void* plp, void* plpt, void* ws, size_t ws_bytes, int B, int T, int O) = 0;
     virtual int sync_weights(hipStream_t s) = 0;
+    virtual int sync_transposed(hipStream_t s) = 0;
     virtual int forward(const float* feats, const float* boxes, const int64_t* ids, const int64_t* seg, const int64_t* mask,
                         float* pooled_out, float* logits_out, int ld_logits, int train, uint64_t seed, hipStream_t s) = 0;
     virtual int loss_backward(const float* target, int ldt, float* loss_out, float grad_scale, int accumulate, hipStream_t s) = 0;

@@ -286,12 +286,18 @@ public:
     int sync_weights(hipStream_t s) override {
         RGQA_REQUIRE(P != nullptr, "sync_weights: engine not bound");
         if (!LP) return RGQA_OK;
+        int r = k_cast_bf16(P, Pb, arena_elems, s);
+        if (r) return r;
+        return sync_transposed(s);
+    }
+    // only the transposed bf16 copies (the optimizer kernel already wrote the direct bf16 copy)
+    int sync_transposed(hipStream_t s) override {
+        RGQA_REQUIRE(P != nullptr, "sync_transposed: engine not bound");
+        if (!LP) return RGQA_OK;
         if (!tdesc_uploaded) {
             RGQA_HIP(hipMemcpyAsync(tdesc, tdesc_host.data(), sizeof(TransDesc) * n_tdesc, hipMemcpyHostToDevice, s));
             tdesc_uploaded = true;
         }
-        int r = k_cast_bf16(P, Pb, arena_elems, s);
-        if (r) return r;
         return k_cast_transpose(P, PbT, tdesc, n_tdesc, tdesc_tiles, s);
     }
 
@@ -321,9 +327,10 @@ public:
         p.aux = aux; p.ldaux = ldaux; p.epi = epi;
     }
     // dW[wrow0 : wrow0+cols, :] (+)= dy[rows, cols]^T @ x[rows, in]   ; WGRAD
-    void add_wgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, const void* x, int ldx, int M, int accumulate) {
+    void add_wgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, const void* x, int ldx, int M, int accumulate, bool with_bias = false) {
         GemmProblem& p = g.p[g.count++];
         memset(&p, 0, sizeof p);
+        if (with_bias) p.colsum_out = G + l.b + wrow0;
         p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.K = M; p.M = wrows; p.N = l.in;
         p.C = G + l.w + (size_t)wrow0 * l.in; p.ldc = l.in; p.epi = accumulate ? EPI_ACCUM : EPI_BIAS;
     }
@@ -573,10 +580,8 @@ public:
                 CK(run_dgrad(g, s));
                 for (int m = 0; m < 2; ++m) if (st.active[m]) {
                     add_wgrad(wg, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, st.sb[m].h, I, seg_rows(m), accumulate);
-                    add_wgrad(wg, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, st.sb[m].x_in, H, seg_rows(m), accumulate);
+                    add_wgrad(wg, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, st.sb[m].x_in, H, seg_rows(m), accumulate, true);
                 }
-                for (int m = 0; m < 2; ++m) if (st.active[m])
-                    CK(colsum_bias(rowp(gh, m, I), I, st.ffn[m]->up, 0, I, seg_rows(m), accumulate, s));
                 gg_init(g);
                 for (int m = 0; m < 2; ++m) if (st.active[m])
                     add_dgrad(g, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, rowp(dx, m, H), H, seg_rows(m), EPI_ADD, rowp(gz, m, H), H);
@@ -635,22 +640,17 @@ public:
             if (shared_all) {
                 const AttP& ap = *st.att[0];
                 add_wgrad(wg, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, R, accumulate);
-                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, 3 * H, st.sb[0].x_in, H, R, accumulate);
-                CK(colsum_bias(gqkv, 3 * H, ap.qkv, 0, 3 * H, R, accumulate, s));
+                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, 3 * H, st.sb[0].x_in, H, R, accumulate, true);
             } else if (cross) {
                 const AttP& ap = *st.att[0];
                 add_wgrad(wg, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, Rl, accumulate);
-                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, H, st.sb[0].x_in, H, Rl, accumulate);
-                add_wgrad(wg, rowp(gqkv, 1, 3 * H) + H, 3 * H, ap.qkv, H, 2 * H, st.sb[1].x_in, H, Rv, accumulate);
-                CK(colsum_bias(gqkv, 3 * H, ap.qkv, 0, H, Rl, accumulate, s));
-                CK(colsum_bias(rowp(gqkv, 1, 3 * H), 3 * H, ap.qkv, H, 2 * H, Rv, accumulate, s));
+                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, H, st.sb[0].x_in, H, Rl, accumulate, true);
+                add_wgrad(wg, rowp(gqkv, 1, 3 * H) + H, 3 * H, ap.qkv, H, 2 * H, st.sb[1].x_in, H, Rv, accumulate, true);
             } else {
                 for (int m = 0; m < 2; ++m) if (st.active[m]) {
                     add_wgrad(wg, rowp(gzm, m, H), H, st.att[m]->o, 0, H, st.sb[m].ctx, H, seg_rows(m), accumulate);
-                    add_wgrad(wg, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, st.sb[m].x_in, H, seg_rows(m), accumulate);
+                    add_wgrad(wg, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, st.sb[m].x_in, H, seg_rows(m), accumulate, true);
                 }
-                for (int m = 0; m < 2; ++m) if (st.active[m])
-                    CK(colsum_bias(rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, seg_rows(m), accumulate, s));
             }
             // input gradient: dx = dqkv @ Wqkv + dz (residual path)
             gg_init(g);

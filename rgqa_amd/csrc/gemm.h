@@ -28,6 +28,7 @@ struct GemmProblem {
     int tile_start;     // first linear tile id of this problem in the grouped launch
     int tiles_n;        // number of tiles along N
     uint32_t drop_site; // mixed into the dropout stream for EPI_RESID_DROP
+    float* colsum_out;  // TN kernels only: colsum_out[m] (+)= sum_k A[k][m]  (bias gradient riding the wgrad GEMM), or null
     int epi;            // GemmEpi
 };
 

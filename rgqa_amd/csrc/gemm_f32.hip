@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g, int tr
     const long sam = trans_a ? 1 : P.lda, sak = trans_a ? P.lda : 1;
     const long sbn = trans_b ? 1 : P.ldb, sbk = trans_b ? P.ldb : 1;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    float acc[4][4];
+    float acc[4][4], cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = P.colsum_out != nullptr && (local % P.tiles_n) == 0 && tx == 0;   // bias gradient: column sums of A
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -58,8 +59,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g, int tr
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+            if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cs[i] += a[i];
+            }
         }
         __syncthreads();
+    }
+    if (do_cs) {
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ty * 4 + i;
+            if (m < P.M) P.colsum_out[m] = (P.epi == EPI_ACCUM) ? P.colsum_out[m] + cs[i] : cs[i];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -194,11 +194,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const GemmGroup g) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][4], cs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_cs = P.colsum_out != nullptr && (local % P.tiles_n) == 0 && wn == 0;   // see gemm_tn_dma_kernel
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
 
     gload(0);
     lwrite(0);
@@ -221,11 +227,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const GemmGroup g) {
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[tn], xa[tm], acc[tm][tn], 0, 0, 0);
+            if (do_cs) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa[tm], cs[tm], 0, 0, 0);
+            }
         }
         if (kt + 1 < nkt) lwrite(buf ^ 1);
         __syncthreads();
     }
     const int fr = lane & 15, fq = lane >> 4;
+    if (do_cs && fq == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int m = m0 + wm * 64 + tm * 16 + fr;
+            if (m < P.M) P.colsum_out[m] = (P.epi == EPI_ACCUM) ? P.colsum_out[m] + cs[tm][0] : cs[tm][0];
+        }
+    }
     {
         const int epi = P.epi;
         float bias_r[4][4];

@@ -317,11 +317,19 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
             __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + bo), (lds_void*)(base + A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][4], cs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // bias gradient = column sums of the A operand: one extra MFMA column against an all-ones fragment, done by the
+    // wn == 0 waves of the first N-tile of every M-tile (wave-uniform condition)
+    const bool do_cs = P.colsum_out != nullptr && (local % P.tiles_n) == 0 && wn == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
 
     issue(0, 0);
     __syncthreads();
@@ -343,8 +351,19 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[tn], xa[tm], acc[tm][tn], 0, 0, 0);
+            if (do_cs) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa[tm], cs[tm], 0, 0, 0);
+            }
         }
         __syncthreads();
+    }
+    if (do_cs && (lane >> 4) == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int m = m0 + wm * 64 + tm * 16 + (lane & 15);
+            if (m < P.M) P.colsum_out[m] = ACCUM ? P.colsum_out[m] + cs[tm][0] : cs[tm][0];
+        }
     }
     const int fr = lane & 15, fq = lane >> 4;
     float* Cc = reinterpret_cast<float*>(P.C);

@@ -190,11 +190,12 @@ class Engine:
             for i, (a, b) in enumerate(rngs):
                 check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
         for a, b in rngs:
+            lp = ptr(self.params_lp[a:b]) if self.precision == "bf16" else None     # the kernel re-casts the bf16 copy in the same pass
             check(self.lib.rgqa_bertadam_step(ptr(self.params[a:b]), ptr(self.grads[a:b]), ptr(self.adam_m[a:b]), ptr(self.adam_v[a:b]),
-                                              None, b - a, lr_t, b1, b2, eps, weight_decay, ptr(self._sumsq) if clip else None,
+                                              lp, b - a, lr_t, b1, b2, eps, weight_decay, ptr(self._sumsq) if clip else None,
                                               max_norm, grad_prescale, s))
         if self.precision == "bf16":
-            self.sync_weights()
+            check(self.lib.rgqa_engine_sync_transposed(self.h, s))
 
     def grad_norm(self):
         self.adam_m if self.adam_m is not None else None
