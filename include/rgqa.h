@@ -77,6 +77,14 @@ int rgqa_engine_backward_pooled(rgqa_engine* e, const float* dpooled, int ld, in
 /* debug / parity: copy a saved activation ("embed_lang", "embed_visn", "l3", "r1", "x2_lang", "x2_visn", "pooled") as f32 */
 int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, size_t cap_elems, void* stream);
 
+/* data-parallel overlap: the gradient arena becomes final range by range while backward runs (head first, embeddings
+ * last). grad_segment k = element range [begin,end) + the id of the event recorded on the backward stream once that
+ * range is final; wait_grad_event makes `stream` wait for it (hipStreamWaitEvent), so an all-reduce of the range can be
+ * enqueued on a side stream before backward has finished on the GPU. Dead parameters are in no segment. */
+int rgqa_engine_num_grad_segments(const rgqa_engine* e, int* out);
+int rgqa_engine_grad_segment(const rgqa_engine* e, int k, size_t* begin, size_t* end, int* event);
+int rgqa_engine_wait_grad_event(rgqa_engine* e, int event, void* stream);
+
 /* measurement: time every GEMM / attention launch with HIP events on the launch stream. profile_read synchronises
  * on the recorded events; categories: 0 gemm NT (fwd + dgrad), 1 gemm TN (wgrad), 2 attention fwd, 3 attention bwd,
  * 4 layernorm, 5 other. flops / bytes are algorithmic (2*M*N*K; operand + result bytes). */

@@ -91,6 +91,19 @@ int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, siz
     return e->impl->get_activation(name, out, cap, S(stream));
 }
 
+int rgqa_engine_num_grad_segments(const rgqa_engine* e, int* out) { NEED(e); *out = (int)e->impl->grad_segs.size(); return RGQA_OK; }
+int rgqa_engine_grad_segment(const rgqa_engine* e, int k, size_t* begin, size_t* end, int* event) {
+    NEED(e);
+    RGQA_REQUIRE(k >= 0 && k < (int)e->impl->grad_segs.size(), "grad_segment: index %d out of range", k);
+    *begin = e->impl->grad_segs[k].begin; *end = e->impl->grad_segs[k].end; *event = e->impl->grad_segs[k].event;
+    return RGQA_OK;
+}
+int rgqa_engine_wait_grad_event(rgqa_engine* e, int event, void* stream) {
+    NEED(e);
+    RGQA_REQUIRE(event >= 0 && event < (int)e->impl->seg_events.size(), "wait_grad_event: event %d has not been recorded (run backward first)", event);
+    RGQA_HIP(hipStreamWaitEvent(S(stream), e->impl->seg_events[event], 0));
+    return RGQA_OK;
+}
 int rgqa_engine_profile(rgqa_engine* e, int enable) { NEED(e); e->impl->profiling = enable != 0; return RGQA_OK; }
 int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* bytes, int64_t* launches, int ncat) {
     NEED(e);

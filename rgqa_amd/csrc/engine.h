@@ -88,6 +88,10 @@ public:
     virtual int loss_backward(const float* target, int ldt, float* loss_out, float grad_scale, int accumulate, hipStream_t s) = 0;
     virtual int backward(const float* dlogits, int ldd, int accumulate, hipStream_t s) = 0;
     virtual int backward_pooled(const float* dpooled, int ld, int accumulate, hipStream_t s) = 0;
+    // gradient-arena ranges in the order backward finishes them (for overlapping the DP exchange with backward)
+    struct GradSeg { size_t begin, end; int event; };
+    std::vector<GradSeg> grad_segs;
+    std::vector<hipEvent_t> seg_events;
     virtual int get_activation(const char* name, float* out, size_t cap_elems, hipStream_t s) = 0;
 };
 

@@ -143,6 +143,49 @@ public:
         cfg = c;
         build_params(cfg, params, mp, arena_elems, dead_begin, dead_end);
         build_transpose_table();
+        build_grad_segments();
+    }
+
+    // Completion order of backward: head+pooler, x-layers last..first, then l/r layers last..first, then the embeddings.
+    // Every layer occupies one contiguous arena range, so each segment is an element range + the event recorded when
+    // its last gradient kernel has been enqueued.
+    int n_seg_events = 0;
+    void build_grad_segments() {
+        grad_segs.clear();
+        int ev = 0;
+        auto seg = [&](size_t b, size_t e, int event) {
+            if (dead_end > dead_begin && b < dead_end && e > dead_begin) {      // cut the never-written dead range out
+                if (b < dead_begin) grad_segs.push_back({b, dead_begin, event});
+                if (e > dead_end) grad_segs.push_back({dead_end, e, event});
+            } else if (e > b) grad_segs.push_back({b, e, event});
+        };
+        seg(mp.pooler.w, arena_elems, ev++);
+        auto att_begin = [](const AttP& a) { return a.qkv.w; };
+        for (int i = cfg.x_layers - 1; i >= 0; --i) {
+            const size_t b = att_begin(mp.x_cross[i]);
+            const size_t e = (i + 1 < cfg.x_layers) ? att_begin(mp.x_cross[i + 1]) : mp.pooler.w;
+            seg(b, e, ev++);
+        }
+        const int nlr = cfg.l_layers > cfg.r_layers ? cfg.l_layers : cfg.r_layers;
+        const size_t l_end = cfg.r_layers ? att_begin(mp.r_att[0]) : (cfg.x_layers ? att_begin(mp.x_cross[0]) : mp.pooler.w);
+        const size_t r_end = cfg.x_layers ? att_begin(mp.x_cross[0]) : mp.pooler.w;
+        for (int i = nlr - 1; i >= 0; --i) {
+            if (i < cfg.l_layers) seg(att_begin(mp.l_att[i]), (i + 1 < cfg.l_layers) ? att_begin(mp.l_att[i + 1]) : l_end, ev);
+            if (i < cfg.r_layers) seg(att_begin(mp.r_att[i]), (i + 1 < cfg.r_layers) ? att_begin(mp.r_att[i + 1]) : r_end, ev);
+            ev++;
+        }
+        const size_t first_layer = cfg.l_layers ? att_begin(mp.l_att[0]) : (cfg.r_layers ? att_begin(mp.r_att[0]) : (cfg.x_layers ? att_begin(mp.x_cross[0]) : mp.pooler.w));
+        seg(0, first_layer, ev++);
+        n_seg_events = ev;
+    }
+    int seg_cursor = 0;
+    int mark_segment(hipStream_t s) {
+        if ((int)seg_events.size() < n_seg_events) {
+            seg_events.resize(n_seg_events);
+            for (auto& e : seg_events) RGQA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (seg_cursor < n_seg_events) RGQA_HIP(hipEventRecord(seg_events[seg_cursor++], s));
+        return RGQA_OK;
     }
 
     void build_transpose_table() {
@@ -557,6 +600,8 @@ public:
         T* dy = gA; T* dx = gB;
         CK(rgqa_check_hip(hipMemsetAsync(dy, 0, (size_t)R * H * sizeof(T), s), "zero dy"));
         gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, dy, Tn * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
+        seg_cursor = 0;
+        CK(mark_segment(s));     // head + pooler gradients are final
 
         // ---- encoder stages in reverse; weight-gradient GEMMs are collected per layer and launched once
         GemmGroup wg; gg_init(wg);
@@ -590,7 +635,7 @@ public:
                 for (int m = 0; m < 2; ++m) if (!st.active[m] && !st.last_dead)
                     CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
                 T* t = dy; dy = dx; dx = t;
-                if (st.layer_first) { CK(run_wgrad(wg, s)); gg_init(wg); }
+                if (st.layer_first) { CK(run_wgrad(wg, s)); gg_init(wg); CK(mark_segment(s)); }
                 continue;
             }
             // ---- attention stage backward
@@ -669,7 +714,7 @@ public:
                     CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
             }
             T* t = dy; dy = dx; dx = t;
-            if (st.layer_first) { CK(run_wgrad(wg, s)); gg_init(wg); }
+            if (st.layer_first) { CK(run_wgrad(wg, s)); gg_init(wg); CK(mark_segment(s)); }
         }
         CK(run_wgrad(wg, s));
         T* gz = gemb;
@@ -691,6 +736,7 @@ public:
             add_wgrad(g, dzf, H, mp.visn_fc, 0, H, in_feats, cfg.feat_dim, Rv, accumulate);
             CK(run_wgrad(g, s, LP ? 1 : 0));
         }
+        CK(mark_segment(s));     // embeddings + visual embedding
         return RGQA_OK;
     }
 

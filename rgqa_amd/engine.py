@@ -170,6 +170,21 @@ class Engine:
         check(self.lib.rgqa_engine_profile_read(self.h, ms, fl, by, ln, n))
         return {c: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=ln[i]) for i, c in enumerate(self.PROFILE_CATS)}
 
+    def grad_segments(self):
+        """[(begin, end, event)] gradient-arena ranges in the order backward finalises them (dead range excluded)."""
+        n = C.c_int()
+        check(self.lib.rgqa_engine_num_grad_segments(self.h, C.byref(n)))
+        out = []
+        b, e, ev = C.c_size_t(), C.c_size_t(), C.c_int()
+        for k in range(n.value):
+            check(self.lib.rgqa_engine_grad_segment(self.h, k, C.byref(b), C.byref(e), C.byref(ev)))
+            out.append((b.value, e.value, ev.value))
+        return out
+
+    def wait_grad_event(self, event, stream):
+        """Makes torch stream `stream` wait until the gradient segment(s) tagged `event` of the last backward are final."""
+        check(self.lib.rgqa_engine_wait_grad_event(self.h, event, C.c_void_p(stream.cuda_stream)))
+
     # ------------------------------------------------------------------ optimizer (fused clip + BertAdam over the arena)
     def live_ranges(self):
         b, e = self.dead_range

@@ -161,13 +161,18 @@ def test_gradient_allreduce_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        res = dict(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
     base = torch.arange(1000, dtype=torch.float32)
     for r in range(2):
         g = res[r]
@@ -188,3 +193,27 @@ def test_synth_batch_contract():
     assert set(np.unique(b["target"])) <= {0.0, 1.0} and (b["target"].sum(1) <= 1).all()
     b2 = synth.synth_batch(8, 20, seed=1)
     assert all(np.array_equal(b[k], b2[k]) for k in b)
+
+
+def test_gradient_segments_cover_live_arena_once():
+    """DP overlap contract: the engine's gradient segments (completion order) tile the live arena exactly once, never touch
+    the dead range, and merge into few large buckets."""
+    from rgqa_amd.engine import Engine
+    from rgqa_amd.parallel import merge_segments
+    e = Engine()
+    segs = e.grad_segments()
+    evs = [ev for _, _, ev in segs]
+    assert evs == sorted(evs) and evs[0] == 0 and len(set(evs)) == 1 + 5 + 9 + 1
+    cover = sorted((b, en) for b, en, _ in segs)
+    assert cover[0][0] == 0 and all(a[1] <= b[0] for a, b in zip(cover, cover[1:]))
+    db, de = e.dead_range
+    holes = [(a[1], b[0]) for a, b in zip(cover, cover[1:]) if a[1] != b[0]]
+    assert holes == [(db, de)] and cover[-1][1] == e.arena_elems
+    buckets = merge_segments(segs, 64 * (1 << 20) // 4)
+    assert sum(b[1] - b[0] for b in buckets) == sum(s[1] - s[0] for s in segs)
+    assert len(buckets) <= 12 and [b[2] for b in buckets] == sorted(b[2] for b in buckets)
+    flat = sorted((b[0], b[1]) for b in buckets)
+    assert all(a[1] <= b[0] for a, b in zip(flat, flat[1:]))
+    # every bucket waits for the LAST event among the segments it contains
+    for b0, b1, ev in buckets:
+        assert ev == max(s[2] for s in segs if b0 <= s[0] and s[1] <= b1)
