@@ -68,6 +68,25 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return cdf + x * pdf;
 }
 
+// Fast erf for the bf16 kernels: Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 absolute (two orders below bf16
+// resolution); the f32 parity kernels keep the library erff above. ~12 VALU instructions vs ~60 for erff.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_fast(float x) {
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
 // ---------------------------------------------------------------- counter-based dropout RNG
 // keep(seed, stream, idx): one 32-bit hash word per element; the same (seed, stream, idx) is re-derived in
 // the backward pass so no mask is stored.  `stream` separates the dropout sites of one step.

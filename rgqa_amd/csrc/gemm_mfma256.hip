@@ -19,6 +19,19 @@
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
+// LDS-DMA issued from inline asm: invisible to hipcc's s_waitcnt bookkeeping, so the compiler does not drain vmcnt(0)
+// in front of every ds_read of a K-step (it cannot prove the reads do not alias the in-flight DMA). Ordering is then
+// entirely ours: counted "s_waitcnt vmcnt(N)" + s_barrier before a stage is read.  lds_dst: wave-uniform LDS byte
+// address of the 1-KiB piece; gsrc: this lane's 16 source bytes. M0 is saved and restored inside the statement.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(p);
+}
+
 __device__ __forceinline__ int xcd_remap256(int b, int nwg) {
     int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
@@ -149,9 +162,9 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
                 for (int j = 0; j < 8; ++j) {
                     float x = v[j] + bias8[j];
                     pre[j] = x;
-                    if (EPI == EPI_GELU) x = gelu_f(x);
+                    if (EPI == EPI_GELU) x = gelu_fast(x);
                     else if (EPI == EPI_RESID_DROP) x = drop_apply(dcf, (uint32_t)m * (uint32_t)N + (uint32_t)(nb + j), x) + (float)ax[j];
-                    else if (EPI == EPI_DGELU) x = x * dgelu_f((float)ax[j]);
+                    else if (EPI == EPI_DGELU) x = x * dgelu_fast((float)ax[j]);
                     else if (EPI == EPI_ADD) x = x + (float)ax[j];
                     v[j] = x;
                 }
@@ -244,7 +257,7 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
 
 // ============================================================================ TN (wgrad) with LDS-DMA
 //   C[M,N] (f32) (+)= A[K,M]^T * B[K,N],  K % 64 == 0:  dW[n,k] = sum_rows dY[row,n] X[row,k]
-// 128 x 256 output tile, 8 waves (2 x 4, 64x64 each), 2 stages x (A 64x128 + B 64x256) bf16 = 96 KiB.
+// 128 x 256 output tile, 8 waves (2 x 4, 64x64 each), 3-stage ring x (A 64x128 + B 64x256) bf16 = 144 KiB.
 // Both operands are row-major over the CONTRACTION index, so the LDS images are natural row-major copies filled
 // by LDS-DMA and the MFMA fragments are fetched with ds_read_b64_tr_b16.  32-byte granules of a row are XOR-
 // swizzled with f(row) = (row&3) | ((row>>3)&1)<<2 so that the 8 (row, 32 B) pieces a half-wave touches per
@@ -283,7 +296,12 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
         if (i < g.count && tile >= g.p[i].tile_start) pi = i;
     const GemmProblem& P = g.p[pi];
-    const int local = tile - P.tile_start;
+    // XCD-aware order inside a problem: blocks that share an XCD (equal id mod 8) get CONSECUTIVE tile numbers, and tile
+    // numbers run over the M-tiles of one N-tile first, so the ~T/8 blocks co-resident on an XCD stream the same B
+    // operand (the wider one) through that XCD's L2: the loop is fabric-bound (48 KiB per K-step per CU) without it.
+    const int tiles_m = cdiv(P.M, WM);
+    const int tix = xcd_remap256(tile - P.tile_start, tiles_m * P.tiles_n);
+    const int local = (tix % tiles_m) * P.tiles_n + (tix / tiles_m);     // back to the m-major id used below
     const int m0 = (local / P.tiles_n) * WM, n0 = (local % P.tiles_n) * WN;
     const int nkt = P.K / TK;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
@@ -306,15 +324,14 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
         if (col > P.ldb - 8) col = P.ldb - 8;
         bsrc[i] = B + (size_t)row * P.ldb + col;
     }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int stage, int kt) {
-        unsigned char* base = lds + stage * STAGE;
+        const unsigned base = lds0 + stage * STAGE;
         const size_t ao = (size_t)kt * TK * P.lda, bo = (size_t)kt * TK * P.ldb;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + ao), (lds_void*)(base + (wave * 2 + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) dma16(asrc[i] + ao, base + (wave * 2 + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + bo), (lds_void*)(base + A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) dma16(bsrc[i] + bo, base + A_BYTES + (wave * 4 + i) * 1024);
     };
 
     f32x4 acc[4][4], cs[4];
@@ -331,11 +348,18 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
 
+    // 3-stage LDS ring, two K-steps of LDS-DMA in flight: every wave issues 6 DMA instructions per stage, so
+    // "s_waitcnt vmcnt(6)" = this wave's stage kt has landed while stage kt+1 stays in flight; the barrier then makes
+    // every wave's stage-kt data visible AND proves everyone is done reading stage kt-1, whose buffer the next issue
+    // overwrites.  __syncthreads() would drain vmcnt to 0 (hipcc) and serialise each K-step behind a full DMA latency.
     issue(0, 0);
-    __syncthreads();
+    if (nkt > 1) issue(1, 1);
     for (int kt = 0; kt < nkt; ++kt) {
-        const int st = kt & 1;
-        if (kt + 1 < nkt) issue(st ^ 1, kt + 1);
+        const int st = kt % 3;
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) issue((kt + 2) % 3, kt + 2);
         const unsigned char* a = lds + st * STAGE;
         const unsigned char* b = a + A_BYTES;
 #pragma unroll
@@ -356,7 +380,6 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
                 for (int tm = 0; tm < 4; ++tm) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa[tm], cs[tm], 0, 0, 0);
             }
         }
-        __syncthreads();
     }
     if (do_cs && (lane >> 4) == 0) {
 #pragma unroll
@@ -405,7 +428,7 @@ int launch_gemm_tn_dma_bf16(GemmGroup& g, hipStream_t s) {
     for (int i = 1; i < g.count; ++i)
         for (int j = i; j > 0 && g.p[j].K > g.p[j - 1].K; --j) { GemmProblem t = g.p[j]; g.p[j] = g.p[j - 1]; g.p[j - 1] = t; }
     gemm_group_finalize(g, WM, WN);
-    constexpr int LDS_BYTES = 2 * (TK * WM * 2 + TK * WN * 2);
+    constexpr int LDS_BYTES = 3 * (TK * WM * 2 + TK * WN * 2);
     static bool attr_set = false;
     if (!attr_set) {
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));

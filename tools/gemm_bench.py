@@ -29,6 +29,8 @@ def nt(M, N, K, epi=0):
     W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
     b = torch.randn(N, device="cuda")
     Cc = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    if epi:
+        print("epilogue %d:" % epi, end=" ")
     res = []
     run = lambda: _lib.check(lib.rgqa_op_linear(P(A), P(W), P(b), P(Cc), M, N, K, K, K, N, epi, 1, S()))
     lib.rgqa_debug_set(0, 1)
@@ -56,6 +58,7 @@ if __name__ == "__main__" and "--ksweep" not in sys.argv:
     for M in (() if "--tn" in sys.argv else (14336, 9216, 5120)):
         for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072)):
             nt(M, N, K)
+    nt(14336, 3072, 768, epi=1)
     nt(8192, 8192, 8192)
     nt(4096, 4096, 4096)
     for M, N in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
