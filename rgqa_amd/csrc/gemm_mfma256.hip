@@ -72,14 +72,14 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
         int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > N - 1) wn_ = N - 1;
         wsrc[i] = W + (size_t)wn_ * P.ldb + lch * 8;
     }
+    constexpr int NS = 2;   // LDS ring depth. 3 stages (MT <= 4 fits) measured SLOWER here: K is short (12 steps) and MT2 loses its 2 blocks/CU
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int stage, int kt) {
-        unsigned char* base = lds + stage * STAGE_BYTES;
+        const unsigned base = lds0 + stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < AG; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + kt * TK), (lds_void*)(base + (wave * AG + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < AG; ++i) dma16(asrc[i] + kt * TK, base + (wave * AG + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void*)(wsrc[i] + kt * TK), (lds_void*)(base + A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * TK, base + A_BYTES + (wave * 4 + i) * 1024);
     };
 
     f32x4 acc[MT][4];
@@ -88,12 +88,18 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ring: stages kt+1 .. kt+NS-2 stay in flight while stage kt is consumed (see gemm_tn_dma_kernel for the protocol)
     issue(0, 0);
-    __syncthreads();
+    if (NS == 3 && nkt > 1) issue(1, 1);
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < nkt; ++kt) {
-        const int st = kt & 1;
-        if (kt + 1 < nkt) issue(st ^ 1, kt + 1);
+        const int st = kt % NS;
+        if (NS == 3 && kt + 1 < nkt) {
+            if (AG == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // AG + 4 DMA instructions per wave per stage
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS, kt + NS - 1);
         const unsigned char* a = lds + st * STAGE_BYTES;
         const unsigned char* w = a + A_BYTES;
 #pragma unroll
@@ -109,8 +115,8 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[tn], xa, acc[tm][tn], 0, 0, 0);
             }
         }
-        __syncthreads();   // vmcnt(0): this wave's LDS-DMA for stage st^1 has landed; barrier: everyone is done with stage st
     }
+    __syncthreads();   // every wave is done with the operand stages before they are reused by the epilogue
     // ---- epilogue. The accumulators are transposed through a wave-private LDS region (the operand stages are dead
     // after the last barrier) so that every global access is a full 128-B line: 8 lanes x 16 B per output row,
     // instead of 16 rows x 32 B per store straight out of the MFMA layout (which ran HBM writes at ~1.5-2.4 TB/s).
