@@ -80,6 +80,20 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float r = 1.0f - p * t * __expf(-ax * ax);
     return copysignf(r, x);
 }
+// gelu(x) and gelu'(x) from one erf / one exp (the exp inside the erf approximation IS the Gaussian pdf term)
+__device__ __forceinline__ void gelu_and_grad_fast(float x, float& g, float& dg) {
+    const float z = x * 0.70710678118654752440f, az = fabsf(z);
+    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-az * az);                 // exp(-x^2/2)
+    const float erfv = copysignf(1.0f - p * t * e, z);
+    const float cdf = 0.5f * (1.0f + erfv);
+    g = x * cdf;
+    dg = cdf + x * 0.39894228040143267794f * e;
+}
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_fast(float x) {
     const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));

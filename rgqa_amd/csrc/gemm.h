@@ -4,10 +4,10 @@
 
 enum GemmEpi {
     EPI_BIAS = 0,        // C = acc + bias
-    EPI_GELU = 1,        // pre = acc + bias; C2 = pre (if C2); C = gelu(pre)            (BertIntermediate)
+    EPI_GELU = 1,        // pre = acc + bias; C = gelu(pre); C2 = gelu'(pre) (if C2)     (BertIntermediate; C2 feeds EPI_DGELU)
     EPI_TANH = 2,        // C = tanh(acc + bias)                                        (BertPooler)
     EPI_RESID_DROP = 3,  // C = dropout(acc + bias) + aux                               (BertAttOutput / BertOutput, pre-LN)
-    EPI_DGELU = 4,       // C = acc * gelu'(aux)                                        (dgrad through GeLU)
+    EPI_DGELU = 4,       // C = acc * aux, aux = the gelu'(pre) saved by EPI_GELU       (dgrad through GeLU)
     EPI_ADD = 5,         // C = acc + aux                                               (dgrad + residual-path gradient)
     EPI_ACCUM = 6,       // C += acc  (C must be f32)                                   (wgrad accumulate)
     EPI_DTANH = 7,       // C = acc * (1 - aux^2)                                       (dgrad through the pooler's tanh)
@@ -54,7 +54,7 @@ __device__ __forceinline__ void gemm_epilogue4_e(const GemmProblem& P, const int
     float pre[4] = {v[0], v[1], v[2], v[3]};
     if (epi == EPI_GELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_f(pre[i]);
+        for (int i = 0; i < 4; ++i) { v[i] = gelu_f(pre[i]); pre[i] = dgelu_f(pre[i]); }
     } else if (epi == EPI_TANH) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = tanhf(pre[i]);
@@ -70,7 +70,7 @@ __device__ __forceinline__ void gemm_epilogue4_e(const GemmProblem& P, const int
                 DropCfg d = drop; d.seed_hi ^= P.drop_site;
                 v[i] = drop_apply(d, idx, v[i]) + a[i];
             } else if (epi == EPI_DGELU) {
-                v[i] = v[i] * dgelu_f(a[i]);
+                v[i] = v[i] * a[i];
             } else if (epi == EPI_DTANH) {
                 v[i] = v[i] * (1.0f - a[i] * a[i]);
             } else {
@@ -147,7 +147,7 @@ __device__ __forceinline__ void epi_finish(const GemmProblem& P, const int epi, 
     float pre[4] = {v[0], v[1], v[2], v[3]};
     if (epi == EPI_GELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_f(pre[i]);
+        for (int i = 0; i < 4; ++i) { v[i] = gelu_f(pre[i]); pre[i] = dgelu_f(pre[i]); }
     } else if (epi == EPI_TANH) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = tanhf(pre[i]);
@@ -157,7 +157,7 @@ __device__ __forceinline__ void epi_finish(const GemmProblem& P, const int epi, 
         for (int i = 0; i < 4; ++i) v[i] = drop_apply(d, (uint32_t)m * (uint32_t)P.N + (uint32_t)(n0 + i), v[i]) + a[i];
     } else if (epi == EPI_DGELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] * dgelu_f(a[i]);
+        for (int i = 0; i < 4; ++i) v[i] = v[i] * a[i];
     } else if (epi == EPI_DTANH) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = v[i] * (1.0f - a[i] * a[i]);

@@ -168,9 +168,9 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
                 for (int j = 0; j < 8; ++j) {
                     float x = v[j] + bias8[j];
                     pre[j] = x;
-                    if (EPI == EPI_GELU) x = gelu_fast(x);
+                    if (EPI == EPI_GELU) gelu_and_grad_fast(pre[j], x, pre[j]);      // C = gelu, C2 = gelu' (consumed by EPI_DGELU)
                     else if (EPI == EPI_RESID_DROP) x = drop_apply(dcf, (uint32_t)m * (uint32_t)N + (uint32_t)(nb + j), x) + (float)ax[j];
-                    else if (EPI == EPI_DGELU) x = x * dgelu_fast((float)ax[j]);
+                    else if (EPI == EPI_DGELU) x = x * (float)ax[j];
                     else if (EPI == EPI_ADD) x = x + (float)ax[j];
                     v[j] = x;
                 }

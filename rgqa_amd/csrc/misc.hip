@@ -84,11 +84,11 @@ int k_to_f32(const T* src, int lds, float* dst, int ldd, int rows, int cols, hip
 template int k_to_f32<float>(const float*, int, float*, int, int, int, hipStream_t);
 template int k_to_f32<bf16_t>(const bf16_t*, int, float*, int, int, int, hipStream_t);
 
-// y = dy * gelu'(pre)   (head backward, where no GEMM sits between LN-bwd and the GeLU)
+// y = dy * dg, dg = the gelu'(pre) saved by the forward EPI_GELU epilogue (head backward: no GEMM between LN-bwd and GeLU)
 template <typename T>
 __global__ void dgelu_mul_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = from_f32<T>(to_f32(dy[i]) * dgelu_f(to_f32(pre[i])));
+        out[i] = from_f32<T>(to_f32(dy[i]) * to_f32(pre[i]));
 }
 template <typename T>
 int k_dgelu_mul(const T* dy, const T* pre, T* out, size_t n, hipStream_t s) {
