@@ -38,88 +38,15 @@ __device__ __forceinline__ int xcd_remap256(int b, int nwg) {
 }
 __device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
 
-// EPI is a compile-time constant: the generic (run-time switched) epilogue inlined 32x stops the compiler from
-// unrolling the accumulator loops and pushes the 128 accumulators into scratch.
+// ---- shared epilogue of the LDS-DMA NT kernels. The accumulators are transposed through a wave-private LDS region
+// (the operand stages are dead after the last barrier) so that every global access is a full 128-B line: 8 lanes x
+// 16 B per output row, instead of 16 rows x 32 B per store straight out of the MFMA layout (which ran HBM writes
+// at ~1.5-2.4 TB/s).
 template <typename OutT, int EPI, int MT>
-__global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroup g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    int tile = xcd_remap256(blockIdx.x, g.total_tiles), pi = 0;
-#pragma unroll
-    for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
-        if (i < g.count && tile >= g.p[i].tile_start) pi = i;
-    const GemmProblem& P = g.p[pi];
-    const int local = tile - P.tile_start;
-    constexpr int TM = 32 * MT, A_BYTES = TM * TK * 2, STAGE_BYTES = A_BYTES + TN * TK * 2, AG = MT / 2;
-    const int m0 = (local / P.tiles_n) * TM, n0 = (local % P.tiles_n) * TN;
-    const int M = P.M, N = P.N, nkt = P.K / TK;
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
-    const bf16_t* W = reinterpret_cast<const bf16_t*>(P.B);
-
-    // LDS-DMA: per stage wave w fills A row groups w*AG .. (8 rows each) and W row groups w*4 .. w*4+3
-    const int lrow = lane >> 3, lch = (lane & 7) ^ lrow;   // source chunk for this lane's linear LDS slot
-    const bf16_t* asrc[AG];
-    const bf16_t* wsrc[4];
-#pragma unroll
-    for (int i = 0; i < AG; ++i) {
-        int am = m0 + (wave * AG + i) * 8 + lrow; if (am > M - 1) am = M - 1;      // clamp: rows past the edge are never stored
-        asrc[i] = A + (size_t)am * P.lda + lch * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > N - 1) wn_ = N - 1;
-        wsrc[i] = W + (size_t)wn_ * P.ldb + lch * 8;
-    }
-    constexpr int NS = 2;   // LDS ring depth. 3 stages (MT <= 4 fits) measured SLOWER here: K is short (12 steps) and MT2 loses its 2 blocks/CU
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
-    auto issue = [&](int stage, int kt) {
-        const unsigned base = lds0 + stage * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < AG; ++i) dma16(asrc[i] + kt * TK, base + (wave * AG + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * TK, base + A_BYTES + (wave * 4 + i) * 1024);
-    };
-
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // ring: stages kt+1 .. kt+NS-2 stay in flight while stage kt is consumed (see gemm_tn_dma_kernel for the protocol)
-    issue(0, 0);
-    if (NS == 3 && nkt > 1) issue(1, 1);
+__device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmProblem& P, unsigned char* lds, int wave, int lane,
+                                               int m0, int n0, int wm, int wn, f32x4 (&acc)[MT][4]) {
+    const int M = P.M, N = P.N;
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int st = kt % NS;
-        if (NS == 3 && kt + 1 < nkt) {
-            if (AG == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // AG + 4 DMA instructions per wave per stage
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS, kt + NS - 1);
-        const unsigned char* a = lds + st * STAGE_BYTES;
-        const unsigned char* w = a + A_BYTES;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 xw[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) xw[t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, s * 4 + fq));
-#pragma unroll
-            for (int tm = 0; tm < MT; ++tm) {
-                const bf16x8 xa = *reinterpret_cast<const bf16x8*>(a + off256(wm * (16 * MT) + tm * 16 + fr, s * 4 + fq));
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[tn], xa, acc[tm][tn], 0, 0, 0);
-            }
-        }
-    }
-    __syncthreads();   // every wave is done with the operand stages before they are reused by the epilogue
-    // ---- epilogue. The accumulators are transposed through a wave-private LDS region (the operand stages are dead
-    // after the last barrier) so that every global access is a full 128-B line: 8 lanes x 16 B per output row,
-    // instead of 16 rows x 32 B per store straight out of the MFMA layout (which ran HBM writes at ~1.5-2.4 TB/s).
     {
         constexpr int TP = MT >= 4 ? MT / 2 : MT;          // m-tiles (16 rows) per pass; TP*4 KiB of f32 per wave
         unsigned char* wl = lds + wave * (TP * 4096);
@@ -190,6 +117,90 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             }
         }
     }
+}
+
+// EPI is a compile-time constant: the generic (run-time switched) epilogue inlined 32x stops the compiler from
+// unrolling the accumulator loops and pushes the 128 accumulators into scratch.
+template <typename OutT, int EPI, int MT>
+__global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tile = xcd_remap256(blockIdx.x, g.total_tiles), pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+        if (i < g.count && tile >= g.p[i].tile_start) pi = i;
+    const GemmProblem& P = g.p[pi];
+    const int local = tile - P.tile_start;
+    constexpr int TM = 32 * MT, A_BYTES = TM * TK * 2, STAGE_BYTES = A_BYTES + TN * TK * 2, AG = MT / 2;
+    const int m0 = (local / P.tiles_n) * TM, n0 = (local % P.tiles_n) * TN;
+    const int M = P.M, N = P.N, nkt = P.K / TK;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(P.B);
+
+    // LDS-DMA: per stage wave w fills A row groups w*AG .. (8 rows each) and W row groups w*4 .. w*4+3
+    const int lrow = lane >> 3, lch = (lane & 7) ^ lrow;   // source chunk for this lane's linear LDS slot
+    const bf16_t* asrc[AG];
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        int am = m0 + (wave * AG + i) * 8 + lrow; if (am > M - 1) am = M - 1;      // clamp: rows past the edge are never stored
+        asrc[i] = A + (size_t)am * P.lda + lch * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > N - 1) wn_ = N - 1;
+        wsrc[i] = W + (size_t)wn_ * P.ldb + lch * 8;
+    }
+    // LDS ring depth 2. Measured alternatives that LOST on these shapes (round 1): 3 stages for MT <= 4 (-10..20 %: MT2 loses
+    // its 2 blocks/CU, K is only 12 steps) and a K-step-32 / 4-stage ring (-15..25 %, also on 8192^3: one barrier per 16 MFMAs).
+    constexpr int NS = 2;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+    auto issue = [&](int stage, int kt) {
+        const unsigned base = lds0 + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < AG; ++i) dma16(asrc[i] + kt * TK, base + (wave * AG + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * TK, base + A_BYTES + (wave * 4 + i) * 1024);
+    };
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ring: stages kt+1 .. kt+NS-2 stay in flight while stage kt is consumed (see gemm_tn_dma_kernel for the protocol)
+    issue(0, 0);
+    if (NS == 3 && nkt > 1) issue(1, 1);
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int st = kt % NS;
+        if (NS == 3 && kt + 1 < nkt) {
+            if (AG == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // AG + 4 DMA instructions per wave per stage
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS, kt + NS - 1);
+        const unsigned char* a = lds + st * STAGE_BYTES;
+        const unsigned char* w = a + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 xw[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xw[t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, s * 4 + fq));
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm) {
+                const bf16x8 xa = *reinterpret_cast<const bf16x8*>(a + off256(wm * (16 * MT) + tm * 16 + fr, s * 4 + fq));
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[tn], xa, acc[tm][tn], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with the operand stages before they are reused by the epilogue
+    nt256_epilogue<OutT, EPI, MT>(g, P, lds, wave, lane, m0, n0, wm, wn, acc);
 }
 
 // Tile height per launch: the MT in {8,6,4,2} (TM = 256/192/128/64) that minimises rounds-over-256-CUs x per-tile cost.
