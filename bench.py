@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--mixup", action="store_true",
+                    help="BASELINE config 4: RoI-mixup finetune (gqa_mixup_vis.py:134-181): every loader batch is doubled on the device "
+                         "(mixup_v1, Beta(1,5)); the model sees 2x rows per QA pair; value still counts loader QA pairs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +108,32 @@ def main():
     init_params(e, seed=0)       # identical replica on every rank
     b = synth.synth_batch(B, T, seed=1234 + rank)
     dev = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
-    e.ensure_shape(B, T, O)
+    MB = B                       # rows the model sees per step
+    if args.mixup:
+        import ctypes as C
+        from rgqa_amd._lib import check, ptr
+        MB = 2 * B
+        rs = np.random.RandomState(777 + rank)
+        dev = {k: torch.cat([v, torch.zeros_like(v)], 0).contiguous() for k, v in dev.items()}
+        dev["input_ids"][B:] = dev["input_ids"][:B]          # sent = sent + sent (gqa_mixup_vis.py:181)
+        dev["input_mask"][B:] = dev["input_mask"][:B]
+
+        def mixup_batch():
+            """host draws exactly as the reference (partner != self, prop ~ Beta(1,5), int(prop*36) shuffled RoI indices),
+            then ONE device gather + target scaling (rgqa_mixup_gather / rgqa_scale_rows)."""
+            partner = (np.arange(B) + rs.randint(1, B, size=B)) % B
+            prop = rs.beta(1.0, 5.0, size=B)
+            take = np.zeros((B, O), dtype=np.uint8)
+            for j in range(B):
+                take[j, rs.permutation(O)[: int(prop[j] * O)]] = 1
+            pg = torch.from_numpy(partner.astype(np.int32)).cuda(non_blocking=True)
+            tg = torch.from_numpy(take).cuda(non_blocking=True)
+            sg = torch.from_numpy(prop.astype(np.float32)).cuda(non_blocking=True)
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            check(e.lib.rgqa_mixup_gather(ptr(dev["feats"]), ptr(dev["boxes"]), ptr(pg), ptr(tg), B, O, 2048, 0, st))
+            check(e.lib.rgqa_scale_rows(ptr(dev["target"]), ptr(sg), B, dev["target"].shape[1], dev["target"].stride(0), B, st))
+            return pg, tg, sg
+    e.ensure_shape(MB, T, O)
     e.sync_weights()
     comm = GradAllReduce(e, dist) if world > 1 else None
     t_total = 10000
@@ -113,6 +141,8 @@ def main():
 
     def step():
         i = state["step"]
+        if args.mixup:
+            state["keep"] = mixup_batch()
         e.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=True, seed=4321 + rank + 1000003 * i)
         e.loss_backward(dev["target"])
         if comm is not None:
@@ -155,8 +185,12 @@ def main():
             per_launch_flops = nt["flops"] / nt["launches"]
             avg_ms = nt["ms"] / nt["launches"]
             ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_nt.json")    # separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+            if os.path.exists(pmc) and B == 256 and T == 20 and not args.mixup:
+                traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=None, kernel="gemm_nt (gemm_nt256_kernel<EPI,MT> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
+                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", algorithmic_bytes_per_launch=round(nt["bytes"] / nt["launches"]), kernel="gemm_nt (gemm_nt256_kernel<EPI,MT> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
                         avg_launch_us=round(avg_ms * 1e3, 2), gflop_per_launch=round(per_launch_flops / 1e9, 3))
     if dist is not None:
         dist.barrier()
@@ -166,12 +200,13 @@ def main():
         cpu = cpu_baseline(T, args.cpu_sample, 2)
 
     if rank == 0:
-        step_tflops = value * FWD_BWD_GFLOP.get(T, FWD_BWD_GFLOP[20]) / 1e3
+        step_tflops = value * FWD_BWD_GFLOP.get(T, FWD_BWD_GFLOP[20]) / 1e3 * (MB // B)
         out = {
             "metric": "QA-pairs/sec (train step) LXMERT-GQA B=256", "value": round(value, 1), "unit": "QA-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "LXMERT-GQA RP finetune train step (fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768",
+            "config": {"workload": ("LXMERT-GQA RoI-mixup finetune train step (device mixup + fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768" if args.mixup else
+                                    "LXMERT-GQA RP finetune train step (fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768"), "model_rows_per_gpu": MB,
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "rois": O, "feat_dim": 2048,
                        "num_answers": 1842, "parallelism": "dp%d" % world, "dropout": 0.1},
             "step_model_tflops_per_gpu": round(step_tflops / world, 1),

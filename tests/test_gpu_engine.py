@@ -177,3 +177,26 @@ def test_dropout_train_mode_is_deterministic_and_consistent():
     e.params.copy_(base)
     num = (vals[0] - vals[1]) / (2 * eps)
     assert abs(num - ana) / max(1e-6, abs(ana)) < 2e-2, (num, ana)
+
+
+def test_config2_forward_b256_f32_logits_vs_cpu():
+    """BASELINE config 2: forward-only inference at B=256 (full 9/5/5 architecture, f32 operands); samples are independent,
+    so the CPU oracle is evaluated on a spread of 6 of the 256 rows and must agree within 1e-3 (observed ~1e-5)."""
+    from oracle import lxmert_ref as R
+    B, T = 256, 20
+    b = synth.synth_batch(B, T, seed=2024)
+    e = make_engine(FULL, "f32")
+    d = dev(b)
+    e.ensure_shape(B, T, 36)
+    e.sync_weights()
+    lg, pl = run(e, d)
+    pick = [0, 1, 77, 128, 200, 255]
+    cfg = R.RefConfig(**FULL)
+    P = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(R.param_shapes(cfg)).items()}
+    with torch.no_grad():
+        lr, pr = R.gqa_forward(P, cfg, torch.from_numpy(b["feats"][pick]), torch.from_numpy(b["boxes"][pick]),
+                               torch.from_numpy(b["input_ids"][pick]), torch.from_numpy(b["input_mask"][pick]))
+    err = float((lg[pick].cpu() - lr).abs().max())
+    assert err <= 1e-3, err
+    assert float((pl[pick].cpu() - pr).abs().max()) <= 1e-3
+    assert torch.isfinite(lg).all()
