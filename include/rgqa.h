@@ -31,6 +31,9 @@ typedef struct rgqa_config {
     int32_t precision;                                            /* RGQA_PRECISION_* */
     float ln_eps;                                                 /* 1e-12 everywhere in the reference */
     float hidden_dropout, attn_dropout;                           /* 0.1 / 0.1, lxrt/modeling.py:182-183 */
+    int32_t arch;     /* 0 = LXMERT-GQA (default); 1 = BUTD-GQA (butd/butd.py:108-221): hidden = 1024, vocab_size = ntoken+1,
+                         hidden_dropout = answer dropout 0.5, attn_dropout = attention dropout 0.2; layer counts / heads / inter unused */
+    int32_t emb_dim;  /* BUTD word-embedding size (300) */
 } rgqa_config;
 
 typedef struct rgqa_engine rgqa_engine;

@@ -322,12 +322,67 @@ def gen_mixup():
     print("g5 ok")
 
 
+BUTD_WORDS = "what color is the dog 's a an on in to left right man woman cat table red blue who holding bottle".split()
+BUTD_SENTS = ["What color is the man's dog?", "Is the cat on the table, to the left?", "who is holding the red bottle", "zebra", ""]
+
+
+def gen_butd():
+    """G7: the reference's GQABUTD (butd/butd.py) with a 22-word dictionary, hidden 1024 is fixed by the class, so the
+    fixture keeps the real architecture and only shrinks the batch (B=5, 36 RoIs): logits, attention, loss, all gradients'
+    norms + samples."""
+    from butd.butd import GQABUTD
+    from butd.preprocess import Dictionary
+    d = Dictionary()
+    for w in BUTD_WORDS:
+        d.add_word(w)
+    NA = 23
+    torch.manual_seed(0)
+    m = GQABUTD(NA, d, dropout=False)
+    sd = m.state_dict()
+    filled = {}
+    for k, v in sd.items():
+        if k.endswith("weight_g"):
+            filled[k] = np.asarray(1.5 + 0.5 * synth.uniform(k, (1,), -1, 1)[0], dtype=np.float32)
+        elif k.endswith("weight_v") or "rnn.weight" in k:
+            filled[k] = synth.uniform(k, tuple(v.shape), -0.05, 0.05)
+        elif k == "w_emb.emb.weight":
+            w = synth.uniform(k, tuple(v.shape), -0.5, 0.5)
+            w[-1] = 0.0      # padding row
+            filled[k] = w
+        else:
+            filled[k] = synth.uniform(k, tuple(v.shape), -0.05, 0.05)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in filled.items()})
+    B = len(BUTD_SENTS)
+    b = synth.synth_batch(B, 8, O=36, F=2048, NA=NA, vocab=64, seed=606, uq_frac=0.2)
+    feat, pos, target = torch.from_numpy(b["feats"]), torch.from_numpy(b["boxes"]), torch.from_numpy(b["target"])
+    toks = m.tokenize(BUTD_SENTS)
+    m.eval()
+    # forward without the hard-coded .cuda() of butd.py:197: same statements, tokens stay on the host
+    w_emb = m.w_emb(toks)
+    q_enc = m.q_enc(w_emb)
+    image_features = torch.cat([feat, pos], dim=2)
+    att = m.att(image_features, q_enc)
+    img_enc = (image_features * att).sum(dim=1)
+    joint = m.q_project(q_enc) * m.img_project(img_enc)
+    logit = m.ans_classifier(joint)
+    loss = torch.nn.BCEWithLogitsLoss()(logit, target) * logit.size(1)
+    loss.backward()
+    z = {"toks": toks.numpy(), "logits": logit.detach().numpy(), "att": att.detach().numpy(), "loss": np.float32(loss.item()),
+         "q_enc": q_enc.detach().numpy()}
+    for k, p in m.named_parameters():
+        g = p.grad.numpy()
+        z["gnorm." + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        z["gsamp." + k] = g.reshape(-1)[sample_idx(k, g.size)]
+    np.savez_compressed(os.path.join(OUT, "g7_butd.npz"), **z)
+    print("g7 loss=%.5f" % loss.item())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     M, OPT, TOK, ENT = import_reference()
-    which = sys.argv[1:] or ["small", "full", "adam", "tok", "mixup"]
+    which = sys.argv[1:] or ["small", "full", "adam", "tok", "mixup", "butd"]
     if "small" in which:
         gen_small(M)
     if "adam" in which:
@@ -336,6 +391,8 @@ def main():
         gen_tokenizer(TOK, ENT)
     if "mixup" in which:
         gen_mixup()
+    if "butd" in which:
+        gen_butd()
     if "full" in which:
         gen_full(M)
 

@@ -11,7 +11,7 @@ PREC_F32, PREC_BF16 = 0, 1
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("vocab_size", "hidden", "heads", "inter", "max_pos", "type_vocab", "l_layers",
                                          "x_layers", "r_layers", "feat_dim", "pos_dim", "num_answers", "precision")] + \
-               [("ln_eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float)]
+               [("ln_eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float), ("arch", C.c_int32), ("emb_dim", C.c_int32)]
 
 
 _vp, _sz, _i, _f, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_uint64

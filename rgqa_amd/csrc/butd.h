@@ -1,0 +1,17 @@
+// BUTD path kernel launchers (butd_kernels.hip).
+#pragma once
+#include "common.h"
+template <typename T> int kb_embed_fwd(const int64_t* toks, const float* table, T* out, int rows, int E, int Ep, hipStream_t s);
+template <typename T> int kb_embed_bwd(const int64_t* toks, const T* dx, float* dtable, int rows, int E, int Ep, int pad_idx, hipStream_t s);
+template <typename T> int kb_gru_fwd(const T* gi, long ldgi, const T* gh, const T* hprev, T* hnew, T* rs, T* zs, T* ns, T* ghn, int B, int H, hipStream_t s);
+template <typename T> int kb_gru_bwd(const T* dh, const T* hprev, const T* rs, const T* zs, const T* ns, const T* ghn, T* dgi, long lddgi, T* dgh, T* dhprev, int B, int H, hipStream_t s);
+template <typename T> int kb_concat(const float* feat, const float* pos, T* out, int rows, int F, int Pd, int Dp, hipStream_t s);
+template <typename T> int kb_attend_fwd(const T* ip, const T* qp, const float* wlin, const float* blin, const T* imgf, float* att, T* img_enc, int B, int O, int H, int Dp, DropCfg drop, hipStream_t s);
+template <typename T> int kb_attend_bwd(const T* dimg, const T* imgf, const float* att, const T* ip, const T* qp, const float* wlin, T* dip, T* dqp, float* dw_part, float* db_part,
+                                        int B, int O, int H, int Dp, DropCfg drop, hipStream_t s);
+template <typename T> int kb_mul_fwd(const T* a, const T* b, T* out, size_t n, hipStream_t s);
+template <typename T> int kb_mul_relu_bwd(const T* dj, const T* a, const T* b, T* da, T* db, size_t n, hipStream_t s);
+// effective weight of a (weight-normed when g != null) linear: w [N, ldo] (+ transposed wt [K, ldt] when wt != null)
+template <typename T> int kb_wn_eff(const float* v, const float* g, const float* sumsq, T* w, int ldo, T* wt, int ldt, int N, int K, hipStream_t s);
+// gradient of V (and g) from the gradient of the effective weight; plain copy when g == null. partial: >= 256 floats
+int kb_wn_bwd(const float* dw, int lddw, const float* v, const float* g, const float* sumsq, float* partial, float* dv, float* dg, int N, int K, int accumulate, hipStream_t s);

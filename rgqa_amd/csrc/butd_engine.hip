@@ -1,0 +1,303 @@
+// BUTD GQA engine (reference src/butd/butd.py:108-221 GQABUTD; BASELINE config 5): same EngineBase /
+// C-ABI surface as the LXMERT engine (rgqa_config.arch = 1).  input_ids carries the front-padded dictionary tokens
+// [B, L]; segment_ids / input_mask are ignored.  The projections run on the shared GEMM kernels (bf16 MFMA or exact f32),
+// weight-norm (scalar g) is folded into an effective-weight copy refreshed by sync_weights().
+#include "engine.h"
+#include "butd.h"
+#include <string.h>
+
+static inline size_t rupb(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+__global__ void butd_bias_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+__global__ void butd_sum_small_kernel(const float* __restrict__ src, int n, float* __restrict__ dst, int accumulate) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += src[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float v = red[0] + red[1] + red[2] + red[3]; dst[0] = accumulate ? dst[0] + v : v; }
+}
+
+struct BLin {            // one linear layer: V (or W) [out, in], optional scalar g, bias [out]
+    size_t v, g, b; int out, in, kp, op; bool wn;
+    size_t eff, efft;    // byte offsets of the effective-weight copies in the workspace
+    int norm;            // index of its ||V||^2 scalar
+};
+
+template <typename T>
+class ButdEngine : public EngineBase {
+public:
+    static constexpr bool LP = !std::is_same<T, float>::value;
+    size_t emb = 0;
+    BLin wih, whh, ip, qp, lin, qproj, iproj, c0, c3;
+    std::vector<BLin*> lins;
+    int H, E, Ep, D, Dp, NA, NAp;
+    // bound
+    float* P = nullptr; float* G = nullptr; char* ws = nullptr; size_t ws_used = 0; bool dry = false;
+    int B = 0, L = 0, O = 0;
+    const float* in_feats = nullptr; const float* in_boxes = nullptr; const int64_t* in_toks = nullptr;
+    int last_train = 0; uint64_t last_seed = 0; bool have_fwd = false;
+    // workspace
+    float *sumsq = nullptr, *partial = nullptr, *wlin_eff = nullptr, *att = nullptr, *logits = nullptr, *dwscr = nullptr, *dw_part = nullptr, *db_part = nullptr, *loss_dev = nullptr;
+    T *X = nullptr, *GI = nullptr, *GH = nullptr, *Hall = nullptr, *Rg = nullptr, *Zg = nullptr, *Ng = nullptr, *GHN = nullptr;
+    T *IF = nullptr, *IP = nullptr, *QP = nullptr, *IE = nullptr, *QR = nullptr, *IR = nullptr, *J = nullptr, *C1 = nullptr, *dlogits = nullptr;
+    T *dC1 = nullptr, *dJ = nullptr, *dQR = nullptr, *dIR = nullptr, *dIE = nullptr, *dIP = nullptr, *dQP = nullptr, *dq = nullptr, *dHa = nullptr, *dHb = nullptr,
+      *dGI = nullptr, *dGH = nullptr, *dX = nullptr, *tmpH = nullptr;
+
+    explicit ButdEngine(const rgqa_config& c) {
+        cfg = c;
+        H = c.hidden; E = c.emb_dim; Ep = (int)rupb(E, 8); D = c.feat_dim + c.pos_dim; Dp = (int)rupb(D, 8); NA = c.num_answers; NAp = (int)rupb(NA, 64);
+        size_t cur = 0;
+        auto add = [&](const std::string& name, long d0, long d1, int nd) {
+            cur = rupb(cur, 64);
+            ParamInfo p; p.name = name; p.offset = cur; p.ndim = nd; p.shape[0] = d0; p.shape[1] = d1; p.is_linear_weight = 0; p.dead_in_x_mode = 0;
+            params.push_back(p);
+            size_t n = nd == 0 ? 1 : (size_t)d0 * (nd == 2 ? (size_t)d1 : 1);
+            size_t off = cur; cur += n; return off;
+        };
+        emb = add("w_emb.emb.weight", c.vocab_size, E, 2);
+        int nnorm = 0;
+        auto plain = [&](BLin& l, const std::string& wname, const std::string& bname, int o, int i) {
+            l.out = o; l.in = i; l.kp = (int)rupb(i, 8); l.op = (int)rupb(o, 64); l.wn = false; l.g = 0; l.norm = -1;
+            l.v = add(wname, o, i, 2);
+            (void)bname;
+        };
+        plain(wih, "q_enc.rnn.weight_ih_l0", "", 3 * H, E);
+        plain(whh, "q_enc.rnn.weight_hh_l0", "", 3 * H, H);
+        wih.b = add("q_enc.rnn.bias_ih_l0", 3 * H, 0, 1);
+        whh.b = add("q_enc.rnn.bias_hh_l0", 3 * H, 0, 1);
+        auto wn = [&](BLin& l, const std::string& name, int o, int i) {
+            l.out = o; l.in = i; l.kp = (int)rupb(i, 8); l.op = (int)rupb(o, 64); l.wn = true; l.norm = nnorm++;
+            l.b = add(name + ".bias", o, 0, 1);
+            l.g = add(name + ".weight_g", 0, 0, 0);
+            l.v = add(name + ".weight_v", o, i, 2);
+        };
+        wn(ip, "att.image_proj.mlp.0", H, D);
+        wn(qp, "att.question_proj.mlp.0", H, H);
+        wn(lin, "att.linear", 1, H);
+        wn(qproj, "q_project.mlp.0", H, H);
+        wn(iproj, "img_project.mlp.0", H, D);
+        wn(c0, "ans_classifier.0", 2 * H, H);
+        wn(c3, "ans_classifier.3", NA, 2 * H);
+        arena_elems = rupb(cur, 64);
+        dead_begin = dead_end = 0;
+        lins = {&wih, &whh, &ip, &qp, &lin, &qproj, &iproj, &c0, &c3};
+        grad_segs.push_back({0, arena_elems, 0});
+    }
+
+    template <typename U> U* take(size_t n) {
+        size_t bytes = rupb(n * sizeof(U), 256);
+        U* p = dry ? nullptr : reinterpret_cast<U*>(ws + ws_used);
+        ws_used += bytes;
+        return p;
+    }
+    void plan(int B_, int L_, int O_) {
+        B = B_; L = L_; O = O_;
+        ws_used = 0;
+        sumsq = take<float>(64); loss_dev = take<float>(64);
+        { size_t pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp; partial = take<float>(256 * pw); }
+        for (BLin* l : lins) {
+            l->eff = ws_used; take<T>((size_t)l->out * l->kp);
+            l->efft = ws_used; take<T>((size_t)l->kp * l->op);
+        }
+        wlin_eff = take<float>(H);
+        X = take<T>((size_t)B * L * Ep); GI = take<T>((size_t)B * L * 3 * H); GH = take<T>((size_t)B * 3 * H);
+        Hall = take<T>((size_t)(L + 1) * B * H);
+        Rg = take<T>((size_t)L * B * H); Zg = take<T>((size_t)L * B * H); Ng = take<T>((size_t)L * B * H); GHN = take<T>((size_t)L * B * H);
+        IF = take<T>((size_t)B * O * Dp); IP = take<T>((size_t)B * O * H); QP = take<T>((size_t)B * H); att = take<float>((size_t)B * O);
+        IE = take<T>((size_t)B * Dp); QR = take<T>((size_t)B * H); IR = take<T>((size_t)B * H); J = take<T>((size_t)B * H); C1 = take<T>((size_t)B * 2 * H);
+        logits = take<float>((size_t)B * NAp); dlogits = take<T>((size_t)B * NAp);
+        dC1 = take<T>((size_t)B * 2 * H); dJ = take<T>((size_t)B * H); dQR = take<T>((size_t)B * H); dIR = take<T>((size_t)B * H); dIE = take<T>((size_t)B * Dp);
+        dIP = take<T>((size_t)B * O * H); dQP = take<T>((size_t)B * H); dq = take<T>((size_t)B * H); dHa = take<T>((size_t)B * H); dHb = take<T>((size_t)B * H);
+        tmpH = take<T>((size_t)B * H);
+        dGI = take<T>((size_t)B * L * 3 * H); dGH = take<T>((size_t)L * B * 3 * H); dX = take<T>((size_t)B * L * Ep);
+        size_t mw = 0;
+        for (BLin* l : lins) { size_t n = (size_t)l->out * l->kp; if (n > mw) mw = n; }
+        dwscr = take<float>(mw); dw_part = take<float>((size_t)B * H); db_part = take<float>(B);
+    }
+    size_t workspace_bytes(int B_, int L_, int O_) override { dry = true; plan(B_, L_, O_); dry = false; return ws_used + 256; }
+    int bind(float* p, float* g, void*, void*, void* w, size_t wb, int B_, int L_, int O_) override {
+        RGQA_REQUIRE(p != nullptr && w != nullptr, "bind: null parameter arena or workspace");
+        RGQA_REQUIRE(B_ > 0 && L_ > 0 && O_ > 0 && O_ <= 64, "bind: B=%d L=%d O=%d unsupported (O <= 64)", B_, L_, O_);
+        size_t need = workspace_bytes(B_, L_, O_);
+        if (wb < need) { rgqa_set_error("bind: workspace too small (%zu < %zu bytes)", wb, need); return RGQA_ERR_WORKSPACE; }
+        P = p; G = g; ws = (char*)w;
+        plan(B_, L_, O_);
+        have_fwd = false; eff_zeroed = false;
+        return RGQA_OK;
+    }
+    bool eff_zeroed = false;
+    T* effp(const BLin& l) const { return reinterpret_cast<T*>(ws + l.eff); }
+    T* efftp(const BLin& l) const { return reinterpret_cast<T*>(ws + l.efft); }
+
+#define CKB(x) do { int _r = (x); if (_r) return _r; } while (0)
+    int sync_weights(hipStream_t s) override {
+        RGQA_REQUIRE(P != nullptr, "sync_weights: engine not bound");
+        if (!eff_zeroed) {   // padding rows / columns of the effective copies must be exact zeros
+            for (BLin* l : lins) {
+                CKB(rgqa_check_hip(hipMemsetAsync(effp(*l), 0, sizeof(T) * (size_t)l->out * l->kp, s), "zero eff"));
+                CKB(rgqa_check_hip(hipMemsetAsync(efftp(*l), 0, sizeof(T) * (size_t)l->kp * l->op, s), "zero efft"));
+            }
+            eff_zeroed = true;
+        }
+        for (BLin* l : lins) {
+            const float* g = nullptr; const float* ss = nullptr;
+            if (l->wn) {
+                CKB(k_sumsq(P + l->v, (size_t)l->out * l->in, partial, sumsq + l->norm, 0, s));
+                g = P + l->g; ss = sumsq + l->norm;
+            }
+            CKB(kb_wn_eff<T>(P + l->v, g, ss, effp(*l), l->kp, LP ? efftp(*l) : nullptr, l->op, l->out, l->in, s));
+        }
+        CKB(kb_wn_eff<float>(P + lin.v, P + lin.g, sumsq + lin.norm, wlin_eff, H, nullptr, 0, 1, H, s));
+        return RGQA_OK;
+    }
+    int sync_transposed(hipStream_t s) override { return sync_weights(s); }
+
+    // ------------------------------------------------------------------ GEMM wrappers (single problem)
+    static void ginit(GemmGroup& g) { memset(&g, 0, sizeof g); g.count = 1; g.drop = make_drop(0.f, 0, 0); }
+    int gemm_fwd(const void* x, int ldx, int M, const BLin& l, void* C, int ldc, int epi, int out_f32, DropCfg drop, uint32_t site, hipStream_t s) {
+        GemmGroup g; ginit(g); g.drop = drop;
+        GemmProblem& p = g.p[0];
+        p.A = x; p.lda = ldx; p.B = effp(l); p.ldb = l.kp; p.C = C; p.ldc = ldc; p.M = M; p.N = l.out; p.K = l.kp; p.bias = P + l.b; p.epi = epi; p.drop_site = site;
+        return LP ? launch_gemm_nt_bf16(g, out_f32, s) : launch_gemm_f32(g, 0, 0, s);
+    }
+    // dx[M, kp] = dy[M, out(op)] @ Weff
+    int gemm_dgrad(const void* dy, int lddy, int M, const BLin& l, void* dx, int lddx, int epi, const void* aux, int ldaux, DropCfg drop, hipStream_t s) {
+        GemmGroup g; ginit(g); g.drop = drop;
+        GemmProblem& p = g.p[0];
+        p.A = dy; p.lda = lddy; p.C = dx; p.ldc = lddx; p.M = M; p.N = l.kp; p.epi = epi; p.aux = aux; p.ldaux = ldaux;
+        if (LP) { p.B = efftp(l); p.ldb = l.op; p.K = (int)rupb(l.out, 8) > l.op ? l.op : (int)rupb(l.out, 8); return launch_gemm_nt_bf16(g, 0, s); }
+        p.B = effp(l); p.ldb = l.kp; p.K = l.out;
+        return launch_gemm_f32(g, 0, 1, s);
+    }
+    // gradient of the effective weight into scratch, then through the weight-norm into G; bias gradient = column sums of dy
+    int gemm_wgrad(const void* dy, int lddy, const void* x, int ldx, int rows, const BLin& l, int accumulate, hipStream_t s) {
+        GemmGroup g; ginit(g);
+        GemmProblem& p = g.p[0];
+        p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.C = dwscr; p.ldc = l.kp; p.M = l.out; p.N = l.kp; p.K = rows; p.epi = EPI_BIAS;
+        CKB(LP ? launch_gemm_tn_bf16(g, 1, s) : launch_gemm_f32(g, 1, 1, s));
+        CKB(kb_wn_bwd(dwscr, l.kp, P + l.v, l.wn ? P + l.g : nullptr, l.wn ? sumsq + l.norm : nullptr, partial, G + l.v, l.wn ? G + l.g : nullptr, l.out, l.in, accumulate, s));
+        // bias gradient: column sums of dy (its padded columns are exact zeros) into scratch, then the first `out` of them
+        CKB(k_colsum<T>((const T*)dy, lddy, partial, dwscr, 0, rows, (int)rupb(l.out, 4), s));
+        hipLaunchKernelGGL(butd_bias_copy_kernel, dim3(cdiv(l.out, 256)), dim3(256), 0, s, dwscr, G + l.b, l.out, accumulate);
+        RGQA_LAUNCH_CHECK("butd_bias_copy_kernel");
+        return RGQA_OK;
+    }
+
+    DropCfg drop_for(float p, uint32_t site) const { DropCfg d = make_drop(last_train ? p : 0.f, last_seed, 0); d.seed_hi ^= site; return d; }
+    DropCfg drop_raw(float p) const { return make_drop(last_train ? p : 0.f, last_seed, 0); }
+
+    // ------------------------------------------------------------------ forward
+    int forward(const float* feats, const float* boxes, const int64_t* toks, const int64_t*, const int64_t*, float* pooled_out, float* logits_out, int ld_logits,
+                int train, uint64_t seed, hipStream_t s) override {
+        RGQA_REQUIRE(P != nullptr && ws != nullptr, "forward: engine not bound");
+        RGQA_REQUIRE(feats && boxes && toks, "forward: null input");
+        in_feats = feats; in_boxes = boxes; in_toks = toks; last_train = train; last_seed = seed;
+        const DropCfg nd = make_drop(0.f, 0, 0);
+        CKB(sync_weights(s));
+        CKB(kb_embed_fwd<T>(toks, P + emb, X, B * L, E, Ep, s));
+        CKB(gemm_fwd(X, Ep, B * L, wih, GI, 3 * H, EPI_BIAS, 0, nd, 0, s));
+        CKB(rgqa_check_hip(hipMemsetAsync(Hall, 0, sizeof(T) * (size_t)B * H, s), "h0"));
+        for (int t = 0; t < L; ++t) {
+            T* hp = Hall + (size_t)t * B * H;
+            CKB(gemm_fwd(hp, H, B, whh, GH, 3 * H, EPI_BIAS, 0, nd, 0, s));
+            CKB(kb_gru_fwd<T>(GI + (size_t)t * 3 * H, (long)L * 3 * H, GH, hp, hp + (size_t)B * H, Rg + (size_t)t * B * H, Zg + (size_t)t * B * H,
+                              Ng + (size_t)t * B * H, GHN + (size_t)t * B * H, B, H, s));
+        }
+        const T* q = Hall + (size_t)L * B * H;
+        CKB(kb_concat<T>(feats, boxes, IF, B * O, cfg.feat_dim, cfg.pos_dim, Dp, s));
+        CKB(gemm_fwd(IF, Dp, B * O, ip, IP, H, EPI_RELU, 0, nd, 0, s));
+        CKB(gemm_fwd(q, H, B, qp, QP, H, EPI_RELU, 0, nd, 0, s));
+        CKB(kb_attend_fwd<T>(IP, QP, wlin_eff, P + lin.b, IF, att, IE, B, O, H, Dp, drop_for(cfg.attn_dropout, 1), s));
+        CKB(gemm_fwd(q, H, B, qproj, QR, H, EPI_RELU, 0, nd, 0, s));
+        CKB(gemm_fwd(IE, Dp, B, iproj, IR, H, EPI_RELU, 0, nd, 0, s));
+        CKB(kb_mul_fwd<T>(QR, IR, J, (size_t)B * H, s));
+        CKB(gemm_fwd(J, H, B, c0, C1, 2 * H, EPI_RELU_DROP, 0, drop_raw(cfg.hidden_dropout), 2, s));
+        CKB(gemm_fwd(C1, 2 * H, B, c3, logits, NAp, EPI_BIAS, 1, nd, 0, s));
+        if (pooled_out) CKB(k_to_f32<T>(J, H, pooled_out, H, B, H, s));
+        if (logits_out) CKB(k_fill_rows<float>(logits_out, ld_logits, logits, NAp, B, NA, s));
+        have_fwd = true;
+        return RGQA_OK;
+    }
+
+    // ------------------------------------------------------------------ backward
+    int loss_backward(const float* target, int ldt, float* loss_out, float grad_scale, int accumulate, hipStream_t s) override {
+        RGQA_REQUIRE(have_fwd && G != nullptr, "loss_backward: no forward pass recorded / no gradient arena");
+        float* dl32 = dwscr;
+        CKB(k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, NA, NAp, grad_scale, s));
+        if (loss_out) CKB(rgqa_check_hip(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s), "loss copy"));
+        CKB(k_cast_pad<T>(dl32, NAp, dlogits, NAp, B, NAp, 1.0f, s));
+        return backward_impl(accumulate, s);
+    }
+    int backward(const float* dl, int ldd, int accumulate, hipStream_t s) override {
+        RGQA_REQUIRE(have_fwd && G != nullptr && dl != nullptr, "backward: no forward pass recorded / null argument");
+        CKB(k_cast_pad<T>(dl, ldd, dlogits, NAp, B, NA, 1.0f, s));
+        return backward_impl(accumulate, s);
+    }
+    int backward_pooled(const float*, int, int, hipStream_t) override { rgqa_set_error("backward_pooled: not available for the BUTD engine"); return RGQA_ERR_ARG; }
+
+    int backward_impl(int accumulate, hipStream_t s) {
+        const DropCfg nd = make_drop(0.f, 0, 0);
+        const T* q = Hall + (size_t)L * B * H;
+        if (!accumulate) CKB(rgqa_check_hip(hipMemsetAsync(G + emb, 0, sizeof(float) * (size_t)cfg.vocab_size * E, s), "zero embedding grad"));
+        // classifier
+        CKB(gemm_wgrad(dlogits, NAp, C1, 2 * H, B, c3, accumulate, s));
+        CKB(gemm_dgrad(dlogits, NAp, B, c3, dC1, 2 * H, EPI_DRELU_DROP, C1, 2 * H, drop_raw(cfg.hidden_dropout), s));
+        CKB(gemm_wgrad(dC1, 2 * H, J, H, B, c0, accumulate, s));
+        CKB(gemm_dgrad(dC1, 2 * H, B, c0, dJ, H, EPI_BIAS, nullptr, 0, nd, s));
+        CKB(kb_mul_relu_bwd<T>(dJ, QR, IR, dQR, dIR, (size_t)B * H, s));
+        // projections
+        CKB(gemm_wgrad(dQR, H, q, H, B, qproj, accumulate, s));
+        CKB(gemm_dgrad(dQR, H, B, qproj, dq, H, EPI_BIAS, nullptr, 0, nd, s));
+        CKB(gemm_wgrad(dIR, H, IE, Dp, B, iproj, accumulate, s));
+        CKB(gemm_dgrad(dIR, H, B, iproj, dIE, Dp, EPI_BIAS, nullptr, 0, nd, s));
+        // attention over regions
+        CKB(kb_attend_bwd<T>(dIE, IF, att, IP, QP, wlin_eff, dIP, dQP, dw_part, db_part, B, O, H, Dp, drop_for(cfg.attn_dropout, 1), s));
+        CKB(k_colsum<float>(dw_part, H, partial, dwscr, 0, B, H, s));
+        CKB(kb_wn_bwd(dwscr, H, P + lin.v, P + lin.g, sumsq + lin.norm, partial, G + lin.v, G + lin.g, 1, H, accumulate, s));
+        hipLaunchKernelGGL(butd_sum_small_kernel, dim3(1), dim3(256), 0, s, db_part, B, G + lin.b, accumulate);
+        RGQA_LAUNCH_CHECK("butd_sum_small_kernel");
+        CKB(gemm_wgrad(dIP, H, IF, Dp, B * O, ip, accumulate, s));
+        CKB(gemm_wgrad(dQP, H, q, H, B, qp, accumulate, s));
+        CKB(gemm_dgrad(dQP, H, B, qp, dHa, H, EPI_ADD, dq, H, nd, s));          // dHa = d q_enc = both question paths
+        // GRU, back through time
+        T* dh = dHa; T* dhn = dHb;
+        for (int t = L - 1; t >= 0; --t) {
+            const T* hp = Hall + (size_t)t * B * H;
+            T* dgh_t = dGH + (size_t)t * B * 3 * H;
+            CKB(kb_gru_bwd<T>(dh, hp, Rg + (size_t)t * B * H, Zg + (size_t)t * B * H, Ng + (size_t)t * B * H, GHN + (size_t)t * B * H,
+                              dGI + (size_t)t * 3 * H, (long)L * 3 * H, dgh_t, tmpH, B, H, s));
+            CKB(gemm_dgrad(dgh_t, 3 * H, B, whh, dhn, H, EPI_ADD, tmpH, H, nd, s));
+            T* x = dh; dh = dhn; dhn = x;
+        }
+        CKB(gemm_wgrad(dGH, 3 * H, Hall, H, L * B, whh, accumulate, s));
+        CKB(gemm_wgrad(dGI, 3 * H, X, Ep, B * L, wih, accumulate, s));
+        CKB(gemm_dgrad(dGI, 3 * H, B * L, wih, dX, Ep, EPI_BIAS, nullptr, 0, nd, s));
+        CKB(kb_embed_bwd<T>(in_toks, dX, G + emb, B * L, E, Ep, cfg.vocab_size - 1, s));
+        return RGQA_OK;
+    }
+
+    int get_activation(const char* name, float* out, size_t cap, hipStream_t s) override {
+        RGQA_REQUIRE(have_fwd, "get_activation: no forward pass recorded");
+        std::string nm(name);
+        if (nm == "att") {
+            RGQA_REQUIRE(cap >= (size_t)B * O, "get_activation: buffer too small");
+            return rgqa_check_hip(hipMemcpyAsync(out, att, sizeof(float) * (size_t)B * O, hipMemcpyDeviceToDevice, s), "att copy");
+        }
+        if (nm == "q_enc") {
+            RGQA_REQUIRE(cap >= (size_t)B * H, "get_activation: buffer too small");
+            return k_to_f32<T>(Hall + (size_t)L * B * H, H, out, H, B, H, s);
+        }
+        rgqa_set_error("get_activation: unknown activation '%s' (BUTD engine: att, q_enc)", name);
+        return RGQA_ERR_ARG;
+    }
+};
+
+EngineBase* make_butd_engine(const rgqa_config& cfg) {
+    if (cfg.precision == RGQA_PRECISION_BF16) return new ButdEngine<bf16_t>(cfg);
+    return new ButdEngine<float>(cfg);
+}

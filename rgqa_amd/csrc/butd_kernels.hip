@@ -1,0 +1,292 @@
+// Kernels of the BUTD GQA path (reference src/butd/butd.py; BASELINE config 5): GloVe embedding
+// gather, GRU gates, product-fusion attention over the 36 regions (softmax over regions, weighted feature sum),
+// weight-norm (scalar g) weight preparation / gradient, and small elementwise helpers.  The projections themselves run
+// on the GEMM kernels shared with the LXMERT path.  All HBM-bound; T = float (parity) or bf16.
+#include "kernels.h"
+#include "butd.h"
+
+// ---------------------------------------------------------------- embedding
+template <typename T>
+__global__ void butd_embed_fwd_kernel(const int64_t* __restrict__ toks, const float* __restrict__ table, T* __restrict__ out, int E, int Ep) {
+    const int row = blockIdx.x;
+    const int64_t id = toks[row];
+    for (int c = threadIdx.x; c < Ep; c += blockDim.x) out[(size_t)row * Ep + c] = from_f32<T>(c < E ? table[(size_t)id * E + c] : 0.f);
+}
+template <typename T>
+__global__ void butd_embed_bwd_kernel(const int64_t* __restrict__ toks, const T* __restrict__ dx, float* __restrict__ dtable, int E, int Ep, int pad_idx) {
+    const int row = blockIdx.x;
+    const int64_t id = toks[row];
+    if (id == pad_idx) return;           // nn.Embedding(padding_idx=ntoken): no gradient (butd.py:36)
+    for (int c = threadIdx.x; c < E; c += blockDim.x) atomicAdd(dtable + (size_t)id * E + c, to_f32(dx[(size_t)row * Ep + c]));
+}
+
+// ---------------------------------------------------------------- GRU gates (gate order r, z, n as torch.nn.GRU)
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T>
+__global__ void gru_gate_fwd_kernel(const T* __restrict__ gi, long ldgi, const T* __restrict__ gh, const T* __restrict__ hprev,
+                                    T* __restrict__ hnew, T* __restrict__ rs, T* __restrict__ zs, T* __restrict__ ns, T* __restrict__ ghn, int B, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, h = i % H;
+    const T* gib = gi + (size_t)b * ldgi;
+    const T* ghb = gh + (size_t)b * 3 * H;
+    const float r = sigm(to_f32(gib[h]) + to_f32(ghb[h]));
+    const float z = sigm(to_f32(gib[H + h]) + to_f32(ghb[H + h]));
+    const float gn = to_f32(ghb[2 * H + h]);
+    const float n = tanhf(to_f32(gib[2 * H + h]) + r * gn);
+    const float hp = to_f32(hprev[i]);
+    hnew[i] = from_f32<T>((1.f - z) * n + z * hp);
+    rs[i] = from_f32<T>(r); zs[i] = from_f32<T>(z); ns[i] = from_f32<T>(n); ghn[i] = from_f32<T>(gn);
+}
+// given dh (gradient w.r.t. h_t): dgi / dgh for this step and the direct part of dh_{t-1} (= dh * z)
+template <typename T>
+__global__ void gru_gate_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ hprev, const T* __restrict__ rs, const T* __restrict__ zs,
+                                    const T* __restrict__ ns, const T* __restrict__ ghn, T* __restrict__ dgi, long lddgi, T* __restrict__ dgh,
+                                    T* __restrict__ dhprev, int B, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, h = i % H;
+    const float d = to_f32(dh[i]), r = to_f32(rs[i]), z = to_f32(zs[i]), n = to_f32(ns[i]), gn = to_f32(ghn[i]), hp = to_f32(hprev[i]);
+    const float dn = d * (1.f - z) * (1.f - n * n);
+    const float dz = d * (hp - n) * z * (1.f - z);
+    const float dr = dn * gn * r * (1.f - r);
+    T* gi = dgi + (size_t)b * lddgi;
+    T* gh = dgh + (size_t)b * 3 * H;
+    gi[h] = from_f32<T>(dr); gi[H + h] = from_f32<T>(dz); gi[2 * H + h] = from_f32<T>(dn);
+    gh[h] = from_f32<T>(dr); gh[H + h] = from_f32<T>(dz); gh[2 * H + h] = from_f32<T>(dn * r);
+    dhprev[i] = from_f32<T>(d * z);
+}
+
+// ---------------------------------------------------------------- image features = cat(feat, pos), padded to a multiple of 8 columns
+template <typename T>
+__global__ void concat_cast_kernel(const float* __restrict__ feat, const float* __restrict__ pos, T* __restrict__ out, int F, int Pd, int Dp) {
+    const int row = blockIdx.x;
+    for (int c = threadIdx.x; c < Dp; c += blockDim.x) {
+        float v = 0.f;
+        if (c < F) v = feat[(size_t)row * F + c];
+        else if (c < F + Pd) v = pos[(size_t)row * Pd + (c - F)];
+        out[(size_t)row * Dp + c] = from_f32<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------- attention over regions (butd.py:87-104, 207-208)
+// one workgroup (256 threads) per sample; O <= 64 regions
+template <typename T>
+__global__ __launch_bounds__(256) void butd_attend_fwd_kernel(const T* __restrict__ ip, const T* __restrict__ qp, const float* __restrict__ wlin, const float* __restrict__ blin,
+                                                              const T* __restrict__ imgf, float* __restrict__ att, T* __restrict__ img_enc, int O, int H, int Dp, DropCfg drop) {
+    __shared__ float lg[64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* ipb = ip + (size_t)b * O * H;
+    for (int k = wave; k < O; k += 4) {
+        float s = 0.f;
+        for (int h = lane; h < H; h += 64) {
+            const float j = to_f32(ipb[(size_t)k * H + h]) * to_f32(qp[(size_t)b * H + h]);
+            s += drop_apply(drop, (uint32_t)((b * O + k) * H + h), j) * wlin[h];
+        }
+        s = wave_sum(s);
+        if (lane == 0) lg[k] = s + blin[0];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const float v = lane < O ? lg[lane] : -INFINITY;
+        const float m = wave_max(v);
+        const float e = lane < O ? __expf(v - m) : 0.f;
+        const float sum = wave_sum(e);
+        if (lane < O) { lg[lane] = e / sum; att[(size_t)b * O + lane] = e / sum; }
+    }
+    __syncthreads();
+    const T* fb = imgf + (size_t)b * O * Dp;
+    for (int f = threadIdx.x; f < Dp; f += 256) {
+        float s = 0.f;
+        for (int k = 0; k < O; ++k) s = fmaf(lg[k], to_f32(fb[(size_t)k * Dp + f]), s);
+        img_enc[(size_t)b * Dp + f] = from_f32<T>(s);
+    }
+}
+
+// backward: d_img_enc -> d(image_proj pre-ReLU) [B,O,H], d(question_proj pre-ReLU) [B,H], per-sample partials of dw_lin [B,H] and db_lin [B]
+template <typename T>
+__global__ __launch_bounds__(256) void butd_attend_bwd_kernel(const T* __restrict__ dimg, const T* __restrict__ imgf, const float* __restrict__ att, const T* __restrict__ ip,
+                                                              const T* __restrict__ qp, const float* __restrict__ wlin, T* __restrict__ dip, T* __restrict__ dqp,
+                                                              float* __restrict__ dw_part, float* __restrict__ db_part, int O, int H, int Dp, DropCfg drop) {
+    __shared__ float dl[64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* fb = imgf + (size_t)b * O * Dp;
+    for (int k = wave; k < O; k += 4) {
+        float s = 0.f;
+        for (int f = lane; f < Dp; f += 64) s = fmaf(to_f32(dimg[(size_t)b * Dp + f]), to_f32(fb[(size_t)k * Dp + f]), s);
+        s = wave_sum(s);
+        if (lane == 0) dl[k] = s;                 // d att_k
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const float a = lane < O ? att[(size_t)b * O + lane] : 0.f;
+        const float da = lane < O ? dl[lane] : 0.f;
+        const float dot = wave_sum(a * da);
+        const float d = a * (da - dot);            // d logit_k
+        const float dbs = wave_sum(d);
+        if (lane < O) dl[lane] = d;
+        if (lane == 0) db_part[b] = dbs;
+    }
+    __syncthreads();
+    const T* ipb = ip + (size_t)b * O * H;
+    T* dipb = dip + (size_t)b * O * H;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const float q = to_f32(qp[(size_t)b * H + h]), w = wlin[h];
+        float dq = 0.f, dw = 0.f;
+        for (int k = 0; k < O; ++k) {
+            const float x = to_f32(ipb[(size_t)k * H + h]);
+            const float keep = drop_apply(drop, (uint32_t)((b * O + k) * H + h), 1.0f);
+            const float dj = dl[k] * w * keep;      // d joint[k][h]
+            dq = fmaf(dj, x, dq);
+            dw = fmaf(dl[k] * keep, x * q, dw);
+            dipb[(size_t)k * H + h] = from_f32<T>(x > 0.f ? dj * q : 0.f);     // through the ReLU of image_proj
+        }
+        dqp[(size_t)b * H + h] = from_f32<T>(q > 0.f ? dq : 0.f);               // through the ReLU of question_proj
+        dw_part[(size_t)b * H + h] = dw;
+    }
+}
+
+// ---------------------------------------------------------------- joint = q_repr * img_repr (both post-ReLU)
+template <typename T>
+__global__ void mul_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = from_f32<T>(to_f32(a[i]) * to_f32(b[i]));
+}
+template <typename T>
+__global__ void mul_relu_bwd_kernel(const T* __restrict__ dj, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ da, T* __restrict__ db, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = to_f32(dj[i]), x = to_f32(a[i]), y = to_f32(b[i]);
+        da[i] = from_f32<T>(x > 0.f ? d * y : 0.f);
+        db[i] = from_f32<T>(y > 0.f ? d * x : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------- weight norm (scalar g): W = g * V / ||V||_F
+// writes the effective weight [N, ldo] (zero padded past K) and, when wt != null, its transpose [K.., ldt]
+template <typename T>
+__global__ __launch_bounds__(256) void wn_eff_kernel(const float* __restrict__ v, const float* __restrict__ gptr, const float* __restrict__ sumsq,
+                                                     T* __restrict__ w, int ldo, T* __restrict__ wt, int ldt, int N, int K) {
+    __shared__ float tile[32][33];
+    const float scale = gptr ? gptr[0] * rsqrtf(sumsq[0]) : 1.0f;
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + ty + r * 8, k = k0 + tx;
+        const float x = (n < N && k < K) ? v[(size_t)n * K + k] * scale : 0.f;
+        tile[ty + r * 8][tx] = x;
+        if (n < N && k < ldo) w[(size_t)n * ldo + k] = from_f32<T>(x);
+    }
+    if (wt == nullptr) return;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + ty + r * 8, n = n0 + tx;
+        if (k < K && n < ldt) wt[(size_t)k * ldt + n] = from_f32<T>(tile[tx][ty + r * 8]);
+    }
+}
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int N, int K, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)N * K; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i / K), k = (int)(i % K);
+        acc = fmaf(a[(size_t)n * lda + k], b[i], acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// dV = s (dW - (dot / ||V||^2) V), dg = dot / ||V||, s = g / ||V||
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ dw, int lddw, const float* __restrict__ v, const float* __restrict__ gptr,
+                                                     const float* __restrict__ sumsq, const float* __restrict__ partial, int nblk, float* __restrict__ dv,
+                                                     float* __restrict__ dg, int N, int K, int accumulate) {
+    __shared__ float dots;
+    if (threadIdx.x == 0) { float d = 0.f; for (int i = 0; i < nblk; ++i) d += partial[i]; dots = d; }
+    __syncthreads();
+    const float dot = dots, ss = sumsq[0], nrm = sqrtf(ss), s = gptr[0] / nrm;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)N * K; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i / K), k = (int)(i % K);
+        const float g = s * (dw[(size_t)n * lddw + k] - dot / ss * v[i]);
+        dv[i] = accumulate ? dv[i] + g : g;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) dg[0] = accumulate ? dg[0] + dot / nrm : dot / nrm;
+}
+// plain copy of a [N, K] block out of a padded gradient buffer (non-weight-normed weights)
+__global__ void copy_block_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int N, int K, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * K; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = src[(size_t)(i / K) * lds + (i % K)];
+        dst[i] = accumulate ? dst[i] + g : g;
+    }
+}
+
+// ---------------------------------------------------------------- host wrappers
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256 > 4096 ? 4096 : ((n) + 255) / 256))
+
+template <typename T> int kb_embed_fwd(const int64_t* toks, const float* table, T* out, int rows, int E, int Ep, hipStream_t s) {
+    hipLaunchKernelGGL(butd_embed_fwd_kernel<T>, dim3(rows), dim3(128), 0, s, toks, table, out, E, Ep);
+    RGQA_LAUNCH_CHECK("butd_embed_fwd_kernel"); return RGQA_OK;
+}
+template <typename T> int kb_embed_bwd(const int64_t* toks, const T* dx, float* dtable, int rows, int E, int Ep, int pad_idx, hipStream_t s) {
+    hipLaunchKernelGGL(butd_embed_bwd_kernel<T>, dim3(rows), dim3(128), 0, s, toks, dx, dtable, E, Ep, pad_idx);
+    RGQA_LAUNCH_CHECK("butd_embed_bwd_kernel"); return RGQA_OK;
+}
+template <typename T> int kb_gru_fwd(const T* gi, long ldgi, const T* gh, const T* hprev, T* hnew, T* rs, T* zs, T* ns, T* ghn, int B, int H, hipStream_t s) {
+    hipLaunchKernelGGL(gru_gate_fwd_kernel<T>, dim3(cdiv((long)B * H, 256)), dim3(256), 0, s, gi, ldgi, gh, hprev, hnew, rs, zs, ns, ghn, B, H);
+    RGQA_LAUNCH_CHECK("gru_gate_fwd_kernel"); return RGQA_OK;
+}
+template <typename T> int kb_gru_bwd(const T* dh, const T* hprev, const T* rs, const T* zs, const T* ns, const T* ghn, T* dgi, long lddgi, T* dgh, T* dhprev, int B, int H, hipStream_t s) {
+    hipLaunchKernelGGL(gru_gate_bwd_kernel<T>, dim3(cdiv((long)B * H, 256)), dim3(256), 0, s, dh, hprev, rs, zs, ns, ghn, dgi, lddgi, dgh, dhprev, B, H);
+    RGQA_LAUNCH_CHECK("gru_gate_bwd_kernel"); return RGQA_OK;
+}
+template <typename T> int kb_concat(const float* feat, const float* pos, T* out, int rows, int F, int Pd, int Dp, hipStream_t s) {
+    hipLaunchKernelGGL(concat_cast_kernel<T>, dim3(rows), dim3(256), 0, s, feat, pos, out, F, Pd, Dp);
+    RGQA_LAUNCH_CHECK("concat_cast_kernel"); return RGQA_OK;
+}
+template <typename T> int kb_attend_fwd(const T* ip, const T* qp, const float* wlin, const float* blin, const T* imgf, float* att, T* img_enc, int B, int O, int H, int Dp, DropCfg drop, hipStream_t s) {
+    RGQA_REQUIRE(O <= 64, "butd attention: at most 64 regions (got %d)", O);
+    hipLaunchKernelGGL(butd_attend_fwd_kernel<T>, dim3(B), dim3(256), 0, s, ip, qp, wlin, blin, imgf, att, img_enc, O, H, Dp, drop);
+    RGQA_LAUNCH_CHECK("butd_attend_fwd_kernel"); return RGQA_OK;
+}
+template <typename T> int kb_attend_bwd(const T* dimg, const T* imgf, const float* att, const T* ip, const T* qp, const float* wlin, T* dip, T* dqp, float* dw_part, float* db_part,
+                                        int B, int O, int H, int Dp, DropCfg drop, hipStream_t s) {
+    hipLaunchKernelGGL(butd_attend_bwd_kernel<T>, dim3(B), dim3(256), 0, s, dimg, imgf, att, ip, qp, wlin, dip, dqp, dw_part, db_part, O, H, Dp, drop);
+    RGQA_LAUNCH_CHECK("butd_attend_bwd_kernel"); return RGQA_OK;
+}
+template <typename T> int kb_mul_fwd(const T* a, const T* b, T* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(mul_fwd_kernel<T>, GRID1(n), dim3(256), 0, s, a, b, out, n);
+    RGQA_LAUNCH_CHECK("mul_fwd_kernel"); return RGQA_OK;
+}
+template <typename T> int kb_mul_relu_bwd(const T* dj, const T* a, const T* b, T* da, T* db, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(mul_relu_bwd_kernel<T>, GRID1(n), dim3(256), 0, s, dj, a, b, da, db, n);
+    RGQA_LAUNCH_CHECK("mul_relu_bwd_kernel"); return RGQA_OK;
+}
+template <typename T> int kb_wn_eff(const float* v, const float* g, const float* sumsq, T* w, int ldo, T* wt, int ldt, int N, int K, hipStream_t s) {
+    const int kk = ldo > K ? ldo : K;
+    hipLaunchKernelGGL(wn_eff_kernel<T>, dim3(cdiv(kk, 32), cdiv(wt ? (ldt > N ? ldt : N) : N, 32)), dim3(256), 0, s, v, g, sumsq, w, ldo, wt, ldt, N, K);
+    RGQA_LAUNCH_CHECK("wn_eff_kernel"); return RGQA_OK;
+}
+int kb_wn_bwd(const float* dw, int lddw, const float* v, const float* g, const float* sumsq, float* partial, float* dv, float* dg, int N, int K, int accumulate, hipStream_t s) {
+    const int nblk = cdiv((long)N * K, 256 * 8) > 256 ? 256 : cdiv((long)N * K, 256 * 8);
+    if (g == nullptr) {
+        hipLaunchKernelGGL(copy_block_kernel, GRID1((size_t)N * K), dim3(256), 0, s, dw, lddw, dv, N, K, accumulate);
+        RGQA_LAUNCH_CHECK("copy_block_kernel"); return RGQA_OK;
+    }
+    hipLaunchKernelGGL(dot_kernel, dim3(nblk), dim3(256), 0, s, dw, lddw, v, N, K, partial);
+    RGQA_LAUNCH_CHECK("dot_kernel");
+    hipLaunchKernelGGL(wn_bwd_kernel, GRID1((size_t)N * K), dim3(256), 0, s, dw, lddw, v, g, sumsq, partial, nblk, dv, dg, N, K, accumulate);
+    RGQA_LAUNCH_CHECK("wn_bwd_kernel"); return RGQA_OK;
+}
+
+#define INST(T)                                                                                                                         \
+    template int kb_embed_fwd<T>(const int64_t*, const float*, T*, int, int, int, hipStream_t);                                          \
+    template int kb_embed_bwd<T>(const int64_t*, const T*, float*, int, int, int, int, hipStream_t);                                     \
+    template int kb_gru_fwd<T>(const T*, long, const T*, const T*, T*, T*, T*, T*, T*, int, int, hipStream_t);                           \
+    template int kb_gru_bwd<T>(const T*, const T*, const T*, const T*, const T*, const T*, T*, long, T*, T*, int, int, hipStream_t);     \
+    template int kb_concat<T>(const float*, const float*, T*, int, int, int, int, hipStream_t);                                          \
+    template int kb_attend_fwd<T>(const T*, const T*, const float*, const float*, const T*, float*, T*, int, int, int, int, DropCfg, hipStream_t); \
+    template int kb_attend_bwd<T>(const T*, const T*, const float*, const T*, const T*, const float*, T*, T*, float*, float*, int, int, int, int, DropCfg, hipStream_t); \
+    template int kb_mul_fwd<T>(const T*, const T*, T*, size_t, hipStream_t);                                                             \
+    template int kb_mul_relu_bwd<T>(const T*, const T*, const T*, T*, T*, size_t, hipStream_t);                                          \
+    template int kb_wn_eff<T>(const float*, const float*, const float*, T*, int, T*, int, int, int, hipStream_t);
+INST(float)
+INST(bf16_t)

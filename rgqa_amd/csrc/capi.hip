@@ -4,6 +4,7 @@
 #include <new>
 
 struct rgqa_engine { EngineBase* impl; };
+EngineBase* make_butd_engine(const rgqa_config& cfg);
 
 #define S(x) reinterpret_cast<hipStream_t>(x)
 #define NEED(e) do { if ((e) == nullptr || (e)->impl == nullptr) { rgqa_set_error("null engine handle"); return RGQA_ERR_ARG; } } while (0)
@@ -24,6 +25,18 @@ int rgqa_debug_set(int key, int value) {
 
 int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out) {
     RGQA_REQUIRE(cfg != nullptr && out != nullptr, "engine_create: null argument");
+    if (cfg->arch == 1) {
+        RGQA_REQUIRE(cfg->hidden > 0 && cfg->hidden % 64 == 0 && cfg->emb_dim > 0 && cfg->vocab_size > 1 && cfg->num_answers > 0 && cfg->feat_dim % 4 == 0 &&
+                     cfg->pos_dim >= 1 && cfg->pos_dim <= 4, "engine_create (BUTD): hidden %% 64, emb_dim, vocab_size, num_answers, feat_dim %% 4 required");
+        RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16, "engine_create: unknown precision %d", cfg->precision);
+        RGQA_REQUIRE(cfg->hidden_dropout >= 0.f && cfg->hidden_dropout < 1.f && cfg->attn_dropout >= 0.f && cfg->attn_dropout < 1.f, "engine_create: dropout out of range");
+        rgqa_engine* eb = new (std::nothrow) rgqa_engine;
+        if (!eb) { rgqa_set_error("engine_create: out of host memory"); return RGQA_ERR_STATE; }
+        eb->impl = make_butd_engine(*cfg);
+        *out = eb;
+        return RGQA_OK;
+    }
+    RGQA_REQUIRE(cfg->arch == 0, "engine_create: unknown arch %d", cfg->arch);
     RGQA_REQUIRE(cfg->hidden > 0 && cfg->heads > 0 && cfg->hidden % cfg->heads == 0,
                  "The hidden size (%d) is not a multiple of the number of attention heads (%d)", cfg->hidden, cfg->heads);  // modeling.py:298-301
     RGQA_REQUIRE(cfg->hidden % 64 == 0 && cfg->hidden <= 1024, "engine_create: hidden (%d) must be a multiple of 64 and <= 1024", cfg->hidden);

@@ -11,6 +11,9 @@ enum GemmEpi {
     EPI_ADD = 5,         // C = acc + aux                                               (dgrad + residual-path gradient)
     EPI_ACCUM = 6,       // C += acc  (C must be f32)                                   (wgrad accumulate)
     EPI_DTANH = 7,       // C = acc * (1 - aux^2)                                       (dgrad through the pooler's tanh)
+    EPI_RELU = 8,        // C = relu(acc + bias)                                        (BUTD MLP, butd.py:8-26)
+    EPI_RELU_DROP = 9,   // C = dropout(relu(acc + bias))                               (BUTD classifier hidden, butd.py:170-178)
+    EPI_DRELU_DROP = 10, // C = acc * (aux > 0 ? 1/(1-p) : 0), aux = the EPI_RELU_DROP output (dgrad through dropout + ReLU)
 };
 
 // One problem: C[M,N] = op(A)[M,K] * op(B)[K,N] (+ epilogue).  Layout depends on the kernel:
@@ -58,7 +61,14 @@ __device__ __forceinline__ void gemm_epilogue4_e(const GemmProblem& P, const int
     } else if (epi == EPI_TANH) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = tanhf(pre[i]);
-    } else if (epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_DTANH) {
+    } else if (epi == EPI_RELU || epi == EPI_RELU_DROP) {
+        DropCfg d = drop; d.seed_hi ^= P.drop_site;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = fmaxf(pre[i], 0.f);
+            if (epi == EPI_RELU_DROP) v[i] = drop_apply(d, (uint32_t)m * (uint32_t)P.N + (uint32_t)(n0 + i), v[i]);
+        }
+    } else if (epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_DTANH || epi == EPI_DRELU_DROP) {
         const AuxT* arow = reinterpret_cast<const AuxT*>(P.aux) + (size_t)m * P.ldaux + n0;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         if (nvalid == 4) load4(arow, a);
@@ -73,6 +83,8 @@ __device__ __forceinline__ void gemm_epilogue4_e(const GemmProblem& P, const int
                 v[i] = v[i] * a[i];
             } else if (epi == EPI_DTANH) {
                 v[i] = v[i] * (1.0f - a[i] * a[i]);
+            } else if (epi == EPI_DRELU_DROP) {
+                v[i] = a[i] > 0.f ? v[i] * drop.scale : 0.f;
             } else {
                 v[i] = v[i] + a[i];
             }
@@ -107,7 +119,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmProblem& P, const DropC
 // memory round trip) instead of one dependent load per 4 outputs (loads cannot be hoisted over the stores in between).
 struct Aux4 { float a[4]; };
 
-__host__ __device__ __forceinline__ bool epi_needs_aux(int epi) { return epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_DTANH; }
+__host__ __device__ __forceinline__ bool epi_needs_aux(int epi) { return epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_DTANH || epi == EPI_DRELU_DROP; }
 
 __device__ __forceinline__ void epi_fetch_bias(const GemmProblem& P, int n0, float b[4]) {
     b[0] = b[1] = b[2] = b[3] = 0.f;
@@ -151,6 +163,16 @@ __device__ __forceinline__ void epi_finish(const GemmProblem& P, const int epi, 
     } else if (epi == EPI_TANH) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = tanhf(pre[i]);
+    } else if (epi == EPI_RELU || epi == EPI_RELU_DROP) {
+        DropCfg d = drop; d.seed_hi ^= P.drop_site;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = fmaxf(pre[i], 0.f);
+            if (epi == EPI_RELU_DROP) v[i] = drop_apply(d, (uint32_t)m * (uint32_t)P.N + (uint32_t)(n0 + i), v[i]);
+        }
+    } else if (epi == EPI_DRELU_DROP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = a[i] > 0.f ? v[i] * drop.scale : 0.f;
     } else if (epi == EPI_RESID_DROP) {
         DropCfg d = drop; d.seed_hi ^= P.drop_site;
 #pragma unroll

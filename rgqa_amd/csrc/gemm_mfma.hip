@@ -285,7 +285,7 @@ static int check_group(const GemmGroup& g, bool tn) {
         RGQA_REQUIRE((p.lda % 8) == 0 && (p.ldb % 8) == 0 && (p.ldc % 4) == 0, "gemm[%d]: lda/ldb must be multiples of 8, ldc of 4 (%d %d %d)", i, p.lda, p.ldb, p.ldc);
         if (!tn) RGQA_REQUIRE((p.K % 8) == 0, "gemm[%d]: NT needs K %% 8 == 0 (K=%d)", i, p.K);
         RGQA_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0 && ((uintptr_t)p.C % 16) == 0, "gemm[%d]: operands must be 16-byte aligned", i);
-        if (p.epi == EPI_RESID_DROP || p.epi == EPI_DGELU || p.epi == EPI_ADD || p.epi == EPI_DTANH)
+        if (epi_needs_aux(p.epi))
             RGQA_REQUIRE(p.aux && (p.ldaux % 4) == 0, "gemm[%d]: epilogue %d needs aux", i, p.epi);
     }
     return RGQA_OK;

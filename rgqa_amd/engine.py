@@ -35,12 +35,12 @@ class Engine:
 
     def __init__(self, vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9,
                  x_layers=5, r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842, precision="bf16",
-                 ln_eps=1e-12, hidden_dropout=0.1, attn_dropout=0.1):
+                 ln_eps=1e-12, hidden_dropout=0.1, attn_dropout=0.1, arch=0, emb_dim=300):
         self.lib = _lib.load()
         self.precision = precision
         prec = {"bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
         self.cfg = Config(vocab_size, hidden, heads, inter, max_pos, type_vocab, l_layers, x_layers, r_layers, feat_dim,
-                          pos_dim, num_answers, prec, ln_eps, hidden_dropout, attn_dropout)
+                          pos_dim, num_answers, prec, ln_eps, hidden_dropout, attn_dropout, arch, emb_dim)
         h = C.c_void_p()
         check(self.lib.rgqa_engine_create(C.byref(self.cfg), C.byref(h)))
         self.h = h

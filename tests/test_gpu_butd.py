@@ -1,0 +1,78 @@
+"""BUTD path (BASELINE config 5) on the HIP engine vs the golden fixture produced by the reference's
+own GQABUTD (tests/golden/g7_butd.npz) and vs the oracle, through the drop-in class."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from oracle.gen_golden import BUTD_WORDS, BUTD_SENTS, sample_idx     # noqa: E402
+from rgqa_amd import synth                                           # noqa: E402
+
+
+def build(precision, dropout=False):
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        from butd.butd import GQABUTD
+        from butd.preprocess import Dictionary
+    finally:
+        sys.path.pop(0)
+    from tests.test_oracle_golden import butd_fill
+    from oracle import butd_ref as BR
+    d = Dictionary()
+    for w in BUTD_WORDS:
+        d.add_word(w)
+    m = GQABUTD(23, d, dropout=dropout, precision=precision)
+    c = BR.ButdConfig(ntoken=len(BUTD_WORDS), num_answers=23)
+    filled = butd_fill(c)
+    assert set(m.state_dict()) == set(filled) and all(tuple(m.state_dict()[k].shape) == tuple(np.shape(filled[k])) for k in filled)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in filled.items()})
+    return m.cuda(), c, filled
+
+
+@pytest.mark.parametrize("precision,tol,gtol", [("f32", 2e-4, 3e-3), ("bf16", 8e-2, 6e-2)])
+def test_butd_vs_reference_golden(golden_dir, precision, tol, gtol):
+    g = np.load(os.path.join(golden_dir, "g7_butd.npz"))
+    m, c, filled = build(precision)
+    b = synth.synth_batch(len(BUTD_SENTS), 8, O=36, F=2048, NA=23, vocab=64, seed=606, uq_frac=0.2)
+    feat, pos, target = (torch.from_numpy(b[k]).cuda() for k in ("feats", "boxes", "target"))
+    assert np.array_equal(m.tokenize(BUTD_SENTS).numpy(), g["toks"])
+    m.eval()
+    logits, att = m(feat, pos, BUTD_SENTS, attention=True)
+    assert att.shape == (len(BUTD_SENTS), 36, 1)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=0, atol=tol)
+    np.testing.assert_allclose(att.cpu().numpy(), g["att"], rtol=0, atol=tol / 4)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, target) * logits.size(1)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=50 * tol / 15)
+    loss.backward()
+    for k, p in m.named_parameters():
+        gr = p.grad.cpu().numpy()
+        ref_norm = float(g["gnorm." + k])
+        assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - ref_norm) <= gtol * ref_norm + 1e-7, k
+        ref = g["gsamp." + k]
+        got = gr.reshape(-1)[sample_idx(k, gr.size)]
+        assert np.abs(got - ref).max() <= 3 * gtol * max(np.abs(ref).max(), 1e-6) + 1e-7, k
+    assert float(dict(m.named_parameters())["w_emb.emb.weight"].grad[-1].abs().max()) == 0.0
+
+
+def test_butd_train_step_runs_with_dropout():
+    from rgqa_amd.lxrt.optimization import BertAdam
+    m, c, _ = build("bf16", dropout=True)
+    b = synth.synth_batch(len(BUTD_SENTS), 8, O=36, F=2048, NA=23, vocab=64, seed=607)
+    feat, pos, target = (torch.from_numpy(b[k]).cuda() for k in ("feats", "boxes", "target"))
+    opt = BertAdam(list(m.parameters()), lr=1e-3, warmup=0.1, t_total=10)
+    m.train()
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        logit = m(feat, pos, BUTD_SENTS)
+        loss = torch.nn.BCEWithLogitsLoss()(logit, target) * logit.size(1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.)
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

@@ -147,3 +147,42 @@ def test_bce_and_uq_column():
     loss = R.bce_loss(z, tt)
     man = (torch.clamp(z, min=0) - z * tt + torch.log1p(torch.exp(-z.abs()))).sum() / 4
     np.testing.assert_allclose(loss.item(), man.item(), rtol=1e-6)
+
+
+def butd_fill(cfgb):
+    from oracle import butd_ref as BR
+    out = {}
+    for k, shp in BR.param_shapes(cfgb).items():
+        if k.endswith("weight_g"):
+            out[k] = np.asarray(1.5 + 0.5 * synth.uniform(k, (1,), -1, 1)[0], dtype=np.float32)
+        elif k == "w_emb.emb.weight":
+            w = synth.uniform(k, shp, -0.5, 0.5)
+            w[-1] = 0.0
+            out[k] = w
+        else:
+            out[k] = synth.uniform(k, shp, -0.05, 0.05)
+    return out
+
+
+def test_g7_butd(golden_dir):
+    """BUTD oracle (oracle/butd_ref.py) vs the reference's GQABUTD run in the build container."""
+    from oracle import butd_ref as BR
+    from oracle.gen_golden import BUTD_WORDS, BUTD_SENTS
+    g = np.load(os.path.join(golden_dir, "g7_butd.npz"))
+    c = BR.ButdConfig(ntoken=len(BUTD_WORDS), num_answers=23)
+    P = {k: torch.from_numpy(np.asarray(v)).requires_grad_(True) for k, v in butd_fill(c).items()}
+    word2idx = {w: i for i, w in enumerate(BUTD_WORDS)}
+    toks = torch.tensor(BR.tokenize(BUTD_SENTS, word2idx))
+    assert np.array_equal(toks.numpy(), g["toks"])
+    b = synth.synth_batch(len(BUTD_SENTS), 8, O=36, F=2048, NA=23, vocab=64, seed=606, uq_frac=0.2)
+    logits, att = BR.butd_forward(P, c, torch.from_numpy(b["feats"]), torch.from_numpy(b["boxes"]), toks, want_att=True)
+    loss = R.bce_loss(logits, torch.from_numpy(b["target"]))
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(att.detach().numpy(), g["att"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    for k, p in P.items():
+        gr = p.grad.numpy()
+        np.testing.assert_allclose(np.sqrt((gr.astype(np.float64) ** 2).sum()), g["gnorm." + k], rtol=2e-4, atol=1e-9, err_msg=k)
+        np.testing.assert_allclose(gr.reshape(-1)[sample_idx(k, gr.size)], g["gsamp." + k], rtol=2e-3, atol=1e-7 + 1e-4 * np.abs(gr).max(), err_msg=k)
+    assert float(P["w_emb.emb.weight"].grad[-1].abs().max()) == 0.0     # padding row gets no gradient
