@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--butd", action="store_true", help="BASELINE config 5: BUTD backbone (butd/butd.py) train step, B per GPU, 40 tokens, dictionary 3000")
     ap.add_argument("--mixup", action="store_true",
                     help="BASELINE config 4: RoI-mixup finetune (gqa_mixup_vis.py:134-181): every loader batch is doubled on the device "
                          "(mixup_v1, Beta(1,5)); the model sees 2x rows per QA pair; value still counts loader QA pairs")
@@ -104,9 +105,19 @@ def main():
     from rgqa_amd.parallel import GradAllReduce
 
     B, T, O = args.batch, args.seq, 36
-    e = Engine(precision=args.precision, **FULL).allocate("cuda")
-    init_params(e, seed=0)       # identical replica on every rank
-    b = synth.synth_batch(B, T, seed=1234 + rank)
+    if args.butd:
+        T = 40
+        e = Engine(arch=1, vocab_size=3001, hidden=1024, emb_dim=300, feat_dim=2048, pos_dim=4, num_answers=1842, precision=args.precision,
+                   hidden_dropout=0.5, attn_dropout=0.2, heads=1, inter=8, l_layers=0, x_layers=0, r_layers=0).allocate("cuda")
+        g = torch.Generator(device=e.device).manual_seed(0)
+        e.params.uniform_(-0.03, 0.03, generator=g)
+        for sp in e.specs:
+            if sp.name.endswith("weight_g"):
+                e.view(e.params, sp).fill_(1.0)
+    else:
+        e = Engine(precision=args.precision, **FULL).allocate("cuda")
+        init_params(e, seed=0)       # identical replica on every rank
+    b = synth.synth_batch(B, T, seed=1234 + rank, vocab=3000 if args.butd else 30522)
     dev = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
     MB = B                       # rows the model sees per step
     if args.mixup:
@@ -200,12 +211,12 @@ def main():
         cpu = cpu_baseline(T, args.cpu_sample, 2)
 
     if rank == 0:
-        step_tflops = value * FWD_BWD_GFLOP.get(T, FWD_BWD_GFLOP[20]) / 1e3 * (MB // B)
+        step_tflops = value * (1.5 if args.butd else FWD_BWD_GFLOP.get(T, FWD_BWD_GFLOP[20])) / 1e3 * (MB // B)     # BUTD ~0.5 GFLOP fwd / QA pair
         out = {
-            "metric": "QA-pairs/sec (train step) LXMERT-GQA B=256", "value": round(value, 1), "unit": "QA-pairs/s",
+            "metric": "QA-pairs/sec (train step) BUTD-GQA B=256" if args.butd else "QA-pairs/sec (train step) LXMERT-GQA B=256", "value": round(value, 1), "unit": "QA-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": ("LXMERT-GQA RoI-mixup finetune train step (device mixup + fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768" if args.mixup else
+            "config": {"workload": "BUTD-GQA finetune train step (GRU 40x1024 + region attention + classifier, fwd+BCE+bwd+clip+BertAdam)" if args.butd else ("LXMERT-GQA RoI-mixup finetune train step (device mixup + fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768" if args.mixup else
                                     "LXMERT-GQA RP finetune train step (fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768"), "model_rows_per_gpu": MB,
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "rois": O, "feat_dim": 2048,
                        "num_answers": 1842, "parallelism": "dp%d" % world, "dropout": 0.1},
