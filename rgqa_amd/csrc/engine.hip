@@ -2,6 +2,7 @@
 #include "engine.h"
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -111,6 +112,8 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 }
 
 // ============================================================================ engine
+int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
+
 template <typename T>
 class Engine : public EngineBase {
 public:
@@ -132,7 +135,10 @@ public:
     T *pooled = nullptr, *h1pre = nullptr, *h1 = nullptr, *h2 = nullptr; float *hd_mean = nullptr, *hd_rstd = nullptr;
     float* logits = nullptr; T* dlogits = nullptr; float* loss_dev = nullptr;
     T *gA = nullptr, *gB = nullptr, *gctx = nullptr;
-    T *gz_s[3] = {nullptr, nullptr, nullptr}, *gzd_s[3] = {nullptr, nullptr, nullptr}, *gqkv_s[3] = {nullptr, nullptr, nullptr}, *gh_s[3] = {nullptr, nullptr, nullptr};
+    T *gz_s[2][3] = {}, *gzd_s[2][3] = {}, *gqkv_s[2][3] = {}, *gh_s[2][3] = {};   // [layer parity][stage slot]
+    hipStream_t s_w = nullptr;                 // side stream: the deferred weight-gradient GEMMs of a layer run beside the next layer's chain
+    hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_wdone[2] = {nullptr, nullptr};
+    bool wdone_valid[2] = {false, false};
     T* gemb = nullptr;
     T *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
@@ -177,6 +183,37 @@ public:
         const size_t first_layer = cfg.l_layers ? att_begin(mp.l_att[0]) : (cfg.r_layers ? att_begin(mp.r_att[0]) : (cfg.x_layers ? att_begin(mp.x_cross[0]) : mp.pooler.w));
         seg(0, first_layer, ev++);
         n_seg_events = ev;
+    }
+    // Launches the collected weight-gradient GEMMs of one layer on the side stream, ordered after everything the main
+    // stream has enqueued for that layer; records the DP segment event there (the segment is final once both the main
+    // stream's bias / LayerNorm gradients and these GEMMs are done).
+    int flush_wgrad(GemmGroup& wg, int par, hipStream_t s) {
+        static const bool serial = getenv("RGQA_WGRAD_SERIAL") != nullptr;
+        if (serial || g_rgqa_wgrad_serial || profiling) {
+            if (int r = run_wgrad(wg, s)) return r;
+            gg_init(wg);
+            return mark_segment(s);
+        }
+        if (s_w == nullptr) {
+            RGQA_HIP(hipStreamCreateWithFlags(&s_w, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                RGQA_HIP(hipEventCreateWithFlags(&ev_chain[i], hipEventDisableTiming));
+                RGQA_HIP(hipEventCreateWithFlags(&ev_wdone[i], hipEventDisableTiming));
+            }
+        }
+        RGQA_HIP(hipEventRecord(ev_chain[par], s));
+        RGQA_HIP(hipStreamWaitEvent(s_w, ev_chain[par], 0));
+        if (int r = run_wgrad(wg, s_w)) return r;
+        gg_init(wg);
+        if (int r = mark_segment(s_w)) return r;
+        RGQA_HIP(hipEventRecord(ev_wdone[par], s_w));
+        wdone_valid[par] = true;
+        return RGQA_OK;
+    }
+    // the main stream must not overwrite a gradient-buffer set while an older wgrad launch still reads it
+    int wait_wgrad(int par, hipStream_t s) {
+        if (wdone_valid[par]) { RGQA_HIP(hipStreamWaitEvent(s, ev_wdone[par], 0)); wdone_valid[par] = false; }
+        return RGQA_OK;
     }
     int seg_cursor = 0;
     int mark_segment(hipStream_t s) {
@@ -292,10 +329,13 @@ public:
         gA = take<T>((size_t)R * H); gB = take<T>((size_t)R * H); gctx = take<T>((size_t)R * H); gemb = take<T>((size_t)R * H);
         // one set of per-stage gradient buffers per stage slot of a layer: the weight-gradient GEMMs of a whole layer are
         // deferred into ONE grouped launch (432-504 tiles: fills the 256 CUs), so their operands must outlive the stage
-        for (int k = 0; k < 3; ++k) {
-            gz_s[k] = take<T>((size_t)R * H); gzd_s[k] = take<T>((size_t)R * H);
-            gqkv_s[k] = take<T>((size_t)R * 3 * H); gh_s[k] = take<T>((size_t)R * I);
-        }
+        // ... and two such sets (layer parity): layer i's wgrad launch reads its set on the side stream while layer i-1
+        // already overwrites the other one on the main stream
+        for (int par = 0; par < 2; ++par)
+            for (int k = 0; k < 3; ++k) {
+                gz_s[par][k] = take<T>((size_t)R * H); gzd_s[par][k] = take<T>((size_t)R * H);
+                gqkv_s[par][k] = take<T>((size_t)R * 3 * H); gh_s[par][k] = take<T>((size_t)R * I);
+            }
         gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
@@ -605,9 +645,11 @@ public:
 
         // ---- encoder stages in reverse; weight-gradient GEMMs are collected per layer and launched once
         GemmGroup wg; gg_init(wg);
+        int par = 0; bool layer_open = false;
         for (int si = (int)stages.size() - 1; si >= 0; --si) {
             Stage& st = stages[si];
-            T* gz = gz_s[st.slot]; T* gzd = gzd_s[st.slot]; T* gqkv = gqkv_s[st.slot]; T* gh = gh_s[st.slot];
+            if (!layer_open) { CK(wait_wgrad(par, s)); layer_open = true; }     // first stage (in backward order) of a layer
+            T* gz = gz_s[par][st.slot]; T* gzd = gzd_s[par][st.slot]; T* gqkv = gqkv_s[par][st.slot]; T* gh = gh_s[par][st.slot];
             const bool cross = st.kind == ST_ATT_CROSS;
             const bool shared_all = cross && st.active[1];
             auto rowp = [&](T* base, int m, int width) { return base + (size_t)(m == 0 ? 0 : Rl) * width; };
@@ -635,7 +677,7 @@ public:
                 for (int m = 0; m < 2; ++m) if (!st.active[m] && !st.last_dead)
                     CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
                 T* t = dy; dy = dx; dx = t;
-                if (st.layer_first) { CK(run_wgrad(wg, s)); gg_init(wg); CK(mark_segment(s)); }
+                if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
                 continue;
             }
             // ---- attention stage backward
@@ -714,9 +756,11 @@ public:
                     CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
             }
             T* t = dy; dy = dx; dx = t;
-            if (st.layer_first) { CK(run_wgrad(wg, s)); gg_init(wg); CK(mark_segment(s)); }
+            if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
         }
         CK(run_wgrad(wg, s));
+        CK(wait_wgrad(0, s));        // everything on the side stream joins the caller's stream before backward returns
+        CK(wait_wgrad(1, s));
         T* gz = gemb;
         // ---- embeddings: dropout -> LN backward -> scatter-add into the three tables
         {

@@ -179,6 +179,34 @@ def test_dropout_train_mode_is_deterministic_and_consistent():
     assert abs(num - ana) / max(1e-6, abs(ana)) < 2e-2, (num, ana)
 
 
+def test_side_stream_wgrad_matches_serial():
+    """The deferred per-layer weight-gradient launches run on a side stream against double-buffered gradient sets;
+    forcing them onto the main stream (rgqa_debug_set key 2) must give bit-identical gradients, repeatedly."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    B, T, O = 64, 20, 36
+    b = dev(synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=5, min_len=3))
+    e = make_engine(FULL, "bf16", dropout=0.1)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
+
+    def grads(serial):
+        assert L.rgqa_debug_set(2, serial) == 0
+        try:
+            run(e, b, True, 77)
+            e.loss_backward(b["target"])
+            torch.cuda.synchronize()
+            return e.grads[first:].clone()
+        finally:
+            L.rgqa_debug_set(2, 0)
+
+    ref = grads(1)
+    assert float(ref.abs().max()) > 0
+    for _ in range(3):
+        assert torch.equal(grads(0), ref)
+
+
 def test_config2_forward_b256_f32_logits_vs_cpu():
     """BASELINE config 2: forward-only inference at B=256 (full 9/5/5 architecture, f32 operands); samples are independent,
     so the CPU oracle is evaluated on a spread of 6 of the 256 rows and must agree within 1e-3 (observed ~1e-5)."""
