@@ -46,6 +46,17 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     *reinterpret_cast<bf16x4*>(p) = t;
 }
 
+// raw (unconverted) 4-element loads: lets a kernel issue the next row's loads before it consumes the current row
+template <typename T> struct raw4;
+template <> struct raw4<float> { float4 v; };
+template <> struct raw4<bf16_t> { bf16x4 v; };
+__device__ __forceinline__ void load_raw4(const float* p, raw4<float>& r) { r.v = *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void load_raw4(const bf16_t* p, raw4<bf16_t>& r) { r.v = *reinterpret_cast<const bf16x4*>(p); }
+__device__ __forceinline__ void cvt_raw4(const raw4<float>& r, float v[4]) { v[0] = r.v.x; v[1] = r.v.y; v[2] = r.v.z; v[3] = r.v.w; }
+__device__ __forceinline__ void cvt_raw4(const raw4<bf16_t>& r, float v[4]) {
+    v[0] = (float)r.v[0]; v[1] = (float)r.v[1]; v[2] = (float)r.v[2]; v[3] = (float)r.v[3];
+}
+
 // ---------------------------------------------------------------- wave (64-lane) reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -131,7 +131,7 @@ public:
     // workspace pieces
     float* maskf = nullptr;
     T *emb_out = nullptr, *emb_z = nullptr; float *emb_mean = nullptr, *emb_rstd = nullptr;
-    T *zf = nullptr, *visn_out = nullptr; float* visn_stats = nullptr;
+    T *zf = nullptr, *visn_out = nullptr, *feats_lp = nullptr; float* visn_stats = nullptr;
     T *pooled = nullptr, *h1pre = nullptr, *h1 = nullptr, *h2 = nullptr; float *hd_mean = nullptr, *hd_rstd = nullptr;
     float* logits = nullptr; T* dlogits = nullptr; float* loss_dev = nullptr;
     T *gA = nullptr, *gB = nullptr, *gctx = nullptr;
@@ -266,6 +266,7 @@ public:
         maskf = take<float>(Rl);
         emb_out = take<T>((size_t)R * H); emb_z = take<T>((size_t)Rl * H); emb_mean = take<float>(Rl); emb_rstd = take<float>(Rl);
         zf = take<T>((size_t)Rv * H); visn_stats = take<float>((size_t)Rv * 4);
+        feats_lp = LP ? take<T>((size_t)Rv * cfg.feat_dim) : nullptr;   // bf16 copy of the RoI features: read by visn_fc forward AND its wgrad
         visn_out = emb_out ? emb_out + (size_t)Rl * H : nullptr;   // [lang; visn] contiguous
         void* cur[2] = {emb_out, visn_out};
         uint32_t site = 16;
@@ -471,10 +472,12 @@ public:
         CK(k_make_mask(mask, maskf, Rl, s));
         CK(k_embed_fwd<T>(ids, seg, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z, emb_mean, emb_rstd,
                           B, Tn, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
-        {   // VisualFeatEncoder: GEMM on the raw f32 features (converted to bf16 while staging), then the fused LN/LN/avg tail
+        {   // VisualFeatEncoder: GEMM on the RoI features (one f32->bf16 cast pass in bf16 precision, so that this GEMM and
+            // its weight-gradient GEMM run on the LDS-DMA kernels), then the fused LN/LN/avg tail
             GemmGroup g; gg_init(g);
-            add_fwd(g, feats, cfg.feat_dim, mp.visn_fc, 0, H, zf, H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
-            CK(run_fwd(g, s, 0, LP ? 1 : 0));
+            if (LP) CK(k_cast_bf16(feats, feats_lp, (size_t)Rv * cfg.feat_dim, s));
+            add_fwd(g, LP ? (const void*)feats_lp : (const void*)feats, cfg.feat_dim, mp.visn_fc, 0, H, zf, H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
+            CK(run_fwd(g, s));
             CK(k_visn_combine_fwd<T>(zf, H, boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.visn_ln.b, P + mp.box_ln.w, P + mp.box_ln.b,
                                      visn_out, H, visn_stats, Rv, H, cfg.pos_dim, cfg.ln_eps, drop_site(pd, 2), s));
         }
@@ -777,8 +780,8 @@ public:
                                      G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.visn_fc.b, G + mp.box_fc.w, G + mp.box_fc.b,
                                      accumulate, Rv, H, cfg.pos_dim, drop_site(pd, 2), s));
             gg_init(g);
-            add_wgrad(g, dzf, H, mp.visn_fc, 0, H, in_feats, cfg.feat_dim, Rv, accumulate);
-            CK(run_wgrad(g, s, LP ? 1 : 0));
+            add_wgrad(g, dzf, H, mp.visn_fc, 0, H, LP ? (const void*)feats_lp : (const void*)in_feats, cfg.feat_dim, Rv, accumulate);
+            CK(run_wgrad(g, s));
         }
         CK(mark_segment(s));     // embeddings + visual embedding
         return RGQA_OK;

@@ -10,8 +10,8 @@ struct FinOut { float* p[FIN_MAXQ]; int stride[FIN_MAXQ]; };
 int k_colsum_finalize(const float* part, int nblk, int nq, int N, const FinOut& fo, int accumulate, hipStream_t s);
 template <typename T>
 int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s);
-int ln_bwd_blocks(int M);
-// part: workspace of ln_bwd_blocks(M)*3*N floats (or null: no column sums). dzd may be null.
+int ln_bwd_blocks(int M, int N);
+// part: workspace of ln_bwd_blocks(M,N)*3*N floats (or null: no column sums). dzd may be null.
 template <typename T>
 int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, const float* mean, const float* rstd, T* dz, T* dzd, int lddz,
              float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s);

@@ -56,43 +56,68 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 // Also emits (optionally) dzd = dropout-masked dz (the gradient entering the preceding dense layer,
 // whose forward epilogue applied that mask) and per-block partial column sums:
 //   part[blk][0][n] = sum dy*xhat (dgamma), part[blk][1][n] = sum dy (dbeta), part[blk][2][n] = sum dzd (dense bias grad)
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
+template <typename T, int NV, int LN_BWD_THREADS>
+__global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dz, T* __restrict__ dzd,
                                                      int lddz, float* __restrict__ part, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale) {
-    __shared__ float red[4][NV * 256];
+    // N <= 768: 16 waves per block (4 per SIMD: the loop is one dependent HBM round trip per row, so it lives on
+    // occupancy; fits the 128-VGPR budget); wider rows: 4 waves per block.  One row per wave per trip, next row's loads
+    // issued before the current row's reductions.
+    constexpr int NW = LN_BWD_THREADS / 64;
+    __shared__ float red[NW / 2][NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = N >> 2;
-    float ag[NV][4], ab[NV][4], ad[NV][4], gm[NV][4];
+    float ag[NV][4], ab[NV][4], ad[NV][4];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ad[i][j] = 0.f; gm[i][j] = 0.f; }
-        if (c < nv) load4(gamma + c * 4, gm[i]);
+        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ad[i][j] = 0.f; }
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
+    const int stride = gridDim.x * NW;
+    int row = blockIdx.x * NW + wave;
+    raw4<T> rd[NV], rz[NV];
+    float mu = 0.f, rs = 0.f;
+    if (row < M) {
+        mu = mean[row]; rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) { load_raw4(dy + (size_t)row * lddy + c * 4, rd[i]); load_raw4(z + (size_t)row * ldz + c * 4, rz[i]); }
+        }
+    }
+    for (; row < M; row += stride) {
         float g[NV][4], xh[NV][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
-                float d[4], zz[4];
-                load4(dy + (size_t)row * lddy + c * 4, d);
-                load4(z + (size_t)row * ldz + c * 4, zz);
+                float d[4], zz[4], gm[4];
+                load4(gamma + c * 4, gm);   // L1/L2-resident; not kept in registers (the 128-VGPR budget of a 16-wave block)
+                cvt_raw4(rd[i], d);
+                cvt_raw4(rz[i], zz);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     d[j] = drop_apply(drop_in, (uint32_t)row * (uint32_t)N + (uint32_t)(c * 4 + j), d[j]) * dy_scale;
                     xh[i][j] = (zz[j] - mu) * rs;
-                    g[i][j] = d[j] * gm[i][j];
+                    g[i][j] = d[j] * gm[j];
                     s1 += g[i][j];
                     s2 += g[i][j] * xh[i][j];
                     ag[i][j] += d[j] * xh[i][j];
                     ab[i][j] += d[j];
                 }
+            }
+        }
+        const float rs_cur = rs;
+        const int nrow = row + stride;
+        if (nrow < M) {
+            mu = mean[nrow]; rs = rstd[nrow];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) { load_raw4(dy + (size_t)nrow * lddy + c * 4, rd[i]); load_raw4(z + (size_t)nrow * ldz + c * 4, rz[i]); }
             }
         }
         s1 = wave_sum(s1) / (float)N;
@@ -104,7 +129,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                 float o[4], od[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
+                    o[j] = rs_cur * (g[i][j] - s1 - xh[i][j] * s2);
                     od[j] = drop_apply(drop, (uint32_t)row * (uint32_t)N + (uint32_t)(c * 4 + j), o[j]);
                     ad[i][j] += od[j];
                 }
@@ -114,50 +139,76 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         }
     }
     if (part == nullptr) return;
-    // cross-wave reduction of the three column accumulators, one at a time through LDS
+    // cross-wave reduction of the three column accumulators through LDS, fixed order (bit-reproducible):
+    // waves NW/2.. park theirs, waves 0..NW/2-1 add and park the pair sums, then every thread folds NW/2 values per column.
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
         __syncthreads();
+        if (wave >= NW / 2) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    red[wave][c * 4 + j] = which == 0 ? ag[i][j] : (which == 1 ? ab[i][j] : ad[i][j]);
+                    for (int j = 0; j < 4; ++j)
+                        red[wave - NW / 2][c * 4 + j] = which == 0 ? ag[i][j] : (which == 1 ? ab[i][j] : ad[i][j]);
+                }
             }
         }
         __syncthreads();
-        for (int n = threadIdx.x; n < N; n += 256)
-            part[((size_t)blockIdx.x * 3 + which) * N + n] = red[0][n] + red[1][n] + red[2][n] + red[3][n];
+        if (wave < NW / 2) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        red[wave][c * 4 + j] += which == 0 ? ag[i][j] : (which == 1 ? ab[i][j] : ad[i][j]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int n = threadIdx.x; n < N; n += LN_BWD_THREADS) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW / 2; ++w) t += red[w][n];
+            part[((size_t)blockIdx.x * 3 + which) * N + n] = t;
+        }
     }
 }
 
 // out[q][n*stride] (+)= sum_blk part[blk][q][n] for q < nq (null output pointers are skipped).
-// Block = 16 columns x 16 partial groups: every thread sums nblk/16 partials (fixed order -> bit-reproducible),
-// then the 16 group sums are folded in a fixed order through LDS.
+// Block = 16 columns (4 lanes x float4) x 64 partial groups: every thread sums nblk/64 float4 partials (fixed order ->
+// bit-reproducible), then the 64 group sums are folded in a fixed order through LDS.  N % 4 == 0.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int nq, int N, FinOut fo, int accumulate) {
-    __shared__ float red[16][17];
-    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int n = blockIdx.x * 16 + c;
+    __shared__ float red[64][17];
+    const int cq = threadIdx.x & 3, grp = threadIdx.x >> 2;
+    const int n4 = blockIdx.x * 16 + cq * 4;
     const int q = blockIdx.y;
     float* o = fo.p[q];
     if (o == nullptr) return;
-    float s = 0.f;
-    if (n < N)
-        for (int b = grp; b < nblk; b += 16) s += part[((size_t)b * nq + q) * N + n];
-    red[grp][c] = s;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n4 < N)
+        for (int b = grp; b < nblk; b += 64) {
+            float v[4];
+            load4(part + ((size_t)b * nq + q) * N + n4, v);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[grp][cq * 4 + j] = s[j];
     __syncthreads();
-    if (grp == 0 && n < N) {
+    const int c = threadIdx.x, n = blockIdx.x * 16 + c;
+    if (c < 16 && n < N) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][c];
+        for (int g = 0; g < 64; ++g) t += red[g][c];
         o += (size_t)n * fo.stride[q];
         *o = accumulate ? *o + t : t;
     }
 }
 
 int k_colsum_finalize(const float* part, int nblk, int nq, int N, const FinOut& fo, int accumulate, hipStream_t s) {
+    RGQA_REQUIRE(N % 4 == 0, "colsum_finalize: N=%d must be a multiple of 4", N);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(N, 16), nq), dim3(256), 0, s, part, nblk, nq, N, fo, accumulate);
     RGQA_LAUNCH_CHECK("colsum_finalize_kernel");
     return RGQA_OK;
@@ -192,15 +243,16 @@ int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, i
     return RGQA_OK;
 }
 
-int ln_bwd_blocks(int M) { int b = cdiv(M, 4); return b > 512 ? 512 : b; }
+static int ln_bwd_waves(int N) { return cdiv(N / 4, 64) <= 3 ? 16 : 4; }
+int ln_bwd_blocks(int M, int N) { const int nw = ln_bwd_waves(N); const int b = cdiv(M, nw), cap = nw == 16 ? 256 : 512; return b > cap ? cap : b; }
 
 template <typename T>
 int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, const float* mean, const float* rstd, T* dz, T* dzd, int lddz,
              float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256, "layernorm bwd: N=%d unsupported", N);
     if (M <= 0) return RGQA_OK;
-    const int nblk = ln_bwd_blocks(M);
-#define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV>), dim3(nblk), dim3(256), 0, s, dy, lddy, z, ldz, gamma, mean, rstd, dz, dzd, lddz, part, M, N, drop, drop_in, dy_scale)
+    const int nblk = ln_bwd_blocks(M, N);
+#define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, (NVV <= 3 ? 1024 : 256)>), dim3(nblk), dim3(NVV <= 3 ? 1024 : 256), 0, s, dy, lddy, z, ldz, gamma, mean, rstd, dz, dzd, lddz, part, M, N, drop, drop_in, dy_scale)
     const int nvl = cdiv(N / 4, 64);
     if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4);
     else if (nvl <= 6) LN_BWD(6); else LN_BWD(8);

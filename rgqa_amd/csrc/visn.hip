@@ -179,7 +179,7 @@ int k_visn_combine_bwd(const T* dout, int lddo, const T* zf, int ldz, const floa
                        float* dWb, float* dbb, int accumulate, int M, int H, int pos_dim, DropCfg drop, hipStream_t s) {
     RGQA_REQUIRE(H % 4 == 0 && H <= 1024 && pos_dim >= 1 && pos_dim <= 4, "visn_combine bwd: H=%d pos_dim=%d unsupported", H, pos_dim);
     if (M <= 0) return RGQA_OK;
-    const int nblk = ln_bwd_blocks(M);
+    const int nblk = cdiv(M, 4) > 512 ? 512 : cdiv(M, 4);   // 4 rows (waves) per block, grid-stride
 #define VB(NVV) hipLaunchKernelGGL((visn_bwd_kernel<T, NVV>), dim3(nblk), dim3(256), 0, s, dout, lddo, zf, ldz, boxes, Wb, bb, g1, g2, stats, dzf, lddz, part, M, H, pos_dim, drop)
     const int nvl = cdiv(H / 4, 64);
     if (nvl <= 1) VB(1); else if (nvl == 2) VB(2); else if (nvl == 3) VB(3); else VB(4);
