@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--padded", action="store_true", help="compute every padded token position (the reference's layout) instead of packing the real tokens")
     ap.add_argument("--butd", action="store_true", help="BASELINE config 5: BUTD backbone (butd/butd.py) train step, B per GPU, 40 tokens, dictionary 3000")
     ap.add_argument("--mixup", action="store_true",
                     help="BASELINE config 4: RoI-mixup finetune (gqa_mixup_vis.py:134-181): every loader batch is doubled on the device "
@@ -119,6 +120,8 @@ def main():
         init_params(e, seed=0)       # identical replica on every rank
     b = synth.synth_batch(B, T, seed=1234 + rank, vocab=3000 if args.butd else 30522)
     dev = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
+    # real token count of every question (host side, as the tokenizer knows it): the engine packs the language rows
+    lengths = None if (args.padded or args.butd) else np.ascontiguousarray(np.tile(b["lengths"], 2 if args.mixup else 1), dtype=np.int32)
     MB = B                       # rows the model sees per step
     if args.mixup:
         import ctypes as C
@@ -154,7 +157,7 @@ def main():
         i = state["step"]
         if args.mixup:
             state["keep"] = mixup_batch()
-        e.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=True, seed=4321 + rank + 1000003 * i)
+        e.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=True, seed=4321 + rank + 1000003 * i, lengths=lengths)
         e.loss_backward(dev["target"])
         if comm is not None:
             comm.all_reduce()
@@ -219,13 +222,19 @@ def main():
             "config": {"workload": "BUTD-GQA finetune train step (GRU 40x1024 + region attention + classifier, fwd+BCE+bwd+clip+BertAdam)" if args.butd else ("LXMERT-GQA RoI-mixup finetune train step (device mixup + fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768" if args.mixup else
                                     "LXMERT-GQA RP finetune train step (fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768"), "model_rows_per_gpu": MB,
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "rois": O, "feat_dim": 2048,
-                       "num_answers": 1842, "parallelism": "dp%d" % world, "dropout": 0.1},
+                       "num_answers": 1842, "parallelism": "dp%d" % world, "dropout": 0.1,
+                       "language_rows": ("padded: all %d token positions computed" % (MB * T)) if lengths is None else
+                                        ("packed: %d real tokens of %d positions (question length ~ U{5..%d}); padding rows are not computed, results identical" % (int(lengths.sum()), MB * T, T))},
+            # FLOPs of the reference's padded computation per second (what the same QA-pairs/s costs the reference) ...
             "step_model_tflops_per_gpu": round(step_tflops / world, 1),
             "step_frac_of_bf16_peak": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
             "roofline": roof, "cpu_baseline": cpu,
         }
         if prof is not None:
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.profile_steps, 3) for k, v in prof.items() if v["launches"]}
+            # ... and the FLOPs the engine actually executed (GEMMs + attention, packed rows) over the measured step time
+            ex = sum(v["flops"] for v in prof.values()) / max(1, args.profile_steps)
+            out["step_executed_tflops_per_gpu"] = round(ex / (ms * 1e-3) / 1e12, 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -80,6 +80,15 @@ int rgqa_engine_backward(rgqa_engine* e, const float* dlogits, int ld, int accum
 int rgqa_engine_backward_pooled(rgqa_engine* e, const float* dpooled, int ld, int accumulate, void* stream);
 /* debug / parity: copy a saved activation ("embed_lang", "embed_visn", "l3", "r1", "x2_lang", "x2_visn", "pooled") as f32 */
 int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, size_t cap_elems, void* stream);
+/* Unpadded language rows for the FOLLOWING forward passes. lengths (HOST array, n = B of the bound shape) holds each
+ * sample's real token count ([CLS] .. [SEP]; what sum(input_mask[b]) is for the prefix masks convert_sents_to_features
+ * builds, lxrt/entry.py:37-79). The reference computes all max_seq_length positions and masks the padding with -10000
+ * (entry.py:119, modeling.py:336): padded positions then carry probability exactly 0 as keys and the pooler reads token 0,
+ * so they reach neither the logits nor any gradient. With lengths set the engine packs only the real rows (GEMM /
+ * LayerNorm rows B*T -> sum(lengths); attention windows per sample) - same logits and gradients, less work; input_mask is
+ * then not read and language activations returned by get_activation are the packed rows. NULL / n = 0 restores the
+ * padded layout (the default after bind). The array is consumed before the call returns. */
+int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n);
 
 /* data-parallel overlap: the gradient arena becomes final range by range while backward runs (head first, embeddings
  * last). grad_segment k = element range [begin,end) + the id of the event recorded on the backward stream once that

@@ -10,14 +10,15 @@ template <typename T>
 __global__ __launch_bounds__(64) void attn_fwd_ref_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
-    const int Lq = a.Lq, Lk = a.Lk, dh = a.dh, dp = dh + 1, kp = Lk + 1;
+    ATTN_SAMPLE_ROWS(a, b)
+    const int dh = a.dh, dp = dh + 1, kp = Lk + 1;
     float* Qs = sm;
     float* Ks = Qs + Lq * dp;
     float* Vs = Ks + Lk * dp;
     float* Ps = Vs + Lk * dp;
-    const T* q = reinterpret_cast<const T*>(a.q) + (size_t)b * Lq * a.ldq + h * dh;
-    const T* k = reinterpret_cast<const T*>(a.k) + (size_t)b * Lk * a.ldk + h * dh;
-    const T* v = reinterpret_cast<const T*>(a.v) + (size_t)b * Lk * a.ldv + h * dh;
+    const T* q = reinterpret_cast<const T*>(a.q) + q0 * a.ldq + h * dh;
+    const T* k = reinterpret_cast<const T*>(a.k) + k0 * a.ldk + h * dh;
+    const T* v = reinterpret_cast<const T*>(a.v) + k0 * a.ldv + h * dh;
     const int tid = threadIdx.x;
     for (int x = tid; x < Lq * dh; x += 64) Qs[(x / dh) * dp + x % dh] = to_f32(q[(size_t)(x / dh) * a.ldq + x % dh]);
     for (int x = tid; x < Lk * dh; x += 64) {
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(64) void attn_fwd_ref_kernel(const AttnArgs a) {
         float s = 0.f;
         for (int d = 0; d < dh; ++d) s = fmaf(Qs[i * dp + d], Ks[j * dp + d], s);
         s *= a.scale;
-        if (a.mask) s += a.mask[(size_t)b * Lk + j];
+        if (a.mask) s += a.mask[(size_t)b * a.Lk + j];
         Ps[i * kp + j] = s;
     }
     __syncthreads();
@@ -42,13 +43,13 @@ __global__ __launch_bounds__(64) void attn_fwd_ref_kernel(const AttnArgs a) {
         for (int j = 0; j < Lk; ++j) { float e = __expf(Ps[i * kp + j] - m); Ps[i * kp + j] = e; sum += e; }
         const float inv = 1.f / sum;
         for (int j = 0; j < Lk; ++j) {
-            uint32_t idx = (uint32_t)(((b * a.nh + h) * Lq + i) * Lk + j);
+            uint32_t idx = (uint32_t)(((b * a.nh + h) * a.Lq + i) * a.Lk + j);
             Ps[i * kp + j] = drop_apply(dc, idx, Ps[i * kp + j] * inv);
         }
-        if (a.lse) a.lse[((size_t)b * a.nh + h) * Lq + i] = m + __logf(sum);
+        if (a.lse) a.lse[((size_t)b * a.nh + h) * a.Lq + i] = m + __logf(sum);
     }
     __syncthreads();
-    T* o = reinterpret_cast<T*>(a.out) + (size_t)b * Lq * a.ldo + h * dh;
+    T* o = reinterpret_cast<T*>(a.out) + q0 * a.ldo + h * dh;
     for (int x = tid; x < Lq * dh; x += 64) {
         const int i = x / dh, d = x % dh;
         float s = 0.f;
@@ -61,17 +62,18 @@ template <typename T>
 __global__ __launch_bounds__(64) void attn_bwd_ref_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
-    const int Lq = a.Lq, Lk = a.Lk, dh = a.dh, dp = dh + 1, kp = Lk + 1;
+    ATTN_SAMPLE_ROWS(a, b)
+    const int dh = a.dh, dp = dh + 1, kp = Lk + 1;
     float* Qs = sm;
     float* Ks = Qs + Lq * dp;
     float* Vs = Ks + Lk * dp;
     float* Os = Vs + Lk * dp;   // dO
     float* Ps = Os + Lq * dp;   // dropped probabilities (what multiplied V)
     float* Ds = Ps + Lq * kp;   // dS
-    const T* q = reinterpret_cast<const T*>(a.q) + (size_t)b * Lq * a.ldq + h * dh;
-    const T* k = reinterpret_cast<const T*>(a.k) + (size_t)b * Lk * a.ldk + h * dh;
-    const T* v = reinterpret_cast<const T*>(a.v) + (size_t)b * Lk * a.ldv + h * dh;
-    const T* dO = reinterpret_cast<const T*>(a.dout) + (size_t)b * Lq * a.lddo + h * dh;
+    const T* q = reinterpret_cast<const T*>(a.q) + q0 * a.ldq + h * dh;
+    const T* k = reinterpret_cast<const T*>(a.k) + k0 * a.ldk + h * dh;
+    const T* v = reinterpret_cast<const T*>(a.v) + k0 * a.ldv + h * dh;
+    const T* dO = reinterpret_cast<const T*>(a.dout) + q0 * a.lddo + h * dh;
     const int tid = threadIdx.x;
     for (int x = tid; x < Lq * dh; x += 64) {
         Qs[(x / dh) * dp + x % dh] = to_f32(q[(size_t)(x / dh) * a.ldq + x % dh]);
@@ -92,9 +94,9 @@ __global__ __launch_bounds__(64) void attn_bwd_ref_kernel(const AttnArgs a) {
             dp_ = fmaf(Os[i * dp + d], Vs[j * dp + d], dp_);
         }
         s *= a.scale;
-        if (a.mask) s += a.mask[(size_t)b * Lk + j];
-        const float p = __expf(s - a.lse[((size_t)b * a.nh + h) * Lq + i]);
-        uint32_t idx = (uint32_t)(((b * a.nh + h) * Lq + i) * Lk + j);
+        if (a.mask) s += a.mask[(size_t)b * a.Lk + j];
+        const float p = __expf(s - a.lse[((size_t)b * a.nh + h) * a.Lq + i]);
+        uint32_t idx = (uint32_t)(((b * a.nh + h) * a.Lq + i) * a.Lk + j);
         const float keep = drop_apply(dc, idx, 1.0f);   // 0 or 1/(1-p)
         Ds[i * kp + j] = p;
         Ps[i * kp + j] = dp_ * keep;                     // dL/dp_ij
@@ -105,15 +107,15 @@ __global__ __launch_bounds__(64) void attn_bwd_ref_kernel(const AttnArgs a) {
         for (int j = 0; j < Lk; ++j) delta = fmaf(Ds[i * kp + j], Ps[i * kp + j], delta);
         for (int j = 0; j < Lk; ++j) {
             const float p = Ds[i * kp + j], dpv = Ps[i * kp + j];
-            uint32_t idx = (uint32_t)(((b * a.nh + h) * Lq + i) * Lk + j);
+            uint32_t idx = (uint32_t)(((b * a.nh + h) * a.Lq + i) * a.Lk + j);
             Ds[i * kp + j] = p * (dpv - delta) * a.scale;   // dS (w.r.t. Q K^T before scaling folded in)
             Ps[i * kp + j] = drop_apply(dc, idx, p);         // dropped P for dV
         }
     }
     __syncthreads();
-    T* dq = reinterpret_cast<T*>(a.dq) + (size_t)b * Lq * a.lddq + h * dh;
-    T* dk = reinterpret_cast<T*>(a.dk) + (size_t)b * Lk * a.lddk + h * dh;
-    T* dv = reinterpret_cast<T*>(a.dv) + (size_t)b * Lk * a.lddv + h * dh;
+    T* dq = reinterpret_cast<T*>(a.dq) + q0 * a.lddq + h * dh;
+    T* dk = reinterpret_cast<T*>(a.dk) + k0 * a.lddk + h * dh;
+    T* dv = reinterpret_cast<T*>(a.dv) + k0 * a.lddv + h * dh;
     for (int x = tid; x < Lq * dh; x += 64) {
         const int i = x / dh, d = x % dh;
         float s = 0.f;

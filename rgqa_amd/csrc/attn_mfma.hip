@@ -61,10 +61,10 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char vs[NKT * 16 * ROWB];
     const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
-    const int Lq = a.Lq, Lk = a.Lk;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * Lq * a.ldq + h * 64;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * Lk * a.ldk + h * 64;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (size_t)b * Lk * a.ldv + h * 64;
+    ATTN_SAMPLE_ROWS(a, b)      // q0, k0: first row of this sample; Lq, Lk: its valid row counts (<= a.Lq, a.Lk)
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + q0 * a.ldq + h * 64;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + k0 * a.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + k0 * a.ldv + h * 64;
     stage_tile(vs, V, Lk, NKT * 16, a.ldv, lane);
 
     bf16x8 qf[NQT][2];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = kt * 16 + 4 * g + r;
-            mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * Lk + key] : 0.f) : -INFINITY;
+            mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
         }
     }
     DropCfg dc = a.drop; dc.seed_hi ^= a.drop_site;
@@ -109,17 +109,17 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
-        if (g == 0 && q < Lq && a.lse) a.lse[((size_t)b * a.nh + h) * Lq + q] = m + __logf(sum);
+        if (g == 0 && q < Lq && a.lse) a.lse[((size_t)b * a.nh + h) * a.Lq + q] = m + __logf(sum);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t idx = (uint32_t)(((b * a.nh + h) * Lq + q) * Lk + kt * 16 + 4 * g + r);
+                const uint32_t idx = (uint32_t)(((b * a.nh + h) * a.Lq + q) * a.Lk + kt * 16 + 4 * g + r);
                 acc[kt][qt][r] = drop_apply(dc, idx, acc[kt][qt][r] * inv);
             }
     }
     // ctx^T[d][q] = sum_key V^T[d][key] P^T[key][q]
-    bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * Lq * a.ldo + h * 64;
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + q0 * a.ldo + h * 64;
     constexpr int NKS = (NKT + 1) / 2;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -153,17 +153,17 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float delta_s[NQT * 16];
     const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
-    const int Lq = a.Lq, Lk = a.Lk;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * Lq * a.ldq + h * 64;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * Lk * a.ldk + h * 64;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (size_t)b * Lk * a.ldv + h * 64;
-    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + (size_t)b * Lq * a.lddo + h * 64;
-    const float* lse = a.lse + ((size_t)b * a.nh + h) * Lq;
+    ATTN_SAMPLE_ROWS(a, b)
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + q0 * a.ldq + h * 64;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + k0 * a.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + k0 * a.ldv + h * 64;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + q0 * a.lddo + h * 64;
+    const float* lse = a.lse + ((size_t)b * a.nh + h) * a.Lq;
     stage_tile(ks_, K, Lk, NKT * 16, a.ldk, lane);
     stage_tile(qs_, Q, Lq, NQT * 16, a.ldq, lane);
     stage_tile(os_, dO, Lq, NQT * 16, a.lddo, lane);
     DropCfg dc = a.drop; dc.seed_hi ^= a.drop_site;
-    const uint32_t idx0 = (uint32_t)((b * a.nh + h) * Lq) * (uint32_t)Lk;
+    const uint32_t idx0 = (uint32_t)((b * a.nh + h) * a.Lq) * (uint32_t)a.Lk;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int NKS = (NKT + 1) / 2, NQS = (NQT + 1) / 2;
 
@@ -178,10 +178,10 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + 4 * g + r;
-                mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * Lk + key] : 0.f) : -INFINITY;
+                mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
             }
         }
-        bf16_t* dQ = reinterpret_cast<bf16_t*>(a.dq) + (size_t)b * Lq * a.lddq + h * 64;
+        bf16_t* dQ = reinterpret_cast<bf16_t*>(a.dq) + q0 * a.lddq + h * 64;
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
             const int q = qt * 16 + fr;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = q < Lq ? __expf(s4[r] * a.scale + mk[kt][r] - lq) : 0.f;
-                    const float keep = drop_apply(dc, idx0 + (uint32_t)(q * Lk + kt * 16 + 4 * g + r), 1.0f);
+                    const float keep = drop_apply(dc, idx0 + (uint32_t)(q * a.Lk + kt * 16 + 4 * g + r), 1.0f);
                     const float dp = dp4[r] * keep;
                     delta += p * dp;
                     s4[r] = p; dp4[r] = dp;
@@ -245,14 +245,14 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
                 dl[qt][r] = delta_s[q];
             }
         }
-        bf16_t* dK = reinterpret_cast<bf16_t*>(a.dk) + (size_t)b * Lk * a.lddk + h * 64;
-        bf16_t* dV = reinterpret_cast<bf16_t*>(a.dv) + (size_t)b * Lk * a.lddv + h * 64;
+        bf16_t* dK = reinterpret_cast<bf16_t*>(a.dk) + k0 * a.lddk + h * 64;
+        bf16_t* dV = reinterpret_cast<bf16_t*>(a.dv) + k0 * a.lddv + h * 64;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const int key = kt * 16 + fr;
             const bf16x8 kf0 = ldfrag(K, key, Lk, a.ldk, 0, g), kf1 = ldfrag(K, key, Lk, a.ldk, 1, g);
             const bf16x8 vf0 = ldfrag(V, key, Lk, a.ldv, 0, g), vf1 = ldfrag(V, key, Lk, a.ldv, 1, g);
-            const float mkk = key < Lk ? (a.mask ? a.mask[(size_t)b * Lk + key] : 0.f) : -INFINITY;
+            const float mkk = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
             f32x4 dsn[NQT], pdn[NQT];
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt) {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     const int q = qt * 16 + 4 * g + r;
                     const float p = q < Lq ? __expf(s4[r] * a.scale + mkk - lq[qt][r]) : 0.f;
-                    const float keep = drop_apply(dc, idx0 + (uint32_t)(q * Lk + key), 1.0f);
+                    const float keep = drop_apply(dc, idx0 + (uint32_t)(q * a.Lk + key), 1.0f);
                     dsn[qt][r] = p * (dp4[r] * keep - dl[qt][r]) * a.scale;
                     pdn[qt][r] = p * keep;
                 }

@@ -106,6 +106,11 @@ int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, siz
     return e->impl->get_activation(name, out, cap, S(stream));
 }
 
+int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n) {
+    NEED(e);
+    return e->impl->set_lengths(lengths, n);
+}
+
 int rgqa_engine_num_grad_segments(const rgqa_engine* e, int* out) { NEED(e); *out = (int)e->impl->grad_segs.size(); return RGQA_OK; }
 int rgqa_engine_grad_segment(const rgqa_engine* e, int k, size_t* begin, size_t* end, int* event) {
     NEED(e);

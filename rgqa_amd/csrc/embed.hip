@@ -2,16 +2,18 @@
 // One wave per token; HBM-bound gather (3 table rows in, 1 activation row out).
 #include "kernels.h"
 
+// row_src (varlen mode): packed row -> b*Tn + t of the token it holds; null = identity (padded layout)
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const float* __restrict__ word,
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const int* __restrict__ row_src, const float* __restrict__ word,
                                                         const float* __restrict__ pos, const float* __restrict__ type, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, int ldo, T* __restrict__ zsave,
                                                         float* __restrict__ mean, float* __restrict__ rstd, int rows, int Tn, int H, float eps, DropCfg drop) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
-    const int t = row % Tn;
-    const int64_t id = ids[row], sg = seg ? seg[row] : 0;
+    const int src = row_src ? row_src[row] : row;
+    const int t = src % Tn;
+    const int64_t id = ids[src], sg = seg ? seg[src] : 0;
     const int nv = H >> 2;
     float v[NV][4];
     float s = 0.f;
@@ -61,12 +63,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 // de [rows, H] f32 -> atomic scatter-add into the tables (dense f32 gradients, as the reference's
 // nn.Embedding produces; rows with index 0 are skipped: padding_idx=0 on all three tables).
 template <typename T>
-__global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict__ de, const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict__ de, const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const int* __restrict__ row_src,
                                                             float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype, int rows, int Tn, int H) {
     const int row = blockIdx.x;
     if (row >= rows) return;
-    const int t = row % Tn;
-    const int64_t id = ids[row], sg = seg ? seg[row] : 0;
+    const int src = row_src ? row_src[row] : row;
+    const int t = src % Tn;
+    const int64_t id = ids[src], sg = seg ? seg[src] : 0;
     for (int n = threadIdx.x; n < H; n += 256) {
         const float g = to_f32(de[(size_t)row * H + n]);
         if (id != 0) atomicAdd(dword + (size_t)id * H + n, g);
@@ -81,12 +84,12 @@ __global__ void make_mask_kernel(const int64_t* __restrict__ m, float* __restric
 }
 
 template <typename T>
-int k_embed_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, int rows, const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
                 T* out, int ldo, T* zsave, float* mean, float* rstd, int B, int Tn, int H, int vocab, int type_vocab, float eps, DropCfg drop, hipStream_t s) {
     RGQA_REQUIRE(H % 4 == 0 && H <= 2048 && ldo % 4 == 0, "embed: hidden %d unsupported", H);
-    const int rows = B * Tn;
+    RGQA_REQUIRE(rows <= B * Tn, "embed: %d rows exceed B*T = %d", rows, B * Tn);
     if (rows <= 0) return RGQA_OK;
-#define EMB(NVV) hipLaunchKernelGGL((embed_fwd_kernel<T, NVV>), dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, seg, word, pos, type, gamma, beta, out, ldo, zsave, mean, rstd, rows, Tn, H, eps, drop)
+#define EMB(NVV) hipLaunchKernelGGL((embed_fwd_kernel<T, NVV>), dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, seg, row_src, word, pos, type, gamma, beta, out, ldo, zsave, mean, rstd, rows, Tn, H, eps, drop)
     const int nvl = cdiv(H / 4, 64);
     if (nvl <= 1) EMB(1); else if (nvl == 2) EMB(2); else if (nvl == 3) EMB(3); else if (nvl == 4) EMB(4); else EMB(8);
 #undef EMB
@@ -95,10 +98,10 @@ int k_embed_fwd(const int64_t* ids, const int64_t* seg, const float* word, const
 }
 
 template <typename T>
-int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, float* dword, float* dpos, float* dtype, int B, int Tn, int H, hipStream_t s) {
-    const int rows = B * Tn;
+int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, hipStream_t s) {
+    RGQA_REQUIRE(rows <= B * Tn, "embed scatter: %d rows exceed B*T = %d", rows, B * Tn);
     if (rows <= 0) return RGQA_OK;
-    hipLaunchKernelGGL(embed_scatter_kernel<T>, dim3(rows), dim3(256), 0, s, de, ids, seg, dword, dpos, dtype, rows, Tn, H);
+    hipLaunchKernelGGL(embed_scatter_kernel<T>, dim3(rows), dim3(256), 0, s, de, ids, seg, row_src, dword, dpos, dtype, rows, Tn, H);
     RGQA_LAUNCH_CHECK("embed_scatter_kernel");
     return RGQA_OK;
 }
@@ -110,7 +113,7 @@ int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s) {
     return RGQA_OK;
 }
 
-template int k_embed_fwd<float>(const int64_t*, const int64_t*, const float*, const float*, const float*, const float*, const float*, float*, int, float*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
-template int k_embed_fwd<bf16_t>(const int64_t*, const int64_t*, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, bf16_t*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
-template int k_embed_scatter<float>(const float*, const int64_t*, const int64_t*, float*, float*, float*, int, int, int, hipStream_t);
-template int k_embed_scatter<bf16_t>(const bf16_t*, const int64_t*, const int64_t*, float*, float*, float*, int, int, int, hipStream_t);
+template int k_embed_fwd<float>(const int64_t*, const int64_t*, const int*, int, const float*, const float*, const float*, const float*, const float*, float*, int, float*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
+template int k_embed_fwd<bf16_t>(const int64_t*, const int64_t*, const int*, int, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, bf16_t*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
+template int k_embed_scatter<float>(const float*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, hipStream_t);
+template int k_embed_scatter<bf16_t>(const bf16_t*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, hipStream_t);

@@ -93,6 +93,8 @@ public:
     std::vector<GradSeg> grad_segs;
     std::vector<hipEvent_t> seg_events;
     virtual int get_activation(const char* name, float* out, size_t cap_elems, hipStream_t s) = 0;
+    // per-sample real token counts for the following forward passes (packed language rows); null: padded layout
+    virtual int set_lengths(const int* lens, int n) { (void)lens; (void)n; rgqa_set_error("set_lengths: not supported by this engine"); return RGQA_ERR_ARG; }
 };
 
 EngineBase* make_engine(const rgqa_config& cfg);

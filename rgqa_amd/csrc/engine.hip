@@ -257,14 +257,20 @@ public:
     }
     static void* rows(void* base, size_t row, size_t width) { return base ? (void*)((T*)base + row * width) : nullptr; }
 
-    void plan(int B_, int T_, int O_) {
-        B = B_; Tn = T_; O = O_; Rl = B * Tn; Rv = B * O; R = Rl + Rv;
+    // Buffers are sized for the padded row count (RlC = B*T language rows); the ACTIVE language row count Rl (<= RlC: the
+    // packed rows of varlen mode, set_lengths()) only moves the [lang; visn] split inside them, so re-planning for another
+    // Rl is pointer arithmetic on the same workspace.
+    void plan(int B_, int T_, int O_, int rl_active = -1) {
+        B = B_; Tn = T_; O = O_; Rv = B * O;
+        const int RlC = B * Tn, RC = RlC + Rv;
+        Rl = rl_active < 0 ? RlC : rl_active; R = Rl + Rv;
         NAp = (int)rup(cfg.num_answers, 64);
         const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads;
         ws_used = 0;
         stages.clear();
-        maskf = take<float>(Rl);
-        emb_out = take<T>((size_t)R * H); emb_z = take<T>((size_t)Rl * H); emb_mean = take<float>(Rl); emb_rstd = take<float>(Rl);
+        maskf = take<float>(RlC);
+        lens_dev = take<int>(B); cu_dev = take<int>(B + 1); row_src_dev = take<int>(RlC); cls_rows = take<T>((size_t)B * H);
+        emb_out = take<T>((size_t)RC * H); emb_z = take<T>((size_t)RlC * H); emb_mean = take<float>(RlC); emb_rstd = take<float>(RlC);
         zf = take<T>((size_t)Rv * H); visn_stats = take<float>((size_t)Rv * 4);
         feats_lp = LP ? take<T>((size_t)Rv * cfg.feat_dim) : nullptr;   // bf16 copy of the RoI features: read by visn_fc forward AND its wgrad
         visn_out = emb_out ? emb_out + (size_t)Rl * H : nullptr;   // [lang; visn] contiguous
@@ -273,12 +279,12 @@ public:
         auto new_stage = [&](int kind, bool al, bool av) -> Stage& {
             Stage st; memset(&st, 0, sizeof st);
             st.kind = kind; st.active[0] = al; st.active[1] = av; st.site = site; site += 8;
-            T* y = take<T>((size_t)R * H);
-            T* z = take<T>((size_t)R * H);
-            float* mean = take<float>(R); float* rstd = take<float>(R);
+            T* y = take<T>((size_t)RC * H);
+            T* z = take<T>((size_t)RC * H);
+            float* mean = take<float>(RC); float* rstd = take<float>(RC);
             T *qkv = nullptr, *ctx = nullptr, *hpre = nullptr, *h = nullptr; float* lse = nullptr;
-            if (kind == ST_FFN) { hpre = take<T>((size_t)R * I); h = take<T>((size_t)R * I); }
-            else { qkv = take<T>((size_t)R * 3 * H); ctx = take<T>((size_t)R * H); lse = take<float>((size_t)B * nh * (Tn + O)); }
+            if (kind == ST_FFN) { hpre = take<T>((size_t)RC * I); h = take<T>((size_t)RC * I); }
+            else { qkv = take<T>((size_t)RC * 3 * H); ctx = take<T>((size_t)RC * H); lse = take<float>((size_t)B * nh * (Tn + O)); }
             for (int m = 0; m < 2; ++m) {
                 const size_t r0 = m == 0 ? 0 : Rl;
                 SegBuf& s = st.sb[m];
@@ -309,7 +315,7 @@ public:
         // otherwise the engine gathers them into x0 (one row copy of the shorter chain's output)
         x0_needed = (cfg.x_layers > 0) && (cfg.l_layers != cfg.r_layers);
         if (x0_needed) {
-            x0 = take<T>((size_t)R * H);
+            x0 = take<T>((size_t)RC * H);
             x0_src[0] = cur[0]; x0_src[1] = cur[1];
             cur[0] = x0; cur[1] = rows(x0, Rl, H);
         }
@@ -327,21 +333,24 @@ public:
         pooled = take<T>((size_t)B * H); h1pre = take<T>((size_t)B * 2 * H); h1 = take<T>((size_t)B * 2 * H); h2 = take<T>((size_t)B * 2 * H);
         hd_mean = take<float>(B); hd_rstd = take<float>(B);
         logits = take<float>((size_t)B * NAp); dlogits = take<T>((size_t)B * NAp); loss_dev = take<float>(64);
-        gA = take<T>((size_t)R * H); gB = take<T>((size_t)R * H); gctx = take<T>((size_t)R * H); gemb = take<T>((size_t)R * H);
+        gA = take<T>((size_t)RC * H); gB = take<T>((size_t)RC * H); gctx = take<T>((size_t)RC * H); gemb = take<T>((size_t)RC * H);
         // one set of per-stage gradient buffers per stage slot of a layer: the weight-gradient GEMMs of a whole layer are
         // deferred into ONE grouped launch (432-504 tiles: fills the 256 CUs), so their operands must outlive the stage
         // ... and two such sets (layer parity): layer i's wgrad launch reads its set on the side stream while layer i-1
         // already overwrites the other one on the main stream
         for (int par = 0; par < 2; ++par)
             for (int k = 0; k < 3; ++k) {
-                gz_s[par][k] = take<T>((size_t)R * H); gzd_s[par][k] = take<T>((size_t)R * H);
-                gqkv_s[par][k] = take<T>((size_t)R * 3 * H); gh_s[par][k] = take<T>((size_t)R * I);
+                gz_s[par][k] = take<T>((size_t)RC * H); gzd_s[par][k] = take<T>((size_t)RC * H);
+                gqkv_s[par][k] = take<T>((size_t)RC * 3 * H); gh_s[par][k] = take<T>((size_t)RC * I);
             }
         gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
         tdesc = take<TransDesc>(n_tdesc + 1);
     }
+    int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr;
+    bool varlen = false, lens_dirty = false, fwd_varlen = false;   // fwd_varlen: layout of the recorded forward pass
+    int n_lang = 0; std::vector<int> lens_host;
     bool x0_needed = false; T* x0 = nullptr; void* x0_src[2] = {nullptr, nullptr}; void* visn_final = nullptr;
 
     size_t workspace_bytes(int B_, int T_, int O_) override {
@@ -361,11 +370,30 @@ public:
         if (wb < need) { rgqa_set_error("bind: workspace too small (%zu < %zu bytes)", wb, need); return RGQA_ERR_WORKSPACE; }
         P = p; G = g; Pb = (T*)plp; PbT = (T*)plpt; ws = (char*)w; ws_bytes_ = wb;
         plan(B_, T_, O_);
+        varlen = false; lens_dirty = false;
         have_fwd = false;
         tdesc_uploaded = false;
         return RGQA_OK;
     }
     bool tdesc_uploaded = false;
+
+    // Unpadded language rows: lens[b] = number of real tokens of sample b ([CLS] .. [SEP], a PREFIX of its T slots - what
+    // convert_sents_to_features builds, lxrt/entry.py:37-79).  Padded positions never reach the logits or any gradient
+    // (-10000 key mask -> probability exactly 0, pooler reads token 0), so the engine then packs only the real rows:
+    // GEMM / LayerNorm rows shrink from B*T to sum(lens), attention windows follow cu[].  null / n == 0: padded layout.
+    int set_lengths(const int* lens, int n) override {
+        if (lens == nullptr || n == 0) { varlen = false; return RGQA_OK; }
+        RGQA_REQUIRE(ws != nullptr, "set_lengths: engine not bound");
+        RGQA_REQUIRE(n == B, "set_lengths: %d lengths for a batch of %d", n, B);
+        long tot = 0;
+        for (int i = 0; i < n; ++i) {
+            RGQA_REQUIRE(lens[i] >= 1 && lens[i] <= Tn, "set_lengths: lengths[%d] = %d outside 1..%d", i, lens[i], Tn);
+            tot += lens[i];
+        }
+        lens_host.assign(lens, lens + n);
+        n_lang = (int)tot; varlen = true; lens_dirty = true;
+        return RGQA_OK;
+    }
 
     int sync_weights(hipStream_t s) override {
         RGQA_REQUIRE(P != nullptr, "sync_weights: engine not bound");
@@ -465,13 +493,20 @@ public:
     int forward(const float* feats, const float* boxes, const int64_t* ids, const int64_t* seg, const int64_t* mask,
                 float* pooled_out, float* logits_out, int ld_logits, int train, uint64_t seed, hipStream_t s) override {
         RGQA_REQUIRE(P != nullptr && ws != nullptr, "forward: engine not bound");
-        RGQA_REQUIRE(feats && boxes && ids && mask, "forward: null input");
+        RGQA_REQUIRE(feats && boxes && ids && (mask || varlen), "forward: null input");
         const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh;
         in_feats = feats; in_boxes = boxes; in_ids = ids; in_seg = seg; last_train = train; last_seed = seed;
         const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
-        CK(k_make_mask(mask, maskf, Rl, s));
-        CK(k_embed_fwd<T>(ids, seg, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z, emb_mean, emb_rstd,
-                          B, Tn, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
+        {   // language row layout of this pass: packed (varlen) or padded
+            const int want = varlen ? n_lang : B * Tn;
+            if (want != Rl) plan(B, Tn, O, want);
+            if (varlen && lens_dirty) { CK(k_set_lengths(lens_host.data(), B, Tn, lens_dev, cu_dev, row_src_dev, s)); lens_dirty = false; }
+            fwd_varlen = varlen;
+        }
+        const int* cu = fwd_varlen ? cu_dev : nullptr;
+        if (!fwd_varlen) CK(k_make_mask(mask, maskf, Rl, s));
+        CK(k_embed_fwd<T>(ids, seg, fwd_varlen ? row_src_dev : nullptr, Rl, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z,
+                          emb_mean, emb_rstd, B, Tn, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
         {   // VisualFeatEncoder: GEMM on the RoI features (one f32->bf16 cast pass in bf16 precision, so that this GEMM and
             // its weight-gradient GEMM run on the LDS-DMA kernels), then the fused LN/LN/avg tail
             GemmGroup g; gg_init(g);
@@ -525,7 +560,8 @@ public:
                 a.q = st.sb[m].qkv; a.ldq = 3 * H;
                 a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
                 a.out = st.sb[m].ctx; a.ldo = H;
-                a.mask = km == 0 ? maskf : nullptr;      // only language keys carry a padding mask (entry.py:119)
+                a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;      // only language keys carry a padding mask (entry.py:119)
+                a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;  // packed language rows: the window IS the mask
                 a.lse = st.sb[m].lse;
                 a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
                 a.scale = 1.0f / sqrtf((float)dh);
@@ -555,7 +591,8 @@ public:
         // ---- BertPooler (modeling.py:575-581) + answer head (gqa_model.py:22-27)
         {
             GemmGroup g; gg_init(g);
-            add_fwd(g, lang_final, Tn * H, mp.pooler, 0, H, pooled, H, B, EPI_TANH, nullptr, 0, nullptr, 0);
+            CK(k_gather_rows<T>((const T*)lang_final, H, cu, Tn, cls_rows, H, B, H, s));     // the [CLS] row of every sample
+            add_fwd(g, cls_rows, H, mp.pooler, 0, H, pooled, H, B, EPI_TANH, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s));
             gg_init(g);
             add_fwd(g, pooled, H, mp.head0, 0, 2 * H, h1, 2 * H, B, EPI_GELU, nullptr, 0, h1pre, 0);
@@ -638,11 +675,13 @@ public:
         const DropCfg nodrop = make_drop(0.f, 0, 0);
         GemmGroup g;
         CK(colsum_bias(gp1, H, mp.pooler, 0, H, B, accumulate, s));
-        gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, lang_final, Tn * H, B, accumulate); CK(run_wgrad(g, s));
+        const int* cu = fwd_varlen ? cu_dev : nullptr;
+        gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, cls_rows, H, B, accumulate); CK(run_wgrad(g, s));
         // gradient w.r.t. the final hidden states: zero except the [CLS] rows of lang
         T* dy = gA; T* dx = gB;
         CK(rgqa_check_hip(hipMemsetAsync(dy, 0, (size_t)R * H * sizeof(T), s), "zero dy"));
-        gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, dy, Tn * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
+        gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, gp2, H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
+        CK(k_scatter_rows<T>(gp2, H, dy, H, cu, Tn, B, H, s));
         seg_cursor = 0;
         CK(mark_segment(s));     // head + pooler gradients are final
 
@@ -713,7 +752,8 @@ public:
                 AttnArgs a; memset(&a, 0, sizeof a);
                 a.q = st.sb[m].qkv; a.ldq = 3 * H;
                 a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
-                a.mask = km == 0 ? maskf : nullptr;
+                a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;
+                a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;
                 a.lse = st.sb[m].lse;
                 a.dout = rowp(gctx, m, H); a.lddo = H;
                 a.dq = rowp(gqkv, m, 3 * H); a.dk = rowp(gqkv, km, 3 * H) + H; a.dv = rowp(gqkv, km, 3 * H) + 2 * H;
@@ -770,7 +810,7 @@ public:
             DropCfg din = drop_site(pd, 1);
             CK(k_ln_bwd<T>(dy, H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
                            nodrop, din, 1.0f, s));
-            CK(k_embed_scatter<T>(gz, in_ids, in_seg, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, s));
+            CK(k_embed_scatter<T>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, s));
         }
         // ---- visual embedding
         {

@@ -40,6 +40,7 @@ struct GemmGroup {
     int count;
     int total_tiles;
     int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
+    const void* zeros;  // TN LDS-DMA kernel: >= 16 zero bytes on the device (source of the contraction tail's A rows)
     DropCfg drop;
     GemmProblem p[GEMM_MAX_PROBLEMS];
 };

@@ -412,9 +412,13 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     const int tix = xcd_remap256(tile - P.tile_start, tiles_m * P.tiles_n);
     const int local = (tix % tiles_m) * P.tiles_n + (tix / tiles_m);     // back to the m-major id used below
     const int m0 = (local / P.tiles_n) * WM, n0 = (local % P.tiles_n) * WN;
-    const int nkt = P.K / TK;
+    // contraction length need not be a multiple of the K-step (packed language rows): in the last, partial step the A rows
+    // past K come from a zero line (they also feed the bias column sums) and the B rows past K re-read row K-1 (finite data
+    // times zero), so no lane predicates its DMA.
+    const int nkt = cdiv(P.K, TK), ktail = P.K % TK;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(P.B);
+    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g.zeros);
 
     // per-lane DMA sources (row within the K-step, column chunk after un-swizzling); columns clamped in-bounds
     const bf16_t* asrc[2];
@@ -437,6 +441,19 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     auto issue = [&](int stage, int kt) {
         const unsigned base = lds0 + stage * STAGE;
         const size_t ao = (size_t)kt * TK * P.lda, bo = (size_t)kt * TK * P.ldb;
+        if (ktail != 0 && kt == nkt - 1) {       // block-uniform
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (wave * 2 + i) * 4 + (lane >> 4);
+                dma16(row < ktail ? asrc[i] + ao : zsrc, base + (wave * 2 + i) * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (wave * 4 + i) * 2 + (lane >> 5);
+                dma16(bsrc[i] + bo - (row < ktail ? (size_t)0 : (size_t)(row - (ktail - 1)) * P.ldb), base + A_BYTES + (wave * 4 + i) * 1024);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(asrc[i] + ao, base + (wave * 2 + i) * 1024);
 #pragma unroll
@@ -526,7 +543,7 @@ bool gemm_tn_dma_eligible(const GemmGroup& g) {
     long tiles = 0;
     for (int i = 0; i < g.count; ++i) {
         const GemmProblem& p = g.p[i];
-        if (p.epi != epi || p.bias != nullptr || p.K % TK != 0 || p.K < TK || p.lda < WM || p.ldb < WN) return false;
+        if (p.epi != epi || p.bias != nullptr || p.K < 1 || p.lda < WM || p.ldb < WN) return false;
         tiles += (long)cdiv(p.M, WM) * cdiv(p.N, WN);
     }
     return tiles >= 48;
@@ -539,6 +556,12 @@ int launch_gemm_tn_dma_bf16(GemmGroup& g, hipStream_t s) {
     gemm_group_finalize(g, WM, WN);
     constexpr int LDS_BYTES = 3 * (TK * WM * 2 + TK * WN * 2);
     static bool attr_set = false;
+    static void* zero_line = nullptr;
+    if (zero_line == nullptr) {
+        RGQA_HIP(hipMalloc(&zero_line, 256));
+        RGQA_HIP(hipMemset(zero_line, 0, 256));
+    }
+    g.zeros = zero_line;
     if (!attr_set) {
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));

@@ -29,11 +29,19 @@ struct AttnArgs {
     // backward only
     const void* dout; int lddo;
     void* dq; void* dk; void* dv; int lddq, lddk, lddv;
-    int B, nh, Lq, Lk, dh;
+    int B, nh, Lq, Lk, dh;                         // Lq / Lk: per-sample row counts (the maxima when cu_q / cu_k are set)
+    // unpadded language rows (engine varlen mode): sample b owns rows cu[b] .. cu[b+1]-1 of the packed operand; null = b*L
+    const int* cu_q; const int* cu_k;
     float scale;
     DropCfg drop;                                  // attention-probability dropout (reference modeling.py:341)
     uint32_t drop_site;
 };
+// per-sample row window of the (possibly packed) q and k/v operands: declares q0, k0 (first row) and Lq, Lk (valid rows)
+#define ATTN_SAMPLE_ROWS(a, b)                                                                   \
+    size_t q0 = (size_t)(b) * (a).Lq, k0 = (size_t)(b) * (a).Lk;                                 \
+    int Lq = (a).Lq, Lk = (a).Lk;                                                                \
+    if ((a).cu_q) { const int c0_ = (a).cu_q[(b)]; q0 = (size_t)c0_; Lq = (a).cu_q[(b) + 1] - c0_; } \
+    if ((a).cu_k) { const int c0_ = (a).cu_k[(b)]; k0 = (size_t)c0_; Lk = (a).cu_k[(b) + 1] - c0_; }
 template <typename T> int k_attn_fwd_ref(const AttnArgs& a, hipStream_t s);
 template <typename T> int k_attn_bwd_ref(const AttnArgs& a, hipStream_t s);
 int k_attn_fwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
@@ -42,12 +50,12 @@ int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
 // ---- embed.hip
 // lang[b*T+t] = dropout(LN(word[ids] + pos[t] + type[seg]))      (reference BertEmbeddings, modeling.py:278-292)
 template <typename T>
-int k_embed_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, int rows, const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
                 T* out, int ldo, T* zsave, float* mean, float* rstd, int B, int Tn, int H, int vocab, int type_vocab, float eps, DropCfg drop, hipStream_t s);
 // de [B*T, H] f32 (gradient w.r.t. the pre-LN embedding sum) scattered into the three tables; row 0 of each
 // table gets no gradient (padding_idx=0, modeling.py:269-271)
 template <typename T>
-int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, float* dword, float* dpos, float* dtype, int B, int Tn, int H, hipStream_t s);
+int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, hipStream_t s);
 // additive key mask (1 - m) * -10000 from the 0/1 int64 attention mask (modeling.py:857-865)
 int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s);
 
@@ -90,5 +98,10 @@ int k_scale_rows(float* target, const float* prop, int B, int NA, int ld, int ro
 template <typename T> int k_fill_rows(T* dst, int ld, const T* src, int lds, int rows, int cols, hipStream_t s);
 template <typename T> int k_cast_pad(const float* src, int lds, T* dst, int ldd, int rows, int cols, float scale, hipStream_t s);
 template <typename T> int k_to_f32(const T* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
+// varlen language rows: lengths (host, passed as kernel arguments) -> lens/cu[B+1]/row_src[sum] on the device
+int k_set_lengths(const int* lens_host, int B, int Tn, int* lens_dev, int* cu_dev, int* row_src_dev, hipStream_t s);
+// row(b) = cu ? cu[b] : b * stride_rows
+template <typename T> int k_gather_rows(const T* src, int lds, const int* cu, int stride_rows, T* dst, int ldd, int rows, int cols, hipStream_t s);
+template <typename T> int k_scatter_rows(const T* src, int lds, T* dst, int ldd, const int* cu, int stride_rows, int rows, int cols, hipStream_t s);
 template <typename T> int k_dgelu_mul(const T* dy, const T* pre, T* out, size_t n, hipStream_t s);
 template <typename T> int k_dtanh_mul(const T* dy, const T* y, T* out, size_t n, hipStream_t s);

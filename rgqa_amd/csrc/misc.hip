@@ -119,3 +119,67 @@ int k_dtanh_mul(const T* dy, const T* y, T* out, size_t n, hipStream_t s) {
 }
 template int k_dtanh_mul<float>(const float*, const float*, float*, size_t, hipStream_t);
 template int k_dtanh_mul<bf16_t>(const bf16_t*, const bf16_t*, bf16_t*, size_t, hipStream_t);
+
+// ---- unpadded ("varlen") language rows: per-sample lengths -> cu (exclusive prefix sums) and the packed-row -> token map.
+// The lengths travel as kernel ARGUMENTS (copied at launch time): no host buffer has to outlive the call and nothing
+// synchronises, unlike a pageable hipMemcpyAsync.
+struct LenPack { int v[512]; };
+__global__ void store_lens_kernel(const LenPack p, int n, int off, int* __restrict__ lens) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lens[off + i] = p.v[i];
+}
+__global__ __launch_bounds__(1024) void build_cu_kernel(const int* __restrict__ lens, int B, int Tn, int* __restrict__ cu, int* __restrict__ row_src) {
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < B; ++b) { cu[b] = acc; acc += lens[b]; }
+        cu[B] = acc;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int c0 = cu[b], n = lens[b];
+        for (int t = 0; t < n; ++t) row_src[c0 + t] = b * Tn + t;
+    }
+}
+int k_set_lengths(const int* lens_host, int B, int Tn, int* lens_dev, int* cu_dev, int* row_src_dev, hipStream_t s) {
+    for (int off = 0; off < B; off += 512) {
+        LenPack p;
+        const int n = B - off < 512 ? B - off : 512;
+        for (int i = 0; i < n; ++i) p.v[i] = lens_host[off + i];
+        for (int i = n; i < 512; ++i) p.v[i] = 0;
+        hipLaunchKernelGGL(store_lens_kernel, dim3(2), dim3(256), 0, s, p, n, off, lens_dev);
+        RGQA_LAUNCH_CHECK("store_lens_kernel");
+    }
+    hipLaunchKernelGGL(build_cu_kernel, dim3(1), dim3(1024), 0, s, lens_dev, B, Tn, cu_dev, row_src_dev);
+    RGQA_LAUNCH_CHECK("build_cu_kernel");
+    return RGQA_OK;
+}
+
+// dst[b][:] = src[row(b)][:] (gather) / dst[row(b)][:] = src[b][:] (scatter); row(b) = cu ? cu[b] : b * stride_rows.
+// The [CLS] rows feeding BertPooler (modeling.py:575-581) in either layout.
+template <typename T, bool SCATTER>
+__global__ void pick_rows_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, const int* __restrict__ cu, int stride_rows, int cols) {
+    const int b = blockIdx.x;
+    const size_t r = cu ? (size_t)cu[b] : (size_t)b * stride_rows;
+    const T* sp = src + (SCATTER ? (size_t)b : r) * lds;
+    T* dp = dst + (SCATTER ? r : (size_t)b) * ldd;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dp[c] = sp[c];
+}
+template <typename T>
+int k_gather_rows(const T* src, int lds, const int* cu, int stride_rows, T* dst, int ldd, int rows, int cols, hipStream_t s) {
+    if (rows <= 0) return RGQA_OK;
+    hipLaunchKernelGGL((pick_rows_kernel<T, false>), dim3(rows), dim3(256), 0, s, src, lds, dst, ldd, cu, stride_rows, cols);
+    RGQA_LAUNCH_CHECK("pick_rows_kernel(gather)");
+    return RGQA_OK;
+}
+template <typename T>
+int k_scatter_rows(const T* src, int lds, T* dst, int ldd, const int* cu, int stride_rows, int rows, int cols, hipStream_t s) {
+    if (rows <= 0) return RGQA_OK;
+    hipLaunchKernelGGL((pick_rows_kernel<T, true>), dim3(rows), dim3(256), 0, s, src, lds, dst, ldd, cu, stride_rows, cols);
+    RGQA_LAUNCH_CHECK("pick_rows_kernel(scatter)");
+    return RGQA_OK;
+}
+template int k_gather_rows<float>(const float*, int, const int*, int, float*, int, int, int, hipStream_t);
+template int k_gather_rows<bf16_t>(const bf16_t*, int, const int*, int, bf16_t*, int, int, int, hipStream_t);
+template int k_scatter_rows<float>(const float*, int, float*, int, const int*, int, int, int, hipStream_t);
+template int k_scatter_rows<bf16_t>(const bf16_t*, int, bf16_t*, int, const int*, int, int, int, hipStream_t);

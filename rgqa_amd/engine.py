@@ -116,9 +116,12 @@ class Engine:
         check(self.lib.rgqa_engine_sync_weights(self.h, _stream()))
 
     # ------------------------------------------------------------------ compute
-    def forward(self, feats, boxes, input_ids, input_mask, segment_ids=None, train=False, seed=0):
+    def forward(self, feats, boxes, input_ids, input_mask, segment_ids=None, train=False, seed=0, lengths=None):
         """feats [B,O,F] f32, boxes [B,O,4] f32, ids/mask/(segment) [B,T] i64, all on the engine's device and
-        contiguous. Returns (logits [B,NA] f32, pooled [B,H] f32) — engine-owned buffers, overwritten by the next call."""
+        contiguous. Returns (logits [B,NA] f32, pooled [B,H] f32) — engine-owned buffers, overwritten by the next call.
+        lengths (host sequence of B ints = input_mask.sum(1) for the prefix masks the tokenizer builds): packs the
+        language rows to the real tokens only (rgqa_engine_set_lengths) — same logits and gradients, B*T -> sum(lengths)
+        rows of work; None computes every padded position as the reference does."""
         B, O, F = feats.shape
         T = input_ids.shape[1]
         if F != self.cfg.feat_dim or boxes.shape != (B, O, self.cfg.pos_dim) or input_mask.shape != (B, T):
@@ -130,6 +133,14 @@ class Engine:
         if segment_ids is not None and (segment_ids.dtype != torch.int64 or not segment_ids.is_contiguous()):
             raise ValueError("segment_ids must be a contiguous int64 tensor")
         self.ensure_shape(B, T, O)
+        if lengths is not None:
+            import numpy as np
+            ln = np.ascontiguousarray(lengths, dtype=np.int32).reshape(-1)
+            check(self.lib.rgqa_engine_set_lengths(self.h, C.c_void_p(ln.ctypes.data), int(ln.shape[0])))
+            self._varlen = True
+        elif getattr(self, "_varlen", False):
+            check(self.lib.rgqa_engine_set_lengths(self.h, None, 0))
+            self._varlen = False
         self._keep = (feats, boxes, input_ids, input_mask, segment_ids)   # backward reads them again
         lg, pl = self._io["logits"], self._io["pooled"]
         check(self.lib.rgqa_engine_forward(self.h, ptr(feats), ptr(boxes), ptr(input_ids), ptr(segment_ids), ptr(input_mask),

@@ -86,15 +86,18 @@ class LXRTEncoder(nn.Module):
         ids = torch.tensor(rows_i, dtype=torch.long)
         mask = torch.tensor(rows_m, dtype=torch.long)
         seg = torch.zeros_like(ids)
-        return ids.to(device, non_blocking=True), seg.to(device, non_blocking=True), mask.to(device, non_blocking=True)
+        # real token counts ([CLS] .. [SEP]; the mask is a prefix of ones, :56-66): lets the engine skip the padding rows.
+        # RGQA_VARLEN=0 computes every padded position, as the reference does.
+        lengths = [sum(m) for m in rows_m] if os.environ.get("RGQA_VARLEN", "1") != "0" else None
+        return ids.to(device, non_blocking=True), seg.to(device, non_blocking=True), mask.to(device, non_blocking=True), lengths
 
     def forward(self, sents, feats, visual_attention_mask=None):
-        input_ids, segment_ids, input_mask = self._tokenize(sents, feats[0].device)
-        return self.model(input_ids, segment_ids, input_mask, visual_feats=feats, visual_attention_mask=visual_attention_mask)
+        input_ids, segment_ids, input_mask, lengths = self._tokenize(sents, feats[0].device)
+        return self.model(input_ids, segment_ids, input_mask, visual_feats=feats, visual_attention_mask=visual_attention_mask, token_lengths=lengths)
 
     def forward_with_head(self, sents, feats):
-        input_ids, segment_ids, input_mask = self._tokenize(sents, feats[0].device)
-        return self.model.forward_with_head(input_ids, segment_ids, input_mask, feats)
+        input_ids, segment_ids, input_mask, lengths = self._tokenize(sents, feats[0].device)
+        return self.model.forward_with_head(input_ids, segment_ids, input_mask, feats, token_lengths=lengths)
 
     def save(self, path):
         torch.save(self.model.state_dict(), os.path.join("%s_LXRT.pth" % path))

@@ -360,9 +360,12 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         if self._seed_base is None:
             self._seed_base = int(torch.initial_seed()) & 0x7FFFFFFFFFFF
         self._fwd_counter += 1
-        return e.forward(feats, boxes, ids, mask, seg, train=train, seed=self._seed_base + 7919 * self._fwd_counter)
+        lengths = self.__dict__.pop("_pending_lengths", None)
+        return e.forward(feats, boxes, ids, mask, seg, train=train, seed=self._seed_base + 7919 * self._fwd_counter, lengths=lengths)
 
-    def _run(self, feats, boxes, ids, mask, seg, want_logits):
+    def _run(self, feats, boxes, ids, mask, seg, want_logits, lengths=None):
+        if lengths is not None:
+            self.__dict__["_pending_lengths"] = lengths      # consumed by the next _engine_forward
         feats = feats.contiguous().float()
         boxes = boxes.contiguous().float()
         if feats.device.type != "cuda":
@@ -376,22 +379,23 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         lg, pl = self._engine_forward(feats, boxes, ids, mask, seg, train=self.training)
         return (lg.clone() if want_logits else None), pl.clone()
 
-    def forward(self, input_ids, token_type_ids=None, attention_mask=None, visual_feats=None, visual_attention_mask=None):
-        """Same signature as the reference (modeling.py:1020-1030); returns pooled_output [B, hidden] for mode 'x'."""
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, visual_feats=None, visual_attention_mask=None, token_lengths=None):
+        """Same signature as the reference (modeling.py:1020-1030); returns pooled_output [B, hidden] for mode 'x'.
+        token_lengths (optional, host ints; LXRTEncoder passes what its tokenizer produced): compute only the real tokens."""
         if visual_attention_mask is not None:
             raise NotImplementedError("visual_attention_mask is None on the GQA path (lxrt/entry.py:109,119)")
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         feats, boxes = visual_feats
-        _, pooled = self._run(feats, boxes, input_ids, attention_mask, token_type_ids, want_logits=False)
+        _, pooled = self._run(feats, boxes, input_ids, attention_mask, token_type_ids, want_logits=False, lengths=token_lengths)
         return pooled
 
-    def forward_with_head(self, input_ids, token_type_ids, attention_mask, visual_feats):
+    def forward_with_head(self, input_ids, token_type_ids, attention_mask, visual_feats, token_lengths=None):
         """Encoder + fused answer head -> (logits, pooled)."""
         if self._head is None:
             raise RuntimeError("no head attached")
         feats, boxes = visual_feats
-        return self._run(feats, boxes, input_ids, attention_mask, token_type_ids, want_logits=True)
+        return self._run(feats, boxes, input_ids, attention_mask, token_type_ids, want_logits=True, lengths=token_lengths)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, state_dict=None, cache_dir=None, *inputs, **kwargs):

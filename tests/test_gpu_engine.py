@@ -228,3 +228,91 @@ def test_config2_forward_b256_f32_logits_vs_cpu():
     assert err <= 1e-3, err
     assert float((pl[pick].cpu() - pr).abs().max()) <= 1e-3
     assert torch.isfinite(lg).all()
+
+
+# ---------------------------------------------------------------------------------------------- unpadded language rows
+def _grads_by_name(e):
+    return {sp.name: e.view(e.grads, sp).clone() for sp in e.specs}
+
+
+@pytest.mark.parametrize("precision,ltol,gtol", [("f32", 2e-5, 2e-4), ("bf16", 6e-2, 8e-2)])
+def test_varlen_matches_padded(precision, ltol, gtol):
+    """rgqa_engine_set_lengths packs the language rows to the real tokens.  Padded positions are masked keys with probability
+    exactly 0 and the pooler reads token 0, so logits, loss and every gradient must agree with the padded pass (f32: to
+    rounding of the differently-tiled sums; bf16: to bf16 rounding), and switching back restores the padded result bit for bit."""
+    B, T, O = 6, 12, 7
+    raw = synth.synth_batch(B, T, O=O, F=MED["feat_dim"], NA=MED["num_answers"], vocab=MED["vocab_size"], seed=21, min_len=2)
+    lengths = raw["lengths"].astype(np.int32)
+    assert lengths.min() < T and (raw["input_mask"].sum(1) == lengths).all()
+    b = dev(raw)
+    e = make_engine(MED, precision)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+
+    def run_pass(lens):
+        lg, pl = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], lengths=lens)
+        lg, pl = lg.clone(), pl.clone()
+        loss = e.loss_backward(b["target"]).item()
+        return lg, pl, loss, _grads_by_name(e)
+
+    lg0, pl0, loss0, g0 = run_pass(None)
+    lg1, pl1, loss1, g1 = run_pass(lengths)
+    assert float((lg1 - lg0).abs().max()) <= ltol * max(1.0, float(lg0.abs().max()))
+    assert float((pl1 - pl0).abs().max()) <= ltol
+    assert abs(loss1 - loss0) <= ltol * max(1.0, abs(loss0))
+    for name, ref in g0.items():
+        tol = gtol * float(ref.abs().max()) + 1e-7
+        assert float((g1[name] - ref).abs().max()) <= tol, name
+    # packed activations are the valid rows of the padded ones
+    n = int(lengths.sum())
+    rows = np.concatenate([np.arange(T * i, T * i + lengths[i]) for i in range(B)])
+    a1 = e.activation("x1_lang", n).cpu().numpy()
+    e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"])
+    a0 = e.activation("x1_lang", B * T).cpu().numpy()[rows]
+    np.testing.assert_allclose(a1, a0, rtol=0, atol=(1e-4 if precision == "f32" else 0.1))
+    lg2, pl2, loss2, g2 = run_pass(None)
+    assert torch.equal(lg2, lg0) and torch.equal(pl2, pl0)
+    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
+    for sp in e.specs:
+        if sp.offset >= first:
+            assert torch.equal(g2[sp.name], g0[sp.name]), sp.name
+
+
+@pytest.mark.parametrize("T", [5, 8])
+def test_varlen_f32_small_vs_golden(golden_dir, T):
+    """The reference's own outputs (fixtures generated by running it) reproduced from the packed layout."""
+    g = np.load(os.path.join(golden_dir, "g1_small_T%d.npz" % T))
+    e = make_engine(SMALL, "f32")
+    raw = small_batch(T)
+    b = dev(raw)
+    e.ensure_shape(3, T, 6)
+    e.sync_weights()
+    lens = raw["input_mask"].sum(1).astype(np.int32)
+    lg, pl = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], lengths=lens)
+    np.testing.assert_allclose(lg.cpu().numpy(), g["logits"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(pl.cpu().numpy(), g["pooled"], rtol=0, atol=1e-4)
+    loss = e.loss_backward(b["target"])
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    dead = set(g["dead"].tolist())
+    for sp in e.specs:
+        if sp.name in dead:
+            continue
+        ref = g["grad." + sp.name]
+        np.testing.assert_allclose(e.view(e.grads, sp).cpu().numpy(), ref, rtol=2e-3, atol=1e-6 + 2e-4 * np.abs(ref).max(), err_msg=sp.name)
+
+
+def test_set_lengths_rejects_bad_input():
+    from rgqa_amd import _lib
+    e = make_engine(MED, "f32")
+    e.ensure_shape(4, 8, 6)
+    L = e.lib
+    import ctypes as C
+    bad_n = np.array([3, 4, 5], dtype=np.int32)
+    assert L.rgqa_engine_set_lengths(e.h, C.c_void_p(bad_n.ctypes.data), 3) != 0
+    assert b"lengths" in L.rgqa_last_error_string()
+    for v in (0, 9):
+        bad = np.array([3, v, 5, 8], dtype=np.int32)
+        assert L.rgqa_engine_set_lengths(e.h, C.c_void_p(bad.ctypes.data), 4) != 0
+    ok = np.array([3, 8, 1, 2], dtype=np.int32)
+    assert L.rgqa_engine_set_lengths(e.h, C.c_void_p(ok.ctypes.data), 4) == 0
+    assert L.rgqa_engine_set_lengths(e.h, None, 0) == 0

@@ -78,7 +78,8 @@ def test_linear_f32(lib, M, N, K):
     np.testing.assert_allclose(Cc[:, :N].cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (768, 768, 1000), (200, 72, 100), (2304, 768, 5120), (768, 3072, 9216), (1000, 1800, 640)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (768, 768, 1000), (200, 72, 100), (2304, 768, 5120), (768, 3072, 9216), (1000, 1800, 640),
+                                   (2304, 768, 3140), (3072, 768, 12356)])   # last two: contraction tails (packed language rows) on the LDS-DMA kernel
 def test_matmul_tn_bf16(lib, M, N, K):
     A = rnd(K, M, seed=4).bfloat16()   # [K, M]
     Bm = rnd(K, N, seed=5).bfloat16()  # [K, N]
@@ -94,7 +95,7 @@ def test_matmul_tn_bf16(lib, M, N, K):
     assert float((got - ref).abs().max()) < 1e-2 * math.sqrt(K)
 
 
-@pytest.mark.parametrize("M,N,K", [(144, 208, 192), (1024, 1536, 192)])
+@pytest.mark.parametrize("M,N,K", [(144, 208, 192), (1024, 1536, 192), (1024, 1536, 197), (1024, 1536, 33), (1024, 1536, 65)])
 def test_matmul_tn_exact_integers(lib, M, N, K):
     A = ((torch.arange(K * M).reshape(K, M) * 5 + 1) % 7 - 3).float().cuda().bfloat16()
     Bm = ((torch.arange(K * N).reshape(K, N) * 3 + 2) % 5 - 2).float().cuda().bfloat16()
