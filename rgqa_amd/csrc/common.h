@@ -113,30 +113,42 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 }
 
 // ---------------------------------------------------------------- counter-based dropout RNG
-// keep(seed, stream, idx): one 32-bit hash word per element; the same (seed, stream, idx) is re-derived in
-// the backward pass so no mask is stored.  `stream` separates the dropout sites of one step.
-__device__ __forceinline__ uint32_t rng_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx) {
-    uint32_t x = idx * 0x9E3779B1u + seed_lo;
+// keep(seed, site, idx): element idx draws the (idx & 1) 16-bit half of ONE 32-bit hash word of (seed, site, idx >> 1), so a
+// hash (3 integer multiplies - the expensive VALU ops of the fused epilogues) serves two neighbouring elements; drop
+// probability = round(p * 65536) / 65536.  The same (seed, site, idx) is re-derived in the backward pass, so no mask is
+// stored.  `site` (folded into seed_hi) separates the dropout sites of one step.
+__device__ __forceinline__ uint32_t rng_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx2) {
+    uint32_t x = (idx2 * 0x9E3779B1u + seed_lo) ^ seed_hi;
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    x += seed_hi;
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
     return x;
 }
 struct DropCfg {
     uint32_t seed_lo, seed_hi;  // seed_hi carries the site id
-    uint32_t thresh;            // drop when hash < thresh  (thresh = p * 2^32); 0 = no dropout
+    uint32_t thresh;            // drop when the element's 16-bit draw < thresh  (thresh = p * 2^16); 0 = no dropout
     float scale;                // 1/(1-p)
 };
 __device__ __forceinline__ float drop_apply(const DropCfg& d, uint32_t idx, float v) {
     if (d.thresh == 0u) return v;
-    return rng_hash(d.seed_lo, d.seed_hi, idx) < d.thresh ? 0.0f : v * d.scale;
+    const uint32_t h = rng_hash(d.seed_lo, d.seed_hi, idx >> 1);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) < d.thresh ? 0.0f : v * d.scale;
+}
+// N (even) consecutive elements starting at an EVEN index: N/2 hashes. Same draws as drop_apply element by element.
+template <int N>
+__device__ __forceinline__ void drop_apply_vec(const DropCfg& d, uint32_t idx0, float (&v)[N]) {
+    if (d.thresh == 0u) return;
+#pragma unroll
+    for (int j = 0; j < N; j += 2) {
+        const uint32_t h = rng_hash(d.seed_lo, d.seed_hi, (idx0 >> 1) + (uint32_t)(j >> 1));
+        v[j] = (h & 0xFFFFu) < d.thresh ? 0.0f : v[j] * d.scale;
+        v[j + 1] = (h >> 16) < d.thresh ? 0.0f : v[j + 1] * d.scale;
+    }
 }
 static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
     DropCfg d;
     d.seed_lo = (uint32_t)seed;
     d.seed_hi = (uint32_t)(seed >> 32) ^ (site * 0x632BE5ABu + 0x7F4A7C15u);
     if (p <= 0.f) { d.thresh = 0u; d.scale = 1.f; }
-    else { double t = (double)p * 4294967296.0; d.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t; d.scale = 1.0f / (1.0f - p); }
+    else { double t = (double)p * 65536.0 + 0.5; d.thresh = t >= 65535.0 ? 65535u : (t < 1.0 ? 1u : (uint32_t)t); d.scale = 1.0f / (1.0f - p); }
     return d;
 }
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -112,11 +112,14 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
             float pre[8];
             const bf16x8 ax = *reinterpret_cast<const bf16x8*>(&auxv[AUX ? pass * 2 * TP + it : 0]);
 #pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+            if (EPI == EPI_RESID_DROP) drop_apply_vec<8>(dcf, (uint32_t)m * (uint32_t)N + (uint32_t)nb, v);   // N % 8 == 0: even index
+#pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float x = v[j] + bias8[j];
+                float x = v[j];
                 pre[j] = x;
                 if (EPI == EPI_GELU) gelu_and_grad_fast(pre[j], x, pre[j]);      // C = gelu, C2 = gelu' (consumed by EPI_DGELU)
-                else if (EPI == EPI_RESID_DROP) x = drop_apply(dcf, (uint32_t)m * (uint32_t)N + (uint32_t)(nb + j), x) + (float)ax[j];
+                else if (EPI == EPI_RESID_DROP) x = x + (float)ax[j];
                 else if (EPI == EPI_DGELU) x = x * (float)ax[j];
                 else if (EPI == EPI_ADD) x = x + (float)ax[j];
                 v[j] = x;

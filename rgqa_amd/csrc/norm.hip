@@ -98,9 +98,10 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const T* __restr
                 load4(gamma + c * 4, gm);   // L1/L2-resident; not kept in registers (the 128-VGPR budget of a 16-wave block)
                 cvt_raw4(rd[i], d);
                 cvt_raw4(rz[i], zz);
+                drop_apply_vec<4>(drop_in, (uint32_t)row * (uint32_t)N + (uint32_t)(c * 4), d);     // N % 4 == 0: even index
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    d[j] = drop_apply(drop_in, (uint32_t)row * (uint32_t)N + (uint32_t)(c * 4 + j), d[j]) * dy_scale;
+                    d[j] *= dy_scale;
                     xh[i][j] = (zz[j] - mu) * rs;
                     g[i][j] = d[j] * gm[j];
                     s1 += g[i][j];
@@ -128,11 +129,10 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const T* __restr
             if (c < nv) {
                 float o[4], od[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = rs_cur * (g[i][j] - s1 - xh[i][j] * s2);
-                    od[j] = drop_apply(drop, (uint32_t)row * (uint32_t)N + (uint32_t)(c * 4 + j), o[j]);
-                    ad[i][j] += od[j];
-                }
+                for (int j = 0; j < 4; ++j) { o[j] = rs_cur * (g[i][j] - s1 - xh[i][j] * s2); od[j] = o[j]; }
+                drop_apply_vec<4>(drop, (uint32_t)row * (uint32_t)N + (uint32_t)(c * 4), od);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ad[i][j] += od[j];
                 store4(dz + (size_t)row * lddz + c * 4, o);
                 if (dzd) store4(dzd + (size_t)row * lddz + c * 4, od);
             }
