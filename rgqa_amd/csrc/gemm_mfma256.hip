@@ -22,9 +22,9 @@
 // first two K-steps are already being DMA'd while this tile's outputs are converted and stored); 160 KiB of LDS in all.
 // MT == 2 keeps two co-resident 80-KiB blocks per CU (scratch aliases the dead stages, one tile per block).
 #define NT256_PERSIST(MT) ((MT) >= 4)
-#define NT256_TP(MT) ((MT) == 4 ? 2 : ((MT) >= 6 ? 1 : (MT)))
+#define NT256_TP(MT) ((MT) == 4 ? 2 : ((MT) >= 5 ? 1 : (MT)))
 #define NT256_LDS(MT) (2 * (32 * (MT) * TK * 2 + TN * TK * 2) + (NT256_PERSIST(MT) ? 8 * NT256_TP(MT) * 4096 : 0))
-// MT = 16-row m-tiles per wave (2 waves along M): tile height TM = 32*MT in {64,128,192,256}; stage = A then W
+// MT = 16-row m-tiles per wave (2 waves along M): tile height TM = 32*MT in {64,128,160,192,224,256}; stage = A then W
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
@@ -140,12 +140,13 @@ template <typename OutT, int EPI, int MT>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr bool PERSIST = NT256_PERSIST(MT);
-    constexpr int TM = 32 * MT, A_BYTES = TM * TK * 2, STAGE_BYTES = A_BYTES + TN * TK * 2, AG = MT / 2;
+    constexpr int TM = 32 * MT, A_BYTES = TM * TK * 2, STAGE_BYTES = A_BYTES + TN * TK * 2, AG = (MT + 1) / 2, NAG = 4 * MT;
     constexpr int EPI_OFF = PERSIST ? 2 * STAGE_BYTES : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    // LDS-DMA: per stage wave w fills A row groups w*AG .. (8 rows each) and W row groups w*4 .. w*4+3
+    // LDS-DMA: per stage wave w fills the A row groups (8 rows each) w, w+8, .. below NAG = 4*MT (odd MT: waves 4-7 fill one
+    // group fewer) and W row groups w*4 .. w*4+3
     const int lrow = lane >> 3, lch = (lane & 7) ^ lrow;   // source chunk for this lane's linear LDS slot
     const bf16_t* asrc[AG];
     const bf16_t* wsrc[4];
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
         const bf16_t* W = reinterpret_cast<const bf16_t*>(P.B);
 #pragma unroll
         for (int i = 0; i < AG; ++i) {
-            int am = m0 + (wave * AG + i) * 8 + lrow; if (am > P.M - 1) am = P.M - 1;   // clamp: rows past the edge are never stored
+            int am = m0 + (i * 8 + wave) * 8 + lrow; if (am > P.M - 1) am = P.M - 1;   // clamp: rows past the edge are never stored
             asrc[i] = A + (size_t)am * P.lda + lch * 8;
         }
 #pragma unroll
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     auto issue = [&](int stage, int kt) {
         const unsigned base = lds0 + stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < AG; ++i) dma16(asrc[i] + kt * TK, base + (wave * AG + i) * 1024);
+        for (int i = 0; i < AG; ++i)
+            if ((MT & 1) == 0 || i * 8 + wave < NAG) dma16(asrc[i] + kt * TK, base + (i * 8 + wave) * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * TK, base + A_BYTES + (wave * 4 + i) * 1024);
     };
@@ -234,15 +236,27 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     }
 }
 
+static int rgqa_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        n &= ~7;                                   // whole XCDs: the tile -> XCD map needs grid % 8 == 0
+        if (n < 8) n = 8;
+    }
+    return n;
+}
+
 // Tile height per launch: the MT in {8,6,4,2} (TM = 256/192/128/64) that minimises rounds-over-256-CUs x per-tile cost.
 static int pick_mt(const GemmGroup& g, long& tiles_out) {
     int best = 8; double best_cost = 1e30; long best_tiles = 0;
-    const int cand[4] = {8, 6, 4, 2};
-    for (int c = 0; c < 4; ++c) {
+    const int cand[6] = {8, 7, 6, 5, 4, 2};
+    const int ncu = rgqa_num_cus();
+    for (int c = 0; c < 6; ++c) {
         const int mt = cand[c];
         long tiles = 0;
         for (int i = 0; i < g.count; ++i) tiles += (long)cdiv(g.p[i].M, 32 * mt) * cdiv(g.p[i].N, TN);
-        const long rounds = (tiles + 255) / 256;
+        const long rounds = (tiles + ncu - 1) / ncu;
         const double cost = (double)rounds * (mt + 1.5);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = mt; best_tiles = tiles; }
     }
@@ -265,17 +279,6 @@ bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
     return tiles >= 96;
 }
 
-static int rgqa_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        n &= ~7;                                   // whole XCDs: the tile -> XCD map needs grid % 8 == 0
-        if (n < 8) n = 8;
-    }
-    return n;
-}
-
 template <int EPI, int MT>
 static int launch256(GemmGroup& g, hipStream_t s) {
     constexpr int LDS_BYTES = NT256_LDS(MT);
@@ -296,7 +299,9 @@ template <int EPI>
 static int launch256_mt(GemmGroup& g, int mt, hipStream_t s) {
     switch (mt) {
         case 8: return launch256<EPI, 8>(g, s);
+        case 7: return launch256<EPI, 7>(g, s);
         case 6: return launch256<EPI, 6>(g, s);
+        case 5: return launch256<EPI, 5>(g, s);
         case 4: return launch256<EPI, 4>(g, s);
         default: return launch256<EPI, 2>(g, s);
     }
@@ -335,11 +340,11 @@ static int tuned_mt(GemmGroup& g, int model_mt, hipStream_t s) {
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess) return model_mt;
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return model_mt; }
-    const int cand[4] = {8, 6, 4, 2};
-    float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+    const int cand[6] = {8, 7, 6, 5, 4, 2};
+    float best[6] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     bool ok = true;
     for (int round = 0; round < 4 && ok; ++round)
-        for (int c = 0; c < 4 && ok; ++c) {
+        for (int c = 0; c < 6 && ok; ++c) {
             ok = hipEventRecord(e0, s) == hipSuccess && launch256_epi(g, cand[c], s) == RGQA_OK && hipEventRecord(e1, s) == hipSuccess &&
                  hipEventSynchronize(e1) == hipSuccess;
             float ms = 0.f;
@@ -349,11 +354,11 @@ static int tuned_mt(GemmGroup& g, int model_mt, hipStream_t s) {
     int mt = model_mt;
     if (ok) {
         int bi = 0;
-        for (int c = 1; c < 4; ++c) if (best[c] < best[bi]) bi = c;
+        for (int c = 1; c < 6; ++c) if (best[c] < best[bi]) bi = c;
         mt = cand[bi];
         if (getenv("RGQA_GEMM_AUTOTUNE_LOG"))
-            fprintf(stderr, "[rgqa] nt256 tune epi=%d n=%d M0=%d N0=%d K0=%d: MT8 %.1f MT6 %.1f MT4 %.1f MT2 %.1f us -> MT%d (model MT%d)\n", g.p[0].epi, g.count,
-                    g.p[0].M, g.p[0].N, g.p[0].K, best[0] * 1e3f, best[1] * 1e3f, best[2] * 1e3f, best[3] * 1e3f, mt, model_mt);
+            fprintf(stderr, "[rgqa] nt256 tune epi=%d n=%d M0=%d N0=%d K0=%d: MT8 %.1f MT7 %.1f MT6 %.1f MT5 %.1f MT4 %.1f MT2 %.1f us -> MT%d (model MT%d)\n", g.p[0].epi, g.count,
+                    g.p[0].M, g.p[0].N, g.p[0].K, best[0] * 1e3f, best[1] * 1e3f, best[2] * 1e3f, best[3] * 1e3f, best[4] * 1e3f, best[5] * 1e3f, mt, model_mt);
     }
     cache[key] = mt;
     return mt;

@@ -56,6 +56,31 @@ def test_linear_bf16(lib, M, N, K, epi):
         assert float((Cc[:, N:].float() - 7.0).abs().max()) == 0.0   # padding untouched
 
 
+@pytest.mark.parametrize("mt", [8, 7, 6, 5, 4, 2])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_linear_bf16_every_tile_height(lib, mt, epi):
+    """The LDS-DMA NT kernel at each tile height (rgqa_debug_set key 1), persistent tile loop included (more tiles than CUs),
+    ragged M: identical results whatever the height - bit for bit against MT=8 - and correct against torch."""
+    M, N, K = 12356, 768, 192
+    A = rnd(M, K, seed=1).bfloat16()
+    W = rnd(N, K, seed=2, scale=0.05).bfloat16()
+    b = rnd(N, seed=3)
+    out = {}
+    try:
+        for m in (8, mt):
+            Cc = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+            assert lib.rgqa_debug_set(1, m) == 0
+            ck(lib.rgqa_op_linear(P(A), P(W), P(b), P(Cc), M, N, K, K, K, N, epi, 1, S()))
+            out[m] = Cc
+    finally:
+        lib.rgqa_debug_set(1, 0)
+    assert torch.equal(out[mt], out[8])
+    ref = A.float() @ W.float().t() + b
+    if epi:
+        ref = torch.nn.functional.gelu(ref)
+    assert float((out[mt].float() - ref).norm() / ref.norm()) < 4e-3
+
+
 def test_linear_bf16_exact_integers(lib):
     # asymmetric small-integer operands: every product and sum is exact in bf16/f32 -> bit-exact layout check
     M, N, K = 192, 160, 128

@@ -36,10 +36,10 @@ def nt(M, N, K, epi=0):
     lib.rgqa_debug_set(0, 1)
     res.append(2.0 * M * N * K / timeit(run) / 1e12)
     lib.rgqa_debug_set(0, 0)
-    for mt in (8, 6, 4, 2, 0):
+    for mt in (8, 7, 6, 5, 4, 2, 0):
         lib.rgqa_debug_set(1, mt)
         res.append(2.0 * M * N * K / timeit(run) / 1e12)
-    print("NT  M=%6d N=%5d K=%5d : 128sq %6.0f | dma MT8 %6.0f  MT6 %6.0f  MT4 %6.0f  MT2 %6.0f | auto %6.0f TF" % ((M, N, K) + tuple(res)), flush=True)
+    print("NT  M=%6d N=%5d K=%5d : 128sq %6.0f | dma MT8 %6.0f MT7 %6.0f MT6 %6.0f MT5 %6.0f MT4 %6.0f MT2 %6.0f | auto %6.0f TF" % ((M, N, K) + tuple(res)), flush=True)
 
 
 def tn(M, N, K):
