@@ -41,7 +41,8 @@ typedef struct rgqa_engine rgqa_engine;
 const char* rgqa_last_error_string(void);
 int rgqa_version(void);
 /* debug / A-B knobs (key 0: 1 forces the 128x128 GEMM kernel everywhere; key 1: forces the NT M-tile;
- * key 2: 1 runs the deferred weight-gradient launches on the main stream instead of the side stream) */
+ * key 2: 1 runs the deferred weight-gradient launches on the main stream instead of the side stream;
+ * key 3: perf ablation of the NT LDS-DMA kernel, results are garbage: 1 = no operand DMA in the K loop, 2 = no LDS reads / MFMAs) */
 int rgqa_debug_set(int key, int value);
 
 /* ---- engine: replaces GQAModel.__init__/forward (tasks/gqa_model.py:14-43), LXRTEncoder.forward after

@@ -15,6 +15,8 @@
 #include <mutex>
 #include <unordered_map>
 
+int g_rgqa_ablate = 0;   // rgqa_debug_set key 3
+
 #define TN 256
 #define TK 64
 #define T256_THREADS 512
@@ -46,7 +48,11 @@ __device__ __forceinline__ int xcd_remap256(int b, int nwg) {
     int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
-__device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
+// LDS image of a [rows][64] bf16 operand tile: 128-B rows, 16-B chunk c of row r at r*128 + ((c ^ ((r>>1)&7))<<4).
+// A ds_read_b128 is served per 16-lane group = 16 consecutive rows at one logical chunk: bank slot (mod 256 B) is
+// (r&1)*8 + (c ^ ((r>>1)&7)) - 16 distinct slots, conflict-free.  (c ^ (r&7), used first, repeats every 8 rows at equal
+// parity: a 2-way conflict on every fragment read.)
+__device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
 // ---- shared epilogue of the LDS-DMA NT kernels. The accumulators are transposed through a wave-private LDS region
 // (the operand stages are dead after the last barrier) so that every global access is a full 128-B line: 8 lanes x
@@ -147,7 +153,10 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     const int wm = wave >> 2, wn = wave & 3;
     // LDS-DMA: per stage wave w fills the A row groups (8 rows each) w, w+8, .. below NAG = 4*MT (odd MT: waves 4-7 fill one
     // group fewer) and W row groups w*4 .. w*4+3
-    const int lrow = lane >> 3, lch = (lane & 7) ^ lrow;   // source chunk for this lane's linear LDS slot
+    const int lrow = lane >> 3;
+    // source chunk for this lane's linear LDS slot in a piece of 8 rows: (lane&7) ^ ((row>>1)&7), row = piece*8 + lrow
+    const int lch_a = (lane & 7) ^ (((wave & 1) << 2) + (lrow >> 1));
+    const int lch_w[2] = {(lane & 7) ^ (lrow >> 1), (lane & 7) ^ (4 + (lrow >> 1))};
     const bf16_t* asrc[AG];
     const bf16_t* wsrc[4];
     int pi = 0, m0 = 0, n0 = 0, nkt = 0;
@@ -166,16 +175,19 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
 #pragma unroll
         for (int i = 0; i < AG; ++i) {
             int am = m0 + (i * 8 + wave) * 8 + lrow; if (am > P.M - 1) am = P.M - 1;   // clamp: rows past the edge are never stored
-            asrc[i] = A + (size_t)am * P.lda + lch * 8;
+            asrc[i] = A + (size_t)am * P.lda + lch_a * 8;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > P.N - 1) wn_ = P.N - 1;
-            wsrc[i] = W + (size_t)wn_ * P.ldb + lch * 8;
+            wsrc[i] = W + (size_t)wn_ * P.ldb + lch_w[i & 1] * 8;
         }
     };
-    // LDS ring depth 2. Measured alternatives that LOST on these shapes (round 1): 3 stages for MT <= 4 (-10..20 %: MT2 loses
-    // its 2 blocks/CU, K is only 12 steps) and a K-step-32 / 4-stage ring (-15..25 %, also on 8192^3: one barrier per 16 MFMAs).
+    // LDS ring depth 2. Measured alternatives on these shapes (round 1): 3 stages for MT <= 4 lost 10..20 % (MT2 loses its
+    // 2 blocks/CU, K is only 12 steps); a K-step-32 / 4-slot ring lost 15..33 % with or without register-double-buffered
+    // fragments (64-B DMA rows halve the useful bytes per L2 line request and the loop is close to delivery-bound: DMA alone
+    // takes 0.85x of LDS+MFMA alone, rgqa_debug_set key 3); moving the barrier between the two K32 halves with the fragments
+    // double-buffered across it (256 VGPRs) changed nothing (+-3 %).
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int stage, int kt) {
         const unsigned base = lds0 + stage * STAGE_BYTES;
@@ -202,9 +214,10 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             const int st = kt & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nkt && !(pre1 && kt == 0)) issue(st ^ 1, kt + 1);
+            if (kt + 1 < nkt && !(pre1 && kt == 0) && g.ablate != 1) issue(st ^ 1, kt + 1);
             const unsigned char* a = lds + st * STAGE_BYTES;
             const unsigned char* w = a + A_BYTES;
+            if (g.ablate == 2) continue;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 xw[4];
@@ -288,6 +301,7 @@ static int launch256(GemmGroup& g, hipStream_t s) {
         attr_set = true;
     }
     gemm_group_finalize(g, 32 * MT, TN);
+    g.ablate = g_rgqa_ablate;
     int grid = g.total_tiles;
     if (NT256_PERSIST(MT) && grid > rgqa_num_cus()) grid = rgqa_num_cus();     // one persistent block per CU
     hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI, MT>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
