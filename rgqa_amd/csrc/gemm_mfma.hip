@@ -44,8 +44,9 @@ __device__ __forceinline__ uint4 cvt8_f32_bf16(const float* p) {
 }
 
 // ============================================================================ NT
-// LDS image per operand: [128 rows][64 k] bf16 = 8 chunks of 16 B per row; chunk' = chunk ^ (row & 7).
-__device__ __forceinline__ int nt_off(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
+// LDS image per operand: [128 rows][64 k] bf16 = 8 chunks of 16 B per row; chunk' = chunk ^ ((row >> 1) & 7): the 16 rows of
+// a fragment read land on 16 distinct 16-B slots of the 256-B bank row (see off256 in gemm_mfma256.hip).
+__device__ __forceinline__ int nt_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
 template <typename OutT, bool A_F32>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const GemmGroup g) {

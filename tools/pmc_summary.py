@@ -1,0 +1,34 @@
+"""Condenses two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command, as
+MI355X_MICROARCH.md prescribes: TCC counters do not fit one pass) into the per-launch HBM-side traffic of the NT GEMM kernels.
+FETCH_SIZE is in KiB-like units of 1024 B and, on gfx950, reports half of a wide coalesced streaming read: doubled here.
+usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter, match):
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and match(r["Kernel_Name"]):
+            tot += float(r["Counter_Value"])
+            n += 1
+    return tot, n
+
+
+def main(fetch_csv, write_csv, out):
+    is_nt = lambda k: "gemm_nt" in k
+    f, nf = per_kernel(fetch_csv, "FETCH_SIZE", is_nt)
+    w, nw = per_kernel(write_csv, "WRITE_SIZE", is_nt)
+    fetch = f * 1024.0 * 2.0 / max(nf, 1)
+    write = w * 1024.0 / max(nw, 1)
+    res = dict(kernel="gemm_nt (all NT GEMM launches of bench.py, B=256, T=20, packed language rows)", launches_sampled=nf,
+               fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, traffic_bytes_per_launch=fetch + write,
+               note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; x1024 -> bytes; FETCH_SIZE doubled per the gfx950 "
+                    "correction for 16-B/lane coalesced streams; WRITE_SIZE as read; Infinity-Cache hits are counted (fabric-side requests)")
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
