@@ -289,7 +289,8 @@ bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
     }
     long tiles = 0;
     pick_mt(g, tiles);
-    return tiles >= 96;
+    static const long min_tiles = []() { const char* e = getenv("RGQA_NT256_MIN_TILES"); return e ? atol(e) : 1L; }();
+    return tiles >= min_tiles;
 }
 
 template <int EPI, int MT>
@@ -568,7 +569,8 @@ bool gemm_tn_dma_eligible(const GemmGroup& g) {
         if (p.epi != epi || p.bias != nullptr || p.K < 1 || p.lda < WM || p.ldb < WN) return false;
         tiles += (long)cdiv(p.M, WM) * cdiv(p.N, WN);
     }
-    return tiles >= 48;
+    static const long min_tiles = []() { const char* e = getenv("RGQA_TN_DMA_MIN_TILES"); return e ? atol(e) : 1L; }();
+    return tiles >= min_tiles;
 }
 
 int launch_gemm_tn_dma_bf16(GemmGroup& g, hipStream_t s) {
