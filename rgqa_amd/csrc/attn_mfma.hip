@@ -159,9 +159,48 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + k0 * a.ldv + h * 64;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + q0 * a.lddo + h * 64;
     const float* lse = a.lse + ((size_t)b * a.nh + h) * a.Lq;
-    stage_tile(ks_, K, Lk, NKT * 16, a.ldk, lane);
-    stage_tile(qs_, Q, Lq, NQT * 16, a.ldq, lane);
-    stage_tile(os_, dO, Lq, NQT * 16, a.lddo, lane);
+    // ONE global-load phase: every operand fragment (both passes use the same 16-B-per-lane row pieces), the log-sum-exp and
+    // the key mask are requested back to back; the three LDS images the transposed reads need are then written from those
+    // registers.  (The first version re-read K/Q/dO from global for the images and again per pass: ~6 dependent L2/HBM
+    // round trips on a 1-wave block.)
+    bf16x8 kf[NKT][2], vf[NKT][2], qf[NQT][2], of[NQT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { kf[kt][s] = ldfrag(K, kt * 16 + fr, Lk, a.ldk, s, g); vf[kt][s] = ldfrag(V, kt * 16 + fr, Lk, a.ldv, s, g); }
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { qf[qt][s] = ldfrag(Q, qt * 16 + fr, Lq, a.ldq, s, g); of[qt][s] = ldfrag(dO, qt * 16 + fr, Lq, a.lddo, s, g); }
+    float lse_t[NQT], lse_n[NQT][4], mk[NKT][4], mkk[NKT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        lse_t[qt] = qt * 16 + fr < Lq ? lse[qt * 16 + fr] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lse_n[qt][r] = qt * 16 + 4 * g + r < Lq ? lse[qt * 16 + 4 * g + r] : 0.f;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
+        }
+        const int key = kt * 16 + fr;
+        mkk[kt] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(ks_ + (kt * 16 + fr) * ROWB + s * 64 + g * 16) = kf[kt][s];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            *reinterpret_cast<bf16x8*>(qs_ + (qt * 16 + fr) * ROWB + s * 64 + g * 16) = qf[qt][s];
+            *reinterpret_cast<bf16x8*>(os_ + (qt * 16 + fr) * ROWB + s * 64 + g * 16) = of[qt][s];
+        }
+    __syncthreads();
     DropCfg dc = a.drop; dc.seed_hi ^= a.drop_site;
     const uint32_t idx0 = (uint32_t)((b * a.nh + h) * a.Lq) * (uint32_t)a.Lk;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -169,25 +208,13 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
 
     // ---------------- pass T: lane = query, registers = keys  ->  delta[q], dQ
     {
-        bf16x8 kf[NKT][2], vf[NKT][2];
-        float mk[NKT][4];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) { kf[kt][s] = ldfrag(K, kt * 16 + fr, Lk, a.ldk, s, g); vf[kt][s] = ldfrag(V, kt * 16 + fr, Lk, a.ldv, s, g); }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + 4 * g + r;
-                mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
-            }
-        }
         bf16_t* dQ = reinterpret_cast<bf16_t*>(a.dq) + q0 * a.lddq + h * 64;
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
             const int q = qt * 16 + fr;
-            const bf16x8 qf0 = ldfrag(Q, q, Lq, a.ldq, 0, g), qf1 = ldfrag(Q, q, Lq, a.ldq, 1, g);
-            const bf16x8 of0 = ldfrag(dO, q, Lq, a.lddo, 0, g), of1 = ldfrag(dO, q, Lq, a.lddo, 1, g);
-            const float lq = q < Lq ? lse[q] : 0.f;
+            const bf16x8 qf0 = qf[qt][0], qf1 = qf[qt][1];
+            const bf16x8 of0 = of[qt][0], of1 = of[qt][1];
+            const float lq = lse_t[qt];
             f32x4 pp[NKT], dpp[NKT];
             float delta = 0.f;
 #pragma unroll
@@ -232,27 +259,19 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     __syncthreads();   // single-wave workgroup: orders the delta_s writes before the reads below
     // ---------------- pass N: lane = key, registers = queries  ->  dK, dV
     {
-        bf16x8 qf[NQT][2], of[NQT][2];
-        float lq[NQT][4], dl[NQT][4];
+        float dl[NQT][4];
 #pragma unroll
-        for (int qt = 0; qt < NQT; ++qt) {
+        for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { qf[qt][s] = ldfrag(Q, qt * 16 + fr, Lq, a.ldq, s, g); of[qt][s] = ldfrag(dO, qt * 16 + fr, Lq, a.lddo, s, g); }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = qt * 16 + 4 * g + r;
-                lq[qt][r] = q < Lq ? lse[q] : 0.f;
-                dl[qt][r] = delta_s[q];
-            }
-        }
+            for (int r = 0; r < 4; ++r) dl[qt][r] = delta_s[qt * 16 + 4 * g + r];
         bf16_t* dK = reinterpret_cast<bf16_t*>(a.dk) + k0 * a.lddk + h * 64;
         bf16_t* dV = reinterpret_cast<bf16_t*>(a.dv) + k0 * a.lddv + h * 64;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const int key = kt * 16 + fr;
-            const bf16x8 kf0 = ldfrag(K, key, Lk, a.ldk, 0, g), kf1 = ldfrag(K, key, Lk, a.ldk, 1, g);
-            const bf16x8 vf0 = ldfrag(V, key, Lk, a.ldv, 0, g), vf1 = ldfrag(V, key, Lk, a.ldv, 1, g);
-            const float mkk = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
+            const bf16x8 kf0 = kf[kt][0], kf1 = kf[kt][1];
+            const bf16x8 vf0 = vf[kt][0], vf1 = vf[kt][1];
+            const float mkk_ = mkk[kt];
             f32x4 dsn[NQT], pdn[NQT];
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt) {
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = qt * 16 + 4 * g + r;
-                    const float p = q < Lq ? __expf(s4[r] * a.scale + mkk - lq[qt][r]) : 0.f;
+                    const float p = q < Lq ? __expf(s4[r] * a.scale + mkk_ - lse_n[qt][r]) : 0.f;
                     const float keep = drop_apply(dc, idx0 + (uint32_t)(q * a.Lk + key), 1.0f);
                     dsn[qt][r] = p * (dp4[r] * keep - dl[qt][r]) * a.scale;
                     pdn[qt][r] = p * keep;
