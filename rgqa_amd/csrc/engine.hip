@@ -229,7 +229,7 @@ public:
         // every [out,in] linear weight gets a transposed low-precision copy at the same arena offset
         auto add = [&](const Lin& l) {
             TransDesc d; d.src_off = (long)l.w; d.dst_off = (long)l.w; d.N = l.out; d.K = l.in; d.ld_dst = l.ldt; d.tile_start = tdesc_tiles;
-            tdesc_tiles += cdiv(l.ldt, 32) * cdiv(l.in, 32);
+            tdesc_tiles += cdiv(l.ldt, TRANSPOSE_TILE) * cdiv(l.in, TRANSPOSE_TILE);
             tdesc_host.push_back(d);
         };
         add(mp.visn_fc);
