@@ -434,7 +434,7 @@ public:
         GemmProblem& p = g.p[g.count++];
         memset(&p, 0, sizeof p);
         p.A = dy; p.lda = lddy; p.M = M; p.N = l.in; p.C = dx; p.ldc = lddx;
-        if (LP) { p.B = PbT + l.w + wrow0; p.ldb = l.ldt; p.K = (wrow0 + wrows == l.out) ? (int)rup(wrows, 8) : wrows; if (p.K > l.ldt - wrow0) p.K = l.ldt - wrow0; }
+        if (LP) { p.B = PbT + l.w + wrow0; p.ldb = l.ldt; p.K = (wrow0 + wrows == l.out) ? (int)rup(wrows, 64) : wrows; if (p.K > l.ldt - wrow0) p.K = l.ldt - wrow0; }   // the transposed copy and dy are zero-padded up to ldt = round_up(out, 64): a whole number of K-steps for the LDS-DMA kernel
         else { p.B = P + l.w + (size_t)wrow0 * l.in; p.ldb = l.in; p.K = wrows; }
         p.aux = aux; p.ldaux = ldaux; p.epi = epi;
     }

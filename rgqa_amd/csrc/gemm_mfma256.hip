@@ -64,7 +64,7 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
     const int M = P.M, N = P.N;
     const int fr = lane & 15, fq = lane >> 4;
     constexpr int TP = NT256_TP(MT);                    // m-tiles (16 rows) per pass; TP*4 KiB of f32 per wave
-    constexpr bool AUX = (EPI == EPI_RESID_DROP || EPI == EPI_DGELU || EPI == EPI_ADD);
+    constexpr bool AUX = (EPI == EPI_RESID_DROP || EPI == EPI_DGELU || EPI == EPI_ADD || EPI == EPI_DTANH || EPI == EPI_DRELU_DROP);
     unsigned char* wl = lds + wave * (TP * 4096);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
     const int nb = n0 + wn * 64 + ecol;                 // first of this lane's 8 output columns
@@ -119,15 +119,22 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
             const bf16x8 ax = *reinterpret_cast<const bf16x8*>(&auxv[AUX ? pass * 2 * TP + it : 0]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += bias8[j];
-            if (EPI == EPI_RESID_DROP) drop_apply_vec<8>(dcf, (uint32_t)m * (uint32_t)N + (uint32_t)nb, v);   // N % 8 == 0: even index
+            if (EPI == EPI_RELU || EPI == EPI_RELU_DROP) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (EPI == EPI_RESID_DROP || EPI == EPI_RELU_DROP) drop_apply_vec<8>(dcf, (uint32_t)m * (uint32_t)N + (uint32_t)nb, v);   // N % 8 == 0: even index
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float x = v[j];
                 pre[j] = x;
                 if (EPI == EPI_GELU) gelu_and_grad_fast(pre[j], x, pre[j]);      // C = gelu, C2 = gelu' (consumed by EPI_DGELU)
+                else if (EPI == EPI_TANH) x = tanhf(x);
                 else if (EPI == EPI_RESID_DROP) x = x + (float)ax[j];
                 else if (EPI == EPI_DGELU) x = x * (float)ax[j];
                 else if (EPI == EPI_ADD) x = x + (float)ax[j];
+                else if (EPI == EPI_DTANH) x = x * (1.0f - (float)ax[j] * (float)ax[j]);
+                else if (EPI == EPI_DRELU_DROP) x = (float)ax[j] > 0.f ? x * g.drop.scale : 0.f;
                 v[j] = x;
             }
             bf16x8 o, op;
@@ -281,7 +288,10 @@ static int pick_mt(const GemmGroup& g, long& tiles_out) {
 bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
     if (g.a_f32 || out_f32) return false;
     const int epi = g.p[0].epi;
-    if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD)) return false;
+    if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_TANH || epi == EPI_DTANH ||
+          epi == EPI_RELU || epi == EPI_RELU_DROP || epi == EPI_DRELU_DROP)) return false;
+    static const bool basic_only = getenv("RGQA_NT256_EPI_BASIC") != nullptr;     // A/B: leave tanh / relu epilogues to the 128x128 kernel
+    if (basic_only && !(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD)) return false;
     for (int i = 0; i < g.count; ++i) {
         const GemmProblem& p = g.p[i];
         if (p.epi != epi || p.K % TK != 0 || p.K < TK || (p.ldc % 8) != 0 || (p.N % 8) != 0) return false;
@@ -329,6 +339,11 @@ static int launch256_epi(GemmGroup& g, int mt, hipStream_t s) {
         case EPI_GELU: return launch256_mt<EPI_GELU>(g, mt, s);
         case EPI_RESID_DROP: return launch256_mt<EPI_RESID_DROP>(g, mt, s);
         case EPI_DGELU: return launch256_mt<EPI_DGELU>(g, mt, s);
+        case EPI_TANH: return launch256_mt<EPI_TANH>(g, mt, s);
+        case EPI_DTANH: return launch256_mt<EPI_DTANH>(g, mt, s);
+        case EPI_RELU: return launch256_mt<EPI_RELU>(g, mt, s);
+        case EPI_RELU_DROP: return launch256_mt<EPI_RELU_DROP>(g, mt, s);
+        case EPI_DRELU_DROP: return launch256_mt<EPI_DRELU_DROP>(g, mt, s);
         default: return launch256_mt<EPI_ADD>(g, mt, s);
     }
 }
