@@ -45,6 +45,19 @@ int rgqa_version(void);
  * key 3: perf ablation of the NT LDS-DMA kernel, results are garbage: 1 = no operand DMA in the K loop, 2 = no LDS reads / MFMAs) */
 int rgqa_debug_set(int key, int value);
 
+/* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over
+ * BertTokenizer.tokenize (lxrt/tokenization.py:174-348) for pure-ASCII sentences. vocab_path: one wordpiece per line
+ * (tokenization.py:48-60). encode() writes, per sentence i, ids[i*T .. i*T+T) = [CLS] pieces.. [SEP] 0.., mask likewise 1../0..,
+ * lengths[i] = number of real tokens (what rgqa_engine_set_lengths takes); a sentence containing a byte >= 0x80 gets
+ * needs_python[i] = 1 and an all-zero row: Unicode normalisation stays with the Python implementation of the same rules.
+ * All buffers are host memory. */
+typedef struct rgqa_tokenizer rgqa_tokenizer;
+int rgqa_tokenizer_create(const char* vocab_path, int do_lower_case, rgqa_tokenizer** out);
+void rgqa_tokenizer_destroy(rgqa_tokenizer* t);
+int rgqa_tokenizer_vocab_size(const rgqa_tokenizer* t, int64_t* out);
+int rgqa_tokenizer_encode(const rgqa_tokenizer* t, const char* const* sents, int n, int max_seq_length, int64_t* ids, int64_t* mask,
+                          int32_t* lengths, uint8_t* needs_python);
+
 /* ---- engine: replaces GQAModel.__init__/forward (tasks/gqa_model.py:14-43), LXRTEncoder.forward after
  * tokenisation (lxrt/entry.py:113-120) and everything below it in lxrt/modeling.py. */
 int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out);

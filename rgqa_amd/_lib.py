@@ -20,6 +20,10 @@ _vp, _sz, _i, _f, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_uint64
 SIGNATURES = {
     "rgqa_version": [],
     "rgqa_debug_set": [_i, _i],
+    "rgqa_tokenizer_create": [C.c_char_p, _i, C.POINTER(_vp)],
+    "rgqa_tokenizer_destroy": [_vp],
+    "rgqa_tokenizer_vocab_size": [_vp, C.POINTER(C.c_int64)],
+    "rgqa_tokenizer_encode": [_vp, C.POINTER(C.c_char_p), _i, _i, _vp, _vp, _vp, _vp],
     "rgqa_engine_create": [C.POINTER(Config), C.POINTER(_vp)],
     "rgqa_engine_destroy": [_vp],
     "rgqa_engine_arena_elems": [_vp, C.POINTER(_sz)],
@@ -54,7 +58,7 @@ SIGNATURES = {
     "rgqa_op_bce": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "rgqa_last_error_string": [],
 }
-_RESTYPES = {"rgqa_last_error_string": C.c_char_p, "rgqa_engine_destroy": None}
+_RESTYPES = {"rgqa_last_error_string": C.c_char_p, "rgqa_engine_destroy": None, "rgqa_tokenizer_destroy": None}
 
 _lib = None
 

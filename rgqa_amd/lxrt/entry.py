@@ -58,6 +58,7 @@ class LXRTEncoder(nn.Module):
             print("initializing all the weights")
             self.model.apply(self.model.init_bert_weights)
         self._id_cache = {}
+        self._native = None
 
     def multi_gpu(self):
         """The reference wraps the inner model in single-process nn.DataParallel (:102-103). Here data parallelism is
@@ -70,26 +71,42 @@ class LXRTEncoder(nn.Module):
         return self.model.config.hidden_size   # 768 for bert-base, the only size the reference ever builds (:105-107)
 
     def _tokenize(self, sents, device):
+        """ids / segment / mask `[B, T]` on `device` + the host token counts. The batch goes through the native tokenizer
+        (rgqa_tokenizer_encode) in one call; sentences it hands back (non-ASCII) take the Python path, memoised per string."""
         if self.tokenizer is None:
             raise RuntimeError("LXRTEncoder has no tokenizer: the BERT vocabulary was not found (set RGQA_BERT_VOCAB)")
+        import numpy as np
         T = self.max_seq_length
-        rows_i, rows_m = [], []
-        for s in sents:
+        n = len(sents)
+        ids = torch.zeros(n, T, dtype=torch.long)
+        mask = torch.zeros(n, T, dtype=torch.long)
+        if device.type == "cuda":
+            ids, mask = ids.pin_memory(), mask.pin_memory()
+        ids_np, mask_np = ids.numpy(), mask.numpy()
+        if self._native is None and os.environ.get("RGQA_NATIVE_TOKENIZER", "1") != "0":
+            from .tokenization import NativeBatchEncoder
+            self._native = NativeBatchEncoder(self.tokenizer)
+        if self._native is not None:
+            lengths, needs = self._native.encode(sents, T, ids_np, mask_np)
+            todo = np.nonzero(needs)[0]
+        else:
+            lengths, todo = np.zeros(n, dtype=np.int32), range(n)
+        for i in todo:
+            s = sents[i]
             hit = self._id_cache.get(s)
             if hit is None:
                 f = convert_sents_to_features([s], T, self.tokenizer)[0]
                 hit = (f.input_ids, f.input_mask)
                 if len(self._id_cache) < 2000000:
                     self._id_cache[s] = hit
-            rows_i.append(hit[0])
-            rows_m.append(hit[1])
-        ids = torch.tensor(rows_i, dtype=torch.long)
-        mask = torch.tensor(rows_m, dtype=torch.long)
-        seg = torch.zeros_like(ids)
+            ids_np[i, :] = hit[0]
+            mask_np[i, :] = hit[1]
+            lengths[i] = sum(hit[1])
+        seg = torch.zeros(n, T, dtype=torch.long, device=device)
         # real token counts ([CLS] .. [SEP]; the mask is a prefix of ones, :56-66): lets the engine skip the padding rows.
         # RGQA_VARLEN=0 computes every padded position, as the reference does.
-        lengths = [sum(m) for m in rows_m] if os.environ.get("RGQA_VARLEN", "1") != "0" else None
-        return ids.to(device, non_blocking=True), seg.to(device, non_blocking=True), mask.to(device, non_blocking=True), lengths
+        lens = [int(v) for v in lengths] if os.environ.get("RGQA_VARLEN", "1") != "0" else None
+        return ids.to(device, non_blocking=True), seg, mask.to(device, non_blocking=True), lens
 
     def forward(self, sents, feats, visual_attention_mask=None):
         input_ids, segment_ids, input_mask, lengths = self._tokenize(sents, feats[0].device)

@@ -123,6 +123,8 @@ class BertTokenizer(object):
         if not os.path.isfile(vocab_file):
             raise ValueError("Can't find a vocabulary file at path '{}'.".format(vocab_file))
         self.vocab = load_vocab(vocab_file)
+        self.vocab_file = vocab_file
+        self.do_lower_case = do_lower_case
         self.ids_to_tokens = collections.OrderedDict((i, t) for t, i in self.vocab.items())
         self.do_basic_tokenize = do_basic_tokenize
         if do_basic_tokenize:
@@ -170,3 +172,44 @@ class BertTokenizer(object):
         logger.error("Vocabulary for '%s' not found (no network here): set RGQA_BERT_VOCAB to a vocab.txt",
                      pretrained_model_name_or_path)
         return None
+
+
+class NativeBatchEncoder(object):
+    """Batch front end of the native tokenizer in librgqa_hip.so (`rgqa_tokenizer_*`, csrc/tokenizer.hip): one call turns a
+    list of sentences into the `[n, T]` id / mask arrays and the token counts that `convert_sents_to_features` (reference
+    lxrt/entry.py:36-71) builds sentence by sentence in Python (~100 us each there, ~1 us here). Sentences with non-ASCII
+    characters or an embedded NUL are reported back (`needs_python`) for the Python implementation of the same rules."""
+
+    def __init__(self, tokenizer):
+        import ctypes as C
+        from .. import _lib
+        self._C, self._lib = C, _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._lib.rgqa_tokenizer_create(tokenizer.vocab_file.encode("utf-8"), 1 if tokenizer.do_lower_case else 0, C.byref(self._h)))
+        n = C.c_int64()
+        _lib.check(self._lib.rgqa_tokenizer_vocab_size(self._h, C.byref(n)))
+        if n.value != len(tokenizer.vocab):
+            raise RuntimeError("native tokenizer read %d vocabulary entries, Python read %d" % (n.value, len(tokenizer.vocab)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.rgqa_tokenizer_destroy(h)
+
+    def encode(self, sents, max_seq_length, ids, mask):
+        """ids, mask: writable contiguous int64 numpy arrays [n, T] (e.g. views of pinned tensors). Returns (lengths int32[n],
+        needs_python uint8[n])."""
+        import numpy as np
+        C = self._C
+        n = len(sents)
+        raw = [s.encode("utf-8") for s in sents]
+        arr = (C.c_char_p * n)(*raw)
+        lengths = np.zeros(n, dtype=np.int32)
+        needs = np.zeros(n, dtype=np.uint8)
+        from .. import _lib
+        _lib.check(self._lib.rgqa_tokenizer_encode(self._h, arr, n, max_seq_length, C.c_void_p(ids.ctypes.data), C.c_void_p(mask.ctypes.data),
+                                                   C.c_void_p(lengths.ctypes.data), C.c_void_p(needs.ctypes.data)))
+        for i, b in enumerate(raw):
+            if b"\x00" in b:
+                needs[i] = 1           # a C string ends at NUL; the reference drops the NUL and keeps going
+        return lengths, needs

@@ -81,6 +81,61 @@ def test_tokenizer_and_features_match_reference_vectors(golden_dir):
     assert BertTokenizer.from_pretrained("/nonexistent-dir-xyz") is None      # reference returns None on a failed fetch
 
 
+def test_native_tokenizer_matches_reference_vectors_and_python_rules(golden_dir):
+    """rgqa_tokenizer_encode (csrc/tokenizer.hip) against (a) the reference-generated G4 ids / masks for every sentence it
+    accepts, (b) the Python implementation of the same rules (itself pinned by G4) on generated ASCII text that exercises
+    control bytes, runs of whitespace, punctuation, the never-split specials, over-long words, truncation and [UNK]s."""
+    import random
+    from rgqa_amd.lxrt.tokenization import BertTokenizer, NativeBatchEncoder
+    from rgqa_amd.lxrt.entry import convert_sents_to_features
+    g = json.load(open(os.path.join(golden_dir, "g4_tokenizer.json"), encoding="utf-8"))
+    tok = BertTokenizer(os.path.join(golden_dir, "g4_vocab.txt"), do_lower_case=True)
+    enc = NativeBatchEncoder(tok)
+    sents = g["sentences"]
+    for T in (20, 30):
+        ids = np.zeros((len(sents), T), dtype=np.int64)
+        mask = np.zeros_like(ids)
+        lens, needs = enc.encode(sents, T, ids, mask)
+        assert 0 < int(needs.sum()) < len(sents) // 2          # the accented sentences go back to Python, the rest is native
+        for i in range(len(sents)):
+            if needs[i]:
+                assert not sents[i].isascii()
+                continue
+            assert ids[i].tolist() == g["T%d" % T]["input_ids"][i], sents[i]
+            assert mask[i].tolist() == g["T%d" % T]["input_mask"][i]
+            assert lens[i] == sum(g["T%d" % T]["input_mask"][i])
+    words = [w for w in tok.vocab if w.isascii() and not w.startswith("##") and not w.startswith("[")]
+    rnd = random.Random(7)
+    pool = words + ["[SEP]", "[CLS]", "[UNK]", "[MASK]", "[PAD]", "qzxv", "Is", "THE", "x" * 101, "un" + "able" * 30, "it's", "left-most", "(red)",
+                    "a\x01b", "tab\there", "what?!", "...", "[sep]", "#", "##able", "3.5", "re_do", "end."]
+    seps = [" ", "  ", "\t", "\n", " \r\n ", "\x0b", "\x1f", ""]
+    gen = []
+    for _ in range(1500):
+        k = rnd.randint(0, 26)
+        txt = rnd.choice(["", " ", "\n"]) + "".join(rnd.choice(pool) + rnd.choice(seps) for _ in range(k))
+        if rnd.random() < 0.3:
+            txt = txt.upper() if rnd.random() < 0.5 else txt.title()
+        gen.append(txt)
+    gen += ["", " ", "\x01", "?", "a" * 100, "a" * 101 + " dog"]
+    T = 20
+    ids = np.zeros((len(gen), T), dtype=np.int64)
+    mask = np.zeros_like(ids)
+    lens, needs = enc.encode(gen, T, ids, mask)
+    assert int(needs.sum()) == 0
+    feats = convert_sents_to_features(gen, T, tok)
+    for i, f in enumerate(feats):
+        assert ids[i].tolist() == f.input_ids, repr(gen[i])
+        assert mask[i].tolist() == f.input_mask, repr(gen[i])
+        assert lens[i] == sum(f.input_mask)
+    # a sentence with an embedded NUL cannot cross a C string: handed back
+    l2, n2 = enc.encode(["a\x00b", "caf\u00e9"], T, np.zeros((2, T), dtype=np.int64), np.zeros((2, T), dtype=np.int64))
+    assert n2.tolist() == [1, 1]
+    with pytest.raises(RuntimeError):
+        tok_bad = BertTokenizer(os.path.join(golden_dir, "g4_vocab.txt"))
+        tok_bad.vocab_file = "/nonexistent/vocab.txt"
+        NativeBatchEncoder(tok_bad)
+
+
 def test_bertadam_validation_and_schedules():
     from rgqa_amd.lxrt.optimization import BertAdam, warmup_linear, warmup_constant, warmup_cosine
     p = [torch.nn.Parameter(torch.zeros(3))]
