@@ -431,10 +431,18 @@ __device__ __forceinline__ bf16x8 tr_frag_dma(const unsigned char* tile, int r0,
     return r;
 }
 
-template <int ACCUM>
+// MTW = 16-row m-tiles per wave (2 waves along M): output tile WMV = 32*MTW rows x 256 columns.
+//   MTW = 4: 128 x 256, 3-slot ring (48 KiB per K-step per CU);  MTW = 8: 256 x 256, 2 slots of 64 KiB: twice the MFMAs per
+//   DMA byte.  The loop is bound by what the LDS-DMA path delivers per CU (~50 GB/s), not by the MFMAs, so the taller tile
+//   costs ~1.5x less CU time per FLOP; it halves the tile count, which only pays when something else fills the idle CUs (the
+//   launch runs on the side stream beside the next layer's chain).
+template <int ACCUM, int MTW>
 __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int A_BYTES = TK * WM * 2, B_BYTES = TK * WN * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int WMV = 32 * MTW, NSLOT = MTW == 4 ? 3 : 2;
+    constexpr int APW = MTW / 2;                       // A pieces (1 KiB) per wave per slot
+    constexpr int ARPP = 1024 / (WMV * 2), ALPR = 64 / ARPP;   // rows per A piece, lanes per A row
+    constexpr int A_BYTES = TK * WMV * 2, B_BYTES = TK * WN * 2, STAGE = A_BYTES + B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -446,10 +454,10 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     // XCD-aware order inside a problem: blocks that share an XCD (equal id mod 8) get CONSECUTIVE tile numbers, and tile
     // numbers run over the M-tiles of one N-tile first, so the ~T/8 blocks co-resident on an XCD stream the same B
     // operand (the wider one) through that XCD's L2: the loop is fabric-bound (48 KiB per K-step per CU) without it.
-    const int tiles_m = cdiv(P.M, WM);
+    const int tiles_m = cdiv(P.M, WMV);
     const int tix = xcd_remap256(tile - P.tile_start, tiles_m * P.tiles_n);
     const int local = (tix % tiles_m) * P.tiles_n + (tix / tiles_m);     // back to the m-major id used below
-    const int m0 = (local / P.tiles_n) * WM, n0 = (local % P.tiles_n) * WN;
+    const int m0 = (local / P.tiles_n) * WMV, n0 = (local % P.tiles_n) * WN;
     // contraction length need not be a multiple of the K-step (packed language rows): in the last, partial step the A rows
     // past K come from a zero line (they also feed the bias column sums) and the B rows past K re-read row K-1 (finite data
     // times zero), so no lane predicates its DMA.
@@ -459,12 +467,12 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g.zeros);
 
     // per-lane DMA sources (row within the K-step, column chunk after un-swizzling); columns clamped in-bounds
-    const bf16_t* asrc[2];
+    const bf16_t* asrc[APW];
     const bf16_t* bsrc[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 4 + (lane >> 4);
-        int col = m0 + (((lane & 15) ^ (tn_f(row) << 1)) << 3);
+    for (int i = 0; i < APW; ++i) {
+        const int row = (wave * APW + i) * ARPP + lane / ALPR;
+        int col = m0 + (((lane % ALPR) ^ (tn_f(row) << 1)) << 3);
         if (col > P.lda - 8) col = P.lda - 8;
         asrc[i] = A + (size_t)row * P.lda + col;
     }
@@ -481,9 +489,9 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
         const size_t ao = (size_t)kt * TK * P.lda, bo = (size_t)kt * TK * P.ldb;
         if (ktail != 0 && kt == nkt - 1) {       // block-uniform
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = (wave * 2 + i) * 4 + (lane >> 4);
-                dma16(row < ktail ? asrc[i] + ao : zsrc, base + (wave * 2 + i) * 1024);
+            for (int i = 0; i < APW; ++i) {
+                const int row = (wave * APW + i) * ARPP + lane / ALPR;
+                dma16(row < ktail ? asrc[i] + ao : zsrc, base + (wave * APW + i) * 1024);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -493,14 +501,14 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(asrc[i] + ao, base + (wave * 2 + i) * 1024);
+        for (int i = 0; i < APW; ++i) dma16(asrc[i] + ao, base + (wave * APW + i) * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma16(bsrc[i] + bo, base + A_BYTES + (wave * 4 + i) * 1024);
     };
 
-    f32x4 acc[4][4], cs[4];
+    f32x4 acc[MTW][4], cs[MTW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MTW; ++i) {
         cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -512,51 +520,48 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
 
-    // 3-stage LDS ring, two K-steps of LDS-DMA in flight: every wave issues 6 DMA instructions per stage, so
-    // "s_waitcnt vmcnt(6)" = this wave's stage kt has landed while stage kt+1 stays in flight; the barrier then makes
-    // every wave's stage-kt data visible AND proves everyone is done reading stage kt-1, whose buffer the next issue
+    // MTW = 4: 3-slot LDS ring, two K-steps of LDS-DMA in flight: every wave issues 6 DMA instructions per slot, so
+    // "s_waitcnt vmcnt(6)" = this wave's slot kt has landed while slot kt+1 stays in flight; the barrier then makes
+    // every wave's slot-kt data visible AND proves everyone is done reading slot kt-1, whose buffer the next issue
     // overwrites.  __syncthreads() would drain vmcnt to 0 (hipcc) and serialise each K-step behind a full DMA latency.
+    // MTW = 8: two 64-KiB slots, one K-step in flight (vmcnt(0) + barrier per step, as in the NT kernel).
     issue(0, 0);
-    if (nkt > 1) issue(1, 1);
+    if (NSLOT == 3 && nkt > 1) issue(1, 1);
     for (int kt = 0; kt < nkt; ++kt) {
-        const int st = kt % 3;
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        const int st = kt % NSLOT;
+        if (NSLOT == 3 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nkt) issue((kt + 2) % 3, kt + 2);
+        if (kt + NSLOT - 1 < nkt) issue((kt + NSLOT - 1) % NSLOT, kt + NSLOT - 1);
         const unsigned char* a = lds + st * STAGE;
         const unsigned char* b = a + A_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 xa[4], xb[4];
+            bf16x8 xb[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                xa[t] = tr_frag_dma<WM * 2>(a, s * 32, wm * 64 + t * 16, lane);
-                xb[t] = tr_frag_dma<WN * 2>(b, s * 32, wn * 64 + t * 16, lane);
-            }
+            for (int t = 0; t < 4; ++t) xb[t] = tr_frag_dma<WN * 2>(b, s * 32, wn * 64 + t * 16, lane);
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
+            for (int tm = 0; tm < MTW; ++tm) {
+                const bf16x8 xa = tr_frag_dma<WMV * 2>(a, s * 32, wm * (16 * MTW) + tm * 16, lane);
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[tn], xa[tm], acc[tm][tn], 0, 0, 0);
-            if (do_cs) {
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa[tm], cs[tm], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[tn], xa, acc[tm][tn], 0, 0, 0);
+                if (do_cs) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa, cs[tm], 0, 0, 0);
             }
         }
     }
     if (do_cs && (lane >> 4) == 0) {
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
-            const int m = m0 + wm * 64 + tm * 16 + (lane & 15);
+        for (int tm = 0; tm < MTW; ++tm) {
+            const int m = m0 + wm * (16 * MTW) + tm * 16 + (lane & 15);
             if (m < P.M) P.colsum_out[m] = ACCUM ? P.colsum_out[m] + cs[tm][0] : cs[tm][0];
         }
     }
     const int fr = lane & 15, fq = lane >> 4;
     float* Cc = reinterpret_cast<float*>(P.C);
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-        const int m = m0 + wm * 64 + tm * 16 + fr;
+    for (int tm = 0; tm < MTW; ++tm) {
+        const int m = m0 + wm * (16 * MTW) + tm * 16 + fr;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
             const int n = n0 + wn * 64 + tn * 16 + 4 * fq;
@@ -588,26 +593,40 @@ bool gemm_tn_dma_eligible(const GemmGroup& g) {
     return tiles >= min_tiles;
 }
 
+int g_rgqa_tn_mtw = 0;     // rgqa_debug_set key 4: force the wgrad tile height (4 = 128 rows, 8 = 256 rows); 0 = default
+template <int ACCUM, int MTW>
+static int launch_tn(GemmGroup& g, hipStream_t s) {
+    constexpr int WMV = 32 * MTW, LDS_BYTES = (MTW == 4 ? 3 : 2) * (TK * WMV * 2 + TK * WN * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<ACCUM, MTW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    gemm_group_finalize(g, WMV, WN);
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<ACCUM, MTW>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_BYTES, s, g);
+    RGQA_LAUNCH_CHECK("gemm_tn_dma_kernel");
+    return RGQA_OK;
+}
+
 int launch_gemm_tn_dma_bf16(GemmGroup& g, hipStream_t s) {
     // longest contraction first: block ids are dispatched in order, so the dispatcher does LPT balancing
     for (int i = 1; i < g.count; ++i)
         for (int j = i; j > 0 && g.p[j].K > g.p[j - 1].K; --j) { GemmProblem t = g.p[j]; g.p[j] = g.p[j - 1]; g.p[j - 1] = t; }
-    gemm_group_finalize(g, WM, WN);
-    constexpr int LDS_BYTES = 3 * (TK * WM * 2 + TK * WN * 2);
-    static bool attr_set = false;
     static void* zero_line = nullptr;
     if (zero_line == nullptr) {
         RGQA_HIP(hipMalloc(&zero_line, 256));
         RGQA_HIP(hipMemset(zero_line, 0, 256));
     }
     g.zeros = zero_line;
-    if (!attr_set) {
-        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
+    // 256-row tiles when every problem has at least 256 output rows and the launch still spreads over >= half the CUs
+    static const int env_mtw = []() { const char* e = getenv("RGQA_TN_MTW"); return e ? atoi(e) : 0; }();
+    int mtw = g_rgqa_tn_mtw ? g_rgqa_tn_mtw : env_mtw;
+    if (mtw != 4 && mtw != 8) {
+        long tiles8 = 0; bool tall = true;
+        for (int i = 0; i < g.count; ++i) { tiles8 += (long)cdiv(g.p[i].M, 256) * cdiv(g.p[i].N, WN); if (g.p[i].M < 256 || g.p[i].lda < 256) tall = false; }
+        mtw = (tall && tiles8 >= rgqa_num_cus() / 2) ? 8 : 4;
     }
-    if (g.p[0].epi == EPI_ACCUM) hipLaunchKernelGGL((gemm_tn_dma_kernel<1>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_BYTES, s, g);
-    else hipLaunchKernelGGL((gemm_tn_dma_kernel<0>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_BYTES, s, g);
-    RGQA_LAUNCH_CHECK("gemm_tn_dma_kernel");
-    return RGQA_OK;
+    const bool acc = g.p[0].epi == EPI_ACCUM;
+    if (mtw == 8) return acc ? launch_tn<1, 8>(g, s) : launch_tn<0, 8>(g, s);
+    return acc ? launch_tn<1, 4>(g, s) : launch_tn<0, 4>(g, s);
 }
