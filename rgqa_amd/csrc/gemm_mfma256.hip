@@ -314,7 +314,8 @@ static int launch256(GemmGroup& g, hipStream_t s) {
     gemm_group_finalize(g, 32 * MT, TN);
     g.ablate = g_rgqa_ablate;
     int grid = g.total_tiles;
-    if (NT256_PERSIST(MT) && grid > rgqa_num_cus()) grid = rgqa_num_cus();     // one persistent block per CU
+    static const bool nonpersist = getenv("RGQA_NT_NONPERSIST") != nullptr;   // experiment: one tile per block, hardware dispatch order
+    if (NT256_PERSIST(MT) && !nonpersist && grid > rgqa_num_cus()) grid = rgqa_num_cus();     // one persistent block per CU
     hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI, MT>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
     RGQA_LAUNCH_CHECK("gemm_nt256_kernel");
     return RGQA_OK;
