@@ -95,11 +95,15 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda unavailable); there is no CPU path")
+    local %= max(1, torch.cuda.device_count())      # rehearsal of N ranks on a box with fewer GPUs (the driver's node has one per rank)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:       # rehearsal only: RCCL refuses two ranks on one device; gloo stages the same all-reduce calls through the host
+            dist.init_process_group("gloo")
 
     from rgqa_amd.engine import Engine
     from rgqa_amd import synth
