@@ -5,6 +5,8 @@
 #include <string>
 #include <vector>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "../../include/rgqa.h"
 
@@ -68,10 +70,16 @@ public:
     // host-synchronising: call after the stream has been synchronised
     void prof_collect(ProfSummary& out) {
         memset(&out, 0, sizeof out);
+        const char* dump = getenv("RGQA_PROF_DUMP");          // per-launch records (category, FLOPs, bytes, ms) for offline analysis
+        FILE* df = dump ? fopen(dump, "a") : nullptr;
         for (auto& r : prof_recs) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { out.ms[r.cat] += ms; out.flops[r.cat] += r.flops; out.bytes[r.cat] += r.bytes; out.launches[r.cat]++; }
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                out.ms[r.cat] += ms; out.flops[r.cat] += r.flops; out.bytes[r.cat] += r.bytes; out.launches[r.cat]++;
+                if (df) fprintf(df, "%d %.6e %.6e %.6f\n", r.cat, r.flops, r.bytes, ms);
+            }
         }
+        if (df) fclose(df);
         prof_recs.clear(); prof_used = 0;
     }
     rgqa_config cfg;
