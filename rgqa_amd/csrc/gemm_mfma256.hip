@@ -16,6 +16,7 @@
 #include <unordered_map>
 
 int g_rgqa_ablate = 0;   // rgqa_debug_set key 3
+int g_rgqa_no_deep = 0;  // rgqa_debug_set key 5: 1 = never use the deep-ring single-round variant (A/B)
 
 #define TN 256
 #define TK 64
@@ -257,6 +258,102 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// "Deep ring" variant for launches that fit ONE round of tiles (tiles <= CUs: the language-only stages, the head, the BUTD
+// GRU steps).  Such a launch cannot hide the operand-DMA latency behind other tiles: with one K-step in flight every step
+// costs a full L2/MALL round trip (~1 us) whatever the MFMA work.  One tile per block, so the whole 160 KiB of LDS can hold
+// the ring: NS = 4 slots for MT = 2 (40 KiB each) - three K-steps in flight under counted vmcnt waits; the epilogue scratch
+// aliases the ring once the last step has been consumed.  (Written for any MT <= 5 / NS; only <MT 2, NS 4> is instantiated.)
+template <typename OutT, int EPI, int MT, int NS>
+__global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int TM = 32 * MT, A_BYTES = TM * TK * 2, STAGE_BYTES = A_BYTES + TN * TK * 2, AG = (MT + 1) / 2, NAG = 4 * MT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lrow = lane >> 3;
+    const int lch_a = (lane & 7) ^ (((wave & 1) << 2) + (lrow >> 1));
+    const int lch_w[2] = {(lane & 7) ^ (lrow >> 1), (lane & 7) ^ (4 + (lrow >> 1))};
+    const int tile = xcd_remap256(blockIdx.x, g.total_tiles);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+        if (i < g.count && tile >= g.p[i].tile_start) pi = i;
+    const GemmProblem& P = g.p[pi];
+    const int local = tile - P.tile_start;
+    const int m0 = (local / P.tiles_n) * TM, n0 = (local % P.tiles_n) * TN, nkt = P.K / TK;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(P.B);
+    const bf16_t* asrc[AG];
+    const bf16_t* wsrc[4];
+    int my_a = 0;                                       // A pieces this wave issues per slot (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        if (i * 8 + wave < NAG) ++my_a;
+        int am = m0 + (i * 8 + wave) * 8 + lrow; if (am > P.M - 1) am = P.M - 1;
+        asrc[i] = A + (size_t)am * P.lda + lch_a * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > P.N - 1) wn_ = P.N - 1;
+        wsrc[i] = W + (size_t)wn_ * P.ldb + lch_w[i & 1] * 8;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+    auto issue = [&](int kt) {
+        const unsigned base = lds0 + (kt % NS) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < AG; ++i)
+            if (i * 8 + wave < NAG) dma16(asrc[i] + kt * TK, base + (i * 8 + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * TK, base + A_BYTES + (wave * 4 + i) * 1024);
+    };
+    // wait until at most `slots` of my slots (my_a + 4 DMA instructions each) are still in flight
+    auto wait_keep = [&](int slots) {
+        if (slots <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        if (slots == 1) {
+            if (my_a == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (my_a == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            return;
+        }
+        if (my_a == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (my_a == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    };
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+        if (i < nkt) issue(i);
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int ahead = nkt - 1 - kt;                 // slots after this one that have been issued at most NS - 2
+        wait_keep(ahead < NS - 2 ? ahead : NS - 2);
+        __builtin_amdgcn_s_barrier();                   // slot kt visible to all; everyone is done reading slot kt-1
+        if (kt + NS - 1 < nkt) issue(kt + NS - 1);      // refills slot (kt-1) % NS
+        const unsigned char* a = lds + (kt % NS) * STAGE_BYTES;
+        const unsigned char* w = a + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 xw[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xw[t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, s * 4 + fq));
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm) {
+                const bf16x8 xa = *reinterpret_cast<const bf16x8*>(a + off256(wm * (16 * MT) + tm * 16 + fr, s * 4 + fq));
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[tn], xa, acc[tm][tn], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // the ring is dead: reuse it as the epilogue's transpose scratch
+    nt256_epilogue<OutT, EPI, MT>(g, P, lds, wave, lane, m0, n0, wm, wn, acc, []() {});
+}
+
 static int rgqa_num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -314,6 +411,22 @@ static int launch256(GemmGroup& g, hipStream_t s) {
     }
     gemm_group_finalize(g, 32 * MT, TN);
     g.ablate = g_rgqa_ablate;
+    // single-round launch of 64-row tiles with a long contraction (language-only FFN-down / dgrad): deep ring. Measured against
+    // the 2-slot loop: +15..18 % at 150 tiles x K >= 2304; -3..7 % on K = 768 launches, on 160/128-row tiles and on 16-tile launches
+    // (those are bound by the per-step barrier, not by the DMA latency), so only this corner takes it.
+    bool deep = MT == 2 && !g_rgqa_no_deep && g.total_tiles <= rgqa_num_cus() && g.total_tiles >= 64;
+    for (int i = 0; i < g.count && deep; ++i) if (g.p[i].K < 32 * TK) deep = false;
+    if (deep) {
+        constexpr int LDS_D = 4 * (32 * 2 * TK * 2 + TN * TK * 2);
+        static bool attr_set_d = false;
+        if (!attr_set_d) {
+            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<bf16_t, EPI, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
+            attr_set_d = true;
+        }
+        hipLaunchKernelGGL((gemm_nt256d_kernel<bf16_t, EPI, 2, 4>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, g);
+        RGQA_LAUNCH_CHECK("gemm_nt256d_kernel");
+        return RGQA_OK;
+    }
     int grid = g.total_tiles;
     static const bool nonpersist = getenv("RGQA_NT_NONPERSIST") != nullptr;   // experiment: one tile per block, hardware dispatch order
     if (NT256_PERSIST(MT) && !nonpersist && grid > rgqa_num_cus()) grid = rgqa_num_cus();     // one persistent block per CU

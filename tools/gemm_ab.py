@@ -18,13 +18,15 @@ def timeit(fn, iters=40):
     return a.elapsed_time(b) / iters * 1e3
 
 shapes = [(12356, 768, 768), (12356, 2304, 768), (12356, 3072, 768), (12356, 768, 3072), (12356, 768, 2304), (3140, 2304, 768), (9216, 768, 2048), (8192, 8192, 8192)]
+if "--small" in sys.argv:
+    shapes = [(3140, 768, 3072), (3140, 3072, 768), (3140, 2304, 768), (3140, 768, 768), (3140, 768, 2304), (256, 3072, 1024), (256, 1024, 3072), (256, 1536, 768), (12356, 768, 768), (12356, 768, 3072), (9216, 1024, 2112)]
 for epi in (0, 1):
     for (M, N, K) in shapes:
         A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
         b = torch.randn(N, device="cuda")
         outs = {}
         line = "epi %d M=%5d N=%4d K=%4d:" % (epi, M, N, K)
-        for mt in (0, 8, 6):
+        for mt in ((0, 2, 4, 5) if "--small" in sys.argv else (0, 8, 6)):
             lib.rgqa_debug_set(1, mt)
             t = {}
             for rep in range(2):
