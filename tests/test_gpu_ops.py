@@ -120,6 +120,29 @@ def test_matmul_tn_bf16(lib, M, N, K):
     assert float((got - ref).abs().max()) < 1e-2 * math.sqrt(K)
 
 
+@pytest.mark.parametrize("mtw", [4, 8])
+@pytest.mark.parametrize("M,N,K", [(1024, 1536, 197), (768, 768, 3140), (2304, 768, 12356), (1000, 520, 4100)])
+def test_matmul_tn_bf16_both_tile_heights(lib, mtw, M, N, K):
+    """The wgrad LDS-DMA kernel at both tile heights (rgqa_debug_set key 4): 128-row / 3-slot ring and 256-row / 2 slots, with
+    contraction tails (K % 64 != 0) and ragged M / N; accumulate mode on top of a first pass."""
+    A = rnd(K, M, seed=4).bfloat16()
+    Bm = rnd(K, N, seed=5).bfloat16()
+    lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    Ap = torch.zeros(K, lda, dtype=torch.bfloat16, device="cuda"); Ap[:, :M] = A
+    Bp = torch.zeros(K, ldb, dtype=torch.bfloat16, device="cuda"); Bp[:, :N] = Bm
+    ldc = (N + 3) // 4 * 4
+    Cc = torch.zeros(M, ldc, device="cuda")
+    try:
+        assert lib.rgqa_debug_set(4, mtw) == 0
+        ck(lib.rgqa_op_matmul_tn(P(Ap), P(Bp), P(Cc), M, N, K, lda, ldb, ldc, 1, S()))
+    finally:
+        lib.rgqa_debug_set(4, 0)
+    ref = A.float().t() @ Bm.float()
+    got = Cc[:, :N]
+    assert float((got - ref).norm() / ref.norm()) < 1e-3
+    assert float((got - ref).abs().max()) < 1e-2 * math.sqrt(K)
+
+
 @pytest.mark.parametrize("M,N,K", [(144, 208, 192), (1024, 1536, 192), (1024, 1536, 197), (1024, 1536, 33), (1024, 1536, 65)])
 def test_matmul_tn_exact_integers(lib, M, N, K):
     A = ((torch.arange(K * M).reshape(K, M) * 5 + 1) % 7 - 3).float().cuda().bfloat16()
