@@ -23,15 +23,6 @@ __device__ __forceinline__ bf16x8 ldfrag(const bf16_t* base, int row, int nrows,
     if (row >= nrows) return z;
     return *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + s * 32 + g * 8);
 }
-// stage a [nrows][64] bf16 matrix (row stride ld) into an LDS image of `trows` rows (zero padded)
-__device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* src, int nrows, int trows, int ld, int lane) {
-    for (int c = lane; c < trows * 8; c += 64) {
-        const int row = c >> 3, ch = c & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < nrows) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
-        *reinterpret_cast<uint4*>(lds + row * ROWB + ch * 16) = v;
-    }
-}
 // transposed fragment: element jj = tile[ (jj<4 ? r0a : r0b) + 4*g + (jj&3) ][ c0 + (lane&15) ]
 __device__ __forceinline__ bf16x8 trfrag(const unsigned char* tile, int r0a, int r0b, bool has_b, int c0, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
@@ -65,9 +56,13 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + q0 * a.ldq + h * 64;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + k0 * a.ldk + h * 64;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + k0 * a.ldv + h * 64;
-    stage_tile(vs, V, Lk, NKT * 16, a.ldv, lane);
-
-    bf16x8 qf[NQT][2];
+    // one global-load phase: Q, K, V fragments and the mask requested back to back; the V image for the transposed reads is
+    // written from the V registers
+    bf16x8 qf[NQT][2], kf[NKT][2], vf[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { kf[kt][s] = ldfrag(K, kt * 16 + fr, Lk, a.ldk, s, g); vf[kt][s] = ldfrag(V, kt * 16 + fr, Lk, a.ldv, s, g); }
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
@@ -75,19 +70,26 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
     f32x4 acc[NKT][NQT];
     float mk[NKT][4];
 #pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
+        }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(vs + (kt * 16 + fr) * ROWB + s * 64 + g * 16) = vf[kt][s];
+    __syncthreads();
+#pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        bf16x8 kf0 = ldfrag(K, kt * 16 + fr, Lk, a.ldk, 0, g), kf1 = ldfrag(K, kt * 16 + fr, Lk, a.ldk, 1, g);
+        const bf16x8 kf0 = kf[kt][0], kf1 = kf[kt][1];
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
             c = MFMA(kf0, qf[qt][0], c);
             c = MFMA(kf1, qf[qt][1], c);
             acc[kt][qt] = c;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + 4 * g + r;
-            mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
         }
     }
     DropCfg dc = a.drop; dc.seed_hi ^= a.drop_site;
