@@ -104,6 +104,10 @@ int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, siz
  * then not read and language activations returned by get_activation are the packed rows. NULL / n = 0 restores the
  * padded layout (the default after bind). The array is consumed before the call returns. */
 int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n);
+/* Input gradients for the FOLLOWING backward calls (the reference's ODIN scorer differentiates w.r.t. the RoI features and boxes,
+ * tasks/gqa_odin.py:97-121): dfeats [B*O, feat_dim] f32, dboxes [B*O, pos_dim] f32 device buffers, either may be NULL (not computed,
+ * the default). */
+int rgqa_engine_set_input_grads(rgqa_engine* e, float* dfeats, float* dboxes);
 
 /* data-parallel overlap: the gradient arena becomes final range by range while backward runs (head first, embeddings
  * last). grad_segment k = element range [begin,end) + the id of the event recorded on the backward stream once that

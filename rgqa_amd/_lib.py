@@ -40,6 +40,7 @@ SIGNATURES = {
     "rgqa_engine_backward_pooled": [_vp, _vp, _i, _vp],
     "rgqa_engine_get_activation": [_vp, C.c_char_p, _vp, _sz, _vp],
     "rgqa_engine_set_lengths": [_vp, _vp, _i],
+    "rgqa_engine_set_input_grads": [_vp, _vp, _vp],
     "rgqa_engine_num_grad_segments": [_vp, C.POINTER(_i)],
     "rgqa_engine_grad_segment": [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i)],
     "rgqa_engine_wait_grad_event": [_vp, _i, _vp],

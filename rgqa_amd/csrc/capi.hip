@@ -112,6 +112,11 @@ int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, siz
     return e->impl->get_activation(name, out, cap, S(stream));
 }
 
+int rgqa_engine_set_input_grads(rgqa_engine* e, float* dfeats, float* dboxes) {
+    NEED(e);
+    return e->impl->set_input_grads(dfeats, dboxes);
+}
+
 int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n) {
     NEED(e);
     return e->impl->set_lengths(lengths, n);

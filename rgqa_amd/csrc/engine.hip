@@ -377,6 +377,10 @@ public:
     }
     bool tdesc_uploaded = false;
 
+    // gradients w.r.t. the inputs (f32 [B*O, feat_dim] / [B*O, pos_dim]) written by the following backward calls; null = not computed
+    float* dfeats_out = nullptr; float* dboxes_out = nullptr;
+    int set_input_grads(float* dfeats, float* dboxes) override { dfeats_out = dfeats; dboxes_out = dboxes; return RGQA_OK; }
+
     // Unpadded language rows: lens[b] = number of real tokens of sample b ([CLS] .. [SEP], a PREFIX of its T slots - what
     // convert_sents_to_features builds, lxrt/entry.py:37-79).  Padded positions never reach the logits or any gradient
     // (-10000 key mask -> probability exactly 0, pooler reads token 0), so the engine then packs only the real rows:
@@ -818,10 +822,19 @@ public:
             T* dzf = gz + (size_t)Rl * H;
             CK(k_visn_combine_bwd<T>(dyv, H, zf, H, in_boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.box_ln.w, visn_stats, dzf, H, part,
                                      G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.visn_fc.b, G + mp.box_fc.w, G + mp.box_fc.b,
-                                     accumulate, Rv, H, cfg.pos_dim, drop_site(pd, 2), s));
+                                     accumulate, Rv, H, cfg.pos_dim, drop_site(pd, 2), dboxes_out, s));
             gg_init(g);
             add_wgrad(g, dzf, H, mp.visn_fc, 0, H, LP ? (const void*)feats_lp : (const void*)in_feats, cfg.feat_dim, Rv, accumulate);
             CK(run_wgrad(g, s));
+            if (dfeats_out) {       // input gradient dL/dfeats [B*O, feat_dim] f32 = dzf . W_visn_fc   (ODIN, tasks/gqa_odin.py:97-121)
+                gg_init(g);
+                add_dgrad(g, dzf, H, mp.visn_fc, 0, H, dfeats_out, cfg.feat_dim, Rv, EPI_BIAS, nullptr, 0);
+                double f, b; gemm_work(g, f, b);
+                prof_begin(PC_GEMM_NT, f, b, s);
+                int r = LP ? launch_gemm_nt_bf16(g, 1, s) : launch_gemm_f32(g, 0, 1, s);
+                prof_end(s);
+                CK(r);
+            }
         }
         CK(mark_segment(s));     // embeddings + visual embedding
         return RGQA_OK;

@@ -68,7 +68,7 @@ int k_visn_combine_fwd(const T* zf, int ldz, const float* boxes, const float* Wb
 template <typename T>
 int k_visn_combine_bwd(const T* dout, int lddo, const T* zf, int ldz, const float* boxes, const float* Wb, const float* bb, const float* g1, const float* g2,
                        const float* stats, T* dzf, int lddz, float* part, float* dg1, float* db1, float* dg2, float* db2, float* dbias_fc,
-                       float* dWb, float* dbb, int accumulate, int M, int H, int pos_dim, DropCfg drop, hipStream_t s);
+                       float* dWb, float* dbb, int accumulate, int M, int H, int pos_dim, DropCfg drop, float* dboxes /* [M,pos_dim] or null */, hipStream_t s);
 
 // ---- loss.hip
 // loss = mean_b sum_n BCEWithLogits(z, t)  (= BCEWithLogitsLoss() * NA, gqa_conf.py:197-198); dz = (sigmoid(z)-t)/B * grad_scale

@@ -71,7 +71,7 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void visn_bwd_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ zf, int ldz, const float* __restrict__ boxes,
                                                        const float* __restrict__ Wb, const float* __restrict__ bb, const float* __restrict__ g1,
                                                        const float* __restrict__ g2, const float* __restrict__ stats, T* __restrict__ dzf, int lddz,
-                                                       float* __restrict__ part, int M, int H, int pd, DropCfg drop) {
+                                                       float* __restrict__ part, int M, int H, int pd, DropCfg drop, float* __restrict__ dboxes) {
     __shared__ float red[4][NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = H >> 2, nq = 6 + pd;
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void visn_bwd_kernel(const T* __restrict__ dou
         for (int k = 0; k < 4; ++k) bx[k] = k < pd ? boxes[(size_t)row * pd + k] : 0.f;
         float d[NV][4], xh[NV][4], yh[NV][4];
         float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
+        float dbx[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
@@ -134,8 +135,19 @@ __global__ __launch_bounds__(256) void visn_bwd_kernel(const T* __restrict__ dou
                     acc[5][i][j] += dzb;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) acc[6 + k][i][j] += dzb * bx[k];
+                    if (dboxes) {
+                        const int n = c * 4 + j;
+                        for (int k = 0; k < pd; ++k) dbx[k] = fmaf(dzb, Wb[(size_t)n * pd + k], dbx[k]);
+                    }
                 }
                 store4(dzf + (size_t)row * lddz + c * 4, o);
+            }
+        }
+        if (dboxes) {       // gradient w.r.t. the box coordinates (input gradients: ODIN, tasks/gqa_odin.py:97-121)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = wave_sum(dbx[k]);
+                if (lane == 0 && k < pd) dboxes[(size_t)row * pd + k] = v;
             }
         }
     }
@@ -176,11 +188,11 @@ int k_visn_combine_fwd(const T* zf, int ldz, const float* boxes, const float* Wb
 template <typename T>
 int k_visn_combine_bwd(const T* dout, int lddo, const T* zf, int ldz, const float* boxes, const float* Wb, const float* bb, const float* g1, const float* g2,
                        const float* stats, T* dzf, int lddz, float* part, float* dg1, float* db1, float* dg2, float* db2, float* dbias_fc,
-                       float* dWb, float* dbb, int accumulate, int M, int H, int pos_dim, DropCfg drop, hipStream_t s) {
+                       float* dWb, float* dbb, int accumulate, int M, int H, int pos_dim, DropCfg drop, float* dboxes, hipStream_t s) {
     RGQA_REQUIRE(H % 4 == 0 && H <= 1024 && pos_dim >= 1 && pos_dim <= 4, "visn_combine bwd: H=%d pos_dim=%d unsupported", H, pos_dim);
     if (M <= 0) return RGQA_OK;
     const int nblk = cdiv(M, 4) > 512 ? 512 : cdiv(M, 4);   // 4 rows (waves) per block, grid-stride
-#define VB(NVV) hipLaunchKernelGGL((visn_bwd_kernel<T, NVV>), dim3(nblk), dim3(256), 0, s, dout, lddo, zf, ldz, boxes, Wb, bb, g1, g2, stats, dzf, lddz, part, M, H, pos_dim, drop)
+#define VB(NVV) hipLaunchKernelGGL((visn_bwd_kernel<T, NVV>), dim3(nblk), dim3(256), 0, s, dout, lddo, zf, ldz, boxes, Wb, bb, g1, g2, stats, dzf, lddz, part, M, H, pos_dim, drop, dboxes)
     const int nvl = cdiv(H / 4, 64);
     if (nvl <= 1) VB(1); else if (nvl == 2) VB(2); else if (nvl == 3) VB(3); else VB(4);
 #undef VB
@@ -194,5 +206,5 @@ int k_visn_combine_bwd(const T* dout, int lddo, const T* zf, int ldz, const floa
 
 template int k_visn_combine_fwd<float>(const float*, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, int, float*, int, int, int, float, DropCfg, hipStream_t);
 template int k_visn_combine_fwd<bf16_t>(const bf16_t*, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, float*, int, int, int, float, DropCfg, hipStream_t);
-template int k_visn_combine_bwd<float>(const float*, int, const float*, int, const float*, const float*, const float*, const float*, const float*, const float*, float*, int, float*, float*, float*, float*, float*, float*, float*, float*, int, int, int, int, DropCfg, hipStream_t);
-template int k_visn_combine_bwd<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, float*, float*, float*, float*, float*, float*, float*, float*, int, int, int, int, DropCfg, hipStream_t);
+template int k_visn_combine_bwd<float>(const float*, int, const float*, int, const float*, const float*, const float*, const float*, const float*, const float*, float*, int, float*, float*, float*, float*, float*, float*, float*, float*, int, int, int, int, DropCfg, float*, hipStream_t);
+template int k_visn_combine_bwd<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, float*, float*, float*, float*, float*, float*, float*, float*, int, int, int, int, DropCfg, float*, hipStream_t);

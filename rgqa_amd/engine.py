@@ -163,6 +163,15 @@ class Engine:
         dpooled = dpooled.contiguous().float()
         check(self.lib.rgqa_engine_backward_pooled(self.h, ptr(dpooled), dpooled.stride(0), 1 if accumulate else 0, _stream()))
 
+    def set_input_grads(self, dfeats=None, dboxes=None):
+        """f32 device tensors [B*O, feat_dim] / [B*O, pos_dim] (or None) that the following backward calls fill with dL/dfeats and
+        dL/dboxes (the reference's ODIN scorer, tasks/gqa_odin.py:97-121)."""
+        for t in (dfeats, dboxes):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device):
+                raise ValueError("input-gradient buffers must be contiguous f32 tensors on %s" % self.device)
+        self._in_grads = (dfeats, dboxes)
+        check(self.lib.rgqa_engine_set_input_grads(self.h, ptr(dfeats), ptr(dboxes)))
+
     def activation(self, name, rows, cols=None):
         out = torch.empty(rows, cols or self.cfg.hidden, dtype=torch.float32, device=self.device)
         check(self.lib.rgqa_engine_get_activation(self.h, name.encode(), ptr(out), out.numel(), _stream()))

@@ -235,6 +235,7 @@ class _EngineFunction(torch.autograd.Function):
     def forward(ctx, anchor, owner, feats, boxes, ids, mask, seg, want_logits):
         lg, pl = owner._engine_forward(feats, boxes, ids, mask, seg, train=owner.training)
         ctx.owner = owner
+        ctx.in_shapes = (tuple(feats.shape), tuple(boxes.shape))
         ctx.want_logits = want_logits
         ctx.gen = owner._fwd_counter
         out_l = lg.clone() if want_logits else lg.new_zeros(())
@@ -252,15 +253,28 @@ class _EngineFunction(torch.autograd.Function):
             raise RuntimeError("rgqa: parameter .grad tensors were replaced by foreign tensors; use zero_grad() / set_to_none")
         acc = state == "views"
         e = b.engine
-        if ctx.want_logits and dlogits is not None:
-            e.backward(dlogits, accumulate=acc)
-            acc = True
-            if dpooled is not None and bool((dpooled != 0).any()):
-                e.backward_pooled(dpooled, accumulate=True)
-        elif dpooled is not None:
-            e.backward_pooled(dpooled, accumulate=acc)
+        # gradients w.r.t. the RoI features / boxes when the caller asked for them (ODIN: tasks/gqa_odin.py:97-121)
+        want_f, want_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        dfeats = torch.empty(ctx.in_shapes[0][0] * ctx.in_shapes[0][1], ctx.in_shapes[0][2], dtype=torch.float32, device=e.device) if want_f else None
+        dboxes = torch.empty(ctx.in_shapes[1][0] * ctx.in_shapes[1][1], ctx.in_shapes[1][2], dtype=torch.float32, device=e.device) if want_b else None
+        if want_f or want_b:
+            e.set_input_grads(dfeats, dboxes)
+        try:
+            two = ctx.want_logits and dlogits is not None and dpooled is not None and bool((dpooled != 0).any())
+            if two and (want_f or want_b):
+                raise RuntimeError("rgqa: input gradients through both the logits and the pooled output of one forward are not supported")
+            if ctx.want_logits and dlogits is not None:
+                e.backward(dlogits, accumulate=acc)
+                acc = True
+                if two:
+                    e.backward_pooled(dpooled, accumulate=True)
+            elif dpooled is not None:
+                e.backward_pooled(dpooled, accumulate=acc)
+        finally:
+            if want_f or want_b:
+                e.set_input_grads(None, None)
         b.attach_grads()
-        return (None,) * 8
+        return (None, None, dfeats.view(ctx.in_shapes[0]) if want_f else None, dboxes.view(ctx.in_shapes[1]) if want_b else None, None, None, None, None)
 
 
 class BertPreTrainedModel(nn.Module):

@@ -199,3 +199,32 @@ def test_train_mode_runs_and_is_seeded(env):
     c = m(feats.cuda(), boxes.cuda(), SENTS)
     d = m(feats.cuda(), boxes.cuda(), SENTS)
     assert torch.equal(c, d)
+
+
+def test_odin_style_input_gradients(env, golden_dir):
+    """What tasks/gqa_odin.py:97-121 does: feats / boxes with requires_grad, a loss on the logits, backward, then the SIGN of
+    feats.grad / boxes.grad perturbs the inputs.  Checked against the oracle's autograd (f32)."""
+    from oracle import lxmert_ref as R
+    T = 20
+    m, filled = build("f32", T)
+    feats, boxes, target = batch(T)
+    vocab = {w.rstrip("\n"): i for i, w in enumerate(open(os.path.join(golden_dir, "g4_vocab.txt"), encoding="utf-8"))}
+    ids, mask, _ = R.sents_to_features(SENTS, T, vocab)
+    ids, mask = torch.tensor(ids), torch.tensor(mask)
+    m.eval()
+    f = feats.cuda().requires_grad_(True)
+    bx = boxes.cuda().requires_grad_(True)
+    logit = m(f, bx, SENTS)
+    labels = logit.detach().argmax(1)
+    loss = torch.nn.functional.cross_entropy(logit / 1000.0, labels)       # temperature-scaled CE on the predicted label (:105-112)
+    loss.backward()
+    assert f.grad is not None and bx.grad is not None and f.grad.shape == f.shape and bx.grad.shape == bx.shape
+    cfg = R.RefConfig(**CFG)
+    P = {k: torch.from_numpy(v.copy()) for k, v in filled.items()}
+    fr, br = feats.clone().requires_grad_(True), boxes.clone().requires_grad_(True)
+    lg, _ = R.gqa_forward(P, cfg, fr, br, ids, mask)
+    torch.nn.functional.cross_entropy(lg / 1000.0, lg.detach().argmax(1)).backward()
+    np.testing.assert_allclose(f.grad.cpu().numpy(), fr.grad.numpy(), rtol=0, atol=2e-3 * float(fr.grad.abs().max()))
+    np.testing.assert_allclose(bx.grad.cpu().numpy(), br.grad.numpy(), rtol=0, atol=2e-3 * float(br.grad.abs().max()))
+    big = fr.grad.abs() > 0.05 * fr.grad.abs().max()
+    assert torch.equal(torch.ge(f.grad.cpu(), 0)[big], torch.ge(fr.grad, 0)[big])      # the sign ODIN uses, away from zero

@@ -316,3 +316,31 @@ def test_set_lengths_rejects_bad_input():
     ok = np.array([3, 8, 1, 2], dtype=np.int32)
     assert L.rgqa_engine_set_lengths(e.h, C.c_void_p(ok.ctypes.data), 4) == 0
     assert L.rgqa_engine_set_lengths(e.h, None, 0) == 0
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-4), ("bf16", 6e-2)])
+def test_input_gradients_vs_golden(golden_dir, precision, tol):
+    """dL/dfeats and dL/dboxes (rgqa_engine_set_input_grads; what the reference's ODIN scorer differentiates, tasks/gqa_odin.py:97-121)
+    against the reference's own autograd result stored in the G1 fixture; parameter gradients are unchanged by asking for them."""
+    T = 8
+    g = np.load(os.path.join(golden_dir, "g1_small_T%d.npz" % T))
+    e = make_engine(SMALL, precision)
+    raw = small_batch(T)
+    b = dev(raw)
+    e.ensure_shape(3, T, 6)
+    e.sync_weights()
+    run(e, b)
+    e.loss_backward(b["target"])
+    g0 = e.grads.clone()
+    dfeats = torch.full((3 * 6, SMALL["feat_dim"]), 7.0, device="cuda")
+    dboxes = torch.full((3 * 6, 4), 7.0, device="cuda")
+    e.set_input_grads(dfeats, dboxes)
+    run(e, b)
+    e.loss_backward(b["target"])
+    e.set_input_grads(None, None)
+    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
+    assert torch.equal(e.grads[first:], g0[first:])
+    rf, rb = g["dfeats"].reshape(18, -1), g["dboxes"].reshape(18, 4)
+    np.testing.assert_allclose(dfeats.cpu().numpy(), rf, rtol=0, atol=tol * np.abs(rf).max())
+    np.testing.assert_allclose(dboxes.cpu().numpy(), rb, rtol=0, atol=tol * np.abs(rb).max())
+    assert np.abs(rf).max() > 0 and np.abs(rb).max() > 0
