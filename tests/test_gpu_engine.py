@@ -344,3 +344,45 @@ def test_input_gradients_vs_golden(golden_dir, precision, tol):
     np.testing.assert_allclose(dfeats.cpu().numpy(), rf, rtol=0, atol=tol * np.abs(rf).max())
     np.testing.assert_allclose(dboxes.cpu().numpy(), rb, rtol=0, atol=tol * np.abs(rb).max())
     assert np.abs(rf).max() > 0 and np.abs(rb).max() > 0
+
+
+SWEEP = [   # (B, T, O, l, x, r, heads, hidden, answers, packed)
+    (1, 3, 1, 1, 1, 1, 1, 64, 8, True),
+    (2, 20, 36, 2, 1, 0, 2, 128, 9, True),       # no r-layers: visn goes straight into the cross layers; odd answer count
+    (5, 7, 5, 0, 2, 2, 2, 128, 64, False),       # no l-layers
+    (3, 33, 17, 1, 1, 3, 2, 128, 130, True),     # T > 32: three query tiles; r deeper than l
+    (7, 2, 64, 2, 2, 1, 4, 256, 24, True),       # shortest possible questions ([CLS][SEP]) on a maximal RoI count
+]
+
+
+@pytest.mark.parametrize("precision,tol,gtol", [("f32", 2e-4, 3e-3), ("bf16", 8e-2, 1e-1)])
+@pytest.mark.parametrize("shape", SWEEP, ids=lambda s: "B%dT%dO%d_l%dx%dr%d_h%d" % (s[0], s[1], s[2], s[3], s[4], s[5], s[6]))
+def test_shape_sweep_vs_oracle(shape, precision, tol, gtol):
+    """Edge shapes of the engine (single sample, no l- or r-layers, T beyond two query tiles, 2-token questions, 64 RoIs, answer
+    counts that are not multiples of 8) against the oracle: logits, loss and every gradient, padded or packed language rows."""
+    B, T, O, l, x, r, heads, hidden, na, packed = shape
+    cfgd = dict(vocab_size=300, hidden=hidden, heads=heads, inter=2 * hidden, max_pos=64, type_vocab=2, l_layers=l, x_layers=x, r_layers=r,
+                feat_dim=48, pos_dim=4, num_answers=na)
+    b = synth.synth_batch(B, T, O=O, F=48, NA=na, vocab=300, seed=100 + B, min_len=2)
+    lg_r, pl_r, loss_r, Pr = oracle_run(cfgd, b)
+    e = make_engine(cfgd, precision)
+    d = dev(b)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    lens = b["lengths"].astype(np.int32) if packed else None
+    lg, pl = e.forward(d["feats"], d["boxes"], d["input_ids"], d["input_mask"], d["segment_ids"], lengths=lens)
+    assert float((lg.cpu() - lg_r).abs().max()) < tol * max(1.0, float(lg_r.abs().max()))
+    assert float((pl.cpu() - pl_r).abs().max()) < tol
+    loss = e.loss_backward(d["target"])
+    assert abs(loss.item() - loss_r) < 50 * tol * max(1.0, abs(loss_r))
+    for sp in e.specs:
+        got = e.view(e.grads, sp).cpu()
+        ref = Pr[sp.name].grad
+        if ref is None or sp.dead:
+            assert float(got.abs().max()) == 0.0, sp.name
+            continue
+        den = float(ref.norm())
+        if den < 1e-8:      # mathematically zero gradients (key biases: softmax is shift-invariant): rounding noise only
+            assert float(got.norm()) < 1e-3 * gtol, sp.name
+            continue
+        assert float((got - ref).norm()) / den < gtol, (sp.name, float((got - ref).norm()) / den)
