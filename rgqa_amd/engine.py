@@ -233,7 +233,7 @@ class Engine:
             check(self.lib.rgqa_engine_sync_transposed(self.h, s))
 
     def grad_norm(self):
-        self.adam_m if self.adam_m is not None else None
+        """Global L2 norm of the live gradient ranges (what clip_grad_norm_ measures, gqa_conf.py:201) as a device scalar."""
         tot = torch.zeros(1, dtype=torch.float32, device=self.device)
         ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
         for i, (a, b) in enumerate(self.live_ranges()):

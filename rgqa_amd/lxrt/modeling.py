@@ -15,7 +15,6 @@ import json
 import logging
 import math
 import os
-import sys
 
 import torch
 from torch import nn
