@@ -192,11 +192,13 @@ def main():
     # live roofline of the dominant kernel (the bf16 MFMA NT GEMM): HIP events around every launch, on the launch stream
     roof = None
     prof = None
+    blocks = None
     if rank == 0:
         e.profile(True)
         for _ in range(args.profile_steps):
             step()
         prof = e.profile_read()
+        blocks = e.profile_blocks() if hasattr(e, "profile_blocks") and not args.butd else None
         e.profile(False)
         nt = prof["gemm_nt"]
         if nt["launches"]:
@@ -239,6 +241,16 @@ def main():
             # ... and the FLOPs the engine actually executed (GEMMs + attention, packed rows) over the measured step time
             ex = sum(v["flops"] for v in prof.values()) / max(1, args.profile_steps)
             out["step_executed_tflops_per_gpu"] = round(ex / (ms * 1e-3) / 1e12, 1)
+            if blocks is not None:
+                # the block the north-star target names: the five LXRTXLayers (cross-attention + self-attention + FFN of both
+                # modalities, forward + backward incl. their weight gradients): executed GEMM + attention FLOPs over the sum of
+                # ALL kernel durations of those layers (LayerNorm, attention and epilogue time included)
+                out["block_ms_per_step"] = {k: round(v["ms"] / args.profile_steps, 3) for k, v in blocks.items()}
+                xb = blocks["cross_modality_layers"]
+                if xb["ms"] > 0:
+                    tf = xb["flops"] / (xb["ms"] * 1e-3) / 1e12
+                    out["cross_attention_block"] = {"ms_per_step": round(xb["ms"] / args.profile_steps, 3), "gflop_per_step": round(xb["flops"] / args.profile_steps / 1e9, 1),
+                                                    "achieved": round(tf, 1), "unit": "TFLOP/s", "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -122,6 +122,10 @@ int rgqa_engine_wait_grad_event(rgqa_engine* e, int event, void* stream);
  * 4 layernorm, 5 other. flops / bytes are algorithmic (2*M*N*K; operand + result bytes). */
 int rgqa_engine_profile(rgqa_engine* e, int enable);
 int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* bytes, int64_t* launches, int ncat);
+/* the same records of the last profile_read, split by model block: 0 input embeddings (text + visual), 1 language / vision
+ * single-modality layers, 2 cross-modality layers (LXRTXLayer, lxrt/modeling.py:439-488: the block the north-star roofline target
+ * names), 3 pooler + answer head + loss; ms = sum of kernel durations, flops = GEMM + attention FLOPs */
+int rgqa_engine_profile_blocks(rgqa_engine* e, double* ms, double* flops, int nblock);
 
 /* ---- optimizer: replaces nn.utils.clip_grad_norm_(params, max_norm) (tasks/gqa_conf.py:201) followed by
  * BertAdam.step (lxrt/optimization.py:101-180) over arena ranges. */

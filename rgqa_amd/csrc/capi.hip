@@ -143,6 +143,12 @@ int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* 
     for (int i = 0; i < PC_COUNT; ++i) { ms[i] = ps.ms[i]; flops[i] = ps.flops[i]; bytes[i] = ps.bytes[i]; launches[i] = ps.launches[i]; }
     return RGQA_OK;
 }
+int rgqa_engine_profile_blocks(rgqa_engine* e, double* ms, double* flops, int nblock) {
+    NEED(e);
+    RGQA_REQUIRE(ms && flops && nblock >= PB_COUNT, "profile_blocks: need room for %d blocks", PB_COUNT);
+    for (int i = 0; i < PB_COUNT; ++i) { ms[i] = e->impl->last_blk_ms[i]; flops[i] = e->impl->last_blk_flops[i]; }
+    return RGQA_OK;
+}
 int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws, float* sumsq_out, int accumulate, void* stream) {
     RGQA_REQUIRE(grads && partial_ws && sumsq_out, "grad_sumsq: null argument");
     return k_sumsq(grads, n, partial_ws, sumsq_out, accumulate, S(stream));

@@ -46,13 +46,16 @@ struct Stage {
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's live roofline figures).
 enum ProfCat { PC_GEMM_NT = 0, PC_GEMM_TN = 1, PC_ATTN_FWD = 2, PC_ATTN_BWD = 3, PC_LN = 4, PC_OTHER = 5, PC_COUNT = 6 };
-struct ProfRec { hipEvent_t a, b; int cat; double flops, bytes; };
+enum ProfBlock { PB_EMBED = 0, PB_LR = 1, PB_X = 2, PB_HEAD = 3, PB_COUNT = 4 };   // input embeddings | l/r layers | cross-modality layers | pooler + head + loss
+struct ProfRec { hipEvent_t a, b; int cat; int block; double flops, bytes; };
 struct ProfSummary { double ms[PC_COUNT]; double flops[PC_COUNT]; double bytes[PC_COUNT]; long launches[PC_COUNT]; };
 
 class EngineBase {
 public:
     virtual ~EngineBase() {}
     bool profiling = false;
+    int prof_block = PB_EMBED;                 // which part of the model the launches being enqueued belong to
+    double last_blk_ms[PB_COUNT] = {0, 0, 0, 0}, last_blk_flops[PB_COUNT] = {0, 0, 0, 0};   // filled by prof_collect
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
@@ -62,7 +65,7 @@ public:
     }
     void prof_begin(int cat, double flops, double bytes, hipStream_t s) {
         if (!profiling) return;
-        ProfRec r; r.a = prof_event(); r.b = prof_event(); r.cat = cat; r.flops = flops; r.bytes = bytes;
+        ProfRec r; r.a = prof_event(); r.b = prof_event(); r.cat = cat; r.block = prof_block; r.flops = flops; r.bytes = bytes;
         hipEventRecord(r.a, s);
         prof_recs.push_back(r);
     }
@@ -70,13 +73,15 @@ public:
     // host-synchronising: call after the stream has been synchronised
     void prof_collect(ProfSummary& out) {
         memset(&out, 0, sizeof out);
+        for (int i = 0; i < PB_COUNT; ++i) { last_blk_ms[i] = 0; last_blk_flops[i] = 0; }
         const char* dump = getenv("RGQA_PROF_DUMP");          // per-launch records (category, FLOPs, bytes, ms) for offline analysis
         FILE* df = dump ? fopen(dump, "a") : nullptr;
         for (auto& r : prof_recs) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
                 out.ms[r.cat] += ms; out.flops[r.cat] += r.flops; out.bytes[r.cat] += r.bytes; out.launches[r.cat]++;
-                if (df) fprintf(df, "%d %.6e %.6e %.6f\n", r.cat, r.flops, r.bytes, ms);
+                if (r.block >= 0 && r.block < PB_COUNT) { last_blk_ms[r.block] += ms; last_blk_flops[r.block] += r.flops; }
+                if (df) fprintf(df, "%d %d %.6e %.6e %.6f\n", r.cat, r.block, r.flops, r.bytes, ms);
             }
         }
         if (df) fclose(df);

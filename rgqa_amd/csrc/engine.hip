@@ -489,6 +489,8 @@ public:
     int attn_bwd_dispatch(const AttnArgs& a, hipStream_t s);
 
 #define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
+// CK + HIP-event timing of the call under profiling (non-GEMM kernels: they count towards the per-block times)
+#define CKP(cat, x) do { prof_begin((cat), 0.0, 0.0, s); int _r = (x); prof_end(s); if (_r) return _r; } while (0)
 
     int seg_rows(int m) const { return m == 0 ? Rl : Rv; }
     int seg_len(int m) const { return m == 0 ? Tn : O; }
@@ -501,6 +503,7 @@ public:
         const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh;
         in_feats = feats; in_boxes = boxes; in_ids = ids; in_seg = seg; last_train = train; last_seed = seed;
         const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
+        prof_block = PB_EMBED;
         {   // language row layout of this pass: packed (varlen) or padded
             const int want = varlen ? n_lang : B * Tn;
             if (want != Rl) plan(B, Tn, O, want);
@@ -508,21 +511,23 @@ public:
             fwd_varlen = varlen;
         }
         const int* cu = fwd_varlen ? cu_dev : nullptr;
-        if (!fwd_varlen) CK(k_make_mask(mask, maskf, Rl, s));
-        CK(k_embed_fwd<T>(ids, seg, fwd_varlen ? row_src_dev : nullptr, Rl, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z,
+        if (!fwd_varlen) CKP(PC_OTHER, k_make_mask(mask, maskf, Rl, s));
+        CKP(PC_OTHER, k_embed_fwd<T>(ids, seg, fwd_varlen ? row_src_dev : nullptr, Rl, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z,
                           emb_mean, emb_rstd, B, Tn, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
         {   // VisualFeatEncoder: GEMM on the RoI features (one f32->bf16 cast pass in bf16 precision, so that this GEMM and
             // its weight-gradient GEMM run on the LDS-DMA kernels), then the fused LN/LN/avg tail
             GemmGroup g; gg_init(g);
-            if (LP) CK(k_cast_bf16(feats, feats_lp, (size_t)Rv * cfg.feat_dim, s));
+            if (LP) CKP(PC_OTHER, k_cast_bf16(feats, feats_lp, (size_t)Rv * cfg.feat_dim, s));
             add_fwd(g, LP ? (const void*)feats_lp : (const void*)feats, cfg.feat_dim, mp.visn_fc, 0, H, zf, H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s));
-            CK(k_visn_combine_fwd<T>(zf, H, boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.visn_ln.b, P + mp.box_ln.w, P + mp.box_ln.b,
+            CKP(PC_OTHER, k_visn_combine_fwd<T>(zf, H, boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.visn_ln.b, P + mp.box_ln.w, P + mp.box_ln.b,
                                      visn_out, H, visn_stats, Rv, H, cfg.pos_dim, cfg.ln_eps, drop_site(pd, 2), s));
         }
         bool gathered = false;
+        const size_t n_lr_stages = 2 * (size_t)(cfg.l_layers > cfg.r_layers ? cfg.l_layers : cfg.r_layers);
         for (size_t si = 0; si < stages.size(); ++si) {
             Stage& st = stages[si];
+            prof_block = si < n_lr_stages ? PB_LR : PB_X;
             if (st.kind == ST_ATT_CROSS && x0_needed && !gathered) {
                 CK(rgqa_check_hip(hipMemcpyAsync(x0, x0_src[0], (size_t)Rl * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather lang"));
                 CK(rgqa_check_hip(hipMemcpyAsync(x0 + (size_t)Rl * H, x0_src[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather visn"));
@@ -538,7 +543,7 @@ public:
                     add_fwd(g, st.sb[m].h, I, st.ffn[m]->down, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
                 CK(run_fwd(g, s));
                 for (int m = 0; m < 2; ++m) if (st.active[m])
-                    CK(k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.ffn[m]->ln.w, P + st.ffn[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
+                    CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.ffn[m]->ln.w, P + st.ffn[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
                 continue;
             }
             // ---- attention stages
@@ -586,28 +591,29 @@ public:
                 CK(run_fwd(g, s));
             }
             if (cross && st.active[1]) {
-                CK(k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
+                CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
             } else {
                 for (int m = 0; m < 2; ++m) if (st.active[m])
-                    CK(k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.att[m]->ln.w, P + st.att[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
+                    CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.att[m]->ln.w, P + st.att[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
             }
         }
         // ---- BertPooler (modeling.py:575-581) + answer head (gqa_model.py:22-27)
+        prof_block = PB_HEAD;
         {
             GemmGroup g; gg_init(g);
-            CK(k_gather_rows<T>((const T*)lang_final, H, cu, Tn, cls_rows, H, B, H, s));     // the [CLS] row of every sample
+            CKP(PC_OTHER, k_gather_rows<T>((const T*)lang_final, H, cu, Tn, cls_rows, H, B, H, s));     // the [CLS] row of every sample
             add_fwd(g, cls_rows, H, mp.pooler, 0, H, pooled, H, B, EPI_TANH, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s));
             gg_init(g);
             add_fwd(g, pooled, H, mp.head0, 0, 2 * H, h1, 2 * H, B, EPI_GELU, nullptr, 0, h1pre, 0);
             CK(run_fwd(g, s));
-            CK(k_ln_fwd<T>(h1, 2 * H, P + mp.head_ln.w, P + mp.head_ln.b, h2, 2 * H, hd_mean, hd_rstd, B, 2 * H, cfg.ln_eps, s));
+            CKP(PC_LN, k_ln_fwd<T>(h1, 2 * H, P + mp.head_ln.w, P + mp.head_ln.b, h2, 2 * H, hd_mean, hd_rstd, B, 2 * H, cfg.ln_eps, s));
             gg_init(g);
             add_fwd(g, h2, 2 * H, mp.head3, 0, cfg.num_answers, logits, NAp, B, EPI_BIAS, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s, 1));
         }
-        if (pooled_out) CK(k_to_f32<T>(pooled, H, pooled_out, H, B, H, s));
-        if (logits_out) CK(k_fill_rows<float>(logits_out, ld_logits, logits, NAp, B, cfg.num_answers, s));
+        if (pooled_out) CKP(PC_OTHER, k_to_f32<T>(pooled, H, pooled_out, H, B, H, s));
+        if (logits_out) CKP(PC_OTHER, k_fill_rows<float>(logits_out, ld_logits, logits, NAp, B, cfg.num_answers, s));
         have_fwd = true;
         return RGQA_OK;
     }
@@ -617,16 +623,17 @@ public:
         RGQA_REQUIRE(have_fwd, "loss_backward: no forward pass recorded");
         RGQA_REQUIRE(G != nullptr, "loss_backward: no gradient arena bound");
         // BCE on the f32 logits; dlogits written as f32 into `logits`' sibling then cast+padded to T
+        prof_block = PB_HEAD;
         float* dl32 = part;   // scratch [B, NAp] f32
-        CK(k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, cfg.num_answers, NAp, grad_scale, s));
+        CKP(PC_OTHER, k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, cfg.num_answers, NAp, grad_scale, s));
         if (loss_out) CK(rgqa_check_hip(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s), "loss copy"));
-        CK(k_cast_pad<T>(dl32, NAp, dlogits, NAp, B, NAp, 1.0f, s));
+        CKP(PC_OTHER, k_cast_pad<T>(dl32, NAp, dlogits, NAp, B, NAp, 1.0f, s));
         return backward_impl(accumulate, s);
     }
     int backward(const float* dl, int ldd, int accumulate, hipStream_t s) override {
         RGQA_REQUIRE(have_fwd, "backward: no forward pass recorded");
         RGQA_REQUIRE(G != nullptr && dl != nullptr, "backward: null gradient arena / dlogits");
-        CK(k_cast_pad<T>(dl, ldd, dlogits, NAp, B, cfg.num_answers, 1.0f, s));
+        CKP(PC_OTHER, k_cast_pad<T>(dl, ldd, dlogits, NAp, B, cfg.num_answers, 1.0f, s));
         return backward_impl(accumulate, s);
     }
 
@@ -635,6 +642,7 @@ public:
     }
 
     int backward_impl(int accumulate, hipStream_t s) {
+        prof_block = PB_HEAD;
         const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh, NA = cfg.num_answers;
         const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
         const DropCfg nodrop = make_drop(0.f, 0, 0);
@@ -646,13 +654,13 @@ public:
         GemmGroup g;
         // ---- head
         // padded columns of dlogits are exact zeros and the bias slot reserves round_up(NA, 64) elements
-        CK(colsum_bias(dlogits, NAp, mp.head3, 0, NAp, B, accumulate, s));
+        CKP(PC_OTHER, colsum_bias(dlogits, NAp, mp.head3, 0, NAp, B, accumulate, s));
         gg_init(g); add_wgrad(g, dlogits, NAp, mp.head3, 0, NA, h2, 2 * H, B, accumulate); CK(run_wgrad(g, s));
         gg_init(g); add_dgrad(g, dlogits, NAp, mp.head3, 0, NA, gp1, 2 * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
-        CK(k_ln_bwd<T>(gp1, 2 * H, h1, 2 * H, P + mp.head_ln.w, hd_mean, hd_rstd, gp2, nullptr, 2 * H, part, G + mp.head_ln.w, G + mp.head_ln.b, nullptr,
+        CKP(PC_LN, k_ln_bwd<T>(gp1, 2 * H, h1, 2 * H, P + mp.head_ln.w, hd_mean, hd_rstd, gp2, nullptr, 2 * H, part, G + mp.head_ln.w, G + mp.head_ln.b, nullptr,
                        accumulate, B, 2 * H, nodrop, nodrop, 1.0f, s));
-        CK(k_dgelu_mul<T>(gp2, h1pre, gp3, (size_t)B * 2 * H, s));
-        CK(colsum_bias(gp3, 2 * H, mp.head0, 0, 2 * H, B, accumulate, s));
+        CKP(PC_OTHER, k_dgelu_mul<T>(gp2, h1pre, gp3, (size_t)B * 2 * H, s));
+        CKP(PC_OTHER, colsum_bias(gp3, 2 * H, mp.head0, 0, 2 * H, B, accumulate, s));
         gg_init(g); add_wgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, pooled, H, B, accumulate); CK(run_wgrad(g, s));
         gg_init(g); add_dgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, gp1, H, B, EPI_DTANH, pooled, H); CK(run_dgrad(g, s));   // gp1[B,H] = d(pooler pre-tanh)
         return backward_encoder(accumulate, s);
@@ -668,24 +676,26 @@ public:
             if (dead_end > dead_begin) CK(rgqa_check_hip(hipMemsetAsync(G + dead_begin, 0, sizeof(float) * (dead_end - dead_begin), s), "zero dead grads"));
             CK(rgqa_check_hip(hipMemsetAsync(G + mp.head0.w, 0, sizeof(float) * (arena_elems - mp.head0.w), s), "zero head grads"));
         }
-        CK(k_cast_pad<T>(dpooled, ld, gp2, H, B, H, 1.0f, s));
-        CK(k_dtanh_mul<T>(gp2, pooled, gp1, (size_t)B * H, s));
+        CKP(PC_OTHER, k_cast_pad<T>(dpooled, ld, gp2, H, B, H, 1.0f, s));
+        CKP(PC_OTHER, k_dtanh_mul<T>(gp2, pooled, gp1, (size_t)B * H, s));
         return backward_encoder(accumulate, s);
     }
 
     int backward_encoder(int accumulate, hipStream_t s) {
+        prof_block = PB_HEAD;
+        const int n_lr_stages = 2 * (cfg.l_layers > cfg.r_layers ? cfg.l_layers : cfg.r_layers);
         const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh;
         const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
         const DropCfg nodrop = make_drop(0.f, 0, 0);
         GemmGroup g;
-        CK(colsum_bias(gp1, H, mp.pooler, 0, H, B, accumulate, s));
+        CKP(PC_OTHER, colsum_bias(gp1, H, mp.pooler, 0, H, B, accumulate, s));
         const int* cu = fwd_varlen ? cu_dev : nullptr;
         gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, cls_rows, H, B, accumulate); CK(run_wgrad(g, s));
         // gradient w.r.t. the final hidden states: zero except the [CLS] rows of lang
         T* dy = gA; T* dx = gB;
         CK(rgqa_check_hip(hipMemsetAsync(dy, 0, (size_t)R * H * sizeof(T), s), "zero dy"));
         gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, gp2, H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
-        CK(k_scatter_rows<T>(gp2, H, dy, H, cu, Tn, B, H, s));
+        CKP(PC_OTHER, k_scatter_rows<T>(gp2, H, dy, H, cu, Tn, B, H, s));
         seg_cursor = 0;
         CK(mark_segment(s));     // head + pooler gradients are final
 
@@ -694,6 +704,7 @@ public:
         int par = 0; bool layer_open = false;
         for (int si = (int)stages.size() - 1; si >= 0; --si) {
             Stage& st = stages[si];
+            prof_block = si < n_lr_stages ? PB_LR : PB_X;
             if (!layer_open) { CK(wait_wgrad(par, s)); layer_open = true; }     // first stage (in backward order) of a layer
             T* gz = gz_s[par][st.slot]; T* gzd = gzd_s[par][st.slot]; T* gqkv = gqkv_s[par][st.slot]; T* gh = gh_s[par][st.slot];
             const bool cross = st.kind == ST_ATT_CROSS;
@@ -703,7 +714,7 @@ public:
                 for (int m = 0; m < 2; ++m) if (st.active[m]) {
                     const FfnP& f = *st.ffn[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
-                    CK(k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                    CKP(PC_LN, k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
                                    d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s));
                 }
                 T* gzm = drop_base(pd).thresh ? gzd : gz;
@@ -731,14 +742,14 @@ public:
             if (shared_all) {
                 const AttP& ap = *st.att[0];
                 DropCfg d = drop_site(pd, st.site + 1);
-                CK(k_ln_bwd<T>(dy, H, (T*)st.sb[0].z, H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
+                CKP(PC_LN, k_ln_bwd<T>(dy, H, (T*)st.sb[0].z, H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
                                G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, R, H, d, nodrop, 1.0f, s));
                 gg_init(g); add_dgrad(g, gzm, H, ap.o, 0, H, gctx, H, R, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
             } else {
                 for (int m = 0; m < 2; ++m) if (st.active[m]) {
                     const AttP& ap = *st.att[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
-                    CK(k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                    CKP(PC_LN, k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
                                    d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s));
                 }
                 gg_init(g);
@@ -805,22 +816,24 @@ public:
             T* t = dy; dy = dx; dx = t;
             if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
         }
+        prof_block = PB_LR;
         CK(run_wgrad(wg, s));
         CK(wait_wgrad(0, s));        // everything on the side stream joins the caller's stream before backward returns
         CK(wait_wgrad(1, s));
+        prof_block = PB_EMBED;
         T* gz = gemb;
         // ---- embeddings: dropout -> LN backward -> scatter-add into the three tables
         {
             DropCfg din = drop_site(pd, 1);
-            CK(k_ln_bwd<T>(dy, H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
+            CKP(PC_LN, k_ln_bwd<T>(dy, H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
                            nodrop, din, 1.0f, s));
-            CK(k_embed_scatter<T>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, s));
+            CKP(PC_OTHER, k_embed_scatter<T>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, s));
         }
         // ---- visual embedding
         {
             T* dyv = dy + (size_t)Rl * H;
             T* dzf = gz + (size_t)Rl * H;
-            CK(k_visn_combine_bwd<T>(dyv, H, zf, H, in_boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.box_ln.w, visn_stats, dzf, H, part,
+            CKP(PC_OTHER, k_visn_combine_bwd<T>(dyv, H, zf, H, in_boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.box_ln.w, visn_stats, dzf, H, part,
                                      G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.visn_fc.b, G + mp.box_fc.w, G + mp.box_fc.b,
                                      accumulate, Rv, H, cfg.pos_dim, drop_site(pd, 2), dboxes_out, s));
             gg_init(g);

@@ -190,6 +190,16 @@ class Engine:
         check(self.lib.rgqa_engine_profile_read(self.h, ms, fl, by, ln, n))
         return {c: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=ln[i]) for i, c in enumerate(self.PROFILE_CATS)}
 
+    PROFILE_BLOCKS = ("embeddings", "single_modality_layers", "cross_modality_layers", "pooler_head_loss")
+
+    def profile_blocks(self):
+        """The records of the last profile_read() split by model block: {block: dict(ms, flops)} (kernel-duration sums; GEMM +
+        attention FLOPs). "cross_modality_layers" is the LXRTXLayer stack the north-star roofline target names."""
+        n = len(self.PROFILE_BLOCKS)
+        ms, fl = (C.c_double * n)(), (C.c_double * n)()
+        check(self.lib.rgqa_engine_profile_blocks(self.h, ms, fl, n))
+        return {b: dict(ms=ms[i], flops=fl[i]) for i, b in enumerate(self.PROFILE_BLOCKS)}
+
     def grad_segments(self):
         """[(begin, end, event)] gradient-arena ranges in the order backward finalises them (dead range excluded)."""
         n = C.c_int()
