@@ -196,7 +196,8 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     // fragments (64-B DMA rows halve the useful bytes per L2 line request and the loop is close to delivery-bound: DMA alone
     // takes 0.85x of LDS+MFMA alone, rgqa_debug_set key 3); moving the barrier between the two K32 halves with the fragments
     // double-buffered across it (256 VGPRs) changed nothing (+-3 %); reading the W fragments of both halves at the top of the
-    // step behind a second barrier, so that W(kt+2) is requested a step earlier (96 KiB in flight), lost 2..7 %.
+    // step behind a second barrier, so that W(kt+2) is requested a step earlier (96 KiB in flight), lost 2..7 %; s_setprio(1) around
+    // each group of 4 MFMAs lost 5..14 % (it pays only inside a multi-phase schedule, as the CDNA guide notes).
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int stage, int kt) {
         const unsigned base = lds0 + stage * STAGE_BYTES;

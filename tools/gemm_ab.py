@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rgqa_amd import _lib
 lib = _lib.load()
 KEY = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+VAL = int(os.environ.get("AB_VAL", "1"))
 S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -31,7 +32,7 @@ for epi in (0, 1):
             t = {}
             for rep in range(2):
                 for var in (0, 1):
-                    lib.rgqa_debug_set(KEY, var)
+                    lib.rgqa_debug_set(KEY, var * VAL)
                     Cc = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
                     run = lambda: _lib.check(lib.rgqa_op_linear(P(A), P(W), P(b), P(Cc), M, N, K, K, K, N, epi, 1, S()))
                     t.setdefault(var, []).append(timeit(run))
