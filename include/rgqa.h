@@ -42,7 +42,7 @@ const char* rgqa_last_error_string(void);
 int rgqa_version(void);
 /* debug / A-B knobs (key 0: 1 forces the 128x128 GEMM kernel everywhere; key 1: forces the NT M-tile;
  * key 2: 1 runs the deferred weight-gradient launches on the main stream instead of the side stream;
- * key 3: perf ablation of the NT LDS-DMA kernel, results are garbage: 1 = no operand DMA in the K loop, 2 = no LDS reads / MFMAs;
+ * key 3: perf ablation of the NT LDS-DMA kernel, results are garbage: 1 = no operand DMA in the K loop, 2 = no LDS reads / MFMAs, 5 = as 2 with twice the DMA bytes in flight;
  * key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots) */
 int rgqa_debug_set(int key, int value);
 

@@ -198,6 +198,13 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     // double-buffered across it (256 VGPRs) changed nothing (+-3 %); reading the W fragments of both halves at the top of the
     // step behind a second barrier, so that W(kt+2) is requested a step earlier (96 KiB in flight), lost 2..7 %; s_setprio(1) around
     // each group of 4 MFMAs lost 5..14 % (it pays only inside a multi-phase schedule, as the CDNA guide notes).
+    // A ping-pong schedule (four barrier slots per K-step - read half 0 / 32 MFMAs / read half 1 / 32 MFMAs - with waves 4-7 one slot
+    // behind waves 0-3, so every SIMD always has one wave on the MFMA pipe) WON the L2-hot micro-benchmark by 1..9 % and LOST 4..8 %
+    // per launch inside the train step: there the operands come from MALL/HBM, a K-step's 64 KiB take ~1.25 us to arrive with one
+    // step of lead (DMA alone: 11.5 TB/s aggregate; 16.6 TB/s with two steps in flight, rgqa_debug_set key 3 = 5), and a faster
+    // compute slot only shortens that lead.  The lever is more operand bytes in flight (a third slot does not fit 160 KiB of LDS
+    // at this tile size), not a denser MFMA stream.  Lesson for A/B work on this loop: decide in situ (tools/ab_bench.sh +
+    // RGQA_PROF_DUMP), not on a hot micro-benchmark.
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int stage, int kt) {
         const unsigned base = lds0 + stage * STAGE_BYTES;
@@ -227,7 +234,8 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             if (kt + 1 < nkt && !(pre1 && kt == 0) && g.ablate != 1) issue(st ^ 1, kt + 1);
             const unsigned char* a = lds + st * STAGE_BYTES;
             const unsigned char* w = a + A_BYTES;
-            if (g.ablate == 2) continue;
+            if (g.ablate == 5 && kt + 1 < nkt) issue(st, kt + 1);      // DMA-only with twice the bytes in flight: latency- or bandwidth-bound?
+            if (g.ablate == 2 || g.ablate == 5) continue;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 xw[4];

@@ -27,7 +27,7 @@ for epi in (0, 1):
         b = torch.randn(N, device="cuda")
         outs = {}
         line = "epi %d M=%5d N=%4d K=%4d:" % (epi, M, N, K)
-        for mt in ((0, 2, 4, 5) if "--small" in sys.argv else (0, 8, 6)):
+        for mt in ((0, 2, 4, 5) if "--small" in sys.argv else ((0, 8, 7, 6, 5, 4) if "--allmt" in sys.argv else (0, 8, 6))):
             lib.rgqa_debug_set(1, mt)
             t = {}
             for rep in range(2):

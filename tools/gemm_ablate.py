@@ -22,8 +22,8 @@ for (M, N, K) in ((14336, 2304, 6144), (14336, 2304, 768), (8192, 8192, 8192)):
     lib.rgqa_debug_set(1, 8)
     res = []
     for rep in range(2):
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 5):
             lib.rgqa_debug_set(3, mode)
             res.append(timeit(run))
     lib.rgqa_debug_set(3, 0); lib.rgqa_debug_set(1, 0)
-    print("M=%d N=%d K=%d MT8: full %.1f / %.1f us | no-DMA %.1f / %.1f | no-MFMA(DMA only) %.1f / %.1f   (full = %.0f TF)" % (M, N, K, res[0], res[3], res[1], res[4], res[2], res[5], 2.0*M*N*K/res[0]/1e6), flush=True)
+    print("M=%d N=%d K=%d MT8: full %.1f / %.1f us | no-DMA %.1f / %.1f | DMA only %.1f / %.1f | DMA only, 2x bytes in flight %.1f / %.1f   (full = %.0f TF)" % (M, N, K, res[0], res[4], res[1], res[5], res[2], res[6], res[3], res[7], 2.0*M*N*K/res[0]/1e6), flush=True)
