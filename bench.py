@@ -210,7 +210,7 @@ def main():
             if os.path.exists(pmc) and B == 256 and T == 20 and not args.mixup:
                 traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", algorithmic_bytes_per_launch=round(nt["bytes"] / nt["launches"]), kernel="gemm_nt (gemm_nt256pp / gemm_nt256 / gemm_nt256d_kernel<EPI,MT> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
+                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", algorithmic_bytes_per_launch=round(nt["bytes"] / nt["launches"]), kernel="gemm_nt (gemm_nt256_kernel / gemm_nt256d_kernel<EPI,MT> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
                         avg_launch_us=round(avg_ms * 1e3, 2), gflop_per_launch=round(per_launch_flops / 1e9, 3))
     if dist is not None:
         dist.barrier()
