@@ -420,21 +420,34 @@ static int launch256(GemmGroup& g, hipStream_t s) {
     }
     gemm_group_finalize(g, 32 * MT, TN);
     g.ablate = g_rgqa_ablate;
-    // single-round launch of 64-row tiles with a long contraction (language-only FFN-down / dgrad): deep ring. Measured against
-    // the 2-slot loop: +15..18 % at 150 tiles x K >= 2304; -3..7 % on K = 768 launches, on 160/128-row tiles and on 16-tile launches
-    // (those are bound by the per-step barrier, not by the DMA latency), so only this corner takes it.
-    bool deep = MT == 2 && !g_rgqa_no_deep && g.total_tiles <= rgqa_num_cus() && g.total_tiles >= 64;
-    for (int i = 0; i < g.count && deep; ++i) if (g.p[i].K < 32 * TK) deep = false;
-    if (deep) {
-        constexpr int LDS_D = 4 * (32 * 2 * TK * 2 + TN * TK * 2);
-        static bool attr_set_d = false;
-        if (!attr_set_d) {
-            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<bf16_t, EPI, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
-            attr_set_d = true;
+    // Launches whose tile height is 64, 128 or 160 rows (the language-only stages, the N = 768 projections, the head, BUTD's GRU
+    // steps) take the deep-ring kernel: 4 / 3 LDS slots, one tile per block.  Measured IN SITU (RGQA_PROF_DUMP, operands arriving
+    // from MALL/HBM): -4..-25 % on those launches, NT total -4 %, step -1.3 %; the L2-hot micro-benchmark had shown -3..7 % for most
+    // of them (there the one-step lead of the 2-slot loop already covers the DMA latency) and +15..18 % only for 64-row tiles at
+    // K >= 2304.  Forcing 160- or 128-row tiles on the big launches to get them onto the deep ring loses 5..30 %.
+    // RGQA_NT_DEEP: 0 never, 1 single-round 64-row launches with K >= 2048 only, 2 every launch of 64-row tiles, 3 (default) also
+    // 128- and 160-row tiles
+    static const int deep_mode = []() { const char* e = getenv("RGQA_NT_DEEP"); return e ? atoi(e) : 3; }();
+    bool deep = false;
+    if (!g_rgqa_no_deep && deep_mode > 0) {
+        if (deep_mode == 1) {
+            deep = MT == 2 && g.total_tiles <= rgqa_num_cus() && g.total_tiles >= 64;
+            for (int i = 0; i < g.count && deep; ++i) if (g.p[i].K < 32 * TK) deep = false;
+        } else deep = MT == 2 || (deep_mode >= 3 && (MT == 4 || MT == 5));
+    }
+    if constexpr (MT == 2 || MT == 4 || MT == 5) {
+        if (deep) {
+            constexpr int NSD = MT == 2 ? 4 : 3;
+            constexpr int LDS_D = NSD * (32 * MT * TK * 2 + TN * TK * 2);
+            static bool attr_set_d = false;
+            if (!attr_set_d) {
+                RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<bf16_t, EPI, MT, NSD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
+                attr_set_d = true;
+            }
+            hipLaunchKernelGGL((gemm_nt256d_kernel<bf16_t, EPI, MT, NSD>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, g);
+            RGQA_LAUNCH_CHECK("gemm_nt256d_kernel");
+            return RGQA_OK;
         }
-        hipLaunchKernelGGL((gemm_nt256d_kernel<bf16_t, EPI, 2, 4>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, g);
-        RGQA_LAUNCH_CHECK("gemm_nt256d_kernel");
-        return RGQA_OK;
     }
     int grid = g.total_tiles;
     static const bool nonpersist = getenv("RGQA_NT_NONPERSIST") != nullptr;   // experiment: one tile per block, hardware dispatch order
@@ -521,7 +534,9 @@ static int tuned_mt(GemmGroup& g, int model_mt, hipStream_t s) {
 int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
     long tiles = 0;
     int mt = pick_mt(g, tiles);
+    static const int env_mt = []() { const char* e = getenv("RGQA_NT_FORCE_MT"); return e ? atoi(e) : 0; }();     // experiments
     if (g_rgqa_force_mt) mt = g_rgqa_force_mt;
+    else if (env_mt) mt = env_mt;
     else mt = tuned_mt(g, mt, s);
     return launch256_epi(g, mt, s);
 }
