@@ -196,7 +196,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     // fragments (64-B DMA rows halve the useful bytes per L2 line request and the loop is close to delivery-bound: DMA alone
     // takes 0.85x of LDS+MFMA alone, rgqa_debug_set key 3); moving the barrier between the two K32 halves with the fragments
     // double-buffered across it (256 VGPRs) changed nothing (+-3 %); reading the W fragments of both halves at the top of the
-    // step behind a second barrier, so that W(kt+2) is requested a step earlier (96 KiB in flight), lost 2..7 %; s_setprio(1) around
+    // step behind a second barrier, so that W(kt+2) is requested a step earlier (96 KiB in flight), lost 2..7 % hot and changed nothing in situ (+-0.5 %); s_setprio(1) around
     // each group of 4 MFMAs lost 5..14 % (it pays only inside a multi-phase schedule, as the CDNA guide notes).
     // A ping-pong schedule (four barrier slots per K-step - read half 0 / 32 MFMAs / read half 1 / 32 MFMAs - with waves 4-7 one slot
     // behind waves 0-3, so every SIMD always has one wave on the MFMA pipe) WON the L2-hot micro-benchmark by 1..9 % and LOST 4..8 %
