@@ -136,6 +136,7 @@ public:
     float* logits = nullptr; T* dlogits = nullptr; float* loss_dev = nullptr;
     T *gA = nullptr, *gB = nullptr, *gctx = nullptr;
     T *gz_s[2][3] = {}, *gzd_s[2][3] = {}, *gqkv_s[2][3] = {}, *gh_s[2][3] = {};   // [layer parity][stage slot]
+    hipStream_t s_v = nullptr; hipEvent_t ev_v[2] = {nullptr, nullptr};   // vision chain of the single-modality layers (forward, experiment)
     hipStream_t s_w = nullptr;                 // side stream: the deferred weight-gradient GEMMs of a layer run beside the next layer's chain
     hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_wdone[2] = {nullptr, nullptr};
     bool wdone_valid[2] = {false, false};
@@ -496,6 +497,76 @@ public:
     int seg_len(int m) const { return m == 0 ? Tn : O; }
 
     // ------------------------------------------------------------------ forward
+    // one stage (self-attention / cross-attention / FFN sub-block) of the forward pass for the modalities st.active[] marks, on stream s
+    int forward_stage(Stage& st, const int* cu, hipStream_t s) {
+        const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh;
+        const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
+        if (st.kind == ST_FFN) {
+            GemmGroup g; gg_init(g);
+            for (int m = 0; m < 2; ++m) if (st.active[m])
+                add_fwd(g, st.sb[m].x_in, H, st.ffn[m]->up, 0, I, st.sb[m].h, I, seg_rows(m), EPI_GELU, nullptr, 0, st.sb[m].hpre, 0);
+            CK(run_fwd(g, s));
+            gg_init(g); g.drop = drop_base(pd);
+            for (int m = 0; m < 2; ++m) if (st.active[m])
+                add_fwd(g, st.sb[m].h, I, st.ffn[m]->down, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
+            CK(run_fwd(g, s));
+            for (int m = 0; m < 2; ++m) if (st.active[m])
+                CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.ffn[m]->ln.w, P + st.ffn[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
+            return RGQA_OK;
+        }
+        // ---- attention stages
+        const bool cross = st.kind == ST_ATT_CROSS;
+        {
+            GemmGroup g; gg_init(g);
+            if (cross) {
+                const AttP& ap = *st.att[0];
+                if (st.active[1]) add_fwd(g, st.sb[0].x_in, H, ap.qkv, 0, 3 * H, st.sb[0].qkv, 3 * H, R, EPI_BIAS, nullptr, 0, nullptr, 0);
+                else {   // final x-layer: only lang queries and visn keys/values are live
+                    add_fwd(g, st.sb[0].x_in, H, ap.qkv, 0, H, st.sb[0].qkv, 3 * H, Rl, EPI_BIAS, nullptr, 0, nullptr, 0);
+                    add_fwd(g, st.sb[1].x_in, H, ap.qkv, H, 2 * H, (T*)st.sb[1].qkv + H, 3 * H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
+                }
+            } else {
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    add_fwd(g, st.sb[m].x_in, H, st.att[m]->qkv, 0, 3 * H, st.sb[m].qkv, 3 * H, seg_rows(m), EPI_BIAS, nullptr, 0, nullptr, 0);
+            }
+            CK(run_fwd(g, s));
+        }
+        for (int m = 0; m < 2; ++m) if (st.active[m]) {
+            const int km = cross ? 1 - m : m;    // modality that provides keys / values
+            AttnArgs a; memset(&a, 0, sizeof a);
+            a.q = st.sb[m].qkv; a.ldq = 3 * H;
+            a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
+            a.out = st.sb[m].ctx; a.ldo = H;
+            a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;      // only language keys carry a padding mask (entry.py:119)
+            a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;  // packed language rows: the window IS the mask
+            a.lse = st.sb[m].lse;
+            a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
+            a.scale = 1.0f / sqrtf((float)dh);
+            a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
+            prof_begin(PC_ATTN_FWD, 4.0 * B * nh * a.Lq * a.Lk * dh, sizeof(T) * (double)B * nh * dh * (2.0 * a.Lq + 2.0 * a.Lk), s);
+            int ra = attn_fwd_dispatch(a, s);
+            prof_end(s);
+            CK(ra);
+        }
+        {
+            GemmGroup g; gg_init(g); g.drop = drop_base(pd);
+            if (cross && st.active[1]) {
+                add_fwd(g, st.sb[0].ctx, H, st.att[0]->o, 0, H, st.sb[0].z, H, R, EPI_RESID_DROP, st.sb[0].x_in, H, nullptr, st.site + 1);
+            } else {
+                for (int m = 0; m < 2; ++m) if (st.active[m])
+                    add_fwd(g, st.sb[m].ctx, H, st.att[m]->o, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
+            }
+            CK(run_fwd(g, s));
+        }
+        if (cross && st.active[1]) {
+            CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
+        } else {
+            for (int m = 0; m < 2; ++m) if (st.active[m])
+                CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.att[m]->ln.w, P + st.att[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
+        }
+            return RGQA_OK;
+    }
+
     int forward(const float* feats, const float* boxes, const int64_t* ids, const int64_t* seg, const int64_t* mask,
                 float* pooled_out, float* logits_out, int ld_logits, int train, uint64_t seed, hipStream_t s) override {
         RGQA_REQUIRE(P != nullptr && ws != nullptr, "forward: engine not bound");
@@ -525,6 +596,17 @@ public:
         }
         bool gathered = false;
         const size_t n_lr_stages = 2 * (size_t)(cfg.l_layers > cfg.r_layers ? cfg.l_layers : cfg.r_layers);
+        static const bool two_env = getenv("RGQA_FWD_TWO_STREAM") != nullptr;
+        const bool two = two_env && !profiling && cfg.l_layers > 0 && cfg.r_layers > 0;
+        if (two) {
+            if (s_v == nullptr) {
+                RGQA_HIP(hipStreamCreateWithFlags(&s_v, hipStreamNonBlocking));
+                RGQA_HIP(hipEventCreateWithFlags(&ev_v[0], hipEventDisableTiming));
+                RGQA_HIP(hipEventCreateWithFlags(&ev_v[1], hipEventDisableTiming));
+            }
+            RGQA_HIP(hipEventRecord(ev_v[0], s));          // embeddings done
+            RGQA_HIP(hipStreamWaitEvent(s_v, ev_v[0], 0));
+        }
         for (size_t si = 0; si < stages.size(); ++si) {
             Stage& st = stages[si];
             prof_block = si < n_lr_stages ? PB_LR : PB_X;
@@ -533,69 +615,20 @@ public:
                 CK(rgqa_check_hip(hipMemcpyAsync(x0 + (size_t)Rl * H, x0_src[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather visn"));
                 gathered = true;
             }
-            if (st.kind == ST_FFN) {
-                GemmGroup g; gg_init(g);
-                for (int m = 0; m < 2; ++m) if (st.active[m])
-                    add_fwd(g, st.sb[m].x_in, H, st.ffn[m]->up, 0, I, st.sb[m].h, I, seg_rows(m), EPI_GELU, nullptr, 0, st.sb[m].hpre, 0);
-                CK(run_fwd(g, s));
-                gg_init(g); g.drop = drop_base(pd);
-                for (int m = 0; m < 2; ++m) if (st.active[m])
-                    add_fwd(g, st.sb[m].h, I, st.ffn[m]->down, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
-                CK(run_fwd(g, s));
-                for (int m = 0; m < 2; ++m) if (st.active[m])
-                    CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.ffn[m]->ln.w, P + st.ffn[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
+            if (two && si < n_lr_stages) {
+                // language and vision chains of the single-modality layers are independent: two streams, so the small language
+                // launches (and the four language-only layers) run beside vision work instead of alone on the chip
+                Stage sl = st, sv = st;
+                sl.active[1] = 0; sv.active[0] = 0;
+                if (sl.active[0]) CK(forward_stage(sl, cu, s));
+                if (sv.active[1]) CK(forward_stage(sv, cu, s_v));
+                if (si + 1 == n_lr_stages) {
+                    RGQA_HIP(hipEventRecord(ev_v[1], s_v));
+                    RGQA_HIP(hipStreamWaitEvent(s, ev_v[1], 0));
+                }
                 continue;
             }
-            // ---- attention stages
-            const bool cross = st.kind == ST_ATT_CROSS;
-            {
-                GemmGroup g; gg_init(g);
-                if (cross) {
-                    const AttP& ap = *st.att[0];
-                    if (st.active[1]) add_fwd(g, st.sb[0].x_in, H, ap.qkv, 0, 3 * H, st.sb[0].qkv, 3 * H, R, EPI_BIAS, nullptr, 0, nullptr, 0);
-                    else {   // final x-layer: only lang queries and visn keys/values are live
-                        add_fwd(g, st.sb[0].x_in, H, ap.qkv, 0, H, st.sb[0].qkv, 3 * H, Rl, EPI_BIAS, nullptr, 0, nullptr, 0);
-                        add_fwd(g, st.sb[1].x_in, H, ap.qkv, H, 2 * H, (T*)st.sb[1].qkv + H, 3 * H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
-                    }
-                } else {
-                    for (int m = 0; m < 2; ++m) if (st.active[m])
-                        add_fwd(g, st.sb[m].x_in, H, st.att[m]->qkv, 0, 3 * H, st.sb[m].qkv, 3 * H, seg_rows(m), EPI_BIAS, nullptr, 0, nullptr, 0);
-                }
-                CK(run_fwd(g, s));
-            }
-            for (int m = 0; m < 2; ++m) if (st.active[m]) {
-                const int km = cross ? 1 - m : m;    // modality that provides keys / values
-                AttnArgs a; memset(&a, 0, sizeof a);
-                a.q = st.sb[m].qkv; a.ldq = 3 * H;
-                a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
-                a.out = st.sb[m].ctx; a.ldo = H;
-                a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;      // only language keys carry a padding mask (entry.py:119)
-                a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;  // packed language rows: the window IS the mask
-                a.lse = st.sb[m].lse;
-                a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
-                a.scale = 1.0f / sqrtf((float)dh);
-                a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
-                prof_begin(PC_ATTN_FWD, 4.0 * B * nh * a.Lq * a.Lk * dh, sizeof(T) * (double)B * nh * dh * (2.0 * a.Lq + 2.0 * a.Lk), s);
-                int ra = attn_fwd_dispatch(a, s);
-                prof_end(s);
-                CK(ra);
-            }
-            {
-                GemmGroup g; gg_init(g); g.drop = drop_base(pd);
-                if (cross && st.active[1]) {
-                    add_fwd(g, st.sb[0].ctx, H, st.att[0]->o, 0, H, st.sb[0].z, H, R, EPI_RESID_DROP, st.sb[0].x_in, H, nullptr, st.site + 1);
-                } else {
-                    for (int m = 0; m < 2; ++m) if (st.active[m])
-                        add_fwd(g, st.sb[m].ctx, H, st.att[m]->o, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
-                }
-                CK(run_fwd(g, s));
-            }
-            if (cross && st.active[1]) {
-                CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
-            } else {
-                for (int m = 0; m < 2; ++m) if (st.active[m])
-                    CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.att[m]->ln.w, P + st.att[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
-            }
+            CK(forward_stage(st, cu, s));
         }
         // ---- BertPooler (modeling.py:575-581) + answer head (gqa_model.py:22-27)
         prof_block = PB_HEAD;
