@@ -869,9 +869,32 @@ public:
             CKP(PC_OTHER, k_visn_combine_bwd<T>(dyv, H, zf, H, in_boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.box_ln.w, visn_stats, dzf, H, part,
                                      G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.visn_fc.b, G + mp.box_fc.w, G + mp.box_fc.b,
                                      accumulate, Rv, H, cfg.pos_dim, drop_site(pd, 2), dboxes_out, s));
-            gg_init(g);
-            add_wgrad(g, dzf, H, mp.visn_fc, 0, H, LP ? (const void*)feats_lp : (const void*)in_feats, cfg.feat_dim, Rv, accumulate);
-            CK(run_wgrad(g, s));
+            // dW_visn_fc [H, feat_dim] contracts over all B*O rows but has only (H/256)*(feat_dim/256) = 24 output tiles, and nothing
+            // is left to run beside it: split the contraction S ways into f32 partials (one grouped launch, S*24 tiles) and fold
+            // them in a fixed order.  The scratch is a gradient buffer that is dead by now (every wgrad launch has been joined).
+            const size_t wsz = (size_t)H * cfg.feat_dim;
+            int S = Rv / 1024; if (S > 8) S = 8;
+            const size_t scratch_bytes = (size_t)(Rl > 0 ? B * Tn + Rv : Rv) * 3 * H * sizeof(T);
+            while (S > 1 && (size_t)S * wsz * sizeof(float) > scratch_bytes) --S;
+            static const bool no_split = getenv("RGQA_VISN_WGRAD_NOSPLIT") != nullptr;
+            if (LP && S >= 2 && !no_split && (wsz % 4) == 0) {
+                float* part_w = reinterpret_cast<float*>(gqkv_s[0][0]);
+                const int kc = (Rv / S) / 64 * 64;
+                gg_init(g);
+                for (int i = 0; i < S; ++i) {
+                    GemmProblem& p = g.p[g.count++];
+                    memset(&p, 0, sizeof p);
+                    const int r0 = i * kc, rows = (i == S - 1) ? Rv - r0 : kc;
+                    p.A = dzf + (size_t)r0 * H; p.lda = H; p.B = feats_lp + (size_t)r0 * cfg.feat_dim; p.ldb = cfg.feat_dim;
+                    p.K = rows; p.M = H; p.N = cfg.feat_dim; p.C = part_w + (size_t)i * wsz; p.ldc = cfg.feat_dim; p.epi = EPI_BIAS;
+                }
+                CK(run_wgrad(g, s));
+                CKP(PC_OTHER, k_sum_partials(part_w, S, wsz, G + mp.visn_fc.w, accumulate, s));
+            } else {
+                gg_init(g);
+                add_wgrad(g, dzf, H, mp.visn_fc, 0, H, LP ? (const void*)feats_lp : (const void*)in_feats, cfg.feat_dim, Rv, accumulate);
+                CK(run_wgrad(g, s));
+            }
             if (dfeats_out) {       // input gradient dL/dfeats [B*O, feat_dim] f32 = dzf . W_visn_fc   (ODIN, tasks/gqa_odin.py:97-121)
                 gg_init(g);
                 add_dgrad(g, dzf, H, mp.visn_fc, 0, H, dfeats_out, cfg.feat_dim, Rv, EPI_BIAS, nullptr, 0);

@@ -763,7 +763,8 @@ int launch_gemm_tn_dma_bf16(GemmGroup& g, hipStream_t s) {
     if (mtw != 4 && mtw != 8) {
         long tiles8 = 0; bool tall = true;
         for (int i = 0; i < g.count; ++i) { tiles8 += (long)cdiv(g.p[i].M, 256) * cdiv(g.p[i].N, WN); if (g.p[i].M < 256 || g.p[i].lda < 256) tall = false; }
-        mtw = (tall && tiles8 >= rgqa_num_cus() / 2) ? 8 : 4;
+        static const long tall_min = []() { const char* e = getenv("RGQA_TN_TALL_MIN"); return e ? atol(e) : 128L; }();
+        mtw = (tall && tiles8 >= tall_min) ? 8 : 4;
     }
     const bool acc = g.p[0].epi == EPI_ACCUM;
     if (mtw == 8) return acc ? launch_tn<1, 8>(g, s) : launch_tn<0, 8>(g, s);

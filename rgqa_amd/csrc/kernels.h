@@ -99,6 +99,7 @@ int k_scale_rows(float* target, const float* prop, int B, int NA, int ld, int ro
 template <typename T> int k_fill_rows(T* dst, int ld, const T* src, int lds, int rows, int cols, hipStream_t s);
 template <typename T> int k_cast_pad(const float* src, int lds, T* dst, int ldd, int rows, int cols, float scale, hipStream_t s);
 template <typename T> int k_to_f32(const T* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
+int k_sum_partials(const float* part, int S, size_t n, float* out, int accumulate, hipStream_t s);
 // varlen language rows: lengths (host, passed as kernel arguments) -> lens/cu[B+1]/row_src[sum] on the device
 int k_set_lengths(const int* lens_host, int B, int Tn, int* lens_dev, int* cu_dev, int* row_src_dev, hipStream_t s);
 // row(b) = cu ? cu[b] : b * stride_rows

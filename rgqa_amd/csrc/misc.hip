@@ -183,3 +183,26 @@ template int k_gather_rows<float>(const float*, int, const int*, int, float*, in
 template int k_gather_rows<bf16_t>(const bf16_t*, int, const int*, int, bf16_t*, int, int, int, hipStream_t);
 template int k_scatter_rows<float>(const float*, int, float*, int, const int*, int, int, int, hipStream_t);
 template int k_scatter_rows<bf16_t>(const bf16_t*, int, bf16_t*, int, const int*, int, int, int, hipStream_t);
+
+// out[i] (+)= sum_s part[s][i]  (fixed order: deterministic split-K reduction of a weight gradient)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int S, size_t n, float* __restrict__ out, int accumulate) {
+    const size_t nv = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate) load4(out + i * 4, a);
+        for (int s = 0; s < S; ++s) {
+            float v[4];
+            load4(part + (size_t)s * n + i * 4, v);
+            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        }
+        store4(out + i * 4, a);
+    }
+}
+int k_sum_partials(const float* part, int S, size_t n, float* out, int accumulate, hipStream_t s) {
+    RGQA_REQUIRE(n % 4 == 0 && S >= 1, "sum_partials: n=%zu must be a multiple of 4", n);
+    size_t nb = (n / 4 + 255) / 256;
+    const int nblk = nb > 2048 ? 2048 : (int)nb;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(nblk), dim3(256), 0, s, part, S, n, out, accumulate);
+    RGQA_LAUNCH_CHECK("sum_partials_kernel");
+    return RGQA_OK;
+}
