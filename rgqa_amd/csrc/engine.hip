@@ -642,7 +642,9 @@ public:
             CK(run_fwd(g, s));
             CKP(PC_LN, k_ln_fwd<T>(h1, 2 * H, P + mp.head_ln.w, P + mp.head_ln.b, h2, 2 * H, hd_mean, hd_rstd, B, 2 * H, cfg.ln_eps, s));
             gg_init(g);
-            add_fwd(g, h2, 2 * H, mp.head3, 0, cfg.num_answers, logits, NAp, B, EPI_BIAS, nullptr, 0, nullptr, 0);
+            // N = NAp (a multiple of 64): the arena slots of logit_fc.3.weight / .bias are zero-padded up to NAp rows, so the extra
+            // logits columns come out as exact zeros and the GEMM runs on the LDS-DMA kernel
+            add_fwd(g, h2, 2 * H, mp.head3, 0, LP ? NAp : cfg.num_answers, logits, NAp, B, EPI_BIAS, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s, 1));
         }
         if (pooled_out) CKP(PC_OTHER, k_to_f32<T>(pooled, H, pooled_out, H, B, H, s));

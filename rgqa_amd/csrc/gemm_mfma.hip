@@ -295,11 +295,12 @@ static int check_group(const GemmGroup& g, bool tn) {
 int g_rgqa_force_gemm128 = 0;
 bool gemm_nt256_eligible(const GemmGroup& g, int out_f32);
 int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s);
+int launch_gemm_nt256_f32out(GemmGroup& g, hipStream_t s);
 
 int launch_gemm_nt_bf16(GemmGroup& g, int out_f32, hipStream_t s) {
     int r = check_group(g, false);
     if (r) return r;
-    if (!g_rgqa_force_gemm128 && gemm_nt256_eligible(g, out_f32)) return launch_gemm_nt256_bf16(g, s);
+    if (!g_rgqa_force_gemm128 && gemm_nt256_eligible(g, out_f32)) return out_f32 ? launch_gemm_nt256_f32out(g, s) : launch_gemm_nt256_bf16(g, s);
     gemm_group_finalize(g, BM, BN);
     dim3 grid(g.total_tiles), block(NTHREADS);
     if (g.a_f32) {

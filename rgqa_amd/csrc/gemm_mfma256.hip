@@ -138,6 +138,11 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
                 else if (EPI == EPI_DRELU_DROP) x = (float)ax[j] > 0.f ? x * g.drop.scale : 0.f;
                 v[j] = x;
             }
+            if (sizeof(OutT) == 4) {        // f32 result (the logits GEMM): two 16-B stores per lane, a full 256-B run per 8 lanes
+                float* cf = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + nb;
+                store4(cf, v); store4(cf + 4, v + 4);
+                continue;
+            }
             bf16x8 o, op;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { o[j] = (bf16_t)v[j]; op[j] = (bf16_t)pre[j]; }
@@ -393,8 +398,16 @@ static int pick_mt(const GemmGroup& g, long& tiles_out) {
 
 // true when every problem of the group can run on the LDS-DMA kernel and the launch fills enough of the chip
 bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
-    if (g.a_f32 || out_f32) return false;
+    if (g.a_f32) return false;
     const int epi = g.p[0].epi;
+    if (out_f32) {      // f32 result: only the plain-bias epilogue on 64-row tiles (deep-ring kernel), e.g. the logits GEMM
+        if (epi != EPI_BIAS) return false;
+        for (int i = 0; i < g.count; ++i) {
+            const GemmProblem& p = g.p[i];
+            if (p.epi != epi || p.K % TK != 0 || p.K < TK || (p.ldc % 4) != 0 || (p.N % 8) != 0 || p.M > 512) return false;
+        }
+        return true;
+    }
     if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID_DROP || epi == EPI_DGELU || epi == EPI_ADD || epi == EPI_TANH || epi == EPI_DTANH ||
           epi == EPI_RELU || epi == EPI_RELU_DROP || epi == EPI_DRELU_DROP)) return false;
     static const bool basic_only = getenv("RGQA_NT256_EPI_BASIC") != nullptr;     // A/B: leave tanh / relu epilogues to the 128x128 kernel
@@ -529,6 +542,20 @@ static int tuned_mt(GemmGroup& g, int model_mt, hipStream_t s) {
     }
     cache[key] = mt;
     return mt;
+}
+
+int launch_gemm_nt256_f32out(GemmGroup& g, hipStream_t s) {
+    constexpr int LDS_D = 4 * (32 * 2 * TK * 2 + TN * TK * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<float, EPI_BIAS, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
+        attr_set = true;
+    }
+    gemm_group_finalize(g, 64, TN);
+    g.ablate = 0;
+    hipLaunchKernelGGL((gemm_nt256d_kernel<float, EPI_BIAS, 2, 4>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, g);
+    RGQA_LAUNCH_CHECK("gemm_nt256d_kernel<float>");
+    return RGQA_OK;
 }
 
 int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
