@@ -142,6 +142,7 @@ public:
     bool wdone_valid[2] = {false, false};
     T* gemb = nullptr;
     T *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
+    bool ln_merge = !(getenv("RGQA_LN_MERGE") && getenv("RGQA_LN_MERGE")[0] == '0');   // one LayerNorm launch over [language | vision] rows
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
     void* lang_final = nullptr;
     std::vector<TransDesc> tdesc_host;
@@ -510,6 +511,12 @@ public:
             for (int m = 0; m < 2; ++m) if (st.active[m])
                 add_fwd(g, st.sb[m].h, I, st.ffn[m]->down, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
             CK(run_fwd(g, s));
+            if (ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0) {
+                // language | vision rows are adjacent in every stage buffer: one launch, per-segment module parameters
+                CKP(PC_LN, k_ln_fwd2<T>((T*)st.sb[0].z, H, P + st.ffn[0]->ln.w, P + st.ffn[0]->ln.b, P + st.ffn[1]->ln.w, P + st.ffn[1]->ln.b, Rl,
+                                        (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
+                return RGQA_OK;
+            }
             for (int m = 0; m < 2; ++m) if (st.active[m])
                 CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.ffn[m]->ln.w, P + st.ffn[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
             return RGQA_OK;
@@ -560,6 +567,9 @@ public:
         }
         if (cross && st.active[1]) {
             CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
+        } else if (ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0) {
+            CKP(PC_LN, k_ln_fwd2<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, P + st.att[1]->ln.w, P + st.att[1]->ln.b, Rl,
+                                    (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
         } else {
             for (int m = 0; m < 2; ++m) if (st.active[m])
                 CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.att[m]->ln.w, P + st.att[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
@@ -746,7 +756,14 @@ public:
             const bool shared_all = cross && st.active[1];
             auto rowp = [&](T* base, int m, int width) { return base + (size_t)(m == 0 ? 0 : Rl) * width; };
             if (st.kind == ST_FFN) {
-                for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0;
+                if (both) {
+                    const FfnP &f0 = *st.ffn[0], &f1 = *st.ffn[1];
+                    CKP(PC_LN, k_ln_bwd2<T>(dy, H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
+                                            Rl, P + f0.ln.w, G + f0.ln.w, G + f0.ln.b, G + f0.down.b, drop_site(pd, st.site + 1),
+                                            Rv, P + f1.ln.w, G + f1.ln.w, G + f1.ln.b, G + f1.down.b, drop_site(pd, st.site + 5), s));
+                }
+                for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const FfnP& f = *st.ffn[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
                     CKP(PC_LN, k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
@@ -781,7 +798,14 @@ public:
                                G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, R, H, d, nodrop, 1.0f, s));
                 gg_init(g); add_dgrad(g, gzm, H, ap.o, 0, H, gctx, H, R, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
             } else {
-                for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0;
+                if (both) {
+                    const AttP &a0 = *st.att[0], &a1 = *st.att[1];
+                    CKP(PC_LN, k_ln_bwd2<T>(dy, H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
+                                            Rl, P + a0.ln.w, G + a0.ln.w, G + a0.ln.b, G + a0.o.b, drop_site(pd, st.site + 1),
+                                            Rv, P + a1.ln.w, G + a1.ln.w, G + a1.ln.b, G + a1.o.b, drop_site(pd, st.site + 5), s));
+                }
+                for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const AttP& ap = *st.att[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
                     CKP(PC_LN, k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),

@@ -6,15 +6,25 @@
 
 // ---- norm.hip
 #define FIN_MAXQ 10
-struct FinOut { float* p[FIN_MAXQ]; int stride[FIN_MAXQ]; };
+struct FinOut { float* p[FIN_MAXQ]; int stride[FIN_MAXQ]; int qsrc[FIN_MAXQ], b0[FIN_MAXQ], b1[FIN_MAXQ]; };   // qsrc / b0 / b1: filled by k_colsum_finalize, or by the caller of _ranges
 int k_colsum_finalize(const float* part, int nblk, int nq, int N, const FinOut& fo, int accumulate, hipStream_t s);
+int k_colsum_finalize_ranges(const float* part, int nq_part, int nout, int N, const FinOut& fo, int accumulate, hipStream_t s);
 template <typename T>
 int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s);
+// rows [0, split) use (gamma, beta), rows [split, M) use (gamma2, beta2): two modules' LayerNorms over adjacent row ranges in one launch
+template <typename T>
+int k_ln_fwd2(const T* x, int ldx, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, T* y, int ldy, float* mean, float* rstd,
+              int M, int N, float eps, hipStream_t s);
 int ln_bwd_blocks(int M, int N);
 // part: workspace of ln_bwd_blocks(M,N)*3*N floats (or null: no column sums). dzd may be null.
 template <typename T>
 int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, const float* mean, const float* rstd, T* dz, T* dzd, int lddz,
              float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s);
+// two adjacent row segments of the same buffers (language | vision), each with its own module parameters, gradients and dropout site
+template <typename T>
+int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, const float* rstd, T* dz, T* dzd, int lddz, float* part, int N, int accumulate,
+              int M0, const float* gamma0, float* dgamma0, float* dbeta0, float* dbias0, DropCfg drop0,
+              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s);
 // out[n] (+)= sum_m x[m][n]; part: workspace of 256*N floats
 template <typename T>
 int k_colsum(const T* x, int ldx, float* part, float* out, int accumulate, int M, int N, hipStream_t s);

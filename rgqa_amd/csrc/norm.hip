@@ -6,12 +6,14 @@
 #define LN_MAXV 8  // up to 8 vec4 chunks per lane -> N <= 2048 (NV = chunks per lane, compile-time)
 
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, T* __restrict__ y, int ldy,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int N, float eps) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const float* gamma,
+                                                     const float* beta, T* __restrict__ y, int ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int N, float eps,
+                                                     int split, const float* __restrict__ gamma2, const float* __restrict__ beta2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
+    if (row >= split) { gamma = gamma2; beta = beta2; }        // second module's parameters (language | vision rows of one launch)
     const int nv = N >> 2;
     float v[NV][4];
     float s = 0.f;
@@ -56,11 +58,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 // Also emits (optionally) dzd = dropout-masked dz (the gradient entering the preceding dense layer,
 // whose forward epilogue applied that mask) and per-block partial column sums:
 //   part[blk][0][n] = sum dy*xhat (dgamma), part[blk][1][n] = sum dy (dbeta), part[blk][2][n] = sum dzd (dense bias grad)
+// One or two row segments per launch (adjacent modules: language | vision): blocks [0, nblk0) work on segment 0, the rest on
+// segment 1; partial column sums are indexed by the global block id, so each segment's partials are a contiguous block range.
+template <typename T>
+struct LnBwdSeg {
+    const T* dy; const T* z; const float* gamma; const float* mean; const float* rstd; T* dz; T* dzd;
+    int M; DropCfg drop, drop_in;
+};
 template <typename T, int NV, int LN_BWD_THREADS>
-__global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
-                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, T* __restrict__ dz, T* __restrict__ dzd,
-                                                     int lddz, float* __restrict__ part, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale) {
+__global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const LnBwdSeg<T> sg0, const LnBwdSeg<T> sg1, int nblk0, int lddy, int ldz, int lddz,
+                                                     float* __restrict__ part, int N, float dy_scale) {
+    const bool second = (int)blockIdx.x >= nblk0;            // block-uniform
+    const LnBwdSeg<T>& sg = second ? sg1 : sg0;
+    const T* __restrict__ dy = sg.dy; const T* __restrict__ z = sg.z;
+    const float* __restrict__ gamma = sg.gamma; const float* __restrict__ mean = sg.mean; const float* __restrict__ rstd = sg.rstd;
+    T* __restrict__ dz = sg.dz; T* __restrict__ dzd = sg.dzd;
+    const int M = sg.M;
+    const DropCfg drop = sg.drop, drop_in = sg.drop_in;
+    const int lblk = second ? (int)blockIdx.x - nblk0 : (int)blockIdx.x, lgrid = second ? (int)gridDim.x - nblk0 : nblk0;
     // N <= 768: 16 waves per block (4 per SIMD: the loop is one dependent HBM round trip per row, so it lives on
     // occupancy; fits the 128-VGPR budget); wider rows: 4 waves per block.  One row per wave per trip, next row's loads
     // issued before the current row's reductions.
@@ -75,8 +90,8 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const T* __restr
 #pragma unroll
         for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ad[i][j] = 0.f; }
     }
-    const int stride = gridDim.x * NW;
-    int row = blockIdx.x * NW + wave;
+    const int stride = lgrid * NW;
+    int row = lblk * NW + wave;
     raw4<T> rd[NV], rz[NV];
     float mu = 0.f, rs = 0.f;
     if (row < M) {
@@ -180,18 +195,19 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const T* __restr
 // out[q][n*stride] (+)= sum_blk part[blk][q][n] for q < nq (null output pointers are skipped).
 // Block = 16 columns (4 lanes x float4) x 64 partial groups: every thread sums nblk/64 float4 partials (fixed order ->
 // bit-reproducible), then the 64 group sums are folded in a fixed order through LDS.  N % 4 == 0.
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int nq, int N, FinOut fo, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nq, int N, FinOut fo, int accumulate) {
     __shared__ float red[64][17];
     const int cq = threadIdx.x & 3, grp = threadIdx.x >> 2;
     const int n4 = blockIdx.x * 16 + cq * 4;
     const int q = blockIdx.y;
     float* o = fo.p[q];
     if (o == nullptr) return;
+    const int qs = fo.qsrc[q], b0 = fo.b0[q], b1 = fo.b1[q];     // quantity index inside a block's partials; block range to fold
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (n4 < N)
-        for (int b = grp; b < nblk; b += 64) {
+        for (int b = b0 + grp; b < b1; b += 64) {
             float v[4];
-            load4(part + ((size_t)b * nq + q) * N + n4, v);
+            load4(part + ((size_t)b * nq + qs) * N + n4, v);
             s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         }
 #pragma unroll
@@ -207,9 +223,19 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     }
 }
 
-int k_colsum_finalize(const float* part, int nblk, int nq, int N, const FinOut& fo, int accumulate, hipStream_t s) {
+// nq quantities per block in `part`; output q folds quantity q of blocks [0, nblk)
+int k_colsum_finalize(const float* part, int nblk, int nq, int N, const FinOut& fo_in, int accumulate, hipStream_t s) {
     RGQA_REQUIRE(N % 4 == 0, "colsum_finalize: N=%d must be a multiple of 4", N);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(N, 16), nq), dim3(256), 0, s, part, nblk, nq, N, fo, accumulate);
+    FinOut fo = fo_in;
+    for (int q = 0; q < nq; ++q) { fo.qsrc[q] = q; fo.b0[q] = 0; fo.b1[q] = nblk; }
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(N, 16), nq), dim3(256), 0, s, part, nq, N, fo, accumulate);
+    RGQA_LAUNCH_CHECK("colsum_finalize_kernel");
+    return RGQA_OK;
+}
+// general form: nout outputs, each with its own source quantity (fo.qsrc) and block range (fo.b0 .. fo.b1)
+int k_colsum_finalize_ranges(const float* part, int nq_part, int nout, int N, const FinOut& fo, int accumulate, hipStream_t s) {
+    RGQA_REQUIRE(N % 4 == 0 && nout <= FIN_MAXQ, "colsum_finalize: N=%d / %d outputs", N, nout);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(N, 16), nout), dim3(256), 0, s, part, nq_part, N, fo, accumulate);
     RGQA_LAUNCH_CHECK("colsum_finalize_kernel");
     return RGQA_OK;
 }
@@ -231,10 +257,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 }
 
 template <typename T>
-int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s) {
+int k_ln_fwd2(const T* x, int ldx, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, T* y, int ldy, float* mean, float* rstd,
+              int M, int N, float eps, hipStream_t s) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: N=%d must be a multiple of 4 and <= %d", N, LN_MAXV * 256);
     if (M <= 0) return RGQA_OK;
-#define LN_FWD(NVV) hipLaunchKernelGGL((ln_fwd_kernel<T, NVV>), dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps)
+#define LN_FWD(NVV) hipLaunchKernelGGL((ln_fwd_kernel<T, NVV>), dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, split, gamma2, beta2)
     const int nvl = cdiv(N / 4, 64);
     if (nvl <= 1) LN_FWD(1); else if (nvl == 2) LN_FWD(2); else if (nvl == 3) LN_FWD(3); else if (nvl == 4) LN_FWD(4);
     else if (nvl <= 6) LN_FWD(6); else LN_FWD(8);
@@ -242,9 +269,24 @@ int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, i
     RGQA_LAUNCH_CHECK("ln_fwd_kernel");
     return RGQA_OK;
 }
+template <typename T>
+int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s) {
+    return k_ln_fwd2<T>(x, ldx, gamma, beta, gamma, beta, M, y, ldy, mean, rstd, M, N, eps, s);
+}
 
 static int ln_bwd_waves(int N) { return cdiv(N / 4, 64) <= 3 ? 16 : 4; }
 int ln_bwd_blocks(int M, int N) { const int nw = ln_bwd_waves(N); const int b = cdiv(M, nw), cap = nw == 16 ? 256 : 512; return b > cap ? cap : b; }
+
+template <typename T>
+static int ln_bwd_launch(const LnBwdSeg<T>& a, const LnBwdSeg<T>& b, int nblk0, int nblk, int lddy, int ldz, int lddz, float* part, int N, float dy_scale, hipStream_t s) {
+#define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, (NVV <= 3 ? 1024 : 256)>), dim3(nblk), dim3(NVV <= 3 ? 1024 : 256), 0, s, a, b, nblk0, lddy, ldz, lddz, part, N, dy_scale)
+    const int nvl = cdiv(N / 4, 64);
+    if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4);
+    else if (nvl <= 6) LN_BWD(6); else LN_BWD(8);
+#undef LN_BWD
+    RGQA_LAUNCH_CHECK("ln_bwd_kernel");
+    return RGQA_OK;
+}
 
 template <typename T>
 int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, const float* mean, const float* rstd, T* dz, T* dzd, int lddz,
@@ -252,12 +294,9 @@ int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, con
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256, "layernorm bwd: N=%d unsupported", N);
     if (M <= 0) return RGQA_OK;
     const int nblk = ln_bwd_blocks(M, N);
-#define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, (NVV <= 3 ? 1024 : 256)>), dim3(nblk), dim3(NVV <= 3 ? 1024 : 256), 0, s, dy, lddy, z, ldz, gamma, mean, rstd, dz, dzd, lddz, part, M, N, drop, drop_in, dy_scale)
-    const int nvl = cdiv(N / 4, 64);
-    if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4);
-    else if (nvl <= 6) LN_BWD(6); else LN_BWD(8);
-#undef LN_BWD
-    RGQA_LAUNCH_CHECK("ln_bwd_kernel");
+    LnBwdSeg<T> a; a.dy = dy; a.z = z; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.dz = dz; a.dzd = dzd; a.M = M; a.drop = drop; a.drop_in = drop_in;
+    int r = ln_bwd_launch<T>(a, a, nblk, nblk, lddy, ldz, lddz, part, N, dy_scale, s);
+    if (r) return r;
     if (part) {
         FinOut fo = {};
         fo.p[0] = dgamma; fo.p[1] = dbeta; fo.p[2] = dbias;
@@ -265,6 +304,28 @@ int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, con
         return k_colsum_finalize(part, nblk, 3, N, fo, accumulate, s);
     }
     return RGQA_OK;
+}
+
+// two adjacent row segments (rows [0,M0) and [M0, M0+M1) of the same buffers, different modules) in one launch + one finalize
+template <typename T>
+int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, const float* rstd, T* dz, T* dzd, int lddz, float* part, int N, int accumulate,
+              int M0, const float* gamma0, float* dgamma0, float* dbeta0, float* dbias0, DropCfg drop0,
+              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s) {
+    RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256 && part != nullptr && M0 > 0 && M1 > 0, "layernorm bwd2: bad arguments (N=%d)", N);
+    const DropCfg nodrop = make_drop(0.f, 0, 0);
+    int nb0 = ln_bwd_blocks(M0, N), nb1 = ln_bwd_blocks(M1, N);
+    if (nb0 > 256) nb0 = 256;                       // the partial-sum scratch holds 512 blocks
+    if (nb1 > 256) nb1 = 256;
+    LnBwdSeg<T> a, b;
+    a.dy = dy; a.z = z; a.gamma = gamma0; a.mean = mean; a.rstd = rstd; a.dz = dz; a.dzd = drop0.thresh ? dzd : nullptr; a.M = M0; a.drop = drop0; a.drop_in = nodrop;
+    b.dy = dy + (size_t)M0 * lddy; b.z = z + (size_t)M0 * ldz; b.gamma = gamma1; b.mean = mean + M0; b.rstd = rstd + M0;
+    b.dz = dz + (size_t)M0 * lddz; b.dzd = drop1.thresh ? dzd + (size_t)M0 * lddz : nullptr; b.M = M1; b.drop = drop1; b.drop_in = nodrop;
+    int r = ln_bwd_launch<T>(a, b, nb0, nb0 + nb1, lddy, ldz, lddz, part, N, 1.0f, s);
+    if (r) return r;
+    FinOut fo = {};
+    float* outs[6] = {dgamma0, dbeta0, dbias0, dgamma1, dbeta1, dbias1};
+    for (int q = 0; q < 6; ++q) { fo.p[q] = outs[q]; fo.stride[q] = 1; fo.qsrc[q] = q % 3; fo.b0[q] = q < 3 ? 0 : nb0; fo.b1[q] = q < 3 ? nb0 : nb0 + nb1; }
+    return k_colsum_finalize_ranges(part, 3, 6, N, fo, accumulate, s);
 }
 
 template <typename T>
@@ -279,8 +340,12 @@ int k_colsum(const T* x, int ldx, float* part, float* out, int accumulate, int M
     return k_colsum_finalize(part, nblk, 1, N, fo, accumulate, s);
 }
 
+template int k_ln_fwd2<float>(const float*, int, const float*, const float*, const float*, const float*, int, float*, int, float*, float*, int, int, float, hipStream_t);
+template int k_ln_fwd2<bf16_t>(const bf16_t*, int, const float*, const float*, const float*, const float*, int, bf16_t*, int, float*, float*, int, int, float, hipStream_t);
 template int k_ln_fwd<float>(const float*, int, const float*, const float*, float*, int, float*, float*, int, int, float, hipStream_t);
 template int k_ln_fwd<bf16_t>(const bf16_t*, int, const float*, const float*, bf16_t*, int, float*, float*, int, int, float, hipStream_t);
+template int k_ln_bwd2<float>(const float*, int, const float*, int, const float*, const float*, float*, float*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t);
+template int k_ln_bwd2<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, bf16_t*, bf16_t*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t);
 template int k_ln_bwd<float>(const float*, int, const float*, int, const float*, const float*, const float*, float*, float*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t);
 template int k_ln_bwd<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, bf16_t*, bf16_t*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t);
 template int k_colsum<float>(const float*, int, float*, float*, int, int, int, hipStream_t);

@@ -207,6 +207,34 @@ def test_side_stream_wgrad_matches_serial():
         assert torch.equal(grads(0), ref)
 
 
+def test_merged_layernorm_matches_per_modality(monkeypatch):
+    """Stages where both modalities run their own module share one LayerNorm launch (forward and backward) over the
+    adjacent [language | vision] rows; RGQA_LN_MERGE=0 keeps one launch per modality. Same arithmetic per row and the same
+    fixed-order fold of the per-block column sums, so logits and every gradient must be bit-identical (packed rows too)."""
+    B, T, O = 48, 20, 36
+    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=9, min_len=3)
+    lens = [int(v) for v in raw["input_mask"].sum(1)]
+    b = dev(raw)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RGQA_LN_MERGE", flag)
+        e = make_engine(FULL, "bf16", dropout=0.1)
+        e.ensure_shape(B, T, O)
+        e.sync_weights()
+        logits = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=31, lengths=lens)[0].clone()
+        e.loss_backward(b["target"])
+        torch.cuda.synchronize()
+        out[flag] = (logits, e.grads.clone())
+        specs = e.specs
+        del e
+    assert float(out["1"][1].abs().max()) > 0
+    assert torch.equal(out["0"][0], out["1"][0])
+    # the embedding tables accumulate with float atomics (order varies run to run): everything downstream must be exact
+    specs = [sp for sp in specs if "_embeddings.weight" not in sp.name]
+    bad = [sp.name for sp in specs if not torch.equal(out["0"][1][sp.offset:sp.offset + sp.numel], out["1"][1][sp.offset:sp.offset + sp.numel])]
+    assert not bad, bad
+
+
 def test_config2_forward_b256_f32_logits_vs_cpu():
     """BASELINE config 2: forward-only inference at B=256 (full 9/5/5 architecture, f32 operands); samples are independent,
     so the CPU oracle is evaluated on a spread of 6 of the 256 rows and must agree within 1e-3 (observed ~1e-5)."""
