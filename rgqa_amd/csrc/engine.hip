@@ -877,8 +877,12 @@ public:
         }
         prof_block = PB_LR;
         CK(run_wgrad(wg, s));
-        CK(wait_wgrad(0, s));        // everything on the side stream joins the caller's stream before backward returns
-        CK(wait_wgrad(1, s));
+        // `par` is now the OLDER gradient-buffer set (its weight-gradient launch precedes the first layer's on the side stream):
+        // join it here - its qkv buffer becomes the split-K scratch below - and let the first layer's weight gradients, still
+        // running on the side stream, overlap the embedding backward; they are joined at the end.
+        static const bool late_join = !(getenv("RGQA_WGRAD_LATE_JOIN") && getenv("RGQA_WGRAD_LATE_JOIN")[0] == '0');
+        CK(wait_wgrad(par, s));
+        if (!late_join) CK(wait_wgrad(par ^ 1, s));
         prof_block = PB_EMBED;
         T* gz = gemb;
         // ---- embeddings: dropout -> LN backward -> scatter-add into the three tables
@@ -897,14 +901,14 @@ public:
                                      accumulate, Rv, H, cfg.pos_dim, drop_site(pd, 2), dboxes_out, s));
             // dW_visn_fc [H, feat_dim] contracts over all B*O rows but has only (H/256)*(feat_dim/256) = 24 output tiles, and nothing
             // is left to run beside it: split the contraction S ways into f32 partials (one grouped launch, S*24 tiles) and fold
-            // them in a fixed order.  The scratch is a gradient buffer that is dead by now (every wgrad launch has been joined).
+            // them in a fixed order.  The scratch is the qkv-gradient buffer of the older buffer set (joined above).
             const size_t wsz = (size_t)H * cfg.feat_dim;
             int S = Rv / 1024; if (S > 8) S = 8;
             const size_t scratch_bytes = (size_t)(Rl > 0 ? B * Tn + Rv : Rv) * 3 * H * sizeof(T);
             while (S > 1 && (size_t)S * wsz * sizeof(float) > scratch_bytes) --S;
             static const bool no_split = getenv("RGQA_VISN_WGRAD_NOSPLIT") != nullptr;
             if (LP && S >= 2 && !no_split && (wsz % 4) == 0) {
-                float* part_w = reinterpret_cast<float*>(gqkv_s[0][0]);
+                float* part_w = reinterpret_cast<float*>(gqkv_s[par][0]);
                 const int kc = (Rv / S) / 64 * 64;
                 gg_init(g);
                 for (int i = 0; i < S; ++i) {
@@ -931,6 +935,7 @@ public:
                 CK(r);
             }
         }
+        CK(wait_wgrad(par ^ 1, s));      // everything on the side stream has joined the caller's stream before backward returns
         CK(mark_segment(s));     // embeddings + visual embedding
         return RGQA_OK;
     }
