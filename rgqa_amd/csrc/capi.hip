@@ -18,6 +18,7 @@ extern int g_rgqa_force_mt;
 extern int g_rgqa_wgrad_serial;
 extern int g_rgqa_ablate;
 extern int g_rgqa_tn_mtw;
+extern int g_rgqa_tn_plan;
 extern int g_rgqa_no_deep;
 // debug / A-B knobs: key 0 = force the 128x128 GEMM kernel; key 1 = force the LDS-DMA kernel's MT (0 = auto)
 int rgqa_debug_set(int key, int value) {
@@ -26,6 +27,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 2) { g_rgqa_wgrad_serial = value; return RGQA_OK; }
     if (key == 3) { g_rgqa_ablate = value; return RGQA_OK; }
     if (key == 4) { g_rgqa_tn_mtw = value; return RGQA_OK; }
+    if (key == 6) { g_rgqa_tn_plan = value; return RGQA_OK; }
     if (key == 5) { g_rgqa_no_deep = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;

@@ -143,6 +143,7 @@ public:
     T* gemb = nullptr;
     T *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
     bool ln_merge = !(getenv("RGQA_LN_MERGE") && getenv("RGQA_LN_MERGE")[0] == '0');   // one LayerNorm launch over [language | vision] rows
+    float* wpart = nullptr; size_t wpart_elems = 0;
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
     void* lang_final = nullptr;
     std::vector<TransDesc> tdesc_host;
@@ -348,6 +349,10 @@ public:
         gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
+        // split-contraction partials of one grouped weight-gradient launch (gemm_mfma256.hip plan_tn): up to 3 extra chunks of
+        // the largest layer's weights (cross + two self-attention blocks + two FFNs), f32
+        wpart_elems = LP ? (size_t)3 * ((size_t)12 * H * H + (size_t)4 * H * I + 65536) : 0;
+        wpart = LP ? take<float>(wpart_elems) : nullptr;
         tdesc = take<TransDesc>(n_tdesc + 1);
     }
     int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr;
@@ -480,6 +485,7 @@ public:
     int run_wgrad(GemmGroup& g, hipStream_t s, int b_f32 = 0) {
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = b_f32;
+        g.tn_scratch = wpart; g.tn_scratch_bytes = wpart_elems * sizeof(float);
         double f, b; gemm_work(g, f, b);
         prof_begin(PC_GEMM_TN, f, b, s);
         int r = LP ? launch_gemm_tn_bf16(g, 1, s) : launch_gemm_f32(g, 1, 1, s);

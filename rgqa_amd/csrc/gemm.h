@@ -42,6 +42,8 @@ struct GemmGroup {
     int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
     int ablate;         // perf ablation (rgqa_debug_set key 3; results are garbage): 1 = no operand DMA in the K loop, 2 = no LDS reads / MFMAs
     const void* zeros;  // TN LDS-DMA kernel: >= 16 zero bytes on the device (source of the contraction tail's A rows)
+    void* tn_scratch;   // TN LDS-DMA kernel, host side only: f32 scratch for split-contraction partials (null: no splitting)
+    size_t tn_scratch_bytes;
     DropCfg drop;
     GemmProblem p[GEMM_MAX_PROBLEMS];
 };

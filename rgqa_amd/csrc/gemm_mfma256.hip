@@ -9,6 +9,7 @@
 // of an LDS-DMA is lane-linear).  The next K-step's 64 KiB are in flight while the current one is consumed
 // (64 MFMAs per wave = ~2k cycles per K-step per SIMD), which is what hides the L2/HBM latency that starved
 // the 128x128 register-staged kernel.  Arithmetic intensity 128 FLOP/B of LDS fill vs 64 for the 128x128 tile.
+#include <string.h>
 #include "gemm.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -602,8 +603,20 @@ __device__ __forceinline__ bf16x8 tr_frag_dma(const unsigned char* tile, int r0,
 //   DMA byte.  The loop is bound by what the LDS-DMA path delivers per CU (~50 GB/s), not by the MFMAs, so the taller tile
 //   costs ~1.5x less CU time per FLOP; it halves the tile count, which only pays when something else fills the idle CUs (the
 //   launch runs on the side stream beside the next layer's chain).
+// ---- XCD-local placement + split contraction (TnPlan, built by plan_tn below).  A grouped weight-gradient launch has few output
+// tiles (36 for a [768,3072] weight) and long, UNEQUAL contractions (3.1 k packed language rows vs 9.2 k vision rows).  Spread
+// round-robin over the 8 XCDs, the tiles of one problem share their operand panels through 8 different L2s: rocprofv3 FETCH_SIZE
+// showed 2.9x the unique operand bytes coming from beyond L2 and the loop ran at the fabric's pace (2.4 us per K-step, 4.2 TB/s of
+// LDS-DMA chip-wide), with the language tiles finishing 3x earlier than the vision tiles beside them.  The plan cuts every
+// problem's contraction into chunks of similar length, keeps the tiles of one (problem, chunk) group on ONE XCD (workgroup b runs
+// on XCD b % 8), balances the XCDs by total K-steps and orders each XCD's list longest-first.  Chunk 0 writes the gradient itself,
+// chunks >= 1 write f32 partials that tn_fold_kernel adds in a fixed order (deterministic, unlike atomics).
+#define TN_MAX_GROUPS 48
+struct TnGroupDesc { int prob, chunk, xcd, start, tiles, tile0, kt0, nk; };      // plain ints: hipcc 7.2 mis-reads 16-bit kernarg fields under a dynamic index
+struct TnPlan { int use, ngroups; TnGroupDesc grp[TN_MAX_GROUPS]; };
+
 template <int ACCUM, int MTW>
-__global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGroup g) {
+__global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGroup g, const TnPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int WMV = 32 * MTW, NSLOT = MTW == 4 ? 3 : 2;
     constexpr int APW = MTW / 2;                       // A pieces (1 KiB) per wave per slot
@@ -612,22 +625,32 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    int tile = blockIdx.x, pi = 0;
+    int tile = blockIdx.x, pi = 0, chunk = 0, kt0 = 0, nk = -1, tix = -1;
+    if (plan.use) {
+        const int x = blockIdx.x & 7, pos = blockIdx.x >> 3;
+        int gi = -1;
+        for (int i = 0; i < plan.ngroups; ++i)
+            if (plan.grp[i].xcd == x && pos >= plan.grp[i].start && pos < plan.grp[i].start + plan.grp[i].tiles) gi = i;
+        if (gi < 0) return;                            // padding block of a shorter XCD list (block-uniform, before any barrier)
+        const TnGroupDesc& gd = plan.grp[gi];
+        pi = gd.prob; chunk = gd.chunk; kt0 = gd.kt0; nk = gd.nk; tix = gd.tile0 + pos - gd.start;
+    } else {
 #pragma unroll
-    for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
-        if (i < g.count && tile >= g.p[i].tile_start) pi = i;
+        for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+            if (i < g.count && tile >= g.p[i].tile_start) pi = i;
+    }
     const GemmProblem& P = g.p[pi];
-    // XCD-aware order inside a problem: blocks that share an XCD (equal id mod 8) get CONSECUTIVE tile numbers, and tile
-    // numbers run over the M-tiles of one N-tile first, so the ~T/8 blocks co-resident on an XCD stream the same B
-    // operand (the wider one) through that XCD's L2: the loop is fabric-bound (48 KiB per K-step per CU) without it.
+    // tile order inside a problem: consecutive ids run over the M-tiles of one N-tile first, so neighbours stream the same B
+    // operand (the wider one).  Without a plan, blocks that share an XCD (equal id mod 8) get consecutive ids.
     const int tiles_m = cdiv(P.M, WMV);
-    const int tix = xcd_remap256(tile - P.tile_start, tiles_m * P.tiles_n);
+    if (tix < 0) tix = xcd_remap256(tile - P.tile_start, tiles_m * P.tiles_n);
     const int local = (tix % tiles_m) * P.tiles_n + (tix / tiles_m);     // back to the m-major id used below
     const int m0 = (local / P.tiles_n) * WMV, n0 = (local % P.tiles_n) * WN;
     // contraction length need not be a multiple of the K-step (packed language rows): in the last, partial step the A rows
     // past K come from a zero line (they also feed the bias column sums) and the B rows past K re-read row K-1 (finite data
     // times zero), so no lane predicates its DMA.
-    const int nkt = cdiv(P.K, TK), ktail = P.K % TK;
+    const int nkt_all = cdiv(P.K, TK), ktail = P.K % TK;
+    const int nkt = nk < 0 ? nkt_all : nk;             // this block's K-steps: kt0 .. kt0 + nkt of the problem's nkt_all
     const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(P.B);
     const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g.zeros);
@@ -652,8 +675,8 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int stage, int kt) {
         const unsigned base = lds0 + stage * STAGE;
-        const size_t ao = (size_t)kt * TK * P.lda, bo = (size_t)kt * TK * P.ldb;
-        if (ktail != 0 && kt == nkt - 1) {       // block-uniform
+        const size_t ao = (size_t)(kt0 + kt) * TK * P.lda, bo = (size_t)(kt0 + kt) * TK * P.ldb;
+        if (ktail != 0 && kt0 + kt == nkt_all - 1) {       // block-uniform
 #pragma unroll
             for (int i = 0; i < APW; ++i) {
                 const int row = (wave * APW + i) * ARPP + lane / ALPR;
@@ -716,15 +739,24 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
             }
         }
     }
+    // chunk 0 -> the gradient (and bias gradient) itself; chunk c >= 1 -> dense f32 partial c-1: [M, N] then the M column sums
+    float* Cc = reinterpret_cast<float*>(P.C);
+    float* cs_out = P.colsum_out;
+    int ldc = P.ldc;
+    const bool accum = ACCUM && chunk == 0;
+    if (chunk > 0) {
+        Cc = reinterpret_cast<float*>(P.C2) + (size_t)(chunk - 1) * ((size_t)P.M * P.N + P.M);
+        cs_out = Cc + (size_t)P.M * P.N;
+        ldc = P.N;
+    }
     if (do_cs && (lane >> 4) == 0) {
 #pragma unroll
         for (int tm = 0; tm < MTW; ++tm) {
             const int m = m0 + wm * (16 * MTW) + tm * 16 + (lane & 15);
-            if (m < P.M) P.colsum_out[m] = ACCUM ? P.colsum_out[m] + cs[tm][0] : cs[tm][0];
+            if (m < P.M) cs_out[m] = accum ? cs_out[m] + cs[tm][0] : cs[tm][0];
         }
     }
     const int fr = lane & 15, fq = lane >> 4;
-    float* Cc = reinterpret_cast<float*>(P.C);
 #pragma unroll
     for (int tm = 0; tm < MTW; ++tm) {
         const int m = m0 + wm * (16 * MTW) + tm * 16 + fr;
@@ -732,13 +764,13 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
         for (int tn = 0; tn < 4; ++tn) {
             const int n = n0 + wn * 64 + tn * 16 + 4 * fq;
             if (m < P.M && n < P.N) {
-                float* c = Cc + (size_t)m * P.ldc + n;
+                float* c = Cc + (size_t)m * ldc + n;
                 float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
                 if (n + 3 < P.N) {
-                    if (ACCUM) { float o[4]; load4(c, o); v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+                    if (accum) { float o[4]; load4(c, o); v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
                     store4(c, v);
                 } else {
-                    for (int i = 0; i < P.N - n; ++i) c[i] = ACCUM ? c[i] + v[i] : v[i];
+                    for (int i = 0; i < P.N - n; ++i) c[i] = accum ? c[i] + v[i] : v[i];
                 }
             }
         }
@@ -760,8 +792,125 @@ bool gemm_tn_dma_eligible(const GemmGroup& g) {
 }
 
 int g_rgqa_tn_mtw = 0;     // rgqa_debug_set key 4: force the wgrad tile height (4 = 128 rows, 8 = 256 rows); 0 = default
+int g_rgqa_tn_plan = -1;   // rgqa_debug_set key 6: 0 = round-robin tiles, no split; 1 = XCD-local placement only; 2 = placement + split contraction; -1 = env RGQA_TN_PLAN / default (0)
+
+// dst (+ its bias gradient) += partial 0 + partial 1 + ... in that order; one entry per split problem
+#define TN_FOLD_MAX 12
+struct TnFoldEntry { float* dst; float* cs_dst; const float* src; int M, N, ldc, nparts, blk0; };
+struct TnFoldArgs { int n, total_blocks; TnFoldEntry e[TN_FOLD_MAX]; };
+#define TN_FOLD_PER_BLOCK 2048          // floats per block: 256 threads x 2 float4
+__global__ __launch_bounds__(256) void tn_fold_kernel(const TnFoldArgs a) {
+    int ei = 0;
+#pragma unroll
+    for (int i = 1; i < TN_FOLD_MAX; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.e[i].blk0) ei = i;
+    const TnFoldEntry& e = a.e[ei];
+    const size_t mn = (size_t)e.M * e.N, pstride = mn + e.M;
+    const size_t base = (size_t)((int)blockIdx.x - e.blk0) * TN_FOLD_PER_BLOCK;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const size_t i = base + (size_t)(r * 256 + threadIdx.x) * 4;
+        if (i < mn) {                                   // N % 4 == 0: a float4 never straddles rows
+            float* d = e.dst + (i / e.N) * e.ldc + (i % e.N);
+            float v[4]; load4(d, v);
+            for (int j = 0; j < e.nparts; ++j) { float t[4]; load4(e.src + j * pstride + i, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+            store4(d, v);
+        } else if (e.cs_dst != nullptr) {               // the M column sums behind the matrix, element-wise
+            for (int k = 0; k < 4; ++k) {
+                const size_t m = i - mn + k;
+                if (m < (size_t)e.M) { float v = e.cs_dst[m]; for (int j = 0; j < e.nparts; ++j) v += e.src[j * pstride + mn + m]; e.cs_dst[m] = v; }
+            }
+        }
+    }
+}
+
+// Builds the placement for one grouped launch (problems already sorted longest contraction first). Returns the grid size.
+static int plan_tn(GemmGroup& g, int wmv, int split, TnPlan& pl, TnFoldArgs& fa) {
+    memset(&pl, 0, sizeof pl); memset(&fa, 0, sizeof fa);
+    struct Grp { int prob, chunk, tile0, tiles, kt0, nk; long w; int xcd, start; };
+    Grp gr[TN_MAX_GROUPS]; int ng = 0;
+    int ks[GEMM_MAX_PROBLEMS], nch[GEMM_MAX_PROBLEMS], tiles[GEMM_MAX_PROBLEMS];
+    int kmin = 1 << 30;
+    for (int i = 0; i < g.count; ++i) {
+        ks[i] = cdiv(g.p[i].K, TK); tiles[i] = cdiv(g.p[i].M, wmv) * cdiv(g.p[i].N, WN);
+        if (ks[i] < kmin) kmin = ks[i];
+        if (tiles[i] > 60000 || ks[i] > 60000) return -1;
+    }
+    const int lref = kmin < 32 ? 32 : kmin;
+    // chunk counts: contraction / reference length, rounded, at most 4; partials must fit the scratch and stay 16-B aligned
+    size_t need = 0; int nfold = 0;
+    for (int i = 0; i < g.count; ++i) {
+        int c = split ? (ks[i] + lref / 2) / lref : 1;
+        if (c < 1) c = 1;
+        if (c > 4) c = 4;
+        if ((g.p[i].N % 4) != 0 || (g.p[i].M % 4) != 0 || g.p[i].C2 != nullptr) c = 1;
+        nch[i] = c;
+        if (c > 1) { need += (size_t)(c - 1) * ((size_t)g.p[i].M * g.p[i].N + g.p[i].M) * sizeof(float); ++nfold; }
+    }
+    if (need > g.tn_scratch_bytes || g.tn_scratch == nullptr || nfold > TN_FOLD_MAX)
+        for (int i = 0; i < g.count; ++i) nch[i] = 1;
+    int ngroups0 = 0;
+    for (int i = 0; i < g.count; ++i) ngroups0 += nch[i];
+    if (ngroups0 > TN_MAX_GROUPS) return -1;
+    float* sc = reinterpret_cast<float*>(g.tn_scratch);
+    long W = 0; int fold_blocks = 0;
+    for (int i = 0; i < g.count; ++i) {
+        for (int j = 0; j < nch[i]; ++j) {
+            Grp& q = gr[ng++];
+            q.prob = i; q.chunk = j; q.tile0 = 0; q.tiles = tiles[i];
+            q.kt0 = (int)((long)ks[i] * j / nch[i]); q.nk = (int)((long)ks[i] * (j + 1) / nch[i]) - q.kt0;
+            q.w = (long)q.tiles * q.nk; W += q.w;
+        }
+        if (nch[i] > 1) {
+            GemmProblem& p = g.p[i];
+            p.C2 = sc;
+            TnFoldEntry& e = fa.e[fa.n++];
+            e.dst = reinterpret_cast<float*>(p.C); e.cs_dst = p.colsum_out; e.src = sc; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.nparts = nch[i] - 1; e.blk0 = fold_blocks;
+            const size_t per = (size_t)p.M * p.N + p.M;
+            fold_blocks += (int)((per + TN_FOLD_PER_BLOCK - 1) / TN_FOLD_PER_BLOCK);
+            sc += (size_t)(nch[i] - 1) * per;
+        }
+    }
+    fa.total_blocks = fold_blocks;
+    // no group heavier than half an XCD's fair share (so the LPT assignment below can balance): halve the heaviest by tiles
+    const long cap = W / 16 > 0 ? W / 16 : 1;
+    while (ng < TN_MAX_GROUPS) {
+        int h = 0;
+        for (int i = 1; i < ng; ++i) if (gr[i].w > gr[h].w) h = i;
+        if (gr[h].w <= cap || gr[h].tiles < 2) break;
+        Grp& a = gr[h]; Grp& b = gr[ng++];
+        b = a;
+        a.tiles = a.tiles / 2; b.tile0 = a.tile0 + a.tiles; b.tiles -= a.tiles;
+        a.w = (long)a.tiles * a.nk; b.w = (long)b.tiles * b.nk;
+    }
+    // LPT: heaviest group first onto the lightest XCD
+    int order[TN_MAX_GROUPS];
+    for (int i = 0; i < ng; ++i) order[i] = i;
+    for (int i = 1; i < ng; ++i)
+        for (int j = i; j > 0 && gr[order[j]].w > gr[order[j - 1]].w; --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < ng; ++k) {
+        int x = 0;
+        for (int i = 1; i < 8; ++i) if (load[i] < load[x]) x = i;
+        gr[order[k]].xcd = x; load[x] += gr[order[k]].w;
+    }
+    // per XCD: longest chunks first (the XCD's 32 CUs take the list in order as they free up)
+    for (int i = 1; i < ng; ++i)
+        for (int j = i; j > 0 && gr[order[j]].nk > gr[order[j - 1]].nk; --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    int len[8] = {0, 0, 0, 0, 0, 0, 0, 0}, maxlen = 0;
+    for (int k = 0; k < ng; ++k) { Grp& q = gr[order[k]]; q.start = len[q.xcd]; len[q.xcd] += q.tiles; if (len[q.xcd] > maxlen) maxlen = len[q.xcd]; }
+    if (maxlen > 60000) return -1;
+    pl.use = 1; pl.ngroups = ng;
+    for (int i = 0; i < ng; ++i) {
+        TnGroupDesc& d = pl.grp[i];
+        d.prob = gr[i].prob; d.chunk = gr[i].chunk; d.xcd = gr[i].xcd;
+        d.start = gr[i].start; d.tiles = gr[i].tiles; d.tile0 = gr[i].tile0; d.kt0 = gr[i].kt0; d.nk = gr[i].nk;
+    }
+    return 8 * maxlen;
+}
+
 template <int ACCUM, int MTW>
-static int launch_tn(GemmGroup& g, hipStream_t s) {
+static int launch_tn(GemmGroup& g, int plan_mode, hipStream_t s) {
     constexpr int WMV = 32 * MTW, LDS_BYTES = (MTW == 4 ? 3 : 2) * (TK * WMV * 2 + TK * WN * 2);
     static bool attr_set = false;
     if (!attr_set) {
@@ -769,8 +918,15 @@ static int launch_tn(GemmGroup& g, hipStream_t s) {
         attr_set = true;
     }
     gemm_group_finalize(g, WMV, WN);
-    hipLaunchKernelGGL((gemm_tn_dma_kernel<ACCUM, MTW>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_BYTES, s, g);
+    TnPlan pl; TnFoldArgs fa;
+    int grid = plan_mode > 0 ? plan_tn(g, WMV, plan_mode > 1, pl, fa) : -1;
+    if (grid <= 0) { memset(&pl, 0, sizeof pl); fa.n = 0; grid = g.total_tiles; }
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<ACCUM, MTW>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g, pl);
     RGQA_LAUNCH_CHECK("gemm_tn_dma_kernel");
+    if (fa.n > 0) {
+        hipLaunchKernelGGL(tn_fold_kernel, dim3(fa.total_blocks), dim3(256), 0, s, fa);
+        RGQA_LAUNCH_CHECK("tn_fold_kernel");
+    }
     return RGQA_OK;
 }
 
@@ -793,7 +949,14 @@ int launch_gemm_tn_dma_bf16(GemmGroup& g, hipStream_t s) {
         static const long tall_min = []() { const char* e = getenv("RGQA_TN_TALL_MIN"); return e ? atol(e) : 128L; }();
         mtw = (tall && tiles8 >= tall_min) ? 8 : 4;
     }
+    // Measured (B=256, 1 x MI355X): with the launches serialised on one stream, placement + split contraction cut the weight-gradient
+    // time from 3.65 to 3.0 ms per step (step 14.33 -> 13.69 ms; placement alone 14.29: the loop is not L2-miss bound, one tile
+    // alone on an idle chip still needs 1.7 us per K-step against 0.86 us of MFMAs - the per-CU LDS-DMA rate, ~38 GB/s here).  On
+    // the side stream, where the main stream's kernels already fill the CUs the unbalanced launch leaves idle, the step did not
+    // move (13.04-13.12 without, 13.13-13.32 ms with).  Hence opt-in: RGQA_TN_PLAN=1 (placement) / 2 (placement + split).
+    static const int env_plan = []() { const char* e = getenv("RGQA_TN_PLAN"); return e ? atoi(e) : 0; }();
+    const int pm = g_rgqa_tn_plan >= 0 ? g_rgqa_tn_plan : env_plan;
     const bool acc = g.p[0].epi == EPI_ACCUM;
-    if (mtw == 8) return acc ? launch_tn<1, 8>(g, s) : launch_tn<0, 8>(g, s);
-    return acc ? launch_tn<1, 4>(g, s) : launch_tn<0, 4>(g, s);
+    if (mtw == 8) return acc ? launch_tn<1, 8>(g, pm, s) : launch_tn<0, 8>(g, pm, s);
+    return acc ? launch_tn<1, 4>(g, pm, s) : launch_tn<0, 4>(g, pm, s);
 }

@@ -235,6 +235,40 @@ def test_merged_layernorm_matches_per_modality(monkeypatch):
     assert not bad, bad
 
 
+def test_wgrad_split_contraction_plan():
+    """Opt-in wgrad plan (rgqa_debug_set key 6 = 2): XCD-local placement + the long (vision) contractions cut into chunks whose
+    f32 partials are folded in a fixed order. Against the default launch: same gradients up to f32 re-association, bit-identical
+    from run to run, and nothing left unwritten (the gradient arena is poisoned before each pass)."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    B, T, O = 96, 20, 36
+    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=12, min_len=3)
+    lens = [int(v) for v in raw["input_mask"].sum(1)]
+    b = dev(raw)
+    e = make_engine(FULL, "bf16", dropout=0.1)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    specs = [sp for sp in e.specs if "_embeddings.weight" not in sp.name and not sp.dead]
+
+    def grads(plan):
+        assert L.rgqa_debug_set(6, plan) == 0
+        try:
+            e.grads.fill_(1.0e6)
+            e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=5, lengths=lens)
+            e.loss_backward(b["target"])
+            torch.cuda.synchronize()
+            return e.grads.clone()
+        finally:
+            L.rgqa_debug_set(6, -1)
+
+    ref, got, again = grads(0), grads(2), grads(2)
+    for sp in specs:
+        r, g = ref[sp.offset:sp.offset + sp.numel], got[sp.offset:sp.offset + sp.numel]
+        assert float(g.abs().max()) < 1.0e5, sp.name                      # no poison left
+        assert float((g - r).norm()) <= 1e-5 * float(r.norm()) + 1e-12, sp.name
+        assert torch.equal(g, again[sp.offset:sp.offset + sp.numel]), sp.name
+
+
 def test_config2_forward_b256_f32_logits_vs_cpu():
     """BASELINE config 2: forward-only inference at B=256 (full 9/5/5 architecture, f32 operands); samples are independent,
     so the CPU oracle is evaluated on a spread of 6 of the 256 rows and must agree within 1e-3 (observed ~1e-5)."""

@@ -143,6 +143,32 @@ def test_matmul_tn_bf16_both_tile_heights(lib, mtw, M, N, K):
     assert float((got - ref).abs().max()) < 1e-2 * math.sqrt(K)
 
 
+@pytest.mark.parametrize("mtw", [4, 8])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 770), (2304, 768, 2304), (768, 3072, 835), (1000, 520, 4100)])
+def test_matmul_tn_xcd_placement_bit_equal(lib, mtw, M, N, K):
+    """Opt-in XCD-local tile placement of the wgrad kernel (rgqa_debug_set key 6 = 1): another block -> tile map, the same
+    arithmetic per tile, so the result must equal the round-robin launch bit for bit - every tile written exactly once."""
+    A = rnd(K, M, seed=14).bfloat16()
+    Bm = rnd(K, N, seed=15).bfloat16()
+    lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    Ap = torch.zeros(K, lda, dtype=torch.bfloat16, device="cuda"); Ap[:, :M] = A
+    Bp = torch.zeros(K, ldb, dtype=torch.bfloat16, device="cuda"); Bp[:, :N] = Bm
+    ldc = (N + 3) // 4 * 4
+    out = {}
+    try:
+        assert lib.rgqa_debug_set(4, mtw) == 0
+        for plan in (0, 1):
+            assert lib.rgqa_debug_set(6, plan) == 0
+            Cc = torch.full((M, ldc), 123.0, device="cuda")
+            ck(lib.rgqa_op_matmul_tn(P(Ap), P(Bp), P(Cc), M, N, K, lda, ldb, ldc, 1, S()))
+            torch.cuda.synchronize()
+            out[plan] = Cc[:, :N].clone()
+    finally:
+        lib.rgqa_debug_set(4, 0)
+        lib.rgqa_debug_set(6, -1)
+    assert torch.equal(out[0], out[1])
+
+
 @pytest.mark.parametrize("M,N,K", [(144, 208, 192), (1024, 1536, 192), (1024, 1536, 197), (1024, 1536, 33), (1024, 1536, 65)])
 def test_matmul_tn_exact_integers(lib, M, N, K):
     A = ((torch.arange(K * M).reshape(K, M) * 5 + 1) % 7 - 3).float().cuda().bfloat16()
