@@ -95,6 +95,14 @@ int rgqa_engine_backward(rgqa_engine* e, const float* dlogits, int ld, int accum
 int rgqa_engine_backward_pooled(rgqa_engine* e, const float* dpooled, int ld, int accumulate, void* stream);
 /* debug / parity: copy a saved activation ("embed_lang", "embed_visn", "l3", "r1", "x2_lang", "x2_visn", "pooled") as f32 */
 int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, size_t cap_elems, void* stream);
+/* Cross-attention probabilities of cross-modality layer `layer` after a forward pass (reference lxrt_vis/modeling.py:337,
+ * 347-348, 458-462: `output_attention=True`): direction 0 = l2v, language queries over vision keys, out [B, heads, T, O];
+ * direction 1 = v2l, vision queries over language keys, out [B, heads, O, T]. f32, softmax(QK^T/sqrt(d) + mask) before
+ * dropout (what eval mode returns). Padded language positions come out as 0 (a padded key's probability is exactly 0 in
+ * the reference as well; padded query rows are not computed when language rows are packed). The vision-query direction of
+ * the LAST layer feeds nothing in mode 'x' and the forward pass skips it; its queries / keys are projected on demand here. */
+int rgqa_engine_get_cross_attention(rgqa_engine* e, int layer, int direction, float* out, size_t cap_elems,
+                                    void* stream);
 /* Unpadded language rows for the FOLLOWING forward passes. lengths (HOST array, n = B of the bound shape) holds each
  * sample's real token count ([CLS] .. [SEP]; what sum(input_mask[b]) is for the prefix masks convert_sents_to_features
  * builds, lxrt/entry.py:37-79). The reference computes all max_seq_length positions and masks the padding with -10000
@@ -142,6 +150,18 @@ int rgqa_mixup_gather(float* feats, float* boxes, const int32_t* partner, const 
                       int F, int mode_v3, void* stream);
 /* target[B+j,:] = target[j,:] * prop[j]   (mixup_v1 / v3 soft targets, gqa_mixup_vis.py:170-171) */
 int rgqa_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, void* stream);
+
+/* ---- test-time scoring of the answer logits -------------------------------------------------
+ * One fused pass per row of logits [B, NA] (f32, row stride ld) for what the reference's RVQA test scripts compute:
+ *   max_score[B], label[B] = torch.sigmoid(logit / temperature).max(1)     tasks/gqa_conf.py:344, gqa_energy.py:184,204,
+ *                                                                            gqa_odin.py:130-131 (temperature), gqa_dropout.py:109
+ *   energy[B]              = torch.log(1 + torch.exp(logit)).sum(1)         tasks/gqa_energy.py:135,185
+ *   topk_val/topk_idx[B,k] = logit.topk(k)  (descending, ties by index)     tasks/gqa_energy.py:205, gqa_check_topk_preds.py:189
+ *   topk_energy[B]         = torch.log(1 + torch.exp(topk values)).sum(1)   tasks/gqa_energy.py:206
+ * Any output pointer may be null; k = 0 skips the top-k part. All pointers are device pointers. */
+int rgqa_score_rows(const float* logits, int ld, int B, int NA, float temperature, int k, float* max_score,
+                    int64_t* label, float* energy, float* topk_val, int64_t* topk_idx, float* topk_energy,
+                    void* stream);
 
 /* ---- stand-alone operators (unit parity tests; the engine calls the same kernels internally) ------------- */
 /* C[M,N] = A[M,K] W[N,K]^T + bias, epilogue 0 none / 1 gelu / 2 tanh; dtype 0 f32, 1 bf16 (A, W, C all dtype) */

@@ -377,12 +377,69 @@ def gen_butd():
     print("g7 loss=%.5f" % loss.item())
 
 
+def gen_scores():
+    """g9: the reference's test-time scoring expressions evaluated by torch on the CPU (tasks/gqa_conf.py:344,
+    gqa_odin.py:130-131, gqa_energy.py:185,205-206, gqa_check_topk_preds.py:189) on seeded logits with the edge
+    cases the kernel must reproduce: saturated sigmoid ties, a softplus overflow, duplicated top values."""
+    B, NA = 12, 1842
+    logit = synth.uniform("scores.logit", (B, NA), -12.0, 6.0)
+    logit[1, 700] = 40.0; logit[1, 30] = 55.0; logit[1, 1500] = 45.0        # sigmoid saturates to 1.0 for all three: first index wins
+    logit[2, 5] = 100.0                                                       # exp overflows: energy = +inf, as the reference's
+    logit[3, :] = -30.0; logit[3, 17] = -29.0
+    logit[4, 100] = logit[4, 900] = logit[4, 1841] = 25.0                     # equal top values
+    logit[5, :] = 0.0
+    t = torch.from_numpy(logit)
+    out = {"logit": logit}
+    for temp in (1.0, 1000.0):
+        score, label = torch.sigmoid(t / temp).max(1)
+        out["max_score_T%g" % temp] = score.numpy(); out["label_T%g" % temp] = label.numpy()
+    out["energy"] = torch.log(1 + torch.exp(t)).sum(1).numpy()
+    for k in (2, 5):
+        tk = t.topk(k=k)
+        out["topk%d_values" % k] = tk.values.numpy()
+        out["topk%d_indices" % k] = tk.indices.numpy()
+        out["topk%d_energy" % k] = torch.log(1 + torch.exp(tk.values)).sum(1).numpy()
+    np.savez_compressed(os.path.join(OUT, "g9_scores.npz"), **out)
+    print("g9_scores.npz written")
+
+
+def gen_xatt():
+    """g8: cross-attention probabilities from the reference's visualisation variant, lxrt_vis/modeling.py
+    (`output_attention=True`, :320-350, 458-462, 564-572), same synthetic weights (identical state_dict keys)."""
+    sys.path.insert(0, REF)
+    import lxrt_vis.modeling as MV
+    z = {}
+    for tag, cfgd, batches in (("small", SMALL, [("T5", small_batch(5)), ("T8", small_batch(8))]), ("full", FULL, [("T20", full_batch(20))])):
+        MV.VISUAL_CONFIG.l_layers, MV.VISUAL_CONFIG.x_layers, MV.VISUAL_CONFIG.r_layers = cfgd["l_layers"], cfgd["x_layers"], cfgd["r_layers"]
+        MV.VISUAL_CONFIG.set_visual_dims(cfgd["feat_dim"], cfgd["pos_dim"])
+        bc = MV.BertConfig(cfgd["vocab_size"], hidden_size=cfgd["hidden"], num_attention_heads=cfgd["heads"],
+                           intermediate_size=cfgd["inter"], max_position_embeddings=cfgd["max_pos"], type_vocab_size=cfgd["type_vocab"])
+        enc = MV.LXRTFeatureExtraction(bc, mode="x")
+        sd = enc.state_dict()
+        filled = synth.fill_state_dict({"lxrt_encoder.model." + k: tuple(v.shape) for k, v in sd.items()})
+        enc.load_state_dict({k: torch.from_numpy(filled["lxrt_encoder.model." + k]) for k in sd})
+        enc.eval()
+        for name, b in batches:
+            t = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
+            with torch.no_grad():
+                pooled, (l2v, v2l) = enc(t["input_ids"], t["segment_ids"], t["input_mask"], visual_feats=(t["feats"], t["boxes"]),
+                                         visual_attention_mask=None, output_attention=True)
+            z["%s_%s.pooled" % (tag, name)] = pooled.numpy()
+            for i, (a, c) in enumerate(zip(l2v, v2l)):
+                if tag == "full" and i not in (0, cfgd["x_layers"] - 1):
+                    continue                              # first and last cross layer of the full model keep the fixture small
+                z["%s_%s.x%d_l2v" % (tag, name, i)] = a.numpy().astype(np.float32)
+                z["%s_%s.x%d_v2l" % (tag, name, i)] = c.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "g8_xatt.npz"), **z)
+    print("g8_xatt.npz written:", sorted(z)[:6], "...")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     M, OPT, TOK, ENT = import_reference()
-    which = sys.argv[1:] or ["small", "full", "adam", "tok", "mixup", "butd"]
+    which = sys.argv[1:] or ["small", "full", "adam", "tok", "mixup", "butd", "scores", "xatt"]
     if "small" in which:
         gen_small(M)
     if "adam" in which:
@@ -393,6 +450,10 @@ def main():
         gen_mixup()
     if "butd" in which:
         gen_butd()
+    if "scores" in which:
+        gen_scores()
+    if "xatt" in which:
+        gen_xatt()
     if "full" in which:
         gen_full(M)
 

@@ -148,9 +148,10 @@ def self_att(P, name, cfg, x, mask):
     return att_output(P, name + ".output", cfg, attention(P, name + ".self", cfg, x, x, mask), x)
 
 
-def cross_att(P, name, cfg, x, ctx, ctx_mask):
-    """BertCrossattLayer.forward (lxrt/modeling.py:370-373); sub-modules `.att`, `.output`."""
-    return att_output(P, name + ".output", cfg, attention(P, name + ".att", cfg, x, ctx, ctx_mask), x)
+def cross_att(P, name, cfg, x, ctx, ctx_mask, probs_out=None):
+    """BertCrossattLayer.forward (lxrt/modeling.py:370-373); sub-modules `.att`, `.output`. probs_out collects the
+    attention probabilities the way lxrt_vis/modeling.py:373-376 hands them back with output_attention=True."""
+    return att_output(P, name + ".output", cfg, attention(P, name + ".att", cfg, x, ctx, ctx_mask, probs_out), x)
 
 
 def ffn(P, inter, output, cfg, x):
@@ -165,11 +166,14 @@ def bert_layer(P, name, cfg, x, mask):
     return ffn(P, name + ".intermediate", name + ".output", cfg, a)
 
 
-def x_layer(P, name, cfg, lang, lang_mask, visn, visn_mask):
+def x_layer(P, name, cfg, lang, lang_mask, visn, visn_mask, att_out=None):
     """LXRTXLayer.forward (lxrt/modeling.py:477-488): cross (shared weights, both from the OLD
     lang/visn, 455-459) -> per-modality self attention (461-465) -> per-modality FFN (467-475)."""
-    l1 = cross_att(P, name + ".visual_attention", cfg, lang, visn, visn_mask)
-    v1 = cross_att(P, name + ".visual_attention", cfg, visn, lang, lang_mask)
+    pl, pv = ([], []) if att_out is not None else (None, None)
+    l1 = cross_att(P, name + ".visual_attention", cfg, lang, visn, visn_mask, pl)
+    v1 = cross_att(P, name + ".visual_attention", cfg, visn, lang, lang_mask, pv)
+    if att_out is not None:      # lxrt_vis/modeling.py:458-462: (l2v_att, v2l_att) of this layer
+        att_out.append((pl[0], pv[0]))
     l2 = self_att(P, name + ".lang_self_att", cfg, l1, lang_mask)
     v2 = self_att(P, name + ".visn_self_att", cfg, v1, visn_mask)
     l3 = ffn(P, name + ".lang_inter", name + ".lang_output", cfg, l2)
@@ -215,9 +219,11 @@ def encoder_forward(P, cfg, input_ids, token_type_ids, attention_mask, feats, bo
         if trace is not None:
             trace["r%d" % i] = visn
     for i in range(cfg.x_layers):
-        lang, visn = x_layer(P, pre + "encoder.x_layers.%d" % i, cfg, lang, ext, visn, None)
+        att = [] if trace is not None else None
+        lang, visn = x_layer(P, pre + "encoder.x_layers.%d" % i, cfg, lang, ext, visn, None, att)
         if trace is not None:
             trace["x%d_lang" % i], trace["x%d_visn" % i] = lang, visn
+            trace["x%d_l2v" % i], trace["x%d_v2l" % i] = att[0]       # [B, heads, T, O], [B, heads, O, T] (lxrt_vis/modeling.py:564-572)
     pooled = torch.tanh(linear(lang[:, 0], P, pre + "pooler.dense"))  # BertPooler (575-581)
     return lang, visn, pooled
 

@@ -39,6 +39,7 @@ SIGNATURES = {
     "rgqa_engine_backward": [_vp, _vp, _i, _i, _vp],
     "rgqa_engine_backward_pooled": [_vp, _vp, _i, _vp],
     "rgqa_engine_get_activation": [_vp, C.c_char_p, _vp, _sz, _vp],
+    "rgqa_engine_get_cross_attention": [_vp, _i, _i, _vp, _sz, _vp],
     "rgqa_engine_set_lengths": [_vp, _vp, _i],
     "rgqa_engine_set_input_grads": [_vp, _vp, _vp],
     "rgqa_engine_num_grad_segments": [_vp, C.POINTER(_i)],
@@ -58,6 +59,7 @@ SIGNATURES = {
     "rgqa_op_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "rgqa_op_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "rgqa_op_bce": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "rgqa_score_rows": [_vp, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rgqa_last_error_string": [],
 }
 _RESTYPES = {"rgqa_last_error_string": C.c_char_p, "rgqa_engine_destroy": None, "rgqa_tokenizer_destroy": None}

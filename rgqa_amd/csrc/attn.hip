@@ -165,6 +165,62 @@ int k_attn_bwd_ref(const AttnArgs& a, hipStream_t s) {
     return RGQA_OK;
 }
 
+// Attention probabilities of one attention call, written out for inspection (reference lxrt_vis/modeling.py:337,347-348:
+// `output_attention=True` returns softmax(QK^T/sqrt(d) + mask)): out[B, nh, a.Lq, a.Lk] f32, recomputed from the Q / K the
+// forward pass left in its qkv buffer.  Rows / columns outside a packed sample's window are written as 0 (a padded key's
+// probability is exp(-10000) = 0 in the reference too; padded QUERY rows are simply not computed in the packed layout).
+template <typename T>
+__global__ __launch_bounds__(64) void attn_probs_kernel(const AttnArgs a, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    ATTN_SAMPLE_ROWS(a, b)
+    const int dh = a.dh, dp = dh + 1, kp = Lk + 1;
+    float* Qs = sm;
+    float* Ks = Qs + Lq * dp;
+    float* Ps = Ks + Lk * dp;
+    const T* q = reinterpret_cast<const T*>(a.q) + q0 * a.ldq + h * dh;
+    const T* k = reinterpret_cast<const T*>(a.k) + k0 * a.ldk + h * dh;
+    const int tid = threadIdx.x;
+    for (int x = tid; x < Lq * dh; x += 64) Qs[(x / dh) * dp + x % dh] = to_f32(q[(size_t)(x / dh) * a.ldq + x % dh]);
+    for (int x = tid; x < Lk * dh; x += 64) Ks[(x / dh) * dp + x % dh] = to_f32(k[(size_t)(x / dh) * a.ldk + x % dh]);
+    __syncthreads();
+    for (int x = tid; x < Lq * Lk; x += 64) {
+        const int i = x / Lk, j = x % Lk;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s = fmaf(Qs[i * dp + d], Ks[j * dp + d], s);
+        s *= a.scale;
+        if (a.mask) s += a.mask[(size_t)b * a.Lk + j];
+        Ps[i * kp + j] = s;
+    }
+    __syncthreads();
+    float* o = out + ((size_t)b * a.nh + h) * a.Lq * a.Lk;
+    for (int i = tid; i < a.Lq; i += 64) {
+        if (i < Lq) {
+            float m = -INFINITY;
+            for (int j = 0; j < Lk; ++j) m = fmaxf(m, Ps[i * kp + j]);
+            float sum = 0.f;
+            for (int j = 0; j < Lk; ++j) { float e = expf(Ps[i * kp + j] - m); Ps[i * kp + j] = e; sum += e; }
+            const float inv = 1.f / sum;
+            for (int j = 0; j < a.Lk; ++j) o[(size_t)i * a.Lk + j] = j < Lk ? Ps[i * kp + j] * inv : 0.f;
+        } else {
+            for (int j = 0; j < a.Lk; ++j) o[(size_t)i * a.Lk + j] = 0.f;
+        }
+    }
+}
+
+template <typename T>
+int k_attn_probs(const AttnArgs& a, float* out, hipStream_t s) {
+    RGQA_REQUIRE(a.q != nullptr && a.k != nullptr && out != nullptr && a.B > 0 && a.nh > 0 && a.Lq > 0 && a.Lk > 0 && a.dh > 0, "attention probabilities: bad arguments");
+    size_t sh = ((size_t)a.Lq * (a.dh + 1) + (size_t)a.Lk * (a.dh + 1) + (size_t)a.Lq * (a.Lk + 1)) * sizeof(float);
+    RGQA_REQUIRE(sh <= 160 * 1024, "attention probabilities: %d x %d x %d does not fit LDS", a.Lq, a.Lk, a.dh);
+    if (sh > 48 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_probs_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(attn_probs_kernel<T>, dim3(a.B * a.nh), dim3(64), sh, s, a, out);
+    RGQA_LAUNCH_CHECK("attn_probs_kernel");
+    return RGQA_OK;
+}
+template int k_attn_probs<float>(const AttnArgs&, float*, hipStream_t);
+template int k_attn_probs<bf16_t>(const AttnArgs&, float*, hipStream_t);
+
 template int k_attn_fwd_ref<float>(const AttnArgs&, hipStream_t);
 template int k_attn_fwd_ref<bf16_t>(const AttnArgs&, hipStream_t);
 template int k_attn_bwd_ref<float>(const AttnArgs&, hipStream_t);

@@ -108,6 +108,11 @@ int rgqa_engine_backward_pooled(rgqa_engine* e, const float* dpooled, int ld, in
     NEED(e);
     return e->impl->backward_pooled(dpooled, ld, accumulate, S(stream));
 }
+int rgqa_engine_get_cross_attention(rgqa_engine* e, int layer, int direction, float* out, size_t cap, void* stream) {
+    NEED(e);
+    RGQA_REQUIRE(out != nullptr, "get_cross_attention: null argument");
+    return e->impl->get_cross_attention(layer, direction, out, cap, S(stream));
+}
 int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, size_t cap, void* stream) {
     NEED(e);
     RGQA_REQUIRE(name && out, "get_activation: null argument");
@@ -218,6 +223,10 @@ int rgqa_op_attention_bwd(const void* qkv, const float* mask, const float* lse, 
     a.dq = dqkv; a.dk = (char*)dqkv + (size_t)H * esz; a.dv = (char*)dqkv + (size_t)2 * H * esz; a.lddq = a.lddk = a.lddv = 3 * H;
     if (dtype == 1) return impl == 1 ? k_attn_bwd_mfma(a, S(stream)) : k_attn_bwd_ref<bf16_t>(a, S(stream));
     return k_attn_bwd_ref<float>(a, S(stream));
+}
+int rgqa_score_rows(const float* logits, int ld, int B, int NA, float temperature, int k, float* max_score, int64_t* label, float* energy,
+                    float* topk_val, int64_t* topk_idx, float* topk_energy, void* stream) {
+    return k_score_rows(logits, ld, B, NA, temperature, k, max_score, label, energy, topk_val, topk_idx, topk_energy, S(stream));
 }
 int rgqa_op_bce(const float* logits, const float* target, float* loss, float* dlogits, int B, int NA, void* stream) {
     return k_bce_fwd_bwd(logits, NA, target, NA, loss, dlogits, NA, B, NA, NA, 1.0f, S(stream));

@@ -946,6 +946,39 @@ public:
         return RGQA_OK;
     }
 
+    // cross-attention probabilities of x-layer `layer` (reference lxrt_vis/modeling.py:458-462: l2v = language queries over
+    // vision keys, v2l = vision queries over language keys), recomputed from the qkv buffer the last forward left behind
+    int get_cross_attention(int layer, int direction, float* out, size_t cap, hipStream_t s) override {
+        RGQA_REQUIRE(have_fwd, "get_cross_attention: no forward pass recorded");
+        RGQA_REQUIRE(layer >= 0 && layer < cfg.x_layers && (direction == 0 || direction == 1), "get_cross_attention: layer %d / direction %d out of range", layer, direction);
+        const int H = cfg.hidden, nh = cfg.heads, dh = H / nh;
+        const int nlr = cfg.l_layers > cfg.r_layers ? cfg.l_layers : cfg.r_layers;
+        Stage& st = stages[2 * nlr + 3 * layer];
+        RGQA_REQUIRE(st.kind == ST_ATT_CROSS, "get_cross_attention: internal stage table mismatch");
+        const int m = direction, km = 1 - m;
+        RGQA_REQUIRE(cap >= (size_t)B * nh * seg_len(m) * seg_len(km), "get_cross_attention: buffer too small");
+        if (direction == 1 && !st.active[1]) {
+            // last cross layer, vision queries over language keys: the dead branch of mode 'x' (its output reaches nothing, so the
+            // forward pass skips it).  lxrt_vis still returns its probabilities: project the vision queries and the language keys
+            // now, into the columns of the stage's qkv buffer that the live directions leave unused.
+            const AttP& ap = *st.att[0];
+            GemmGroup g; gg_init(g);
+            add_fwd(g, st.sb[1].x_in, H, ap.qkv, 0, H, st.sb[1].qkv, 3 * H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
+            if (Rl > 0) add_fwd(g, st.sb[0].x_in, H, ap.qkv, H, H, (T*)st.sb[0].qkv + H, 3 * H, Rl, EPI_BIAS, nullptr, 0, nullptr, 0);
+            int r = run_fwd(g, s);
+            if (r) return r;
+        }
+        AttnArgs a; memset(&a, 0, sizeof a);
+        a.q = st.sb[m].qkv; a.ldq = 3 * H;
+        a.k = (T*)st.sb[km].qkv + H; a.ldk = 3 * H;
+        a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;
+        const int* cu = fwd_varlen ? cu_dev : nullptr;
+        a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;
+        a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
+        a.scale = 1.0f / sqrtf((float)dh);
+        return k_attn_probs<T>(a, out, s);
+    }
+
     int get_activation(const char* name, float* out, size_t cap, hipStream_t s) override {
         RGQA_REQUIRE(have_fwd, "get_activation: no forward pass recorded");
         const int H = cfg.hidden;

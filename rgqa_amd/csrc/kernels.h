@@ -54,6 +54,7 @@ struct AttnArgs {
     if ((a).cu_k) { const int c0_ = (a).cu_k[(b)]; k0 = (size_t)c0_; Lk = (a).cu_k[(b) + 1] - c0_; }
 template <typename T> int k_attn_fwd_ref(const AttnArgs& a, hipStream_t s);
 template <typename T> int k_attn_bwd_ref(const AttnArgs& a, hipStream_t s);
+template <typename T> int k_attn_probs(const AttnArgs& a, float* out /* [B, nh, Lq, Lk] */, hipStream_t s);
 int k_attn_fwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
 int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
 
@@ -104,6 +105,9 @@ int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 
 // ---- misc.hip
 // RoI-mixup gather (gqa_mixup_vis.py:134-181): rows [B,2B) of feats/boxes built from partner + positive rows
+// test-time scoring of logits rows (score.hip)
+int k_score_rows(const float* logits, int ld, int B, int NA, float temperature, int k, float* max_score, int64_t* label, float* energy,
+                 float* topk_val, int64_t* topk_idx, float* topk_energy, hipStream_t s);
 int k_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uint8_t* take_pos /*[B,O]*/, int B, int O, int F, int mode_v3, hipStream_t s);
 int k_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, hipStream_t s);
 template <typename T> int k_fill_rows(T* dst, int ld, const T* src, int lds, int rows, int cols, hipStream_t s);

@@ -177,6 +177,16 @@ class Engine:
         check(self.lib.rgqa_engine_get_activation(self.h, name.encode(), ptr(out), out.numel(), _stream()))
         return out
 
+    def cross_attention(self, layer, direction):
+        """Attention probabilities of cross-modality layer `layer` from the last forward pass (lxrt_vis `output_attention`):
+        direction 'l2v' -> [B, heads, T, O], 'v2l' -> [B, heads, O, T]; f32."""
+        d = {"l2v": 0, "v2l": 1}[direction]
+        B, T, O = self.shape
+        shp = (B, self.cfg.heads, T, O) if d == 0 else (B, self.cfg.heads, O, T)
+        out = torch.empty(shp, dtype=torch.float32, device=self.device)
+        check(self.lib.rgqa_engine_get_cross_attention(self.h, int(layer), d, ptr(out), out.numel(), _stream()))
+        return out
+
     PROFILE_CATS = ("gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "layernorm", "other")
 
     def profile(self, enable):

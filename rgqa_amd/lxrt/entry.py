@@ -47,12 +47,14 @@ def set_visual_config(args):
 
 
 class LXRTEncoder(nn.Module):
+    MODEL_CLASS = VisualBertForLXRFeature      # lxrt_vis substitutes its variant
+
     def __init__(self, args, max_seq_length, mode='x'):
         super().__init__()
         self.max_seq_length = max_seq_length
         set_visual_config(args)
         self.tokenizer = BertTokenizer.from_pretrained("bert-base-uncased", do_lower_case=True)
-        self.model = VisualBertForLXRFeature.from_pretrained("bert-base-uncased", mode=mode)
+        self.model = self.MODEL_CLASS.from_pretrained("bert-base-uncased", mode=mode)
         self.model.load_pending_bert()
         if getattr(args, "from_scratch", False):
             print("initializing all the weights")

@@ -269,6 +269,46 @@ def test_wgrad_split_contraction_plan():
         assert torch.equal(g, again[sp.offset:sp.offset + sp.numel]), sp.name
 
 
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("tag,T,prec,tol", [("small", 5, "f32", 2e-5), ("small", 8, "f32", 2e-5), ("full", 20, "f32", 1e-4), ("full", 20, "bf16", 3e-2)])
+def test_cross_attention_probabilities_vs_golden(golden_dir, tag, T, prec, tol, packed):
+    """rgqa_engine_get_cross_attention vs the reference's lxrt_vis `output_attention=True` vectors (g8): both directions
+    of every stored cross layer; packed language rows give the same probabilities on the real tokens, zeros elsewhere
+    (a padded KEY has probability exactly 0 in the reference too); the last layer's vision-query direction - dead in mode 'x',
+    skipped by the forward pass - is projected on demand."""
+    g = np.load(os.path.join(golden_dir, "g8_xatt.npz"))
+    cfgd = SMALL if tag == "small" else FULL
+    raw = small_batch(T) if tag == "small" else full_batch(T)
+    b = dev(raw)
+    B, O = raw["feats"].shape[0], raw["feats"].shape[1]
+    lens = [int(v) for v in raw["input_mask"].sum(1)]
+    e = make_engine(cfgd, prec)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], lengths=lens if packed else None)
+    pre = "%s_T%d." % (tag, T)
+    seen = 0
+    for k in [k for k in g.files if k.startswith(pre + "x")]:
+        layer, direction = int(k[len(pre) + 1]), k[-3:]
+        got = e.cross_attention(layer, direction).cpu().numpy()
+        ref = g[k]
+        assert got.shape == ref.shape
+        for i, n in enumerate(lens):
+            if direction == "l2v":       # queries = language tokens
+                np.testing.assert_allclose(got[i, :, :n], ref[i, :, :n], rtol=0, atol=tol, err_msg=k)
+                if packed:
+                    assert not got[i, :, n:].any()
+                else:
+                    np.testing.assert_allclose(got[i, :, n:], ref[i, :, n:], rtol=0, atol=tol, err_msg=k)
+            else:                        # keys = language tokens: padded columns are 0 on both sides
+                np.testing.assert_allclose(got[i], ref[i], rtol=0, atol=tol, err_msg=k)
+                assert not got[i, :, :, n:].any()
+        seen += 1
+    assert seen >= 4
+    with pytest.raises(RuntimeError):
+        e.cross_attention(cfgd["x_layers"], "l2v")
+
+
 def test_config2_forward_b256_f32_logits_vs_cpu():
     """BASELINE config 2: forward-only inference at B=256 (full 9/5/5 architecture, f32 operands); samples are independent,
     so the CPU oracle is evaluated on a spread of 6 of the 256 rows and must agree within 1e-3 (observed ~1e-5)."""

@@ -186,3 +186,28 @@ def test_g7_butd(golden_dir):
         np.testing.assert_allclose(np.sqrt((gr.astype(np.float64) ** 2).sum()), g["gnorm." + k], rtol=2e-4, atol=1e-9, err_msg=k)
         np.testing.assert_allclose(gr.reshape(-1)[sample_idx(k, gr.size)], g["gsamp." + k], rtol=2e-3, atol=1e-7 + 1e-4 * np.abs(gr).max(), err_msg=k)
     assert float(P["w_emb.emb.weight"].grad[-1].abs().max()) == 0.0     # padding row gets no gradient
+
+
+@pytest.mark.parametrize("tag,T", [("small", 5), ("small", 8), ("full", 20)])
+def test_g8_cross_attention_probabilities(golden_dir, tag, T):
+    """Oracle cross-attention probabilities vs the reference's lxrt_vis variant (`output_attention=True`); the same
+    fixture's pooled output must equal the plain lxrt goldens, i.e. lxrt_vis computes what lxrt computes."""
+    g = np.load(os.path.join(golden_dir, "g8_xatt.npz"))
+    cfgd = SMALL if tag == "small" else FULL
+    cfg = R.RefConfig(**cfgd)
+    P = load_params(cfg)
+    b = to_t(small_batch(T) if tag == "small" else full_batch(T))
+    trace = {}
+    with torch.no_grad():
+        _, pooled = R.gqa_forward(P, cfg, b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], trace)
+    pre = "%s_T%d." % (tag, T)
+    np.testing.assert_allclose(pooled.numpy(), g[pre + "pooled"], rtol=0, atol=5e-6)
+    ref_file = "g1_small_T%d.npz" % T if tag == "small" else "g2_full_T%d.npz" % T
+    np.testing.assert_allclose(g[pre + "pooled"], np.load(os.path.join(golden_dir, ref_file))["pooled"], rtol=0, atol=5e-6)
+    keys = [k for k in g.files if k.startswith(pre + "x")]
+    assert len(keys) == (2 * cfgd["x_layers"] if tag == "small" else 4)
+    for k in keys:
+        got = trace[k[len(pre):]].numpy()
+        assert got.shape == g[k].shape
+        np.testing.assert_allclose(got, g[k], rtol=0, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-5)
