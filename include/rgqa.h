@@ -151,6 +151,17 @@ int rgqa_mixup_gather(float* feats, float* boxes, const int32_t* partner, const 
 /* target[B+j,:] = target[j,:] * prop[j]   (mixup_v1 / v3 soft targets, gqa_mixup_vis.py:170-171) */
 int rgqa_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, void* stream);
 
+/* ---- input path: a staged batch from the binary feature store -> engine inputs, on the device ----------
+ * Replaces, per batch, what GQATorchDataset.__getitem__ does per sample on the host (tasks/gqa_data.py:173-238):
+ *   feats_in [B,O,F] f16 (feats_f16 = 1) or f32 -> feats_out [B,O,F] f32                (the store keeps utils.py:16-54's features)
+ *   boxes_in [B,O,4] pixels, img_hw [B,2] int32 (img_h, img_w) -> boxes_out: x / img_w, y / img_h   (gqa_data.py:197-200)
+ *   labels in CSR form (offsets [B+1], labels = ans2label[ans] or -1, scores) -> target [B,NA] f32, zeros elsewhere
+ *                                                                                        (gqa_data.py:213-217; also :224-228, :235-239)
+ * Any of the three parts is skipped when its input pointer (feats_in / boxes_in / target) is null. Device pointers. */
+int rgqa_batch_prepare(const void* feats_in, int feats_f16, float* feats_out, const float* boxes_in, const int32_t* img_hw,
+                       float* boxes_out, const int32_t* offsets, const int32_t* labels, const float* scores, float* target,
+                       int ld_target, int B, int O, int F, int NA, void* stream);
+
 /* ---- test-time scoring of the answer logits -------------------------------------------------
  * One fused pass per row of logits [B, NA] (f32, row stride ld) for what the reference's RVQA test scripts compute:
  *   max_score[B], label[B] = torch.sigmoid(logit / temperature).max(1)     tasks/gqa_conf.py:344, gqa_energy.py:184,204,

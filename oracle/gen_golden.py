@@ -434,12 +434,43 @@ def gen_xatt():
     print("g8_xatt.npz written:", sorted(z)[:6], "...")
 
 
+def gen_loader():
+    """g10: a synthetic detection TSV (oracle/loader_ref.write_synthetic_tsv) decoded by the reference's own
+    utils.load_obj_tsv (utils.py:16-54); box normalisation / target exactly as tasks/gqa_data.py:197-200, 213-217 write them."""
+    import tempfile
+    sys.path.insert(0, REF)
+    import utils as RU
+    from oracle import loader_ref as LR
+    NA = 23
+    with tempfile.TemporaryDirectory() as d:
+        path = LR.write_synthetic_tsv(os.path.join(d, "syn_obj36.tsv"), n_images=5, O=36, F=64, seed=3)
+        imgs = RU.load_obj_tsv(path)
+    z = {"img_ids": np.array([im["img_id"] for im in imgs]), "img_hw": np.array([[im["img_h"], im["img_w"]] for im in imgs], dtype=np.int32),
+         "boxes_raw": np.stack([im["boxes"] for im in imgs]), "features": np.stack([im["features"] for im in imgs])}
+    data, ans2label = LR.synthetic_questions([im["img_id"] for im in imgs], NA)
+    by_id = {im["img_id"]: im for im in imgs}
+    nb, tg = [], []
+    for dt in data:
+        im = by_id[dt["img_id"]]
+        boxes = im["boxes"].copy()
+        boxes[:, (0, 2)] /= im["img_w"]
+        boxes[:, (1, 3)] /= im["img_h"]
+        target = torch.zeros(NA)
+        for ans, score in dt["label"].items():
+            if ans in ans2label:
+                target[ans2label[ans]] = score
+        nb.append(boxes); tg.append(target.numpy())
+    z["boxes_norm"] = np.stack(nb); z["target"] = np.stack(tg)
+    np.savez_compressed(os.path.join(OUT, "g10_loader.npz"), **z)
+    print("g10_loader.npz written")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     M, OPT, TOK, ENT = import_reference()
-    which = sys.argv[1:] or ["small", "full", "adam", "tok", "mixup", "butd", "scores", "xatt"]
+    which = sys.argv[1:] or ["small", "full", "adam", "tok", "mixup", "butd", "scores", "xatt", "loader"]
     if "small" in which:
         gen_small(M)
     if "adam" in which:
@@ -454,6 +485,8 @@ def main():
         gen_scores()
     if "xatt" in which:
         gen_xatt()
+    if "loader" in which:
+        gen_loader()
     if "full" in which:
         gen_full(M)
 

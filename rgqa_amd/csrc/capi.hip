@@ -224,6 +224,11 @@ int rgqa_op_attention_bwd(const void* qkv, const float* mask, const float* lse, 
     if (dtype == 1) return impl == 1 ? k_attn_bwd_mfma(a, S(stream)) : k_attn_bwd_ref<bf16_t>(a, S(stream));
     return k_attn_bwd_ref<float>(a, S(stream));
 }
+int rgqa_batch_prepare(const void* feats_in, int feats_f16, float* feats_out, const float* boxes_in, const int32_t* img_hw, float* boxes_out,
+                       const int32_t* offsets, const int32_t* labels, const float* scores, float* target, int ld_target,
+                       int B, int O, int F, int NA, void* stream) {
+    return k_batch_prepare(feats_in, feats_f16, feats_out, boxes_in, img_hw, boxes_out, offsets, labels, scores, target, ld_target, B, O, F, NA, S(stream));
+}
 int rgqa_score_rows(const float* logits, int ld, int B, int NA, float temperature, int k, float* max_score, int64_t* label, float* energy,
                     float* topk_val, int64_t* topk_idx, float* topk_energy, void* stream) {
     return k_score_rows(logits, ld, B, NA, temperature, k, max_score, label, energy, topk_val, topk_idx, topk_energy, S(stream));

@@ -105,6 +105,10 @@ int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 
 // ---- misc.hip
 // RoI-mixup gather (gqa_mixup_vis.py:134-181): rows [B,2B) of feats/boxes built from partner + positive rows
+// device-side batch preparation from the binary feature store (loader.hip)
+int k_batch_prepare(const void* feats_in, int feats_f16, float* feats_out, const float* boxes_in, const int32_t* img_hw, float* boxes_out,
+                    const int32_t* offsets, const int32_t* labels, const float* scores, float* target, int ld_target,
+                    int B, int O, int F, int NA, hipStream_t s);
 // test-time scoring of logits rows (score.hip)
 int k_score_rows(const float* logits, int ld, int B, int NA, float temperature, int k, float* max_score, int64_t* label, float* energy,
                  float* topk_val, int64_t* topk_idx, float* topk_energy, hipStream_t s);
