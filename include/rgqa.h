@@ -162,6 +162,11 @@ int rgqa_batch_prepare(const void* feats_in, int feats_f16, float* feats_out, co
                        float* boxes_out, const int32_t* offsets, const int32_t* labels, const float* scores, float* target,
                        int ld_target, int B, int O, int F, int NA, void* stream);
 
+/* Host helper of the same path: dst[i] = src[rows[i]] for n rows of row_bytes each, copied by `threads` host threads (the
+ * batch gather out of the mmap'ed store into pinned memory; replaces the per-sample `.copy()` of gqa_data.py:189-190). */
+int rgqa_host_gather_rows(const void* src, size_t row_bytes, size_t n_src_rows, const int64_t* rows, int n, void* dst,
+                          int threads);
+
 /* ---- test-time scoring of the answer logits -------------------------------------------------
  * One fused pass per row of logits [B, NA] (f32, row stride ld) for what the reference's RVQA test scripts compute:
  *   max_score[B], label[B] = torch.sigmoid(logit / temperature).max(1)     tasks/gqa_conf.py:344, gqa_energy.py:184,204,

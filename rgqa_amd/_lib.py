@@ -60,6 +60,7 @@ SIGNATURES = {
     "rgqa_op_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "rgqa_op_bce": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "rgqa_batch_prepare": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "rgqa_host_gather_rows": [_vp, _sz, _sz, _vp, _i, _vp, _i],
     "rgqa_score_rows": [_vp, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rgqa_last_error_string": [],
 }

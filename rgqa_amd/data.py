@@ -66,7 +66,8 @@ def tsv_to_store(tsv_paths, prefix, dtype="f16", topk=None):
 
 
 class FeatureStore(object):
-    def __init__(self, prefix):
+    def __init__(self, prefix, threads=None):
+        self.threads = int(threads or os.environ.get("RGQA_LOADER_THREADS", 8))     # host threads of the batch gather
         with open(prefix + ".meta.json") as f:
             self.meta = json.load(f)
         self.O, self.F, self.dtype = self.meta["O"], self.meta["F"], self.meta["dtype"]
@@ -85,8 +86,12 @@ class FeatureStore(object):
 
     def gather(self, rows, feats_out, boxes_out, hw_out):
         """rows: store rows of a batch; the *_out arrays are (pinned) host buffers of shape [B,O,F], [B,O,4], [B,2]."""
-        rows = np.asarray(rows, dtype=np.int64)
-        np.take(self.feats, rows, axis=0, out=feats_out)
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        if not (feats_out.flags.c_contiguous and feats_out.dtype == self.np_dtype and feats_out.shape == (len(rows), self.O, self.F)):
+            raise ValueError("gather: feats_out must be a C-contiguous [%d,%d,%d] %s array" % (len(rows), self.O, self.F, self.dtype))
+        lib = _lib.load()
+        _lib.check(lib.rgqa_host_gather_rows(C.c_void_p(self.feats.ctypes.data), self.O * self.F * self.feats.itemsize, self.N,
+                                             C.c_void_p(rows.ctypes.data), len(rows), C.c_void_p(feats_out.ctypes.data), self.threads))
         np.take(self.boxes, rows, axis=0, out=boxes_out)
         np.take(self.img_hw, rows, axis=0, out=hw_out)
 
