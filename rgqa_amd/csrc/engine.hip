@@ -321,6 +321,11 @@ public:
             x0 = take<T>((size_t)RC * H);
             x0_src[0] = cur[0]; x0_src[1] = cur[1];
             cur[0] = x0; cur[1] = rows(x0, Rl, H);
+            // the last stage of each chain writes its output straight into x0 (no row copy); a chain without layers still copies
+            // its embedding output
+            for (int m = 0; m < 2; ++m)
+                for (int si = (int)stages.size() - 1; si >= 0; --si)
+                    if (stages[si].active[m]) { stages[si].sb[m].y = cur[m]; x0_src[m] = nullptr; break; }
         }
         for (int i = 0; i < cfg.x_layers; ++i) {
             const bool last = (i == cfg.x_layers - 1);
@@ -517,8 +522,8 @@ public:
             for (int m = 0; m < 2; ++m) if (st.active[m])
                 add_fwd(g, st.sb[m].h, I, st.ffn[m]->down, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
             CK(run_fwd(g, s));
-            if (ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0) {
-                // language | vision rows are adjacent in every stage buffer: one launch, per-segment module parameters
+            if (ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && (T*)st.sb[1].y == (T*)st.sb[0].y + (size_t)Rl * H) {
+                // language | vision rows are adjacent in the stage buffers: one launch, per-segment module parameters
                 CKP(PC_LN, k_ln_fwd2<T>((T*)st.sb[0].z, H, P + st.ffn[0]->ln.w, P + st.ffn[0]->ln.b, P + st.ffn[1]->ln.w, P + st.ffn[1]->ln.b, Rl,
                                         (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
                 return RGQA_OK;
@@ -573,7 +578,7 @@ public:
         }
         if (cross && st.active[1]) {
             CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
-        } else if (ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0) {
+        } else if (ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && (T*)st.sb[1].y == (T*)st.sb[0].y + (size_t)Rl * H) {
             CKP(PC_LN, k_ln_fwd2<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, P + st.att[1]->ln.w, P + st.att[1]->ln.b, Rl,
                                     (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
         } else {
@@ -627,8 +632,8 @@ public:
             Stage& st = stages[si];
             prof_block = si < n_lr_stages ? PB_LR : PB_X;
             if (st.kind == ST_ATT_CROSS && x0_needed && !gathered) {
-                CK(rgqa_check_hip(hipMemcpyAsync(x0, x0_src[0], (size_t)Rl * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather lang"));
-                CK(rgqa_check_hip(hipMemcpyAsync(x0 + (size_t)Rl * H, x0_src[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather visn"));
+                if (x0_src[0] && Rl > 0) CK(rgqa_check_hip(hipMemcpyAsync(x0, x0_src[0], (size_t)Rl * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather lang"));
+                if (x0_src[1]) CK(rgqa_check_hip(hipMemcpyAsync(x0 + (size_t)Rl * H, x0_src[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather visn"));
                 gathered = true;
             }
             if (two && si < n_lr_stages) {
@@ -743,10 +748,25 @@ public:
         const int* cu = fwd_varlen ? cu_dev : nullptr;
         gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, cls_rows, H, B, accumulate); CK(run_wgrad(g, s));
         // gradient w.r.t. the final hidden states: zero except the [CLS] rows of lang
-        T* dy = gA; T* dx = gB;
-        CK(rgqa_check_hip(hipMemsetAsync(dy, 0, (size_t)R * H * sizeof(T), s), "zero dy"));
+        // Gradient w.r.t. the current stage's output, one pointer per modality: a stage moves only the modalities it computes to
+        // the other buffer, so a modality that merely passes through (vision under the language-only layers) stays where it is
+        // instead of being copied.  Stages that treat [language | vision] as one row range need the two adjacent; single-modality
+        // stages come in pairs (attention + FFN), so adjacency is back whenever it is needed - adjacent() re-establishes it otherwise.
+        T* dyp[2] = {gA, gA + (size_t)Rl * H};
+        T* dxp[2] = {gB, gB + (size_t)Rl * H};
+        auto adjacent = [&]() -> int {
+            if (dyp[1] != dyp[0] + (size_t)Rl * H) {
+                T* want = dyp[0] + (size_t)Rl * H;
+                int r = rgqa_check_hip(hipMemcpyAsync(want, dyp[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad rows adjacent");
+                if (r) return r;
+                dxp[1] = dyp[1]; dyp[1] = want;
+            }
+            if (dxp[1] != dxp[0] + (size_t)Rl * H) dxp[1] = dxp[0] + (size_t)Rl * H;      // the free halves always pair up again
+            return RGQA_OK;
+        };
+        CK(rgqa_check_hip(hipMemsetAsync(dyp[0], 0, (size_t)R * H * sizeof(T), s), "zero dy"));
         gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, gp2, H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
-        CKP(PC_OTHER, k_scatter_rows<T>(gp2, H, dy, H, cu, Tn, B, H, s));
+        CKP(PC_OTHER, k_scatter_rows<T>(gp2, H, dyp[0], H, cu, Tn, B, H, s));
         seg_cursor = 0;
         CK(mark_segment(s));     // head + pooler gradients are final
 
@@ -762,17 +782,17 @@ public:
             const bool shared_all = cross && st.active[1];
             auto rowp = [&](T* base, int m, int width) { return base + (size_t)(m == 0 ? 0 : Rl) * width; };
             if (st.kind == ST_FFN) {
-                const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0;
+                const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && dyp[1] == dyp[0] + (size_t)Rl * H;
                 if (both) {
                     const FfnP &f0 = *st.ffn[0], &f1 = *st.ffn[1];
-                    CKP(PC_LN, k_ln_bwd2<T>(dy, H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
+                    CKP(PC_LN, k_ln_bwd2<T>(dyp[0], H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
                                             Rl, P + f0.ln.w, G + f0.ln.w, G + f0.ln.b, G + f0.down.b, drop_site(pd, st.site + 1),
                                             Rv, P + f1.ln.w, G + f1.ln.w, G + f1.ln.b, G + f1.down.b, drop_site(pd, st.site + 5), s));
                 }
                 for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const FfnP& f = *st.ffn[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
-                    CKP(PC_LN, k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                    CKP(PC_LN, k_ln_bwd<T>(dyp[m], H, (T*)st.sb[m].z, H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
                                    d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s));
                 }
                 T* gzm = drop_base(pd).thresh ? gzd : gz;
@@ -786,12 +806,10 @@ public:
                 }
                 gg_init(g);
                 for (int m = 0; m < 2; ++m) if (st.active[m])
-                    add_dgrad(g, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, rowp(dx, m, H), H, seg_rows(m), EPI_ADD, rowp(gz, m, H), H);
+                    add_dgrad(g, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, dxp[m], H, seg_rows(m), EPI_ADD, rowp(gz, m, H), H);
                 CK(run_dgrad(g, s));
-                // inactive modality: its gradient passes through untouched
-                for (int m = 0; m < 2; ++m) if (!st.active[m] && !st.last_dead)
-                    CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
-                T* t = dy; dy = dx; dx = t;
+                // an inactive modality's gradient passes through untouched: its pointers simply do not move
+                for (int m = 0; m < 2; ++m) if (st.active[m]) { T* t = dyp[m]; dyp[m] = dxp[m]; dxp[m] = t; }
                 if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
                 continue;
             }
@@ -800,21 +818,22 @@ public:
             if (shared_all) {
                 const AttP& ap = *st.att[0];
                 DropCfg d = drop_site(pd, st.site + 1);
-                CKP(PC_LN, k_ln_bwd<T>(dy, H, (T*)st.sb[0].z, H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
+                CK(adjacent());
+                CKP(PC_LN, k_ln_bwd<T>(dyp[0], H, (T*)st.sb[0].z, H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
                                G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, R, H, d, nodrop, 1.0f, s));
                 gg_init(g); add_dgrad(g, gzm, H, ap.o, 0, H, gctx, H, R, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
             } else {
-                const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0;
+                const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && dyp[1] == dyp[0] + (size_t)Rl * H;
                 if (both) {
                     const AttP &a0 = *st.att[0], &a1 = *st.att[1];
-                    CKP(PC_LN, k_ln_bwd2<T>(dy, H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
+                    CKP(PC_LN, k_ln_bwd2<T>(dyp[0], H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
                                             Rl, P + a0.ln.w, G + a0.ln.w, G + a0.ln.b, G + a0.o.b, drop_site(pd, st.site + 1),
                                             Rv, P + a1.ln.w, G + a1.ln.w, G + a1.ln.b, G + a1.o.b, drop_site(pd, st.site + 5), s));
                 }
                 for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const AttP& ap = *st.att[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
-                    CKP(PC_LN, k_ln_bwd<T>(rowp(dy, m, H), H, (T*)st.sb[m].z, H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                    CKP(PC_LN, k_ln_bwd<T>(dyp[m], H, (T*)st.sb[m].z, H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
                                    d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s));
                 }
                 gg_init(g);
@@ -865,20 +884,17 @@ public:
             // input gradient: dx = dqkv @ Wqkv + dz (residual path)
             gg_init(g);
             if (shared_all) {
-                add_dgrad(g, gqkv, 3 * H, st.att[0]->qkv, 0, 3 * H, dx, H, R, EPI_ADD, gz, H);
+                add_dgrad(g, gqkv, 3 * H, st.att[0]->qkv, 0, 3 * H, dxp[0], H, R, EPI_ADD, gz, H);
             } else if (cross) {
-                add_dgrad(g, gqkv, 3 * H, st.att[0]->qkv, 0, H, dx, H, Rl, EPI_ADD, gz, H);
-                add_dgrad(g, rowp(gqkv, 1, 3 * H) + H, 3 * H, st.att[0]->qkv, H, 2 * H, rowp(dx, 1, H), H, Rv, EPI_BIAS, nullptr, 0);
+                add_dgrad(g, gqkv, 3 * H, st.att[0]->qkv, 0, H, dxp[0], H, Rl, EPI_ADD, gz, H);
+                add_dgrad(g, rowp(gqkv, 1, 3 * H) + H, 3 * H, st.att[0]->qkv, H, 2 * H, dxp[1], H, Rv, EPI_BIAS, nullptr, 0);
             } else {
                 for (int m = 0; m < 2; ++m) if (st.active[m])
-                    add_dgrad(g, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, rowp(dx, m, H), H, seg_rows(m), EPI_ADD, rowp(gz, m, H), H);
+                    add_dgrad(g, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, dxp[m], H, seg_rows(m), EPI_ADD, rowp(gz, m, H), H);
             }
             CK(run_dgrad(g, s));
-            if (!cross) {
-                for (int m = 0; m < 2; ++m) if (!st.active[m] && !st.last_dead)
-                    CK(rgqa_check_hip(hipMemcpyAsync(rowp(dx, m, H), rowp(dy, m, H), (size_t)seg_rows(m) * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad passthrough"));
-            }
-            T* t = dy; dy = dx; dx = t;
+            // a cross stage writes both modalities' input gradients (the dead last layer too: vision keys / values are live)
+            for (int m = 0; m < 2; ++m) if (st.active[m] || cross) { T* t = dyp[m]; dyp[m] = dxp[m]; dxp[m] = t; }
             if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
         }
         prof_block = PB_LR;
@@ -894,13 +910,13 @@ public:
         // ---- embeddings: dropout -> LN backward -> scatter-add into the three tables
         {
             DropCfg din = drop_site(pd, 1);
-            CKP(PC_LN, k_ln_bwd<T>(dy, H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
+            CKP(PC_LN, k_ln_bwd<T>(dyp[0], H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
                            nodrop, din, 1.0f, s));
             CKP(PC_OTHER, k_embed_scatter<T>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, s));
         }
         // ---- visual embedding
         {
-            T* dyv = dy + (size_t)Rl * H;
+            T* dyv = dyp[1];
             T* dzf = gz + (size_t)Rl * H;
             CKP(PC_OTHER, k_visn_combine_bwd<T>(dyv, H, zf, H, in_boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.box_ln.w, visn_stats, dzf, H, part,
                                      G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.visn_fc.b, G + mp.box_fc.w, G + mp.box_fc.b,
