@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--padded", action="store_true", help="compute every padded token position (the reference's layout) instead of packing the real tokens")
     ap.add_argument("--butd", action="store_true", help="BASELINE config 5: BUTD backbone (butd/butd.py) train step, B per GPU, 40 tokens, dictionary 3000")
+    ap.add_argument("--uniter", action="store_true", help="UNITER backbone (uniter/uniter.py GQAUNITER): 12 BertLayers over [20 text ; 36 region] sequences, bert-base-cased sizes")
     ap.add_argument("--mixup", action="store_true",
                     help="BASELINE config 4: RoI-mixup finetune (gqa_mixup_vis.py:134-181): every loader batch is doubled on the device "
                          "(mixup_v1, Beta(1,5)); the model sees 2x rows per QA pair; value still counts loader QA pairs")
@@ -119,10 +120,18 @@ def main():
         for sp in e.specs:
             if sp.name.endswith("weight_g"):
                 e.view(e.params, sp).fill_(1.0)
+    elif args.uniter:
+        e = Engine(precision=args.precision, arch=2, vocab_size=28996, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=12, x_layers=0,
+                   r_layers=0, feat_dim=2048, pos_dim=7, num_answers=1842).allocate("cuda")
+        init_params(e, seed=0)
     else:
         e = Engine(precision=args.precision, **FULL).allocate("cuda")
         init_params(e, seed=0)       # identical replica on every rank
-    b = synth.synth_batch(B, T, seed=1234 + rank, vocab=3000 if args.butd else 30522)
+    b = synth.synth_batch(B, T, seed=1234 + rank, vocab=3000 if args.butd else (28996 if args.uniter else 30522))
+    if args.uniter:      # 7-d region position features (x1, y1, x2, y2, w, h, area; tasks/gqa_data.py:240-250)
+        bx = b["boxes"]
+        w_, h_ = bx[:, :, 2] - bx[:, :, 0], bx[:, :, 3] - bx[:, :, 1]
+        b["boxes"] = np.ascontiguousarray(np.stack([bx[:, :, 0], bx[:, :, 1], bx[:, :, 2], bx[:, :, 3], w_, h_, w_ * h_], 2).astype(np.float32))
     dev = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
     # real token count of every question (host side, as the tokenizer knows it): the engine packs the language rows
     lengths = None if (args.padded or args.butd) else np.ascontiguousarray(np.tile(b["lengths"], 2 if args.mixup else 1), dtype=np.int32)
@@ -198,7 +207,7 @@ def main():
         for _ in range(args.profile_steps):
             step()
         prof = e.profile_read()
-        blocks = e.profile_blocks() if hasattr(e, "profile_blocks") and not args.butd else None
+        blocks = e.profile_blocks() if hasattr(e, "profile_blocks") and not (args.butd or args.uniter) else None
         e.profile(False)
         nt = prof["gemm_nt"]
         if nt["launches"]:
@@ -207,7 +216,7 @@ def main():
             ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_nt.json")    # separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-            if os.path.exists(pmc) and B == 256 and T == 20 and not args.mixup:
+            if os.path.exists(pmc) and B == 256 and T == 20 and not (args.mixup or args.uniter or args.butd):
                 traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", algorithmic_bytes_per_launch=round(nt["bytes"] / nt["launches"]), kernel="gemm_nt (gemm_nt256_kernel / gemm_nt256d_kernel<EPI,MT> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
@@ -216,16 +225,18 @@ def main():
         dist.barrier()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.uniter:
         cpu = cpu_baseline(T, args.cpu_sample, 2)
 
     if rank == 0:
-        step_tflops = value * (1.5 if args.butd else FWD_BWD_GFLOP.get(T, FWD_BWD_GFLOP[20])) / 1e3 * (MB // B)     # BUTD ~0.5 GFLOP fwd / QA pair
+        # UNITER, padded: 12 layers x (56 x 7,077,888 + 2 x 56^2 x 768) MAC + 36 x 2048 x 768 + head = 4.880 GMAC fwd per QA pair; x2 FLOP, x3 fwd+bwd
+        per_pair = 1.5 if args.butd else (29.28 if args.uniter else FWD_BWD_GFLOP.get(T, FWD_BWD_GFLOP[20]))
+        step_tflops = value * per_pair / 1e3 * (MB // B)     # BUTD ~0.5 GFLOP fwd / QA pair
         out = {
-            "metric": "QA-pairs/sec (train step) BUTD-GQA B=256" if args.butd else "QA-pairs/sec (train step) LXMERT-GQA B=256", "value": round(value, 1), "unit": "QA-pairs/s",
+            "metric": "QA-pairs/sec (train step) BUTD-GQA B=256" if args.butd else ("QA-pairs/sec (train step) UNITER-GQA B=256" if args.uniter else "QA-pairs/sec (train step) LXMERT-GQA B=256"), "value": round(value, 1), "unit": "QA-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "BUTD-GQA finetune train step (GRU 40x1024 + region attention + classifier, fwd+BCE+bwd+clip+BertAdam)" if args.butd else ("LXMERT-GQA RoI-mixup finetune train step (device mixup + fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768" if args.mixup else
+            "config": {"workload": "BUTD-GQA finetune train step (GRU 40x1024 + region attention + classifier, fwd+BCE+bwd+clip+BertAdam)" if args.butd else "UNITER-GQA finetune train step (fwd+BCE+bwd+clip+BertAdam), 12 BertLayers over [text ; 36 regions], H=768" if args.uniter else ("LXMERT-GQA RoI-mixup finetune train step (device mixup + fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768" if args.mixup else
                                     "LXMERT-GQA RP finetune train step (fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768"), "model_rows_per_gpu": MB,
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "rois": O, "feat_dim": 2048,
                        "num_answers": 1842, "parallelism": "dp%d" % world, "dropout": 0.1,

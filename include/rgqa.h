@@ -32,7 +32,10 @@ typedef struct rgqa_config {
     float ln_eps;                                                 /* 1e-12 everywhere in the reference */
     float hidden_dropout, attn_dropout;                           /* 0.1 / 0.1, lxrt/modeling.py:182-183 */
     int32_t arch;     /* 0 = LXMERT-GQA (default); 1 = BUTD-GQA (butd/butd.py:108-221): hidden = 1024, vocab_size = ntoken+1,
-                         hidden_dropout = answer dropout 0.5, attn_dropout = attention dropout 0.2; layer counts / heads / inter unused */
+                         hidden_dropout = answer dropout 0.5, attn_dropout = attention dropout 0.2; layer counts / heads / inter unused;
+                         2 = UNITER-GQA (uniter/modeling.py:560-655, uniter/uniter.py:15-44): l_layers BertLayers over one sequence
+                         [text ; regions] per sample (x_layers = r_layers = 0), pos_dim = 7, state_dict keys `encoder.model.uniter.*`;
+                         `boxes` carries the 7-d position features, set_lengths takes the TEXT token counts */
     int32_t emb_dim;  /* BUTD word-embedding size (300) */
 } rgqa_config;
 

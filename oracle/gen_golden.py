@@ -465,12 +465,97 @@ def gen_loader():
     print("g10_loader.npz written")
 
 
+U_SMALL = dict(vocab_size=64, hidden=64, heads=4, inter=128, max_pos=32, type_vocab=2, l_layers=3, x_layers=0, r_layers=0,
+               feat_dim=32, pos_dim=7, num_answers=11)
+U_FULL = dict(vocab_size=28996, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=12, x_layers=0, r_layers=0,
+              feat_dim=2048, pos_dim=7, num_answers=1842)
+
+
+def uniter_batch(cfgd, T, B, O, seed):
+    """Deterministic UNITER batch: a synth LXMERT batch + 7-d position features (normalised box, w, h, area: entry of
+    GQATorchDataset._uniterBoxes, tasks/gqa_data.py:240-250)."""
+    b = synth.synth_batch(B, T, O=O, F=cfgd["feat_dim"], NA=cfgd["num_answers"], vocab=cfgd["vocab_size"], seed=seed, min_len=2)
+    if B >= 3:
+        b["input_ids"][1, 1:] = 0          # a 1-token question
+        b["input_ids"][1, 0] = 2 if cfgd["vocab_size"] < 1000 else 101
+        b["input_ids"][2, :] = np.maximum(b["input_ids"][2, :], 3)        # a full-length question (no padding)
+        b["input_mask"] = (b["input_ids"] != 0).astype(np.int64)
+    bx = b["boxes"]
+    w, h = bx[:, :, 2] - bx[:, :, 0], bx[:, :, 3] - bx[:, :, 1]
+    b["pos7"] = np.stack([bx[:, :, 0], bx[:, :, 1], bx[:, :, 2], bx[:, :, 3], w, h, w * h], 2).astype(np.float32)
+    return b
+
+
+def gen_uniter():
+    """g11: the reference's UNITER-GQA model (uniter/modeling.py UniterFeatureExtraction + the answer head of uniter/uniter.py:22-31)
+    on synthetic weights: logits, pooled, loss, the joint embedding output, every layer output, gradients."""
+    sys.path.insert(0, REF)
+    import uniter.modeling as UM
+    for tag, cfgd, cases in (("small", U_SMALL, [(5, 3, 6, 91), (8, 3, 6, 92)]), ("full", U_FULL, [(20, 4, 36, 93)])):
+        UM.VISUAL_CONFIG.set_visual_dims(cfgd["feat_dim"], 4)
+        bc = UM.BertConfig(cfgd["vocab_size"], hidden_size=cfgd["hidden"], num_hidden_layers=cfgd["l_layers"], num_attention_heads=cfgd["heads"],
+                           intermediate_size=cfgd["inter"], max_position_embeddings=cfgd["max_pos"], type_vocab_size=cfgd["type_vocab"])
+        H = cfgd["hidden"]
+
+        class Wrap(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.encoder = torch.nn.Module()
+                self.encoder.model = UM.UniterFeatureExtraction(bc)
+                self.logit_fc = torch.nn.Sequential(torch.nn.Linear(H, 2 * H), UM.GeLU(), UM.BertLayerNorm(2 * H, eps=1e-12), torch.nn.Linear(2 * H, cfgd["num_answers"]))
+
+            def forward(self, feat, pos7, ids, seg, mask):
+                B, O = feat.shape[0], feat.shape[1]
+                x = self.encoder.model(input_ids=ids, token_type_ids=seg, attention_mask=mask, visual_feats=feat,
+                                       visual_token_type_ids=torch.ones(B, O, dtype=torch.long), visual_attention_mask=torch.ones(B, O, dtype=torch.long),
+                                       img_pos_feat=pos7)
+                return self.logit_fc(x), x
+        m = Wrap()
+        sd = m.state_dict()
+        filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()})
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+        m.eval()
+        for (T, B, O, seed) in cases:
+            b = uniter_batch(cfgd, T, B, O, seed)
+            t = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
+            tr = {}
+            um = m.encoder.model.uniter
+            hooks = [um.encoder.layer[i].register_forward_hook((lambda i: lambda mod, inp, out: tr.__setitem__("l%d" % i, out.detach().numpy().copy()))(i)) for i in range(cfgd["l_layers"])]
+            hooks.append(um.encoder.register_forward_hook(lambda mod, inp, out: tr.__setitem__("embed", (inp[0] if inp else None))))
+            m.zero_grad()
+            logits, pooled = m(t["feats"], t["pos7"], t["input_ids"], t["segment_ids"], t["input_mask"])
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, t["target"]) * logits.size(1)
+            loss.backward()
+            for h_ in hooks:
+                h_.remove()
+            z = {"logits": logits.detach().numpy(), "pooled": pooled.detach().numpy(), "loss": np.float32(loss.item()), "input_ids": b["input_ids"]}
+            if tag == "small":
+                for k, v in tr.items():
+                    if k != "embed" and v is not None:
+                        z["act." + k] = v
+                for k, p in m.named_parameters():
+                    z["grad." + k] = p.grad.numpy().copy()
+            else:
+                z["act.l0"], z["act.l%d" % (cfgd["l_layers"] - 1)] = tr["l0"][:, ::7], tr["l%d" % (cfgd["l_layers"] - 1)][:, ::7]
+                names, counts, samples = [], [], []
+                tot = 0.0
+                for k, p in m.named_parameters():
+                    g = p.grad.numpy().reshape(-1)
+                    tot += float((g.astype(np.float64) ** 2).sum())
+                    idx = sample_idx(k, g.size)
+                    names.append(k); counts.append(len(idx)); samples.append(g[idx])
+                z["grad_names"], z["grad_counts"], z["grad_samples"] = np.array(names), np.array(counts), np.concatenate(samples)
+                z["grad_norm"] = np.float32(np.sqrt(tot))
+            np.savez_compressed(os.path.join(OUT, "g11_uniter_%s_T%d.npz" % (tag, T)), **z)
+            print("g11 %s T=%d loss=%.6f" % (tag, T, loss.item()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     M, OPT, TOK, ENT = import_reference()
-    which = sys.argv[1:] or ["small", "full", "adam", "tok", "mixup", "butd", "scores", "xatt", "loader"]
+    which = sys.argv[1:] or ["small", "full", "adam", "tok", "mixup", "butd", "scores", "xatt", "loader", "uniter"]
     if "small" in which:
         gen_small(M)
     if "adam" in which:
@@ -487,6 +572,8 @@ def main():
         gen_xatt()
     if "loader" in which:
         gen_loader()
+    if "uniter" in which:
+        gen_uniter()
     if "full" in which:
         gen_full(M)
 

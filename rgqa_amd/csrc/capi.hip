@@ -46,13 +46,16 @@ int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out) {
         *out = eb;
         return RGQA_OK;
     }
-    RGQA_REQUIRE(cfg->arch == 0, "engine_create: unknown arch %d", cfg->arch);
+    RGQA_REQUIRE(cfg->arch == 0 || cfg->arch == 2, "engine_create: unknown arch %d", cfg->arch);
+    if (cfg->arch == 2)      // UNITER: one stream of BertLayers over [text ; regions] (uniter/modeling.py:615-635)
+        RGQA_REQUIRE(cfg->x_layers == 0 && cfg->r_layers == 0 && cfg->l_layers >= 1 && cfg->type_vocab >= 2 && cfg->pos_dim <= 8,
+                     "engine_create (UNITER): layers go in l_layers (x_layers = r_layers = 0), type_vocab >= 2, pos_dim <= 8");
     RGQA_REQUIRE(cfg->hidden > 0 && cfg->heads > 0 && cfg->hidden % cfg->heads == 0,
                  "The hidden size (%d) is not a multiple of the number of attention heads (%d)", cfg->hidden, cfg->heads);  // modeling.py:298-301
     RGQA_REQUIRE(cfg->hidden % 64 == 0 && cfg->hidden <= 1024, "engine_create: hidden (%d) must be a multiple of 64 and <= 1024", cfg->hidden);
     RGQA_REQUIRE(cfg->hidden / cfg->heads <= 64, "engine_create: head size %d > 64 unsupported", cfg->hidden / cfg->heads);
     RGQA_REQUIRE(cfg->inter % 8 == 0 && cfg->feat_dim % 8 == 0, "engine_create: intermediate (%d) and feature (%d) sizes must be multiples of 8", cfg->inter, cfg->feat_dim);
-    RGQA_REQUIRE(cfg->pos_dim >= 1 && cfg->pos_dim <= 4, "engine_create: pos_dim %d unsupported", cfg->pos_dim);
+    RGQA_REQUIRE(cfg->pos_dim >= 1 && cfg->pos_dim <= (cfg->arch == 2 ? 8 : 4), "engine_create: pos_dim %d unsupported", cfg->pos_dim);
     RGQA_REQUIRE(cfg->vocab_size > 0 && cfg->max_pos > 0 && cfg->type_vocab > 0 && cfg->num_answers > 0, "engine_create: empty table");
     RGQA_REQUIRE(cfg->l_layers >= 0 && cfg->x_layers >= 0 && cfg->r_layers >= 0, "engine_create: negative layer count");
     RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16, "engine_create: unknown precision %d", cfg->precision);

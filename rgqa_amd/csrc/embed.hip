@@ -3,8 +3,10 @@
 #include "kernels.h"
 
 // row_src (varlen mode): packed row -> b*Tn + t of the token it holds; null = identity (padded layout)
+// row_dst (UNITER joint layout): output row of `out` for this token; the saved pre-LN sum, the statistics and the dropout stream stay
+// indexed by the token's own (contiguous) row
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const int* __restrict__ row_src, const float* __restrict__ word,
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const int* __restrict__ row_src, const int* __restrict__ row_dst, const float* __restrict__ word,
                                                         const float* __restrict__ pos, const float* __restrict__ type, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, int ldo, T* __restrict__ zsave,
                                                         float* __restrict__ mean, float* __restrict__ rstd, int rows, int Tn, int H, float eps, DropCfg drop) {
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 o[j] = drop_apply(drop, (uint32_t)row * (uint32_t)H + (uint32_t)(c * 4 + j), (v[i][j] - mu) * rs * g[j] + b[j]);
-            store4(out + (size_t)row * ldo + c * 4, o);
+            store4(out + (size_t)(row_dst ? row_dst[row] : row) * ldo + c * 4, o);
         }
     }
     if (lane == 0) {
@@ -61,10 +63,11 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 }
 
 // de [rows, H] f32 -> atomic scatter-add into the tables (dense f32 gradients, as the reference's
-// nn.Embedding produces; rows with index 0 are skipped: padding_idx=0 on all three tables).
+// nn.Embedding produces; rows with index 0 are skipped: padding_idx=0 on all three tables in LXMERT (pad0_all), on the word
+// table only in UNITER (uniter/modeling.py:563-568)).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict__ de, const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const int* __restrict__ row_src,
-                                                            float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype, int rows, int Tn, int H) {
+                                                            float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype, int rows, int Tn, int H, int pad0_all) {
     const int row = blockIdx.x;
     if (row >= rows) return;
     const int src = row_src ? row_src[row] : row;
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict_
     for (int n = threadIdx.x; n < H; n += 256) {
         const float g = to_f32(de[(size_t)row * H + n]);
         if (id != 0) atomicAdd(dword + (size_t)id * H + n, g);
-        if (t != 0) atomicAdd(dpos + (size_t)t * H + n, g);
-        if (sg != 0) atomicAdd(dtype + (size_t)sg * H + n, g);
+        if (t != 0 || !pad0_all) atomicAdd(dpos + (size_t)t * H + n, g);
+        if (sg != 0 || !pad0_all) atomicAdd(dtype + (size_t)sg * H + n, g);
     }
 }
 
@@ -84,12 +87,12 @@ __global__ void make_mask_kernel(const int64_t* __restrict__ m, float* __restric
 }
 
 template <typename T>
-int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, int rows, const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, const int* row_dst, int rows, const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
                 T* out, int ldo, T* zsave, float* mean, float* rstd, int B, int Tn, int H, int vocab, int type_vocab, float eps, DropCfg drop, hipStream_t s) {
     RGQA_REQUIRE(H % 4 == 0 && H <= 2048 && ldo % 4 == 0, "embed: hidden %d unsupported", H);
     RGQA_REQUIRE(rows <= B * Tn, "embed: %d rows exceed B*T = %d", rows, B * Tn);
     if (rows <= 0) return RGQA_OK;
-#define EMB(NVV) hipLaunchKernelGGL((embed_fwd_kernel<T, NVV>), dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, seg, row_src, word, pos, type, gamma, beta, out, ldo, zsave, mean, rstd, rows, Tn, H, eps, drop)
+#define EMB(NVV) hipLaunchKernelGGL((embed_fwd_kernel<T, NVV>), dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, seg, row_src, row_dst, word, pos, type, gamma, beta, out, ldo, zsave, mean, rstd, rows, Tn, H, eps, drop)
     const int nvl = cdiv(H / 4, 64);
     if (nvl <= 1) EMB(1); else if (nvl == 2) EMB(2); else if (nvl == 3) EMB(3); else if (nvl == 4) EMB(4); else EMB(8);
 #undef EMB
@@ -98,10 +101,10 @@ int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, int 
 }
 
 template <typename T>
-int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, hipStream_t s) {
+int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, int pad0_all, hipStream_t s) {
     RGQA_REQUIRE(rows <= B * Tn, "embed scatter: %d rows exceed B*T = %d", rows, B * Tn);
     if (rows <= 0) return RGQA_OK;
-    hipLaunchKernelGGL(embed_scatter_kernel<T>, dim3(rows), dim3(256), 0, s, de, ids, seg, row_src, dword, dpos, dtype, rows, Tn, H);
+    hipLaunchKernelGGL(embed_scatter_kernel<T>, dim3(rows), dim3(256), 0, s, de, ids, seg, row_src, dword, dpos, dtype, rows, Tn, H, pad0_all);
     RGQA_LAUNCH_CHECK("embed_scatter_kernel");
     return RGQA_OK;
 }
@@ -113,7 +116,7 @@ int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s) {
     return RGQA_OK;
 }
 
-template int k_embed_fwd<float>(const int64_t*, const int64_t*, const int*, int, const float*, const float*, const float*, const float*, const float*, float*, int, float*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
-template int k_embed_fwd<bf16_t>(const int64_t*, const int64_t*, const int*, int, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, bf16_t*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
-template int k_embed_scatter<float>(const float*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, hipStream_t);
-template int k_embed_scatter<bf16_t>(const bf16_t*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, hipStream_t);
+template int k_embed_fwd<float>(const int64_t*, const int64_t*, const int*, const int*, int, const float*, const float*, const float*, const float*, const float*, float*, int, float*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
+template int k_embed_fwd<bf16_t>(const int64_t*, const int64_t*, const int*, const int*, int, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, bf16_t*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
+template int k_embed_scatter<float>(const float*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, hipStream_t);
+template int k_embed_scatter<bf16_t>(const bf16_t*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, hipStream_t);

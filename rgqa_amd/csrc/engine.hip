@@ -10,6 +10,7 @@ static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct ModelParams {
     size_t word, pos, type; LNp emb_ln;
     Lin visn_fc; LNp visn_ln; Lin box_fc; LNp box_ln;
+    LNp img_ln;      // UNITER only: UniterImageEmbeddings.LayerNorm
     std::vector<AttP> l_att, r_att; std::vector<FfnP> l_ffn, r_ffn;
     std::vector<AttP> x_cross, x_latt, x_vatt; std::vector<FfnP> x_lffn, x_vffn;
     Lin pooler, head0; LNp head_ln; Lin head3;
@@ -68,6 +69,34 @@ struct TableBuilder {
 static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, ModelParams& mp, size_t& total, size_t& dead_b, size_t& dead_e) {
     TableBuilder tb(tab);
     const int H = c.hidden, I = c.inter;
+    if (c.arch == 2) {
+        // GQAUNITER (uniter/uniter.py:15-44): encoder = UniterEncoder, .model = UniterFeatureExtraction, .uniter = UniterModel
+        // (uniter/modeling.py:615-655); 12 BertLayers named encoder.layer.N like BERT's
+        const std::string pre = "encoder.model.uniter.";
+        mp.word = tb.add(pre + "embeddings.word_embeddings.weight", c.vocab_size, H, 2, 0, 0);
+        mp.pos = tb.add(pre + "embeddings.position_embeddings.weight", c.max_pos, H, 2, 0, 0);
+        mp.type = tb.add(pre + "embeddings.token_type_embeddings.weight", c.type_vocab, H, 2, 0, 0);
+        mp.emb_ln = tb.ln(pre + "embeddings.LayerNorm", H);
+        mp.visn_fc = tb.lin(pre + "img_embeddings.img_linear", H, c.feat_dim);
+        mp.visn_ln = tb.ln(pre + "img_embeddings.img_layer_norm", H);
+        mp.box_ln = tb.ln(pre + "img_embeddings.pos_layer_norm", H);
+        mp.box_fc = tb.lin(pre + "img_embeddings.pos_linear", H, c.pos_dim);
+        mp.img_ln = tb.ln(pre + "img_embeddings.LayerNorm", H);
+        char b2[64];
+        for (int i = 0; i < c.l_layers; ++i) {
+            snprintf(b2, sizeof b2, "encoder.layer.%d", i);
+            std::string n = pre + b2;
+            mp.l_att.push_back(tb.att(n + ".attention.self", n + ".attention.output", H));
+            mp.l_ffn.push_back(tb.ffn(n + ".intermediate", n + ".output", H, I));
+        }
+        dead_b = dead_e = 0;
+        mp.pooler = tb.lin(pre + "pooler.dense", H, H);
+        mp.head0 = tb.lin("logit_fc.0", 2 * H, H);
+        mp.head_ln = tb.ln("logit_fc.2", 2 * H);
+        mp.head3 = tb.lin("logit_fc.3", c.num_answers, 2 * H);
+        total = rup(tb.cur, 64);
+        return;
+    }
     const std::string pre = "lxrt_encoder.model.bert.";
     mp.word = tb.add(pre + "embeddings.word_embeddings.weight", c.vocab_size, H, 2, 0, 0);
     mp.pos = tb.add(pre + "embeddings.position_embeddings.weight", c.max_pos, H, 2, 0, 0);
@@ -150,6 +179,7 @@ public:
 
     explicit Engine(const rgqa_config& c) {
         cfg = c;
+        joint = cfg.arch == 2;
         build_params(cfg, params, mp, arena_elems, dead_begin, dead_end);
         build_transpose_table();
         build_grad_segments();
@@ -264,6 +294,7 @@ public:
     // packed rows of varlen mode, set_lengths()) only moves the [lang; visn] split inside them, so re-planning for another
     // Rl is pointer arithmetic on the same workspace.
     void plan(int B_, int T_, int O_, int rl_active = -1) {
+        if (joint && O_ > 0) { Tt = T_; Oi = O_; T_ = Tt + Oi; O_ = 0; jstate = 0; }       // a new shape; re-plans pass (Tn, 0)
         B = B_; Tn = T_; O = O_; Rv = B * O;
         const int RlC = B * Tn, RC = RlC + Rv;
         Rl = rl_active < 0 ? RlC : rl_active; R = Rl + Rv;
@@ -354,6 +385,14 @@ public:
         gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
+        if (joint) {
+            const size_t ni = (size_t)B * Oi, nt = (size_t)B * Tt;
+            tlens_dev = take<int>(B); tcu_dev = take<int>(B + 1); trow_src_dev = take<int>(nt); text_dst_dev = take<int>(nt); img_dst_dev = take<int>(ni);
+            u_zf = take<T>(ni * H); u_zp = take<T>(ni * H); u_a1 = take<T>(ni * H); u_a2 = take<T>(ni * H); u_x3 = take<T>(ni * H);
+            u_g = take<T>(ni * H); u_dx3 = take<T>(ni * H); u_dz = take<T>(ni * H); u_gt = take<T>(nt * H); u_de = take<T>(nt * H);
+            u_st = take<float>(6 * ni);
+            feats_lp = LP ? take<T>(ni * cfg.feat_dim) : nullptr;
+        }
         // split-contraction partials of one grouped weight-gradient launch (gemm_mfma256.hip plan_tn): up to 3 extra chunks of
         // the largest layer's weights (cross + two self-attention blocks + two FFNs), f32
         wpart_elems = LP ? (size_t)3 * ((size_t)12 * H * H + (size_t)4 * H * I + 65536) : 0;
@@ -361,6 +400,13 @@ public:
         tdesc = take<TransDesc>(n_tdesc + 1);
     }
     int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr;
+    // UNITER (arch 2): ONE sequence per sample, [text tokens ; image regions], laid out as the engine's language modality with
+    // Tn = Tt + Oi rows per sample (packed: real text tokens + Oi) and no vision modality; only the embedding front-end differs.
+    bool joint = false; int Tt = 0, Oi = 0, jstate = 0, n_text = 0;      // jstate: index arrays built for 1 = padded / 2 = packed rows
+    std::vector<int> tlens_host;
+    int *tlens_dev = nullptr, *tcu_dev = nullptr, *trow_src_dev = nullptr, *text_dst_dev = nullptr, *img_dst_dev = nullptr;
+    T *u_zf = nullptr, *u_zp = nullptr, *u_a1 = nullptr, *u_a2 = nullptr, *u_x3 = nullptr, *u_g = nullptr, *u_dx3 = nullptr, *u_dz = nullptr, *u_gt = nullptr, *u_de = nullptr;
+    float *u_st = nullptr;     // [6][B*Oi]: mean / rstd of img_layer_norm, pos_layer_norm, LayerNorm
     bool varlen = false, lens_dirty = false, fwd_varlen = false;   // fwd_varlen: layout of the recorded forward pass
     int n_lang = 0; std::vector<int> lens_host;
     bool x0_needed = false; T* x0 = nullptr; void* x0_src[2] = {nullptr, nullptr}; void* visn_final = nullptr;
@@ -402,6 +448,17 @@ public:
         RGQA_REQUIRE(ws != nullptr, "set_lengths: engine not bound");
         RGQA_REQUIRE(n == B, "set_lengths: %d lengths for a batch of %d", n, B);
         long tot = 0;
+        if (joint) {       // lengths count TEXT tokens; a sample's row window is its text tokens followed by its Oi regions
+            for (int i = 0; i < n; ++i) {
+                RGQA_REQUIRE(lens[i] >= 1 && lens[i] <= Tt, "set_lengths: lengths[%d] = %d outside 1..%d", i, lens[i], Tt);
+                tot += lens[i] + Oi;
+            }
+            tlens_host.assign(lens, lens + n);
+            lens_host.resize(n);
+            for (int i = 0; i < n; ++i) lens_host[i] = lens[i] + Oi;
+            n_lang = (int)tot; varlen = true; lens_dirty = true;
+            return RGQA_OK;
+        }
         for (int i = 0; i < n; ++i) {
             RGQA_REQUIRE(lens[i] >= 1 && lens[i] <= Tn, "set_lengths: lengths[%d] = %d outside 1..%d", i, lens[i], Tn);
             tot += lens[i];
@@ -588,6 +645,52 @@ public:
             return RGQA_OK;
     }
 
+    // UNITER embeddings (uniter/modeling.py:560-612, 628-631) written straight into the joint row layout
+    int forward_joint_embeddings(const float* feats, const float* boxes, const int64_t* ids, const int64_t* seg, const int64_t* mask, hipStream_t s) {
+        const int H = cfg.hidden, ni = B * Oi;
+        const float pd = cfg.hidden_dropout;
+        if (!fwd_varlen) CKP(PC_OTHER, k_uniter_mask(mask, maskf, B, Tt, Oi, s));
+        // text: word + position + token type -> LayerNorm -> dropout; pre-LN sums and statistics kept in text order for the backward
+        CKP(PC_OTHER, k_embed_fwd<T>(ids, seg, trow_src_dev, text_dst_dev, n_text, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z,
+                                     emb_mean, emb_rstd, B, Tt, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
+        // image: LN(img_linear(feat)) + LN(pos_linear(pos)) + type_emb[1] -> LayerNorm -> dropout
+        GemmGroup g; gg_init(g);
+        if (LP) CKP(PC_OTHER, k_cast_bf16(feats, feats_lp, (size_t)ni * cfg.feat_dim, s));
+        add_fwd(g, LP ? (const void*)feats_lp : (const void*)feats, cfg.feat_dim, mp.visn_fc, 0, H, u_zf, H, ni, EPI_BIAS, nullptr, 0, nullptr, 0);
+        CK(run_fwd(g, s));
+        CKP(PC_LN, k_ln_fwd<T>(u_zf, H, P + mp.visn_ln.w, P + mp.visn_ln.b, u_a1, H, u_st, u_st + ni, ni, H, cfg.ln_eps, s));
+        CKP(PC_OTHER, k_pos_proj<T>(boxes, cfg.pos_dim, P + mp.box_fc.w, P + mp.box_fc.b, u_zp, H, ni, H, s));
+        CKP(PC_LN, k_ln_fwd<T>(u_zp, H, P + mp.box_ln.w, P + mp.box_ln.b, u_a2, H, u_st + 2 * ni, u_st + 3 * ni, ni, H, cfg.ln_eps, s));
+        CKP(PC_LN, k_sum3_ln_fwd<T>(u_a1, u_a2, H, P + mp.type + H, P + mp.img_ln.w, P + mp.img_ln.b, img_dst_dev, emb_out, H, u_x3, u_st + 4 * ni, u_st + 5 * ni,
+                                    ni, H, cfg.ln_eps, drop_site(pd, 2), s));
+        return RGQA_OK;
+    }
+    // dy = gradient w.r.t. the joint embedding rows
+    int backward_joint_embeddings(const T* dy, int accumulate, hipStream_t s) {
+        const int H = cfg.hidden, ni = B * Oi;
+        const float pd = cfg.hidden_dropout;
+        const DropCfg nodrop = make_drop(0.f, 0, 0);
+        RGQA_REQUIRE(dfeats_out == nullptr && dboxes_out == nullptr, "backward: input gradients are not available for the UNITER backbone");
+        // text rows -> text order, LayerNorm backward, scatter into the tables (only the word table has padding_idx, :563-568)
+        CKP(PC_OTHER, k_gather_rows<T>(dy, H, text_dst_dev, 0, u_gt, H, n_text, H, s));
+        CKP(PC_LN, k_ln_bwd<T>(u_gt, H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, u_de, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, n_text, H,
+                               nodrop, drop_site(pd, 1), 1.0f, s));
+        CKP(PC_OTHER, k_embed_scatter<T>(u_de, in_ids, in_seg, trow_src_dev, n_text, G + mp.word, G + mp.pos, G + mp.type, B, Tt, H, 0, s));
+        // image rows: final LayerNorm, then the same gradient enters both branch LayerNorms and the type-1 embedding row
+        CKP(PC_OTHER, k_gather_rows<T>(dy, H, img_dst_dev, 0, u_g, H, ni, H, s));
+        CKP(PC_LN, k_ln_bwd<T>(u_g, H, u_x3, H, P + mp.img_ln.w, u_st + 4 * ni, u_st + 5 * ni, u_dx3, nullptr, H, part, G + mp.img_ln.w, G + mp.img_ln.b, nullptr, accumulate, ni, H,
+                               nodrop, drop_site(pd, 2), 1.0f, s));
+        CKP(PC_OTHER, k_colsum<T>(u_dx3, H, part, G + mp.type + H, 1, ni, H, s));       // the tables were zeroed (or hold the accumulated sum)
+        CKP(PC_LN, k_ln_bwd<T>(u_dx3, H, u_zp, H, P + mp.box_ln.w, u_st + 2 * ni, u_st + 3 * ni, u_dz, nullptr, H, part, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.box_fc.b, accumulate, ni, H,
+                               nodrop, nodrop, 1.0f, s));
+        CKP(PC_OTHER, k_pos_wgrad<T>(u_dz, H, in_boxes, cfg.pos_dim, part, G + mp.box_fc.w, accumulate, ni, H, s));
+        CKP(PC_LN, k_ln_bwd<T>(u_dx3, H, u_zf, H, P + mp.visn_ln.w, u_st, u_st + ni, u_dz, nullptr, H, part, G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.visn_fc.b, accumulate, ni, H,
+                               nodrop, nodrop, 1.0f, s));
+        GemmGroup g; gg_init(g);
+        add_wgrad(g, u_dz, H, mp.visn_fc, 0, H, LP ? (const void*)feats_lp : (const void*)in_feats, cfg.feat_dim, ni, accumulate);
+        return run_wgrad(g, s);
+    }
+
     int forward(const float* feats, const float* boxes, const int64_t* ids, const int64_t* seg, const int64_t* mask,
                 float* pooled_out, float* logits_out, int ld_logits, int train, uint64_t seed, hipStream_t s) override {
         RGQA_REQUIRE(P != nullptr && ws != nullptr, "forward: engine not bound");
@@ -599,12 +702,26 @@ public:
         {   // language row layout of this pass: packed (varlen) or padded
             const int want = varlen ? n_lang : B * Tn;
             if (want != Rl) plan(B, Tn, O, want);
+            if (joint) {
+                // the row maps of the joint layout are needed in both layouts (padded = every text position is a row)
+                if (!varlen && jstate != 1) { tlens_host.assign(B, Tt); lens_host.assign(B, Tn); lens_dirty = true; }
+                if (lens_dirty) {
+                    CK(k_set_lengths(lens_host.data(), B, Tn, lens_dev, cu_dev, row_src_dev, s));
+                    CK(k_set_lengths(tlens_host.data(), B, Tt, tlens_dev, tcu_dev, trow_src_dev, s));
+                    CK(k_uniter_dst(tcu_dev, cu_dev, B, Oi, text_dst_dev, img_dst_dev, s));
+                    n_text = 0;
+                    for (int v : tlens_host) n_text += v;
+                    lens_dirty = false; jstate = varlen ? 2 : 1;
+                }
+            } else
             if (varlen && lens_dirty) { CK(k_set_lengths(lens_host.data(), B, Tn, lens_dev, cu_dev, row_src_dev, s)); lens_dirty = false; }
             fwd_varlen = varlen;
         }
         const int* cu = fwd_varlen ? cu_dev : nullptr;
+        if (joint) CK(forward_joint_embeddings(feats, boxes, ids, seg, mask, s));
+        else {
         if (!fwd_varlen) CKP(PC_OTHER, k_make_mask(mask, maskf, Rl, s));
-        CKP(PC_OTHER, k_embed_fwd<T>(ids, seg, fwd_varlen ? row_src_dev : nullptr, Rl, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z,
+        CKP(PC_OTHER, k_embed_fwd<T>(ids, seg, fwd_varlen ? row_src_dev : nullptr, nullptr, Rl, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z,
                           emb_mean, emb_rstd, B, Tn, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
         {   // VisualFeatEncoder: GEMM on the RoI features (one f32->bf16 cast pass in bf16 precision, so that this GEMM and
             // its weight-gradient GEMM run on the LDS-DMA kernels), then the fused LN/LN/avg tail
@@ -614,6 +731,7 @@ public:
             CK(run_fwd(g, s));
             CKP(PC_OTHER, k_visn_combine_fwd<T>(zf, H, boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.visn_ln.b, P + mp.box_ln.w, P + mp.box_ln.b,
                                      visn_out, H, visn_stats, Rv, H, cfg.pos_dim, cfg.ln_eps, drop_site(pd, 2), s));
+        }
         }
         bool gathered = false;
         const size_t n_lr_stages = 2 * (size_t)(cfg.l_layers > cfg.r_layers ? cfg.l_layers : cfg.r_layers);
@@ -906,13 +1024,19 @@ public:
         CK(wait_wgrad(par, s));
         if (!late_join) CK(wait_wgrad(par ^ 1, s));
         prof_block = PB_EMBED;
+        if (joint) {
+            CK(backward_joint_embeddings(dyp[0], accumulate, s));
+            CK(wait_wgrad(par ^ 1, s));
+            CK(mark_segment(s));
+            return RGQA_OK;
+        }
         T* gz = gemb;
         // ---- embeddings: dropout -> LN backward -> scatter-add into the three tables
         {
             DropCfg din = drop_site(pd, 1);
             CKP(PC_LN, k_ln_bwd<T>(dyp[0], H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
                            nodrop, din, 1.0f, s));
-            CKP(PC_OTHER, k_embed_scatter<T>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, s));
+            CKP(PC_OTHER, k_embed_scatter<T>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, 1, s));
         }
         // ---- visual embedding
         {

@@ -61,14 +61,23 @@ int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
 // ---- embed.hip
 // lang[b*T+t] = dropout(LN(word[ids] + pos[t] + type[seg]))      (reference BertEmbeddings, modeling.py:278-292)
 template <typename T>
-int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, int rows, const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, const int* row_dst /* output row map or null */, int rows, const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
                 T* out, int ldo, T* zsave, float* mean, float* rstd, int B, int Tn, int H, int vocab, int type_vocab, float eps, DropCfg drop, hipStream_t s);
 // de [B*T, H] f32 (gradient w.r.t. the pre-LN embedding sum) scattered into the three tables; row 0 of each
 // table gets no gradient (padding_idx=0, modeling.py:269-271)
 template <typename T>
-int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, hipStream_t s);
+int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, int pad0_all, hipStream_t s);
 // additive key mask (1 - m) * -10000 from the 0/1 int64 attention mask (modeling.py:857-865)
 int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s);
+
+// ---- uniter.hip (UNITER embedding front-end, reference uniter/modeling.py:560-635)
+int k_uniter_dst(const int* tcu, const int* jcu, int B, int O, int* text_dst, int* img_dst, hipStream_t s);
+int k_uniter_mask(const int64_t* input_mask, float* out, int B, int T, int O, hipStream_t s);
+template <typename T> int k_pos_proj(const float* pos, int pd, const float* Wp, const float* bp, T* out, int ldo, int M, int H, hipStream_t s);
+template <typename T> int k_pos_wgrad(const T* dzp, int ld, const float* pos, int pd, float* part, float* dWp, int accumulate, int M, int H, hipStream_t s);
+template <typename T>
+int k_sum3_ln_fwd(const T* a, const T* b, int ld, const float* trow, const float* gamma, const float* beta, const int* dst, T* out, int ldo, T* xsave, float* mean, float* rstd,
+                  int M, int H, float eps, DropCfg drop, hipStream_t s);
 
 // ---- visn.hip
 // out = dropout((LN(zf) + LN(boxes Wb^T + bb)) / 2)            (reference VisualFeatEncoder, modeling.py:507-517)

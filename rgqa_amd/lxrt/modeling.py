@@ -299,6 +299,7 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
     """Engine-backed LXMERT encoder. mode='x' (pooled cross-modal output) is the GQA path and the only one built."""
 
     HEAD_PLACEHOLDER = 64
+    TREE_PREFIX = "lxrt_encoder.model."      # state_dict prefix of this module's parameters inside the task model (gqa_model.py:17-19)
 
     def __init__(self, config, mode='x', precision=None):
         super().__init__(config)
@@ -312,7 +313,7 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         self._seed_base = None
         self.__dict__["_anchor"] = None
         self._make_engine(self.HEAD_PLACEHOLDER)
-        _build_tree(self, self._binding.engine.specs, "lxrt_encoder.model.")
+        _build_tree(self, self._binding.engine.specs, self.TREE_PREFIX)
         self._rebind()
         self.apply(self.init_bert_weights)      # as LXRTModel / LXRTFeatureExtraction do (modeling.py:843, 1018)
 
@@ -327,7 +328,7 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
                                       hidden_dropout=c.hidden_dropout_prob, attn_dropout=c.attention_probs_dropout_prob)
 
     def _named_for_binding(self):
-        named = {"lxrt_encoder.model." + k: v for k, v in self.named_parameters()}
+        named = {self.TREE_PREFIX + k: v for k, v in self.named_parameters()}
         if self._head is not None:
             named.update({"logit_fc." + k: v for k, v in self._head.named_parameters()})
         else:
