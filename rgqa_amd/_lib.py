@@ -77,6 +77,8 @@ def load():
     # torch bundles its own libamdhip64.so.7; it must be the HIP runtime already resident when our library is
     # mapped, otherwise the process ends up with two runtimes and torch's device pointers / streams mean nothing to ours
     import torch  # noqa: F401
+    global LIB_PATH
+    LIB_PATH = os.environ.get("RGQA_LIB", LIB_PATH)          # A/B of differently built kernels (tools/ab_bench.sh)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("rgqa_amd: %s not found. Build it with `python -m rgqa_amd.build` "
                            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)

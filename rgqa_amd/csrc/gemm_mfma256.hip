@@ -56,6 +56,58 @@ __device__ __forceinline__ int xcd_remap256(int b, int nwg) {
 // parity: a 2-way conflict on every fragment read.)
 __device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
+// One K-step of MFMAs for a wave's (16*MT) x 64 slice.  RGQA_NT_PIPE / RGQA_TN_PIPE (build-time ring depth, 0 = plain loop): the
+// A fragments come through a register ring PD deep - the LDS read for fragment i+PD is issued right after the MFMAs of fragment i,
+// pinned by sched_barrier - instead of being requested two at a time just before their use, which is what the compiler makes of the
+// plain loop (2 ds_read_b128, s_waitcnt, 8 MFMAs, ...: every group of 8 MFMAs starts behind a full LDS round trip that only the
+// SIMD's other wave can cover).  Measured in situ (B=256 train step, libraries built both ways, tools/ab_bench.sh): NT ring 3
+// -0.18 ms, wgrad ring 3 -0.26 ms, together 13.26 -> 12.81 ms; depth 4 = depth 3; depth 2 within noise of 3.
+#ifndef RGQA_NT_PIPE
+#define RGQA_NT_PIPE 3
+#endif
+#ifndef RGQA_TN_PIPE
+#define RGQA_TN_PIPE 3
+#endif
+template <int MT>
+__device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsigned char* w, int wm, int wn, int fr, int fq, f32x4 (&acc)[MT][4]) {
+#if RGQA_NT_PIPE
+    constexpr int PD = RGQA_NT_PIPE, NF = 2 * MT;
+    auto lda = [&](int i) { return *reinterpret_cast<const bf16x8*>(a + off256(wm * (16 * MT) + (i % MT) * 16 + fr, (i / MT) * 4 + fq)); };
+    bf16x8 xw[2][4], ring[PD];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xw[0][t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, fq));
+#pragma unroll
+    for (int i = 0; i < PD; ++i) ring[i] = lda(i);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int s = i / MT, tm = i % MT;
+        const bf16x8 xa = ring[i % PD];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[s][tn], xa, acc[tm][tn], 0, 0, 0);
+        if (i + PD < NF) ring[i % PD] = lda(i + PD);
+        if (s == 0 && tm == MT - 1 - (MT > 2 ? 2 : 0)) {          // second half's W fragments, two fragments of lead
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xw[1][t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, 4 + fq));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bf16x8 xw[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xw[t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, s * 4 + fq));
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm) {
+            const bf16x8 xa = *reinterpret_cast<const bf16x8*>(a + off256(wm * (16 * MT) + tm * 16 + fr, s * 4 + fq));
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[tn], xa, acc[tm][tn], 0, 0, 0);
+        }
+    }
+#endif
+}
+
 // ---- shared epilogue of the LDS-DMA NT kernels. The accumulators are transposed through a wave-private LDS region
 // (the operand stages are dead after the last barrier) so that every global access is a full 128-B line: 8 lanes x
 // 16 B per output row, instead of 16 rows x 32 B per store straight out of the MFMA layout (which ran HBM writes
@@ -242,19 +294,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             const unsigned char* w = a + A_BYTES;
             if (g.ablate == 5 && kt + 1 < nkt) issue(st, kt + 1);      // DMA-only with twice the bytes in flight: latency- or bandwidth-bound?
             if (g.ablate == 2 || g.ablate == 5) continue;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 xw[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) xw[t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, s * 4 + fq));
-#pragma unroll
-                for (int tm = 0; tm < MT; ++tm) {
-                    const bf16x8 xa = *reinterpret_cast<const bf16x8*>(a + off256(wm * (16 * MT) + tm * 16 + fr, s * 4 + fq));
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[tn], xa, acc[tm][tn], 0, 0, 0);
-                }
-            }
+            nt256_kstep<MT>(a, w, wm, wn, fr, fq, acc);
         }
         __syncthreads();   // every wave is done with the operand stages: they may be refilled (PERSIST) or reused as scratch
         const int cpi = pi, cm0 = m0, cn0 = n0;
@@ -351,19 +391,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
         if (kt + NS - 1 < nkt) issue(kt + NS - 1);      // refills slot (kt-1) % NS
         const unsigned char* a = lds + (kt % NS) * STAGE_BYTES;
         const unsigned char* w = a + A_BYTES;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 xw[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) xw[t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, s * 4 + fq));
-#pragma unroll
-            for (int tm = 0; tm < MT; ++tm) {
-                const bf16x8 xa = *reinterpret_cast<const bf16x8*>(a + off256(wm * (16 * MT) + tm * 16 + fr, s * 4 + fq));
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[tn], xa, acc[tm][tn], 0, 0, 0);
-            }
-        }
+        nt256_kstep<MT>(a, w, wm, wn, fr, fq, acc);
     }
     __syncthreads();   // the ring is dead: reuse it as the epilogue's transpose scratch
     nt256_epilogue<OutT, EPI, MT>(g, P, lds, wave, lane, m0, n0, wm, wn, acc, []() {});
@@ -724,6 +752,32 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
         if (kt + NSLOT - 1 < nkt) issue((kt + NSLOT - 1) % NSLOT, kt + NSLOT - 1);
         const unsigned char* a = lds + st * STAGE;
         const unsigned char* b = a + A_BYTES;
+#if RGQA_TN_PIPE
+        {   // A fragments through a register ring, as in nt256_kstep
+            constexpr int PD = RGQA_TN_PIPE, NF = 2 * MTW;
+            auto lda = [&](int i) { return tr_frag_dma<WMV * 2>(a, (i / MTW) * 32, wm * (16 * MTW) + (i % MTW) * 16, lane); };
+            bf16x8 xb[2][4], ring[PD];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xb[0][t] = tr_frag_dma<WN * 2>(b, 0, wn * 64 + t * 16, lane);
+#pragma unroll
+            for (int i = 0; i < PD; ++i) ring[i] = lda(i);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int sh = i / MTW, tm = i % MTW;
+                const bf16x8 xa = ring[i % PD];
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[sh][tn], xa, acc[tm][tn], 0, 0, 0);
+                if (do_cs) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa, cs[tm], 0, 0, 0);
+                if (i + PD < NF) ring[i % PD] = lda(i + PD);
+                if (sh == 0 && tm == MTW - 3) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xb[1][t] = tr_frag_dma<WN * 2>(b, 32, wn * 64 + t * 16, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 xb[4];
@@ -738,6 +792,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
                 if (do_cs) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa, cs[tm], 0, 0, 0);
             }
         }
+#endif
     }
     // chunk 0 -> the gradient (and bias gradient) itself; chunk c >= 1 -> dense f32 partial c-1: [M, N] then the M column sums
     float* Cc = reinterpret_cast<float*>(P.C);
