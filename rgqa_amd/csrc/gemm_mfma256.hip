@@ -61,7 +61,8 @@ __device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch
 // pinned by sched_barrier - instead of being requested two at a time just before their use, which is what the compiler makes of the
 // plain loop (2 ds_read_b128, s_waitcnt, 8 MFMAs, ...: every group of 8 MFMAs starts behind a full LDS round trip that only the
 // SIMD's other wave can cover).  Measured in situ (B=256 train step, libraries built both ways, tools/ab_bench.sh): NT ring 3
-// -0.18 ms, wgrad ring 3 -0.26 ms, together 13.26 -> 12.81 ms; depth 4 = depth 3; depth 2 within noise of 3.
+// -0.18 ms, wgrad ring 3 -0.26 ms, together 13.26 -> 12.81 ms; depth 4 = depth 3 (NT) / spills (wgrad, +9 %); depth 2 within noise of 3.
+// Issuing the next K-step's DMA instructions one or two per fragment slot inside this stream instead of all up front: +8..14 % (step).
 #ifndef RGQA_NT_PIPE
 #define RGQA_NT_PIPE 3
 #endif
