@@ -1005,6 +1005,8 @@ public:
                 add_dgrad(g, gqkv, 3 * H, st.att[0]->qkv, 0, 3 * H, dxp[0], H, R, EPI_ADD, gz, H);
             } else if (cross) {
                 add_dgrad(g, gqkv, 3 * H, st.att[0]->qkv, 0, H, dxp[0], H, Rl, EPI_ADD, gz, H);
+                CK(run_dgrad(g, s));          // two launches: a grouped launch needs ONE epilogue to stay on the LDS-DMA kernels
+                gg_init(g);
                 add_dgrad(g, rowp(gqkv, 1, 3 * H) + H, 3 * H, st.att[0]->qkv, H, 2 * H, dxp[1], H, Rv, EPI_BIAS, nullptr, 0);
             } else {
                 for (int m = 0; m < 2; ++m) if (st.active[m])

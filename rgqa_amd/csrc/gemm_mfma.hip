@@ -301,6 +301,11 @@ int launch_gemm_nt_bf16(GemmGroup& g, int out_f32, hipStream_t s) {
     int r = check_group(g, false);
     if (r) return r;
     if (!g_rgqa_force_gemm128 && gemm_nt256_eligible(g, out_f32)) return out_f32 ? launch_gemm_nt256_f32out(g, s) : launch_gemm_nt256_bf16(g, s);
+    static const bool log_fb = getenv("RGQA_GEMM_LOG_FALLBACK") != nullptr;       // which launches still take the 128x128 register-staged kernel
+    if (log_fb && !g_rgqa_force_gemm128)
+        for (int i = 0; i < g.count; ++i)
+            fprintf(stderr, "rgqa: NT fallback M=%d N=%d K=%d lda=%d ldb=%d ldc=%d ldaux=%d epi=%d a_f32=%d out_f32=%d\n", g.p[i].M, g.p[i].N, g.p[i].K, g.p[i].lda, g.p[i].ldb,
+                    g.p[i].ldc, g.p[i].ldaux, g.p[i].epi, g.a_f32, out_f32);
     gemm_group_finalize(g, BM, BN);
     dim3 grid(g.total_tiles), block(NTHREADS);
     if (g.a_f32) {
