@@ -114,12 +114,15 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 
 // ---------------------------------------------------------------- counter-based dropout RNG
 // keep(seed, site, idx): element idx draws the (idx & 1) 16-bit half of ONE 32-bit hash word of (seed, site, idx >> 1), so a
-// hash (3 integer multiplies - the expensive VALU ops of the fused epilogues) serves two neighbouring elements; drop
+// hash (integer multiplies - the expensive VALU ops of the fused epilogues) serves two neighbouring elements; drop
 // probability = round(p * 65536) / 65536.  The same (seed, site, idx) is re-derived in the backward pass, so no mask is
 // stored.  `site` (folded into seed_hi) separates the dropout sites of one step.
+// (seed, site) enter through ONE multiply on wave-uniform values (scalar ALU, free); the per-element part is the two-multiply
+// "lowbias32" finaliser (v_mul_lo_u32 is a quarter-rate instruction: the hash is the most expensive part of the dropout epilogues
+// and of the attention kernels, 216 of 4171 instructions in attn_bwd<3,3>).
 __device__ __forceinline__ uint32_t rng_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx2) {
-    uint32_t x = (idx2 * 0x9E3779B1u + seed_lo) ^ seed_hi;
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    uint32_t x = idx2 ^ (seed_lo + seed_hi * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
 }
 struct DropCfg {
