@@ -163,6 +163,8 @@ def main():
     e.ensure_shape(MB, T, O)
     e.sync_weights()
     comm = GradAllReduce(e, dist) if world > 1 else None
+    if world == 1 and not args.butd and os.environ.get("RGQA_SEG_SUMSQ", "1") != "0":
+        e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
     t_total = 10000
     state = dict(step=0)
 

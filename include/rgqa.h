@@ -119,6 +119,12 @@ int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n);
  * tasks/gqa_odin.py:97-121): dfeats [B*O, feat_dim] f32, dboxes [B*O, pos_dim] f32 device buffers, either may be NULL (not computed,
  * the default). */
 int rgqa_engine_set_input_grads(rgqa_engine* e, float* dfeats, float* dboxes);
+/* Per-segment sum of squared gradients for clip_grad_norm_ (tasks/gqa_conf.py:201): slots (device, n >= rgqa_engine_num_grad_segments
+ * floats, or null to switch off) receives, during every following backward call, sum(g^2) of gradient segment k as soon as that segment
+ * is final - on the stream that finished it, beside the rest of backward - so the optimizer can add n numbers instead of re-reading
+ * the whole gradient arena. Valid for the gradients as backward leaves them (single GPU; after a data-parallel all-reduce the norm
+ * must be taken from the reduced arena with rgqa_grad_sumsq). */
+int rgqa_engine_set_grad_sumsq_slots(rgqa_engine* e, float* slots, int n);
 
 /* data-parallel overlap: the gradient arena becomes final range by range while backward runs (head first, embeddings
  * last). grad_segment k = element range [begin,end) + the id of the event recorded on the backward stream once that

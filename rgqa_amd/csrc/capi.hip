@@ -122,6 +122,12 @@ int rgqa_engine_get_activation(rgqa_engine* e, const char* name, float* out, siz
     return e->impl->get_activation(name, out, cap, S(stream));
 }
 
+int rgqa_engine_set_grad_sumsq_slots(rgqa_engine* e, float* slots, int n) {
+    NEED(e);
+    RGQA_REQUIRE(slots == nullptr || n >= (int)e->impl->grad_segs.size(), "set_grad_sumsq_slots: %d slots for %d gradient segments", n, (int)e->impl->grad_segs.size());
+    e->impl->sumsq_slots = slots;
+    return RGQA_OK;
+}
 int rgqa_engine_set_input_grads(rgqa_engine* e, float* dfeats, float* dboxes) {
     NEED(e);
     return e->impl->set_input_grads(dfeats, dboxes);

@@ -107,6 +107,8 @@ public:
     std::vector<hipEvent_t> seg_events;
     virtual int get_activation(const char* name, float* out, size_t cap_elems, hipStream_t s) = 0;
     virtual int get_cross_attention(int, int, float*, size_t, hipStream_t) { rgqa_set_error("get_cross_attention: this engine has no cross-modality layers"); return RGQA_ERR_ARG; }
+    // per-segment sum of squared gradients, written as each segment becomes final during backward (null = off)
+    float* sumsq_slots = nullptr; float* sumsq_ws = nullptr; int sumsq_ws_segs = 0;
     virtual int set_input_grads(float* dfeats, float* dboxes) { (void)dfeats; (void)dboxes; rgqa_set_error("set_input_grads: not supported by this engine"); return RGQA_ERR_ARG; }
     // per-sample real token counts for the following forward passes (packed language rows); null: padded layout
     virtual int set_lengths(const int* lens, int n) { (void)lens; (void)n; rgqa_set_error("set_lengths: not supported by this engine"); return RGQA_ERR_ARG; }

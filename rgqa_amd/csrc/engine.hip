@@ -254,7 +254,18 @@ public:
             seg_events.resize(n_seg_events);
             for (auto& e : seg_events) RGQA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        if (seg_cursor < n_seg_events) RGQA_HIP(hipEventRecord(seg_events[seg_cursor++], s));
+        if (seg_cursor < n_seg_events) {
+            const int ev = seg_cursor;
+            RGQA_HIP(hipEventRecord(seg_events[seg_cursor++], s));
+            // clip_grad_norm_ needs sum(g^2) over everything: take each segment's share here, on the stream that finished it (the
+            // weight-gradient side stream for the layers), instead of one 0.8-GB read of the whole arena after backward
+            if (sumsq_slots != nullptr && sumsq_ws != nullptr)
+                for (int k = 0; k < (int)grad_segs.size() && k < sumsq_ws_segs; ++k)
+                    if (grad_segs[k].event == ev) {
+                        int r = k_sumsq(G + grad_segs[k].begin, grad_segs[k].end - grad_segs[k].begin, sumsq_ws + (size_t)k * 1024, sumsq_slots + k, 0, s);
+                        if (r) return r;
+                    }
+        }
         return RGQA_OK;
     }
 
@@ -385,6 +396,7 @@ public:
         gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
+        sumsq_ws_segs = (int)grad_segs.size(); sumsq_ws = take<float>((size_t)sumsq_ws_segs * 1024);
         if (joint) {
             const size_t ni = (size_t)B * Oi, nt = (size_t)B * Tt;
             tlens_dev = take<int>(B); tcu_dev = take<int>(B + 1); trow_src_dev = take<int>(nt); text_dst_dev = take<int>(nt); img_dst_dev = take<int>(ni);

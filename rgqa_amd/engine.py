@@ -61,6 +61,8 @@ class Engine:
         self.device = None
         self.params = self.grads = self.params_lp = self.params_lp_t = self.workspace = None
         self.adam_m = self.adam_v = None
+        self._seg_sumsq = None
+        self._seg_sumsq_valid = False
         self.shape = None
         self._io = {}
 
@@ -153,11 +155,13 @@ class Engine:
             raise ValueError("target must be f32 with unit inner stride")
         check(self.lib.rgqa_engine_loss_backward(self.h, ptr(target), target.stride(0), ptr(self._io["loss"]), grad_scale,
                                                  1 if accumulate else 0, _stream()))
+        self._seg_sumsq_valid = self._seg_sumsq is not None
         return self._io["loss"]
 
     def backward(self, dlogits, accumulate=False):
         dlogits = dlogits.contiguous().float()
         check(self.lib.rgqa_engine_backward(self.h, ptr(dlogits), dlogits.stride(0), 1 if accumulate else 0, _stream()))
+        self._seg_sumsq_valid = self._seg_sumsq is not None
 
     def backward_pooled(self, dpooled, accumulate=False):
         dpooled = dpooled.contiguous().float()
@@ -225,6 +229,23 @@ class Engine:
         """Makes torch stream `stream` wait until the gradient segment(s) tagged `event` of the last backward are final."""
         check(self.lib.rgqa_engine_wait_grad_event(self.h, event, C.c_void_p(stream.cuda_stream)))
 
+    def enable_segment_sumsq(self, on=True):
+        """Single-GPU training loops: let backward leave sum(g^2) of every gradient segment behind (rgqa_engine_set_grad_sumsq_slots),
+        so adam_step(clip=True) adds ~20 numbers instead of re-reading the gradient arena. Anything that changes the gradients after
+        backward (a data-parallel all-reduce, manual edits) must call invalidate_segment_sumsq()."""
+        if on:
+            n = C.c_int(0)
+            check(self.lib.rgqa_engine_num_grad_segments(self.h, C.byref(n)))
+            self._seg_sumsq = torch.zeros(n.value, dtype=torch.float32, device=self.device)
+            check(self.lib.rgqa_engine_set_grad_sumsq_slots(self.h, ptr(self._seg_sumsq), n.value))
+        else:
+            check(self.lib.rgqa_engine_set_grad_sumsq_slots(self.h, None, 0))
+            self._seg_sumsq = None
+        self._seg_sumsq_valid = False
+
+    def invalidate_segment_sumsq(self):
+        self._seg_sumsq_valid = False
+
     # ------------------------------------------------------------------ optimizer (fused clip + BertAdam over the arena)
     def live_ranges(self):
         b, e = self.dead_range
@@ -241,9 +262,12 @@ class Engine:
             self._sq_ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
         s = _stream()
         rngs = self.live_ranges()
-        if clip:
+        if clip and self._seg_sumsq is not None and self._seg_sumsq_valid:
+            torch.sum(self._seg_sumsq, dim=0, keepdim=True, out=self._sumsq)      # the segments' shares, taken during backward
+        elif clip:
             for i, (a, b) in enumerate(rngs):
                 check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
+        self._seg_sumsq_valid = False
         for a, b in rngs:
             lp = ptr(self.params_lp[a:b]) if self.precision == "bf16" else None     # the kernel re-casts the bf16 copy in the same pass
             check(self.lib.rgqa_bertadam_step(ptr(self.params[a:b]), ptr(self.grads[a:b]), ptr(self.adam_m[a:b]), ptr(self.adam_v[a:b]),

@@ -60,6 +60,8 @@ class GradAllReduce:
         """Call right after the engine's backward returned (its work is enqueued, not necessarily finished)."""
         g = self.e.grads if grads is None else grads
         dist = self.dist
+        if hasattr(self.e, "invalidate_segment_sumsq"):
+            self.e.invalidate_segment_sumsq()          # the norm must come from the REDUCED gradients
         if not self.overlap or not g.is_cuda:
             hs = [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b, _ in self.buckets]
             for h in hs:

@@ -535,3 +535,39 @@ def test_split_k_visual_projection_wgrad():
     assert torch.equal(got[0], got[1])
     ref = Pr[name].grad
     assert float((got[0].cpu() - ref).norm() / ref.norm()) < 8e-2
+
+
+def test_segment_sumsq_matches_full_norm():
+    """rgqa_engine_set_grad_sumsq_slots: the per-segment sums backward leaves behind add up to the sum of squares of the live gradient
+    ranges (what clip_grad_norm_ measures), in both stream configurations; an optimizer step taken from them equals the step taken from
+    the full-arena reduction up to the f32 rounding of the norm."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    B, T, O = 32, 20, 36
+    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=15, min_len=3)
+    lens = [int(v) for v in raw["input_mask"].sum(1)]
+    b = dev(raw)
+    e = make_engine(FULL, "bf16", dropout=0.1)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    e.enable_segment_sumsq(True)
+    for serial in (0, 1):
+        assert L.rgqa_debug_set(2, serial) == 0
+        try:
+            e._seg_sumsq.fill_(-1.0)
+            e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=3, lengths=lens)
+            e.loss_backward(b["target"])
+            torch.cuda.synchronize()
+        finally:
+            L.rgqa_debug_set(2, 0)
+        assert float(e._seg_sumsq.min()) >= 0.0
+        full = float(e.grad_norm().item()) ** 2
+        np.testing.assert_allclose(float(e._seg_sumsq.double().sum()), full, rtol=1e-5)
+    p0 = e.params.clone()
+    e.adam_step(1e-3, max_norm=0.5)                      # uses the slots (valid after loss_backward)
+    p_slots = e.params.clone()
+    e.params.copy_(p0); e.adam_m.zero_(); e.adam_v.zero_()
+    e.invalidate_segment_sumsq()
+    e.adam_step(1e-3, max_norm=0.5)                      # full-arena reduction
+    assert float((e.params - p_slots).abs().max()) <= 1e-6 * float(p0.abs().max()) + 1e-9
+    assert float((p_slots - p0).abs().max()) > 0
