@@ -5,78 +5,126 @@
 
 #define VISN_MAXPOS 8
 
-template <typename T, int NV>
+// PDT = compile-time pos_dim (4 on the GQA path: the projection weights sit in registers as float4) or 0 = run-time pos_dim.
+// Rows are grid-strided so that the per-lane constants (box weights, both LayerNorm affine pairs) are loaded once per wave: with one
+// row per wave and a run-time K loop the kernel issued ~60 scalar-sized global loads per row and ran at 0.4 TB/s.
+template <typename T, int NV, int PDT>
 __global__ __launch_bounds__(256) void visn_fwd_kernel(const T* __restrict__ zf, int ldz, const float* __restrict__ boxes, const float* __restrict__ Wb,
                                                        const float* __restrict__ bb, const float* __restrict__ g1, const float* __restrict__ b1,
                                                        const float* __restrict__ g2, const float* __restrict__ b2, T* __restrict__ out, int ldo,
-                                                       float* __restrict__ stats, int M, int H, int pd, float eps, DropCfg drop) {
+                                                       float* __restrict__ stats, int M, int H, int pd_rt, float eps, DropCfg drop) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= M) return;
     const int nv = H >> 2;
-    float bx[VISN_MAXPOS];
-#pragma unroll
-    for (int c = 0; c < VISN_MAXPOS; ++c) bx[c] = c < pd ? boxes[(size_t)row * pd + c] : 0.f;
-    float x[NV][4], y[NV][4];
-    float sx = 0.f, sy = 0.f;
+    const int pd = PDT ? PDT : pd_rt;
+    constexpr int PDM = PDT ? PDT : VISN_MAXPOS;
+    float W[NV][4][PDM], Bb[NV][4], G1[NV][4], B1[NV][4], G2[NV][4], B2[NV][4];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Bb[i][j] = G1[i][j] = B1[i][j] = G2[i][j] = B2[i][j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < PDM; ++k) W[i][j][k] = 0.f;
+        }
         if (c < nv) {
-            load4(zf + (size_t)row * ldz + c * 4, x[i]);
+            load4(bb + c * 4, Bb[i]); load4(g1 + c * 4, G1[i]); load4(b1 + c * 4, B1[i]); load4(g2 + c * 4, G2[i]); load4(b2 + c * 4, B2[i]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = c * 4 + j;
-                float a = bb[n];
-                for (int k = 0; k < pd; ++k) a = fmaf(bx[k], Wb[(size_t)n * pd + k], a);
-                y[i][j] = a;
-                sx += x[i][j];
-                sy += a;
+                if (PDT == 4) load4(Wb + (size_t)n * 4, W[i][j]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < PDM; ++k) if (k < pd) W[i][j][k] = Wb[(size_t)n * pd + k];
+                }
             }
         }
     }
-    const float mx = wave_sum(sx) / (float)H, my = wave_sum(sy) / (float)H;
-    float qx = 0.f, qy = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        float bx[PDM];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
+        for (int c = 0; c < PDM; ++c) bx[c] = c < pd ? boxes[(size_t)row * pd + c] : 0.f;
+        float x[NV][4], y[NV][4];
+        float sx = 0.f, sy = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { float d = x[i][j] - mx; qx += d * d; float e = y[i][j] - my; qy += e * e; }
-        }
-    }
-    const float rx = rsqrtf(wave_sum(qx) / (float)H + eps), ry = rsqrtf(wave_sum(qy) / (float)H + eps);
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                load4(zf + (size_t)row * ldz + c * 4, x[i]);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            float G1[4], B1[4], G2[4], B2[4], o[4];
-            load4(g1 + c * 4, G1); load4(b1 + c * 4, B1); load4(g2 + c * 4, G2); load4(b2 + c * 4, B2);
+                for (int j = 0; j < 4; ++j) {
+                    float a = Bb[i][j];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = 0.5f * (((x[i][j] - mx) * rx * G1[j] + B1[j]) + ((y[i][j] - my) * ry * G2[j] + B2[j]));
-                o[j] = drop_apply(drop, (uint32_t)row * (uint32_t)H + (uint32_t)(c * 4 + j), v);
+                    for (int k = 0; k < PDM; ++k) a = fmaf(bx[k], W[i][j][k], a);
+                    y[i][j] = a;
+                    sx += x[i][j];
+                    sy += a;
+                }
             }
-            store4(out + (size_t)row * ldo + c * 4, o);
         }
-    }
-    if (lane == 0 && stats) {
-        stats[(size_t)row * 4 + 0] = mx; stats[(size_t)row * 4 + 1] = rx;
-        stats[(size_t)row * 4 + 2] = my; stats[(size_t)row * 4 + 3] = ry;
+        const float mx = wave_sum(sx) / (float)H, my = wave_sum(sy) / (float)H;
+        float qx = 0.f, qy = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { float d = x[i][j] - mx; qx += d * d; float e = y[i][j] - my; qy += e * e; }
+            }
+        }
+        const float rx = rsqrtf(wave_sum(qx) / (float)H + eps), ry = rsqrtf(wave_sum(qy) / (float)H + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.5f * (((x[i][j] - mx) * rx * G1[i][j] + B1[i][j]) + ((y[i][j] - my) * ry * G2[i][j] + B2[i][j]));
+                    o[j] = drop_apply(drop, (uint32_t)row * (uint32_t)H + (uint32_t)(c * 4 + j), v);
+                }
+                store4(out + (size_t)row * ldo + c * 4, o);
+            }
+        }
+        if (lane == 0 && stats) {
+            stats[(size_t)row * 4 + 0] = mx; stats[(size_t)row * 4 + 1] = rx;
+            stats[(size_t)row * 4 + 2] = my; stats[(size_t)row * 4 + 3] = ry;
+        }
     }
 }
 
 // partial layout: part[blk][q][n], q: 0 dg1, 1 db1, 2 dbias_fc, 3 dg2, 4 db2, 5 dbb, 6.. dWb[:,k]
-template <typename T, int NV>
+template <typename T, int NV, int PDT>
 __global__ __launch_bounds__(256) void visn_bwd_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ zf, int ldz, const float* __restrict__ boxes,
                                                        const float* __restrict__ Wb, const float* __restrict__ bb, const float* __restrict__ g1,
                                                        const float* __restrict__ g2, const float* __restrict__ stats, T* __restrict__ dzf, int lddz,
-                                                       float* __restrict__ part, int M, int H, int pd, DropCfg drop, float* __restrict__ dboxes) {
+                                                       float* __restrict__ part, int M, int H, int pd_rt, DropCfg drop, float* __restrict__ dboxes) {
     __shared__ float red[4][NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pd = PDT ? PDT : pd_rt;
     const int nv = H >> 2, nq = 6 + pd;
     float acc[6 + 4][NV][4];   // pos_dim <= 4 accumulated in registers
     float G1[NV][4], G2[NV][4];
+    float W[NV][4][4], Bb[NV][4];   // box projection weights / bias of this lane's columns, loaded once
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Bb[i][j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) W[i][j][k] = 0.f;
+            if (c < nv) {
+                const int n = c * 4 + j;
+                Bb[i][j] = bb[n];
+                if (PDT == 4) load4(Wb + (size_t)n * 4, W[i][j]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < pd) W[i][j][k] = Wb[(size_t)n * pd + k];
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
@@ -108,8 +156,9 @@ __global__ __launch_bounds__(256) void visn_bwd_kernel(const T* __restrict__ dou
                     const int n = c * 4 + j;
                     d[i][j] = 0.5f * drop_apply(drop, (uint32_t)row * (uint32_t)H + (uint32_t)n, dd[j]);
                     xh[i][j] = (zz[j] - mx) * rx;
-                    float a = bb[n];
-                    for (int k = 0; k < pd; ++k) a = fmaf(bx[k], Wb[(size_t)n * pd + k], a);
+                    float a = Bb[i][j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a = fmaf(bx[k], W[i][j][k], a);
                     yh[i][j] = (a - my) * ry;
                     const float gx = d[i][j] * G1[i][j], gy = d[i][j] * G2[i][j];
                     s1 += gx; s2 += gx * xh[i][j]; t1 += gy; t2 += gy * yh[i][j];
@@ -136,8 +185,8 @@ __global__ __launch_bounds__(256) void visn_bwd_kernel(const T* __restrict__ dou
 #pragma unroll
                     for (int k = 0; k < 4; ++k) acc[6 + k][i][j] += dzb * bx[k];
                     if (dboxes) {
-                        const int n = c * 4 + j;
-                        for (int k = 0; k < pd; ++k) dbx[k] = fmaf(dzb, Wb[(size_t)n * pd + k], dbx[k]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dbx[k] = fmaf(dzb, W[i][j][k], dbx[k]);
                     }
                 }
                 store4(dzf + (size_t)row * lddz + c * 4, o);
@@ -177,7 +226,9 @@ int k_visn_combine_fwd(const T* zf, int ldz, const float* boxes, const float* Wb
                        const float* b2, T* out, int ldo, float* stats, int M, int H, int pos_dim, float eps, DropCfg drop, hipStream_t s) {
     RGQA_REQUIRE(H % 4 == 0 && H <= 1024 && pos_dim >= 1 && pos_dim <= 4, "visn_combine: H=%d pos_dim=%d unsupported", H, pos_dim);
     if (M <= 0) return RGQA_OK;
-#define VF(NVV) hipLaunchKernelGGL((visn_fwd_kernel<T, NVV>), dim3(cdiv(M, 4)), dim3(256), 0, s, zf, ldz, boxes, Wb, bb, g1, b1, g2, b2, out, ldo, stats, M, H, pos_dim, eps, drop)
+    const int nblk = cdiv(M, 4) > 1024 ? 1024 : cdiv(M, 4);      // 4 rows (waves) per block, grid-stride
+#define VF(NVV) do { if (pos_dim == 4) hipLaunchKernelGGL((visn_fwd_kernel<T, NVV, 4>), dim3(nblk), dim3(256), 0, s, zf, ldz, boxes, Wb, bb, g1, b1, g2, b2, out, ldo, stats, M, H, pos_dim, eps, drop); \
+                     else hipLaunchKernelGGL((visn_fwd_kernel<T, NVV, 0>), dim3(nblk), dim3(256), 0, s, zf, ldz, boxes, Wb, bb, g1, b1, g2, b2, out, ldo, stats, M, H, pos_dim, eps, drop); } while (0)
     const int nvl = cdiv(H / 4, 64);
     if (nvl <= 1) VF(1); else if (nvl == 2) VF(2); else if (nvl == 3) VF(3); else VF(4);
 #undef VF
@@ -192,7 +243,8 @@ int k_visn_combine_bwd(const T* dout, int lddo, const T* zf, int ldz, const floa
     RGQA_REQUIRE(H % 4 == 0 && H <= 1024 && pos_dim >= 1 && pos_dim <= 4, "visn_combine bwd: H=%d pos_dim=%d unsupported", H, pos_dim);
     if (M <= 0) return RGQA_OK;
     const int nblk = cdiv(M, 4) > 512 ? 512 : cdiv(M, 4);   // 4 rows (waves) per block, grid-stride
-#define VB(NVV) hipLaunchKernelGGL((visn_bwd_kernel<T, NVV>), dim3(nblk), dim3(256), 0, s, dout, lddo, zf, ldz, boxes, Wb, bb, g1, g2, stats, dzf, lddz, part, M, H, pos_dim, drop, dboxes)
+#define VB(NVV) do { if (pos_dim == 4) hipLaunchKernelGGL((visn_bwd_kernel<T, NVV, 4>), dim3(nblk), dim3(256), 0, s, dout, lddo, zf, ldz, boxes, Wb, bb, g1, g2, stats, dzf, lddz, part, M, H, pos_dim, drop, dboxes); \
+                     else hipLaunchKernelGGL((visn_bwd_kernel<T, NVV, 0>), dim3(nblk), dim3(256), 0, s, dout, lddo, zf, ldz, boxes, Wb, bb, g1, g2, stats, dzf, lddz, part, M, H, pos_dim, drop, dboxes); } while (0)
     const int nvl = cdiv(H / 4, 64);
     if (nvl <= 1) VB(1); else if (nvl == 2) VB(2); else if (nvl == 3) VB(3); else VB(4);
 #undef VB
