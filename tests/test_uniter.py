@@ -152,7 +152,7 @@ def test_engine_train_mode_dropout_consistent_between_layouts():
         loss = e.loss_backward(b["target"])
         torch.cuda.synchronize()
         out.append((loss.item(), e.grads.clone()))
-    assert np.isfinite(out[0][0]) and out[0][0] == out[1][0]
+    assert np.isfinite(out[0][0]) and abs(out[0][0] - out[1][0]) <= 1e-6 * abs(out[0][0])      # the scalar loss is an atomic sum over blocks
     live = [sp for sp in e.specs if "_embeddings.weight" not in sp.name]
     for sp in live:
         a, c = out[0][1][sp.offset:sp.offset + sp.numel], out[1][1][sp.offset:sp.offset + sp.numel]
