@@ -10,6 +10,7 @@
 // (64 MFMAs per wave = ~2k cycles per K-step per SIMD), which is what hides the L2/HBM latency that starved
 // the 128x128 register-staged kernel.  Arithmetic intensity 128 FLOP/B of LDS fill vs 64 for the 128x128 tile.
 #include <string.h>
+#include <type_traits>
 #include "gemm.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -746,6 +747,9 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     // MTW = 8: two 64-KiB slots, one K-step in flight (vmcnt(0) + barrier per step, as in the NT kernel).
     issue(0, 0);
     if (NSLOT == 3 && nkt > 1) issue(1, 1);
+    // the bias-gradient MFMA is wave-uniform: two copies of the loop instead of a branch after every fragment's MFMAs
+    auto kloop = [&](auto CS) {
+    constexpr bool DO_CS = decltype(CS)::value;
     for (int kt = 0; kt < nkt; ++kt) {
         const int st = kt % NSLOT;
         if (NSLOT == 3 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[sh][tn], xa, acc[tm][tn], 0, 0, 0);
-                if (do_cs) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa, cs[tm], 0, 0, 0);
+                if (DO_CS) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa, cs[tm], 0, 0, 0);
                 if (i + PD < NF) ring[i % PD] = lda(i + PD);
                 if (sh == 0 && tm == MTW - 3) {
 #pragma unroll
@@ -791,11 +795,13 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[tn], xa, acc[tm][tn], 0, 0, 0);
-                if (do_cs) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa, cs[tm], 0, 0, 0);
+                if (DO_CS) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xa, cs[tm], 0, 0, 0);
             }
         }
 #endif
     }
+    };
+    if (do_cs) kloop(std::true_type{}); else kloop(std::false_type{});
     // chunk 0 -> the gradient (and bias gradient) itself; chunk c >= 1 -> dense f32 partial c-1: [M, N] then the M column sums
     float* Cc = reinterpret_cast<float*>(P.C);
     float* cs_out = P.colsum_out;
