@@ -114,11 +114,18 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
         if (g == 0 && q < Lq && a.lse) a.lse[((size_t)b * a.nh + h) * a.Lq + q] = m + __logf(sum);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
+        {
+            // four consecutive keys of one query row: with an even row length the index is even and one hash serves two elements
+            const uint32_t idx = (uint32_t)(((b * a.nh + h) * a.Lq + q) * a.Lk + kt * 16 + 4 * g);
+            float v[4] = {acc[kt][qt][0] * inv, acc[kt][qt][1] * inv, acc[kt][qt][2] * inv, acc[kt][qt][3] * inv};
+            if ((a.Lk & 1) == 0) drop_apply_vec<4>(dc, idx, v);
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t idx = (uint32_t)(((b * a.nh + h) * a.Lq + q) * a.Lk + kt * 16 + 4 * g + r);
-                acc[kt][qt][r] = drop_apply(dc, idx, acc[kt][qt][r] * inv);
+                for (int r = 0; r < 4; ++r) v[r] = drop_apply(dc, idx + (uint32_t)r, v[r]);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[kt][qt][r] = v[r];
+        }
     }
     // ctx^T[d][q] = sum_key V^T[d][key] P^T[key][q]
     bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + q0 * a.ldo + h * 64;
@@ -224,10 +231,19 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
                 f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
                 s4 = MFMA(kf[kt][0], qf0, s4); s4 = MFMA(kf[kt][1], qf1, s4);
                 dp4 = MFMA(vf[kt][0], of0, dp4); dp4 = MFMA(vf[kt][1], of1, dp4);
+                float keep4[4] = {1.f, 1.f, 1.f, 1.f};
+                {
+                    const uint32_t idx = idx0 + (uint32_t)(q * a.Lk + kt * 16 + 4 * g);
+                    if ((a.Lk & 1) == 0) drop_apply_vec<4>(dc, idx, keep4);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) keep4[r] = drop_apply(dc, idx + (uint32_t)r, 1.0f);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = q < Lq ? __expf(s4[r] * a.scale + mk[kt][r] - lq) : 0.f;
-                    const float keep = drop_apply(dc, idx0 + (uint32_t)(q * a.Lk + kt * 16 + 4 * g + r), 1.0f);
+                    const float keep = keep4[r];
                     const float dp = dp4[r] * keep;
                     delta += p * dp;
                     s4[r] = p; dp4[r] = dp;
