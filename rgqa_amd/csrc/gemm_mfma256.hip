@@ -65,6 +65,8 @@ __device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch
 // -0.18 ms, wgrad ring 3 -0.26 ms, together 13.26 -> 12.81 ms; depth 4 = depth 3 (NT) / spills (wgrad, +9 %); depth 2 within noise of 3.
 // Issuing the next K-step's DMA instructions one or two per fragment slot inside this stream instead of all up front: +8..14 % (step).
 // __builtin_amdgcn_iglp_opt(0 / 1) on the plain loop instead of the ring: +1..3 % against the ring.
+// The next K-step's DMA issued after this step's first fragment reads (behind sched_barriers) instead of before them: 3.3x slower
+// (the compiler then drains vmcnt before the fragment waits).
 #ifndef RGQA_NT_PIPE
 #define RGQA_NT_PIPE 3
 #endif
