@@ -495,7 +495,7 @@ public:
             RGQA_HIP(hipMemcpyAsync(tdesc, tdesc_host.data(), sizeof(TransDesc) * n_tdesc, hipMemcpyHostToDevice, s));
             tdesc_uploaded = true;
         }
-        return k_cast_transpose(P, PbT, tdesc, n_tdesc, tdesc_tiles, s);
+        return k_cast_transpose(Pb, 1, PbT, tdesc, n_tdesc, tdesc_tiles, s);     // from the bf16 copy (the optimizer kernel / sync_weights wrote it): half the read bytes
     }
 
     // ------------------------------------------------------------------ GEMM helpers

@@ -109,7 +109,7 @@ int k_bertadam(const AdamArgs& a, hipStream_t s);
 // dst_t[k][n] = (bf16) src[n][k] for each listed [N,K] matrix; desc on device: {src_off, dst_off, N, K, tile_start}
 #define TRANSPOSE_TILE 64   // tile_start counts cdiv(ld_dst, TRANSPOSE_TILE) * cdiv(K, TRANSPOSE_TILE) tiles per matrix
 struct TransDesc { long src_off, dst_off; int N, K, ld_dst, tile_start; };
-int k_cast_transpose(const float* src, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s);
+int k_cast_transpose(const void* src, int src_is_bf16, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s);
 int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 
 // ---- misc.hip

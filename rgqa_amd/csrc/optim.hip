@@ -105,7 +105,8 @@ int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
 // Batched cast + transpose of every linear weight: dst[k][n] = bf16(src[n][k]); TRANSPOSE_TILE^2 (64x64) tiles through LDS:
 // float4 reads of 256-B row pieces, 8-B writes of full 128-B destination lines (the 32x32 / 2-B-store version ran at 58 % of
 // the copy's byte floor).
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc) {
+template <typename S>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc) {
     constexpr int TT = TRANSPOSE_TILE;
     __shared__ float tile[TT][TT + 1];
     int lo = 0, hi = ndesc - 1;
@@ -121,9 +122,9 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         const int n = n0 + ty + r * 16, k = k0 + tx * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (n < d.N) {
-            const float* sp = src + d.src_off + (size_t)n * d.K + k;
+            const S* sp = src + d.src_off + (size_t)n * d.K + k;
             if (k4 && k + 4 <= d.K) load4(sp, v);
-            else { for (int j = 0; j < 4; ++j) if (k + j < d.K) v[j] = sp[j]; }
+            else { for (int j = 0; j < 4; ++j) if (k + j < d.K) v[j] = to_f32(sp[j]); }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) tile[ty + r * 16][tx * 4 + j] = v[j];
@@ -142,9 +143,11 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         else { for (int j = 0; j < 4; ++j) if (n + j < d.ld_dst) dp[j] = (bf16_t)v[j]; }
     }
 }
-int k_cast_transpose(const float* src, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s) {
+// src: the f32 master weights, or (src_is_bf16) their bf16 copy at the same element offsets - half the bytes to read, same result
+int k_cast_transpose(const void* src, int src_is_bf16, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s) {
     if (ndesc <= 0 || total_tiles <= 0) return RGQA_OK;
-    hipLaunchKernelGGL(cast_transpose_kernel, dim3(total_tiles), dim3(256), 0, s, src, reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc);
+    if (src_is_bf16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc);
+    else hipLaunchKernelGGL(cast_transpose_kernel<float>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const float*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc);
     RGQA_LAUNCH_CHECK("cast_transpose_kernel");
     return RGQA_OK;
 }
