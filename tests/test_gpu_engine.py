@@ -571,3 +571,31 @@ def test_segment_sumsq_matches_full_norm():
     e.adam_step(1e-3, max_norm=0.5)                      # full-arena reduction
     assert float((e.params - p_slots).abs().max()) <= 1e-6 * float(p0.abs().max()) + 1e-9
     assert float((p_slots - p0).abs().max()) > 0
+
+
+def test_full_size_batch_independence_and_roi_permutation():
+    """Size-independent properties at BASELINE's full size (B=256, T=20, 36 RoIs, 9/5/5 layers, bf16, eval):
+    (1) samples are independent - a sample's logits in the batch of 256 equal its logits in a batch of 3 (same per-row arithmetic
+        whatever the tile shapes; packed language rows in both);
+    (2) the encoder has no RoI order: permuting a sample's 36 (feature, box) pairs changes only the order of the attention sums."""
+    B, T, O = 256, 20, 36
+    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=77, min_len=3)
+    lens = [int(v) for v in raw["input_mask"].sum(1)]
+    b = dev(raw)
+    e = make_engine(FULL, "bf16")
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    full = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], lengths=lens)[0].clone()
+    assert bool(torch.isfinite(full).all())
+    pick = [0, 131, 255]
+    sub = {k: v[pick].contiguous() for k, v in b.items()}
+    small = e.forward(sub["feats"], sub["boxes"], sub["input_ids"], sub["input_mask"], sub["segment_ids"], lengths=[lens[i] for i in pick])[0].clone()
+    scale = float(full.abs().max())
+    assert float((small - full[pick]).abs().max()) <= 2e-3 * scale          # observed: bit-equal or last-bit differences of bf16 activations
+    # RoI permutation of every sample
+    perm = torch.stack([torch.randperm(O, generator=torch.Generator().manual_seed(i)) for i in range(B)]).cuda()
+    feats_p = torch.gather(b["feats"], 1, perm[:, :, None].expand(-1, -1, b["feats"].shape[2])).contiguous()
+    boxes_p = torch.gather(b["boxes"], 1, perm[:, :, None].expand(-1, -1, 4)).contiguous()
+    permuted = e.forward(feats_p, boxes_p, b["input_ids"], b["input_mask"], b["segment_ids"], lengths=lens)[0]
+    assert float((permuted - full).abs().max()) <= 3e-2 * scale
+    assert float((permuted - full).abs().mean()) <= 3e-3 * scale
