@@ -272,3 +272,14 @@ def test_gradient_segments_cover_live_arena_once():
     # every bucket waits for the LAST event among the segments it contains
     for b0, b1, ev in buckets:
         assert ev == max(s[2] for s in segs if b0 <= s[0] and s[1] <= b1)
+
+
+def test_bench_profiling_section_has_no_collective():
+    """bench.py profiles kernels on rank 0 only, after the timed region, while the other ranks wait at a barrier: the profiled
+    steps must not contain the gradient all-reduce (that deadlocked every N>1 launch with the default --profile-steps)."""
+    import inspect
+    import bench
+    src = inspect.getsource(bench.main)
+    prof = src[src.index("e.profile(True)"):src.index("e.profile(False)")]
+    assert "step(exchange=False)" in prof and "step()" not in prof
+    assert "if comm is not None and exchange:" in src
