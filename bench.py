@@ -2,6 +2,7 @@
 bf16 MFMA operands / f32 accumulate, synthetic inputs already resident in HBM.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without WORLD_SIZE: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -23,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 FWD_BWD_GFLOP = {20: 30.3388, 30: 37.0403}   # per QA pair, SURVEY.md §8 D3
 PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16, MI355X_MICROARCH.md
+PMC_PROFILE = "r02_pmc_gemm_nt.json"
 FULL = dict(vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9, x_layers=5,
             r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842)
 
@@ -41,8 +43,20 @@ def init_params(e, seed):
             v.fill_(1.0 if ("LayerNorm.weight" in sp.name or "layer_norm.weight" in sp.name or sp.name == "logit_fc.2.weight") else 0.0)
 
 
-def cpu_baseline(T, sample_b, iters):
-    """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this box's host cores."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(T, sample_b, iters, warm=2, extra=True):
+    """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this box's host cores: `warm` untimed +
+    `iters` timed full train steps at B=sample_b (the headline entry), plus SURVEY §8 D4's other cases in `cases`:
+    BASELINE config 1 (B=4 train step) and the B=256 eval forward."""
     from oracle import lxmert_ref as R
     from rgqa_amd import synth
     cfg = R.RefConfig(**FULL)
@@ -56,18 +70,100 @@ def cpu_baseline(T, sample_b, iters):
     for k, shp in R.param_shapes(cfg).items():
         t = torch.randn(shp) * 0.02 if len(shp) > 1 else (torch.ones(shp) if "LayerNorm.weight" in k or "layer_norm.weight" in k else torch.zeros(shp))
         P[k] = t.requires_grad_(True)
-    b = synth.synth_batch(sample_b, T, seed=99)
-    batch = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
     opt = R.BertAdamRef(list(P.values()), lr=1e-5, warmup=0.1, t_total=1000)
-    R.train_step(P, cfg, batch, opt)
-    ts = []
-    for _ in range(iters):
-        t0 = time.time()
-        R.train_step(P, cfg, batch, opt)
-        ts.append(time.time() - t0)
-    t = float(np.median(ts))
-    return dict(value=sample_b / t, unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample="full train step (fwd+BCE+bwd+clip+BertAdam), B=%d T=%d, fp32, %d timed iters, median %.2fs" % (sample_b, T, iters, t))
+
+    def timed(fn, n_warm, n):
+        for _ in range(n_warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    def train_case(bsz, n_warm, n):
+        b = synth.synth_batch(bsz, T, seed=99)
+        batch = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
+        return timed(lambda: R.train_step(P, cfg, batch, opt), n_warm, n)
+
+    t = train_case(sample_b, warm, iters)
+    out = dict(value=sample_b / t, unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port", cpu_model=_cpu_model(),
+               sample="full train step (fwd+BCE+bwd+clip+BertAdam), B=%d T=%d, fp32, %d warm-up + %d timed iters, median %.2fs" % (sample_b, T, warm, iters, t))
+    if extra:
+        cases = {}
+        t4 = train_case(4, 1, 3)
+        cases["train_step_B4"] = dict(value=round(4 / t4, 2), unit="QA-pairs/s", sample="BASELINE config 1: full train step B=4 T=%d, 1 warm-up + 3 timed, median %.2fs" % (T, t4))
+        b = synth.synth_batch(256, T, seed=98)
+        batch = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
+        with torch.no_grad():
+            Pd = {k: v.detach() for k, v in P.items()}
+            te = timed(lambda: R.gqa_forward(Pd, cfg, batch["feats"], batch["boxes"], batch["input_ids"], batch["input_mask"], batch["segment_ids"]), 0, 2)
+        cases["eval_forward_B256"] = dict(value=round(256 / te, 2), unit="QA-pairs/s", sample="eval forward B=256 T=%d, 2 timed, median %.2fs" % (T, te))
+        out["cases"] = cases
+    return out
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this parent - which never touches the GPU, so nothing
+    that has initialised HIP is ever exec'd or forked - starts N fresh rank processes of this same command line with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what lxrt/entry.py:102-103's nn.DataParallel switch is to the reference),
+    relays rank 0's JSON line and returns non-zero when any rank fails (the survivors are then ended by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RGQA_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))     # only rank 0 writes to stdout
+    deadline = time.time() + float(os.environ.get("RGQA_BENCH_LAUNCH_TIMEOUT", "1500"))
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        for pr in list(live):
+            c = pr.poll()
+            if c is not None:
+                live.remove(pr)
+                if c != 0:
+                    rc = c if c > 0 else 1
+        if time.time() > deadline:
+            rc = 124
+        if live and rc == 0:
+            time.sleep(0.05)
+    for pr in live:             # a rank failed (or the launch timed out): end exactly the processes started here
+        pr.terminate()
+    for pr in live:
+        try:
+            pr.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank process failed (exit code %d); %d rank(s) were ended\n" % (rc, len(live)))
+    return rc
+
+
+def launch_check(world, rank, fail_rank):
+    """rehearsal of the launch path without a GPU (tests/test_host.py): rendezvous over gloo, one all-reduce, one JSON line"""
+    import torch.distributed as dist
+    if rank == fail_rank:
+        raise SystemExit(3)
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(t)
+        seen = dist.get_world_size()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "n_ranks_seen": seen, "sum": float(t.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -87,13 +183,19 @@ def main():
     ap.add_argument("--mixup", action="store_true",
                     help="BASELINE config 4: RoI-mixup finetune (gqa_mixup_vis.py:134-181): every loader batch is doubled on the device "
                          "(mixup_v1, Beta(1,5)); the model sees 2x rows per QA pair; value still counts loader QA pairs")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)          # CPU rehearsal of the N-rank launch path
+    ap.add_argument("--launch-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))     # before any torch.cuda / HIP call
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(world, rank, args.launch_check_fail_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda unavailable); there is no CPU path")
     local %= max(1, torch.cuda.device_count())      # rehearsal of N ranks on a box with fewer GPUs (the driver's node has one per rank)
@@ -166,13 +268,13 @@ def main():
     if world == 1 and not args.butd and os.environ.get("RGQA_SEG_SUMSQ", "1") != "0":
         e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
     t_total = 10000
-    state = dict(step=0)
+    state = dict(step=0, lengths=lengths)
 
     def step(exchange=True):
         i = state["step"]
         if args.mixup:
             state["keep"] = mixup_batch()
-        e.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=True, seed=4321 + rank + 1000003 * i, lengths=lengths)
+        e.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=True, seed=4321 + rank + 1000003 * i, lengths=state["lengths"])
         e.loss_backward(dev["target"])
         if comm is not None and exchange:
             comm.all_reduce()
@@ -199,6 +301,39 @@ def main():
         dt = float(tt.item())
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
+    n_ranks_seen = dist.get_world_size() if dist is not None else 1
+
+    def timed_leg(n, **kw):
+        """n more steps, bracketed like the timed region; max over ranks, ms per step"""
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            step(**kw)
+        fence()
+        d = time.perf_counter() - t1
+        if dist is not None:
+            t2 = torch.tensor([d], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            d = float(t2.item())
+        return d / n * 1e3
+
+    # diagnostics outside the timed region (every rank takes part): the step without the gradient exchange -> what the exchange
+    # costs beyond what backward hides; the reference's padded layout (all B*T token positions computed)
+    exposed_comm_ms = None
+    if dist is not None:
+        n2 = max(3, min(args.steps, 10))
+        exposed_comm_ms = round(ms - timed_leg(n2, exchange=False), 3)
+    padded_leg = None
+    if lengths is not None and not (args.butd or args.uniter or args.mixup):
+        n2 = max(3, min(args.steps, 10))
+        state["lengths"] = None
+        for _ in range(2):
+            step()
+        pms = timed_leg(n2)
+        state["lengths"] = lengths
+        step()
+        padded_leg = {"ms_per_step": round(pms, 3), "value": round(B * world / pms * 1e3, 1), "unit": "QA-pairs/s",
+                      "note": "same build, all %d token positions computed as the reference does (bench.py --padded); %d steps outside the timed region" % (MB * T, n2)}
 
     # live roofline of the dominant kernel (the bf16 MFMA NT GEMM): HIP events around every launch, on the launch stream
     roof = None
@@ -216,19 +351,24 @@ def main():
             per_launch_flops = nt["flops"] / nt["launches"]
             avg_ms = nt["ms"] / nt["launches"]
             ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_nt.json")    # separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-            if os.path.exists(pmc) and B == 256 and T == 20 and not (args.mixup or args.uniter or args.butd):
-                traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
+            traffic, traffic_note = None, "no PMC profile for this workload"
+            pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)    # separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), tools/pmc_summary.py
+            if os.path.exists(pmc) and B == 256 and T == 20 and not (args.mixup or args.uniter or args.butd or args.padded):
+                from rgqa_amd.build import source_digest
+                pj = json.load(open(pmc))
+                if pj.get("kernel_source_digest") == source_digest():
+                    traffic, traffic_note = round(pj["traffic_bytes_per_launch"]), "profiles/%s (same kernel sources)" % PMC_PROFILE
+                else:       # the kernels changed since the counters were collected: a stale figure is worse than none
+                    traffic_note = "profiles/%s was collected on other kernel sources (digest mismatch): not reported" % PMC_PROFILE
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", algorithmic_bytes_per_launch=round(nt["bytes"] / nt["launches"]), kernel="gemm_nt (gemm_nt256_kernel / gemm_nt256d_kernel<EPI,MT> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
+                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_note, algorithmic_bytes_per_launch=round(nt["bytes"] / nt["launches"]), kernel="gemm_nt (gemm_nt8p_kernel / gemm_nt256_kernel / gemm_nt256d_kernel<EPI,MT> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
                         avg_launch_us=round(avg_ms * 1e3, 2), gflop_per_launch=round(per_launch_flops / 1e9, 3))
     if dist is not None:
         dist.barrier()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.uniter:
-        cpu = cpu_baseline(T, args.cpu_sample, 2)
+        cpu = cpu_baseline(T, args.cpu_sample, 5)
 
     if rank == 0:
         # UNITER, padded: 12 layers x (56 x 7,077,888 + 2 x 56^2 x 768) MAC + 36 x 2048 x 768 + head = 4.880 GMAC fwd per QA pair; x2 FLOP, x3 fwd+bwd
@@ -244,16 +384,23 @@ def main():
                        "num_answers": 1842, "parallelism": "dp%d" % world, "dropout": 0.1,
                        "language_rows": ("padded: all %d token positions computed" % (MB * T)) if lengths is None else
                                         ("packed: %d real tokens of %d positions (question length ~ U{5..%d}); padding rows are not computed, results identical" % (int(lengths.sum()), MB * T, T))},
-            # FLOPs of the reference's padded computation per second (what the same QA-pairs/s costs the reference) ...
-            "step_model_tflops_per_gpu": round(step_tflops / world, 1),
-            "step_frac_of_bf16_peak": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
+            "n_ranks_seen": n_ranks_seen,
             "roofline": roof, "cpu_baseline": cpu,
+            # NOT a utilisation figure: the FLOPs the REFERENCE's padded computation would need for the same QA-pairs/s
+            # (30.339 GFLOP per QA pair); with packed language rows part of them is never executed here
+            "reference_equivalent_tflops_per_gpu": round(step_tflops / world, 1),
         }
+        if exposed_comm_ms is not None:
+            out["exposed_comm_ms"] = exposed_comm_ms      # step time with the gradient exchange minus without it
+            out["dp_exchange"] = comm.describe() if hasattr(comm, "describe") else "all_reduce"
+        if padded_leg is not None:
+            out["padded_layout"] = padded_leg
         if prof is not None:
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.profile_steps, 3) for k, v in prof.items() if v["launches"]}
-            # ... and the FLOPs the engine actually executed (GEMMs + attention, packed rows) over the measured step time
+            # the utilisation figure: FLOPs the engine actually executed (GEMMs + attention, packed rows) over the measured step time
             ex = sum(v["flops"] for v in prof.values()) / max(1, args.profile_steps)
             out["step_executed_tflops_per_gpu"] = round(ex / (ms * 1e-3) / 1e12, 1)
+            out["step_executed_frac_of_bf16_peak"] = round(ex / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
             if blocks is not None and args.profile_steps > 0:
                 # the block the north-star target names: the five LXRTXLayers (cross-attention + self-attention + FFN of both
                 # modalities, forward + backward incl. their weight gradients): executed GEMM + attention FLOPs over the sum of

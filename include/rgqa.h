@@ -192,6 +192,11 @@ int rgqa_score_rows(const float* logits, int ld, int B, int NA, float temperatur
 /* C[M,N] = A[M,K] W[N,K]^T + bias, epilogue 0 none / 1 gelu / 2 tanh; dtype 0 f32, 1 bf16 (A, W, C all dtype) */
 int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
                    int ldc, int epilogue, int dtype, void* stream);
+/* bf16 only, any epilogue of the grouped NT GEMM (rgqa_amd/csrc/gemm.h GemmEpi: 0 bias, 1 gelu (+ C2 = gelu'), 2 tanh,
+ * 3 dropout(x)+aux, 4 x*aux, 5 x+aux, 7 x*(1-aux^2), 8 relu, 9 dropout(relu), 10 relu/dropout gradient); aux / C2 may be
+ * NULL when the epilogue does not use them.  Kernel parity tests and tools/lab only. */
+int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const void* aux, void* C, void* C2, int M, int N,
+                      int K, int lda, int ldw, int ldc, int ldaux, int epilogue, float drop_p, void* stream);
 /* C[M,N] f32 = A[K,M]^T B[K,N]   (wgrad form); dtype of A and B */
 int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int dtype, void* stream);

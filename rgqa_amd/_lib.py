@@ -37,7 +37,7 @@ SIGNATURES = {
     "rgqa_engine_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _vp],
     "rgqa_engine_loss_backward": [_vp, _vp, _i, _vp, _f, _i, _vp],
     "rgqa_engine_backward": [_vp, _vp, _i, _i, _vp],
-    "rgqa_engine_backward_pooled": [_vp, _vp, _i, _vp],
+    "rgqa_engine_backward_pooled": [_vp, _vp, _i, _i, _vp],
     "rgqa_engine_get_activation": [_vp, C.c_char_p, _vp, _sz, _vp],
     "rgqa_engine_get_cross_attention": [_vp, _i, _i, _vp, _sz, _vp],
     "rgqa_engine_set_lengths": [_vp, _vp, _i],
@@ -54,6 +54,7 @@ SIGNATURES = {
     "rgqa_mixup_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_scale_rows": [_vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rgqa_op_linear_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "rgqa_op_matmul_tn": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rgqa_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
     "rgqa_op_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -33,6 +33,16 @@ def _compile(src, force):
     return obj, True
 
 
+def source_digest():
+    """sha1 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): ties a committed counter profile to the code it measured"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)

@@ -20,6 +20,7 @@ extern int g_rgqa_ablate;
 extern int g_rgqa_tn_mtw;
 extern int g_rgqa_tn_plan;
 extern int g_rgqa_no_deep;
+extern int g_rgqa_nt8p;
 // debug / A-B knobs: key 0 = force the 128x128 GEMM kernel; key 1 = force the LDS-DMA kernel's MT (0 = auto)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -29,6 +30,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 4) { g_rgqa_tn_mtw = value; return RGQA_OK; }
     if (key == 6) { g_rgqa_tn_plan = value; return RGQA_OK; }
     if (key == 5) { g_rgqa_no_deep = value; return RGQA_OK; }
+    if (key == 7) { g_rgqa_nt8p = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }
@@ -193,6 +195,18 @@ int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int
     p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.epi = epilogue;
     RGQA_REQUIRE(epilogue >= 0 && epilogue <= 2, "op_linear: epilogue must be 0..2");
     return dtype == 1 ? launch_gemm_nt_bf16(g, 0, S(stream)) : launch_gemm_f32(g, 0, 0, S(stream));
+}
+// bf16 only: every epilogue of the grouped NT GEMM on one problem (kernel parity tests, tools/lab).  epilogue = GemmEpi value.
+int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const void* aux, void* C, void* C2, int M, int N, int K, int lda, int ldw, int ldc,
+                      int ldaux, int epilogue, float drop_p, void* stream) {
+    RGQA_REQUIRE(epilogue >= 0 && epilogue <= EPI_DRELU_DROP && epilogue != EPI_ACCUM, "op_linear_ex: bad epilogue %d", epilogue);
+    RGQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "op_linear_ex: dropout out of range");
+    GemmGroup g; memset(&g, 0, sizeof g);
+    g.count = 1; g.drop = make_drop(drop_p, 0x1234567ull, 0);
+    GemmProblem& p = g.p[0];
+    p.A = A; p.B = W; p.C = C; p.C2 = C2; p.bias = bias; p.aux = aux; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.ldaux = ldaux;
+    p.epi = epilogue; p.drop_site = 17u;
+    return launch_gemm_nt_bf16(g, 0, S(stream));
 }
 int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {
     GemmGroup g; memset(&g, 0, sizeof g);

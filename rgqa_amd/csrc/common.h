@@ -91,19 +91,22 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float r = 1.0f - p * t * __expf(-ax * ax);
     return copysignf(r, x);
 }
-// gelu(x) and gelu'(x) from one erf / one exp (the exp inside the erf approximation IS the Gaussian pdf term)
+// gelu(x) and gelu'(x) from one erf / one exp (the exp inside the erf approximation IS the Gaussian pdf term).
+// Phi(x) = 1 - h for x >= 0, h for x < 0, with h = 0.5 * erfc(|x|/sqrt 2) = (p(t) * t) * exp(-x^2/2), t = 1/(1 + 0.3275911 |x|/sqrt 2)
+// (Abramowitz-Stegun 7.1.26, coefficients pre-multiplied by 0.5; |error| of Phi <= 8e-8).  v_rcp_f32 (1 ulp) instead of an IEEE
+// division and a select instead of copysign + two FMAs: 17 VALU slots per element against 26 (the GELU epilogue is VALU-bound,
+// ~11 us per 256 x 256 tile with the matrix pipe idle).
 __device__ __forceinline__ void gelu_and_grad_fast(float x, float& g, float& dg) {
-    const float z = x * 0.70710678118654752440f, az = fabsf(z);
-    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __expf(-az * az);                 // exp(-x^2/2)
-    const float erfv = copysignf(1.0f - p * t * e, z);
-    const float cdf = 0.5f * (1.0f + erfv);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));     // exp(-x^2/2)
+    const float h = p * t * e;
+    const float cdf = x >= 0.f ? 1.0f - h : h;
     g = x * cdf;
-    dg = cdf + x * 0.39894228040143267794f * e;
+    dg = fmaf(x, 0.39894228040143267794f * e, cdf);
 }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_fast(float x) {

@@ -20,42 +20,7 @@
 int g_rgqa_ablate = 0;   // rgqa_debug_set key 3
 int g_rgqa_no_deep = 0;  // rgqa_debug_set key 5: 1 = never use the deep-ring single-round variant (A/B)
 
-#define TN 256
-#define TK 64
-#define T256_THREADS 512
-// MT >= 4: persistent tile loop, the epilogue's transpose scratch lives BEHIND the two operand stages (so the next tile's
-// first two K-steps are already being DMA'd while this tile's outputs are converted and stored); 160 KiB of LDS in all.
-// MT == 2 keeps two co-resident 80-KiB blocks per CU (scratch aliases the dead stages, one tile per block).
-#define NT256_PERSIST(MT) ((MT) >= 4)
-#define NT256_TP(MT) ((MT) == 4 ? 2 : ((MT) >= 5 ? 1 : (MT)))
-#define NT256_LDS(MT) (2 * (32 * (MT) * TK * 2 + TN * TK * 2) + (NT256_PERSIST(MT) ? 8 * NT256_TP(MT) * 4096 : 0))
-// MT = 16-row m-tiles per wave (2 waves along M): tile height TM = 32*MT in {64,128,160,192,224,256}; stage = A then W
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void glb_void;
-
-// LDS-DMA issued from inline asm: invisible to hipcc's s_waitcnt bookkeeping, so the compiler does not drain vmcnt(0)
-// in front of every ds_read of a K-step (it cannot prove the reads do not alias the in-flight DMA). Ordering is then
-// entirely ours: counted "s_waitcnt vmcnt(N)" + s_barrier before a stage is read.  lds_dst: wave-uniform LDS byte
-// address of the 1-KiB piece; gsrc: this lane's 16 source bytes. M0 is saved and restored inside the statement.
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(p);
-}
-
-__device__ __forceinline__ int xcd_remap256(int b, int nwg) {
-    int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
-// LDS image of a [rows][64] bf16 operand tile: 128-B rows, 16-B chunk c of row r at r*128 + ((c ^ ((r>>1)&7))<<4).
-// A ds_read_b128 is served per 16-lane group = 16 consecutive rows at one logical chunk: bank slot (mod 256 B) is
-// (r&1)*8 + (c ^ ((r>>1)&7)) - 16 distinct slots, conflict-free.  (c ^ (r&7), used first, repeats every 8 rows at equal
-// parity: a 2-way conflict on every fragment read.)
-__device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+#include "gemm256_dev.h"
 
 // One K-step of MFMAs for a wave's (16*MT) x 64 slice.  RGQA_NT_PIPE / RGQA_TN_PIPE (build-time ring depth, 0 = plain loop): the
 // A fragments come through a register ring PD deep - the LDS read for fragment i+PD is issued right after the MFMAs of fragment i,
@@ -113,103 +78,6 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
 #endif
 }
 
-// ---- shared epilogue of the LDS-DMA NT kernels. The accumulators are transposed through a wave-private LDS region
-// (the operand stages are dead after the last barrier) so that every global access is a full 128-B line: 8 lanes x
-// 16 B per output row, instead of 16 rows x 32 B per store straight out of the MFMA layout (which ran HBM writes
-// at ~1.5-2.4 TB/s).
-template <typename OutT, int EPI, int MT, typename F>
-__device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmProblem& P, unsigned char* lds, int wave, int lane,
-                                               int m0, int n0, int wm, int wn, f32x4 (&acc)[MT][4], F&& after_loads) {
-    const int M = P.M, N = P.N;
-    const int fr = lane & 15, fq = lane >> 4;
-    constexpr int TP = NT256_TP(MT);                    // m-tiles (16 rows) per pass; TP*4 KiB of f32 per wave
-    constexpr bool AUX = (EPI == EPI_RESID_DROP || EPI == EPI_DGELU || EPI == EPI_ADD || EPI == EPI_DTANH || EPI == EPI_DRELU_DROP);
-    unsigned char* wl = lds + wave * (TP * 4096);
-    const int ecol = (lane & 7) * 8, erow = lane >> 3;
-    const int nb = n0 + wn * 64 + ecol;                 // first of this lane's 8 output columns
-    // N % 8 == 0 (eligibility): a lane's 8 columns are all inside or all outside; loads use clamped (always valid) addresses
-    // so that they are branch-free and stay in flight together, only the stores are guarded.
-    const int nbc = nb < N ? nb : N - 8;
-    float bias8[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
-    if (P.bias != nullptr) { load4(P.bias + nbc, bias8); load4(P.bias + nbc + 4, bias8 + 4); }
-    DropCfg dcf = g.drop; dcf.seed_hi ^= P.drop_site;
-    // the whole tile's aux rows (residual / gelu'), coalesced 16 B per lane, in flight before anything else happens
-    uint4 auxv[AUX ? 2 * MT : 1];
-    if (AUX) {
-#pragma unroll
-        for (int it = 0; it < 2 * MT; ++it) {
-            int m = m0 + wm * (16 * MT) + it * 8 + erow; if (m > M - 1) m = M - 1;
-            auxv[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(P.aux) + (size_t)m * P.ldaux + nbc);
-        }
-    }
-    after_loads();      // persistent kernel: the next tile's first K-steps are DMA'd from here on
-#pragma unroll
-    for (int pass = 0; pass < MT / TP; ++pass) {
-#pragma unroll
-        for (int t = 0; t < TP; ++t)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                const int r = t * 16 + fr, c = tn * 4 + fq;
-                *reinterpret_cast<f32x4*>(wl + r * 256 + ((c ^ (r & 15)) << 4)) = acc[pass * TP + t][tn];
-            }
-        // Pin the waits for the (lane-conditional) bias / aux loads HERE, on every path: left to their first use inside the
-        // row guard below, they stay "possibly pending" on the path that skips it, and in the persistent kernel the
-        // compiler then drains vmcnt(0) - our in-flight operand DMA included - before the first ds_read of every K-step.
-        if (pass == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(bias8[j]));
-            if (AUX) {
-#pragma unroll
-                for (int it = 0; it < 2 * MT; ++it) asm volatile("" :: "v"(auxv[it].x), "v"(auxv[it].y), "v"(auxv[it].z), "v"(auxv[it].w));
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 2 * TP; ++it) {
-            const int r = it * 8 + erow;
-            const int m = m0 + wm * (16 * MT) + pass * TP * 16 + r;
-            const int c0 = (lane & 7) * 2;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((c0 ^ (r & 15)) << 4));
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((c0 + 1) ^ (r & 15)) << 4));
-            if (m >= M || nb >= N) continue;
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            float pre[8];
-            const bf16x8 ax = *reinterpret_cast<const bf16x8*>(&auxv[AUX ? pass * 2 * TP + it : 0]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += bias8[j];
-            if (EPI == EPI_RELU || EPI == EPI_RELU_DROP) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            if (EPI == EPI_RESID_DROP || EPI == EPI_RELU_DROP) drop_apply_vec<8>(dcf, (uint32_t)m * (uint32_t)N + (uint32_t)nb, v);   // N % 8 == 0: even index
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float x = v[j];
-                pre[j] = x;
-                if (EPI == EPI_GELU) gelu_and_grad_fast(pre[j], x, pre[j]);      // C = gelu, C2 = gelu' (consumed by EPI_DGELU)
-                else if (EPI == EPI_TANH) x = tanhf(x);
-                else if (EPI == EPI_RESID_DROP) x = x + (float)ax[j];
-                else if (EPI == EPI_DGELU) x = x * (float)ax[j];
-                else if (EPI == EPI_ADD) x = x + (float)ax[j];
-                else if (EPI == EPI_DTANH) x = x * (1.0f - (float)ax[j] * (float)ax[j]);
-                else if (EPI == EPI_DRELU_DROP) x = (float)ax[j] > 0.f ? x * g.drop.scale : 0.f;
-                v[j] = x;
-            }
-            if (sizeof(OutT) == 4) {        // f32 result (the logits GEMM): two 16-B stores per lane, a full 256-B run per 8 lanes
-                float* cf = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + nb;
-                store4(cf, v); store4(cf + 4, v + 4);
-                continue;
-            }
-            bf16x8 o, op;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { o[j] = (bf16_t)v[j]; op[j] = (bf16_t)pre[j]; }
-            bf16_t* cp = reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + nb;
-            *reinterpret_cast<bf16x8*>(cp) = o;
-            if (EPI == EPI_GELU && P.C2 != nullptr) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(P.C2) + (size_t)m * P.ldc + nb) = op;
-        }
-    }
-}
 
 // EPI is a compile-time constant: the generic (run-time switched) epilogue inlined 32x stops the compiler from
 // unrolling the accumulator loops and pushes the 128 accumulators into scratch.
@@ -592,6 +460,10 @@ int launch_gemm_nt256_f32out(GemmGroup& g, hipStream_t s) {
     return RGQA_OK;
 }
 
+bool gemm_nt8p_eligible(const GemmGroup& g);
+int launch_gemm_nt8p_bf16(GemmGroup& g, int mt, hipStream_t s);
+extern int g_rgqa_nt8p;
+
 int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
     long tiles = 0;
     int mt = pick_mt(g, tiles);
@@ -599,6 +471,8 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
     if (g_rgqa_force_mt) mt = g_rgqa_force_mt;
     else if (env_mt) mt = env_mt;
     else mt = tuned_mt(g, mt, s);
+    // 256-row launches (and, in mode 2, every launch) take the phase-interleaved kernel when it is enabled (gemm_nt8p.hip)
+    if (mt >= 5 && gemm_nt8p_eligible(g)) return launch_gemm_nt8p_bf16(g, mt, s);
     return launch256_epi(g, mt, s);
 }
 

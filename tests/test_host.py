@@ -25,6 +25,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.rgqa_version() >= 100
 
 
+def test_ctypes_signatures_match_header_arity():
+    """Every SIGNATURES entry has exactly as many argtypes as the prototype in include/rgqa.h has parameters (a short list
+    still 'works' on x86-64 by accident of the calling convention), and pointer / integer / float classes agree."""
+    import ctypes as C
+    from rgqa_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "rgqa.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = dict(re.findall(r"\b(rgqa_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S))
+    assert len(protos) >= 25
+    for name, args in _lib.SIGNATURES.items():
+        assert name in protos, "%s has a ctypes signature but no prototype in include/rgqa.h" % name
+        params = [a.strip() for a in protos[name].replace("\n", " ").split(",")]
+        if params == ["void"] or params == [""]:
+            params = []
+        assert len(params) == len(args), "%s: header has %d parameters, ctypes signature %d" % (name, len(params), len(args))
+        for prm, ct in zip(params, args):
+            is_ptr = "*" in prm or "[" in prm
+            ct_ptr = ct in (C.c_void_p, C.c_char_p) or hasattr(ct, "contents") or getattr(ct, "_type_", None) is not None and not isinstance(ct._type_, str)
+            assert is_ptr == bool(ct_ptr), "%s: parameter '%s' vs ctypes %s" % (name, prm, ct)
+            if not is_ptr:
+                want_float = re.search(r"\b(float|double)\b", prm) is not None
+                assert want_float == (ct in (C.c_float, C.c_double)), "%s: parameter '%s' vs ctypes %s" % (name, prm, ct)
+
+
 def test_engine_layout_matches_reference_state_dict_contract():
     """Engine parameter table == the reference's GQAModel state_dict keys/shapes (SURVEY.md §8 B4), full 9/5/5 config;
     fused-QKV contiguity and 64-element alignment hold; the dead range is exactly x_layers.4.visn_*."""
@@ -233,6 +257,23 @@ def test_gradient_allreduce_gloo_world2():
         g = res[r]
         assert torch.equal(g[:300], base[:300] * 3) and torch.equal(g[364:], base[364:] * 3)
         assert torch.equal(g[300:364], base[300:364] * (r + 1))
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_is_present():
+    """`python bench.py --gpus N` (the driver's command; WORLD_SIZE unset) starts N rank processes itself: rendezvous over gloo on
+    the CPU, one JSON line from rank 0 with n_ranks_seen == N; a failing rank makes the parent exit non-zero (ADVICE r1, VERDICT r1 #2)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_ranks_seen"] == 2 and out["n_gpus"] == 2 and out["sum"] == 2.0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--launch-check-fail-rank", "1"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_synth_batch_contract():

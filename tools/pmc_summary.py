@@ -4,7 +4,11 @@ FETCH_SIZE is in KiB-like units of 1024 B and, on gfx950, reports half of a wide
 usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rgqa_amd.build import source_digest
 
 
 def per_kernel(path, counter, match):
@@ -23,7 +27,7 @@ def main(fetch_csv, write_csv, out):
     fetch = f * 1024.0 * 2.0 / max(nf, 1)
     write = w * 1024.0 / max(nw, 1)
     res = dict(kernel="gemm_nt (all NT GEMM launches of bench.py, B=256, T=20, packed language rows)", launches_sampled=nf,
-               fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, traffic_bytes_per_launch=fetch + write,
+               kernel_source_digest=source_digest(), fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, traffic_bytes_per_launch=fetch + write,
                note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; x1024 -> bytes; FETCH_SIZE doubled per the gfx950 "
                     "correction for 16-B/lane coalesced streams; WRITE_SIZE as read; Infinity-Cache hits are counted (fabric-side requests)")
     json.dump(res, open(out, "w"), indent=1)
