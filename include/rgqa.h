@@ -152,6 +152,13 @@ int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp 
                        float lr_t, float b1, float b2, float eps, float weight_decay,
                        const float* sumsq /* device scalar or null */, float max_norm, float grad_prescale, void* stream);
 
+/* ---- data-parallel gradient exchange helpers (rgqa_amd/parallel.py; replaces what nn.DataParallel's gather/reduce does at
+ * lxrt/entry.py:102-103).  rgqa_cast_bf16: dst[i] = bf16(src[i]) (the gradient payload that goes on the wire).
+ * rgqa_sum_bf16_parts: dst[i] = sum over r < nparts of f32(parts[r * part_stride + i]), r ascending: the f32 accumulation,
+ * at the rank that owns the range, of the bf16 shards it received from every rank (part_stride % 8 == 0). */
+int rgqa_cast_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+int rgqa_sum_bf16_parts(const void* parts_bf16, size_t part_stride, int nparts, float* dst, size_t n, void* stream);
+
 /* ---- batch construction: replaces the host loop of RoI-mixup (tasks/gqa_mixup_vis.py:134-181).
  * feats [2B,O,F] / boxes [2B,O,4] with rows [0,B) filled; partner [B] i32; take_pos [B,O] u8 (1 = RoI taken from
  * the positive sample). Writes rows [B,2B). */

@@ -51,6 +51,8 @@ SIGNATURES = {
     "rgqa_engine_profile_blocks": [_vp, _vp, _vp, _i],
     "rgqa_grad_sumsq": [_vp, _sz, _vp, _vp, _i, _vp],
     "rgqa_bertadam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _f, _f, _vp],
+    "rgqa_cast_bf16": [_vp, _vp, _sz, _vp],
+    "rgqa_sum_bf16_parts": [_vp, _sz, _i, _vp, _sz, _vp],
     "rgqa_mixup_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_scale_rows": [_vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -178,6 +178,15 @@ int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp,
     a.sumsq = sumsq; a.max_norm = max_norm; a.grad_prescale = grad_prescale;
     return k_bertadam(a, S(stream));
 }
+int rgqa_cast_bf16(const float* src, void* dst_bf16, size_t n, void* stream) {
+    RGQA_REQUIRE(src && dst_bf16, "cast_bf16: null argument");
+    RGQA_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst_bf16 % 8) == 0, "cast_bf16: src must be 16-byte, dst 8-byte aligned");
+    return k_cast_bf16(src, dst_bf16, n, S(stream));
+}
+int rgqa_sum_bf16_parts(const void* parts_bf16, size_t part_stride, int nparts, float* dst, size_t n, void* stream) {
+    RGQA_REQUIRE(parts_bf16 && dst && nparts >= 1, "sum_bf16_parts: bad argument");
+    return k_sum_bf16_parts(parts_bf16, part_stride, nparts, dst, n, S(stream));
+}
 int rgqa_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uint8_t* take_pos, int B, int O, int F, int mode_v3, void* stream) {
     RGQA_REQUIRE(feats && boxes && partner && take_pos, "mixup_gather: null argument");
     return k_mixup_gather(feats, boxes, partner, take_pos, B, O, F, mode_v3, S(stream));

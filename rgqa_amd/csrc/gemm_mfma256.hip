@@ -471,8 +471,17 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
     if (g_rgqa_force_mt) mt = g_rgqa_force_mt;
     else if (env_mt) mt = env_mt;
     else mt = tuned_mt(g, mt, s);
-    // 256-row launches (and, in mode 2, every launch) take the phase-interleaved kernel when it is enabled (gemm_nt8p.hip)
-    if (mt >= 5 && gemm_nt8p_eligible(g)) return launch_gemm_nt8p_bf16(g, mt, s);
+    // The phase-interleaved kernel (gemm_nt8p.hip) keeps 80 KiB of operands in flight instead of <= 64: on cold operands it is 7-13 %
+    // faster than the two-slot kernel at every tile height (tools/lab/gemm_lab: 8192^3 1.39 vs 1.20 PFLOP/s; the encoder's
+    // N = 2304 / 3072 launches -7..-10 %).  IN SITU (activations just written by the previous kernel; rocprofv3 kernel trace of
+    // bench.py, profiles/r02_*): 256- and 224-row tiles tie (+-1 %, +4 % for the DGELU dgrad), 192-row tiles gain 2-6 %, and the
+    // single-round 160-row launches lose 12 % to the deep-ring kernel, which has 104 KiB in flight.  Default (RGQA_NT8P=1): 192-row
+    // tiles only; 2 = every launch of 160..256-row tiles (what a cold / large-K caller wants); 0 = never.
+    if (mt >= 5 && gemm_nt8p_eligible(g)) {
+        static const int env = []() { const char* e = getenv("RGQA_NT8P"); return e ? atoi(e) : 1; }();
+        const int mode = g_rgqa_nt8p >= 0 ? g_rgqa_nt8p : env;
+        if (mode >= 2 || mt == 6) return launch_gemm_nt8p_bf16(g, mt, s);
+    }
     return launch256_epi(g, mt, s);
 }
 

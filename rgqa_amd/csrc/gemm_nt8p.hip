@@ -32,13 +32,27 @@
 #define P8_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-int g_rgqa_nt8p = -1;    // rgqa_debug_set key 7: 1 = use this kernel for every eligible 256-row launch, 0 = never, -1 = env RGQA_NT8P / default
+// diagnostic build only (tools/lab/stamp_lab.cpp defines P8_STAMPS and g_p8_stamps): wave 0 of every block stamps the shader
+// clock (s_memtime) and the 100 MHz wall clock (s_memrealtime) at the phase boundaries of its tiles; nothing reads the stamps
+#ifdef P8_STAMPS
+__device__ unsigned long long* g_p8_stamps;     // [blocks][32][2]
+#define P8_STAMP() do { if (wave == 0 && n_stamp < 32) { unsigned long long* q_ = g_p8_stamps + ((size_t)blockIdx.x * 32 + n_stamp) * 2; \
+        q_[0] = __builtin_amdgcn_s_memtime(); q_[1] = __builtin_amdgcn_s_memrealtime(); } ++n_stamp; } while (0)
+// interval accounting (waves 0 and 4): cycles from interval start to "my part is done" (work) and from there to the barrier's release (wait)
+#define P8_T() __builtin_amdgcn_s_memtime()
+#define P8_ACC(slot) do { const unsigned long long n_ = P8_T(); iv[slot] += n_ - t_prev; t_prev = n_; } while (0)
+#else
+#define P8_STAMP() do { } while (0)
+#define P8_ACC(slot) do { } while (0)
+#endif
+
+int g_rgqa_nt8p = -1;    // rgqa_debug_set key 7: 2 = every eligible launch of 160..256-row tiles, 1 = 192-row tiles only, 0 = never, -1 = env RGQA_NT8P (default 1); 3 = as 2 with the balanced read schedule (A/B builds)
 
 // one wave's share of an A unit of 8*RW rows: rows RW*w .. RW*w+RW-1, moved by two LDS-DMA instructions of R1 and RW-R1 rows
 // (8 + 8, 8 + 4 or 4 + 4; the short ones run with the upper lanes masked off), so every unit costs every wave two vmcnt slots
 template <int RW> struct P8Split { static constexpr int R1 = RW >= 12 ? 8 : 4; static constexpr int R2 = RW - R1; };
 
-template <typename OutT, int EPI, int MT>
+template <typename OutT, int EPI, int MT, int P8_BALANCED>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup g) {
     constexpr int MA0 = (MT + 1) / 2, MA1 = MT / 2, TM = 32 * MT;
     constexpr int RW0 = 4 * MA0, RW1 = 4 * MA1;
@@ -52,14 +66,22 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
     const int lch = (lane & 7) ^ (((wave & 1) << 2) + (lrow >> 1));
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     const int nblk = (int)gridDim.x;
+#ifdef P8_STAMPS
+    int n_stamp = 0;
+    unsigned long long iv[4] = {0, 0, 0, 0}, t_prev = 0;      // read work, read-barrier wait, MFMA issue, MFMA-barrier wait
+#endif
+    P8_STAMP();                                     // 0: entry
 
-    // ---- issue cursor: the (tile, K-tile) whose units are being requested
+    // ---- issue cursor: the (tile, K-tile) whose units are being requested.  Sources = wave-uniform base of the tile's operand
+    // panel at the cursor's K-tile (SGPRs, advanced by 128 B per K-tile) + per-lane byte offsets (row clamped to the matrix, swizzled chunk)
     int i_vt = blockIdx.x, i_kt = 0, i_nkt = 0;
-    const bf16_t* asrc[2][2];     // [U0 | U3][instruction]
-    const bf16_t* wsrc[2][2];     // [U1 | U2][piece]
-    auto a_ptr = [&](const GemmProblem& P, int m0, int ur, int rows_per_wr, int sub_off) {      // unit row -> source row, swizzled chunk
-        int am = m0 + (ur / rows_per_wr) * (16 * MT) + sub_off + (ur % rows_per_wr); if (am > P.M - 1) am = P.M - 1;   // rows past the edge are never stored
-        return reinterpret_cast<const bf16_t*>(P.A) + (size_t)am * P.lda + (((lane & 7) ^ ((ur >> 1) & 7)) << 3);
+    unsigned aoff[2][2];          // [U0 | U3][instruction]
+    unsigned woff[2][2];          // [U1 | U2][piece]
+    const unsigned char* sA = nullptr;
+    const unsigned char* sW = nullptr;
+    auto a_off = [&](const GemmProblem& P, int m0, int ur, int rows_per_wr, int sub_off) {      // unit row -> tile row (clamped), swizzled chunk
+        int r = (ur / rows_per_wr) * (16 * MT) + sub_off + (ur % rows_per_wr); if (r > P.M - 1 - m0) r = P.M - 1 - m0;   // rows past the edge are never stored
+        return (unsigned)(r * P.lda * 2 + (((lane & 7) ^ ((ur >> 1) & 7)) << 4));
     };
     auto locate_issue = [&](int vt) {
         const int tile = xcd_remap256(vt, g.total_tiles);
@@ -71,36 +93,37 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
         const int local = tile - P.tile_start;
         const int m0 = (local / P.tiles_n) * TM, n0 = (local % P.tiles_n) * 256;
         i_nkt = P.K / TK;
-        const bf16_t* W = reinterpret_cast<const bf16_t*>(P.B);
-        asrc[0][0] = a_ptr(P, m0, RW0 * wave + lrow, 16 * MA0, 0);
-        asrc[0][1] = a_ptr(P, m0, RW0 * wave + P8Split<RW0>::R1 + lrow, 16 * MA0, 0);
-        asrc[1][0] = a_ptr(P, m0, RW1 * wave + lrow, 16 * MA1, 16 * MA0);
-        asrc[1][1] = a_ptr(P, m0, RW1 * wave + P8Split<RW1>::R1 + lrow, 16 * MA1, 16 * MA0);
+        sA = reinterpret_cast<const unsigned char*>(P.A) + (size_t)m0 * P.lda * 2;
+        sW = reinterpret_cast<const unsigned char*>(P.B) + (size_t)n0 * P.ldb * 2;
+        aoff[0][0] = a_off(P, m0, RW0 * wave + lrow, 16 * MA0, 0);
+        aoff[0][1] = a_off(P, m0, RW0 * wave + P8Split<RW0>::R1 + lrow, 16 * MA0, 0);
+        aoff[1][0] = a_off(P, m0, RW1 * wave + lrow, 16 * MA1, 16 * MA0);
+        aoff[1][1] = a_off(P, m0, RW1 * wave + P8Split<RW1>::R1 + lrow, 16 * MA1, 16 * MA0);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) {
-                int wn_ = n0 + (pc * 2 + (wave >> 2)) * 64 + u * 32 + (wave & 3) * 8 + lrow; if (wn_ > P.N - 1) wn_ = P.N - 1;
-                wsrc[u][pc] = W + (size_t)wn_ * P.ldb + lch * 8;
+                int r = (pc * 2 + (wave >> 2)) * 64 + u * 32 + (wave & 3) * 8 + lrow; if (r > P.N - 1 - n0) r = P.N - 1 - n0;
+                woff[u][pc] = (unsigned)(r * P.ldb * 2 + lch * 16);
             }
     };
     auto advance = [&]() {      // next K-tile of this block's stream; past the last tile the last K-tile is re-requested (into dead units)
-        if (i_kt + 1 < i_nkt) { ++i_kt; return; }
+        if (i_kt + 1 < i_nkt) { ++i_kt; sA += TK * 2; sW += TK * 2; return; }
         const int nvt = i_vt + nblk;
         if (nvt < g.total_tiles) { i_vt = nvt; i_kt = 0; locate_issue(nvt); }
     };
     auto issue_a = [&](int u, unsigned dst) {
         if (u == 0) {
-            if (P8Split<RW0>::R1 == 8 || lrow < P8Split<RW0>::R1) dma16(asrc[0][0] + i_kt * TK, dst + (RW0 * wave) * 128);
-            if (P8Split<RW0>::R2 == 8 || lrow < P8Split<RW0>::R2) dma16(asrc[0][1] + i_kt * TK, dst + (RW0 * wave + P8Split<RW0>::R1) * 128);
+            if (P8Split<RW0>::R1 == 8 || lrow < P8Split<RW0>::R1) dma16o(aoff[0][0], sA, dst + (RW0 * wave) * 128);
+            if (P8Split<RW0>::R2 == 8 || lrow < P8Split<RW0>::R2) dma16o(aoff[0][1], sA, dst + (RW0 * wave + P8Split<RW0>::R1) * 128);
         } else {
-            if (P8Split<RW1>::R1 == 8 || lrow < P8Split<RW1>::R1) dma16(asrc[1][0] + i_kt * TK, dst + (RW1 * wave) * 128);
-            if (P8Split<RW1>::R2 == 8 || lrow < P8Split<RW1>::R2) dma16(asrc[1][1] + i_kt * TK, dst + (RW1 * wave + P8Split<RW1>::R1) * 128);
+            if (P8Split<RW1>::R1 == 8 || lrow < P8Split<RW1>::R1) dma16o(aoff[1][0], sA, dst + (RW1 * wave) * 128);
+            if (P8Split<RW1>::R2 == 8 || lrow < P8Split<RW1>::R2) dma16o(aoff[1][1], sA, dst + (RW1 * wave + P8Split<RW1>::R1) * 128);
         }
     };
     auto issue_w = [&](int u, unsigned dst) {
-        dma16(wsrc[u][0] + i_kt * TK, dst + wave * 1024);
-        dma16(wsrc[u][1] + i_kt * TK, dst + (wave + 8) * 1024);
+        dma16o(woff[u][0], sW, dst + wave * 1024);
+        dma16o(woff[u][1], sW, dst + (wave + 8) * 1024);
     };
 
     // ---- compute cursor
@@ -132,6 +155,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
     issue_a(0, lds0 + P8_BUF + 0 * P8_UNIT); issue_w(0, lds0 + P8_BUF + 1 * P8_UNIT); issue_w(1, lds0 + P8_BUF + 2 * P8_UNIT);
     P8_WAIT(10);                                    // U0, U1 of K-tile 0 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
+    P8_STAMP();                                     // 1: first units landed
     if (wr == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run one interval behind waves 0-3
 
     int vk = 0;                                     // K-tiles consumed so far (buffer = vk & 1)
@@ -142,11 +166,15 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        bf16x8 a0[MA0][2];                         // P8_BALANCED: carried across K-tiles (read one phase early)
+#ifdef P8_STAMPS
+        t_prev = P8_T();
+#endif
         for (int kt = 0; kt < c_nkt; ++kt, ++vk) {
             const int b = vk & 1;
             const unsigned char* buf = lds + b * P8_BUF;
             const unsigned cur = lds0 + b * P8_BUF, oth = lds0 + (b ^ 1) * P8_BUF;
-            bf16x8 a0[MA0][2], a1[MA1][2], w0[2][2], w1[2][2];
+            bf16x8 a1[MA1][2], w0[2][2], w1[2][2];
             // ---------------- phase 1: quadrant (0,0)
             issue_a(1, oth + 3 * P8_UNIT);          // U3 of K-tile vk+1
 #pragma unroll
@@ -154,14 +182,18 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) w0[tn][ks] = ldw(buf, 0, tn, ks);
             __builtin_amdgcn_sched_barrier(0);
+            if (!P8_BALANCED || kt == 0) {          // balanced: only a tile's first K-tile reads its U0 here, the others did in phase 4
 #pragma unroll
-            for (int tm = 0; tm < MA0; ++tm)
+                for (int tm = 0; tm < MA0; ++tm)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) a0[tm][ks] = lda(buf, 0, tm, ks);
+                    for (int ks = 0; ks < 2; ++ks) a0[tm][ks] = lda(buf, 0, tm, ks);
+            }
             P8_WAIT(10);                            // U2 of this K-tile
             P8_LGKM0();
             __builtin_amdgcn_sched_barrier(0);
+            P8_ACC(0);
             __builtin_amdgcn_s_barrier();
+            P8_ACC(1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -171,7 +203,9 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
                     for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[tn][ks], a0[tm][ks], acc[tm][tn], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            P8_ACC(2);
             __builtin_amdgcn_s_barrier();
+            P8_ACC(3);
             // ---------------- phase 2: quadrant (0,1)
             advance();
             issue_a(0, cur + 0 * P8_UNIT);          // U0 of K-tile vk+2
@@ -182,7 +216,9 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
             P8_WAIT(10);                            // U3 of this K-tile
             P8_LGKM0();
             __builtin_amdgcn_sched_barrier(0);
+            P8_ACC(0);
             __builtin_amdgcn_s_barrier();
+            P8_ACC(1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -192,16 +228,21 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
                     for (int tn = 0; tn < 2; ++tn) acc[tm][2 + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[tn][ks], a0[tm][ks], acc[tm][2 + tn], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            P8_ACC(2);
             __builtin_amdgcn_s_barrier();
+            P8_ACC(3);
             // ---------------- phase 3: quadrant (1,1)
             issue_w(0, cur + 1 * P8_UNIT);          // U1 of K-tile vk+2
 #pragma unroll
             for (int tm = 0; tm < MA1; ++tm)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) a1[tm][ks] = lda(buf, 1, tm, ks);
+            if (P8_BALANCED) P8_WAIT(10);           // U0 of K-tile vk+1 (read in phase 4)
             P8_LGKM0();
             __builtin_amdgcn_sched_barrier(0);
+            P8_ACC(0);
             __builtin_amdgcn_s_barrier();
+            P8_ACC(1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -211,12 +252,29 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
                     for (int tn = 0; tn < 2; ++tn) acc[MA0 + tm][2 + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[tn][ks], a1[tm][ks], acc[MA0 + tm][2 + tn], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            P8_ACC(2);
             __builtin_amdgcn_s_barrier();
+            P8_ACC(3);
             // ---------------- phase 4: quadrant (1,0)
             issue_w(1, cur + 2 * P8_UNIT);          // U2 of K-tile vk+2
-            P8_WAIT(10);                            // U0, U1 of K-tile vk+1
+            P8_WAIT(10);                            // U0, U1 of K-tile vk+1 (balanced: U1; U0 was waited for in phase 3)
+            // P8_BALANCED spreads the fragment reads 4 / 4 / 8 / 8 over the phases instead of 12 / 4 / 8 / 0.  Measured (tools/lab, A/B in one
+            // process): no gain, -1..+7 % - the read intervals are long because of the two LDS-DMA issues (~100-180 cycles each
+            // beside fragment reads), not because of phase 1's read burst; kept for A/B builds only (-DP8_AB_BUILD).
+            if (P8_BALANCED) {
+                if (kt + 1 < c_nkt) {
+                    const unsigned char* nbuf = lds + (b ^ 1) * P8_BUF;
+#pragma unroll
+                    for (int tm = 0; tm < MA0; ++tm)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) a0[tm][ks] = lda(nbuf, 0, tm, ks);
+                }
+                P8_LGKM0();
+            }
             __builtin_amdgcn_sched_barrier(0);
+            P8_ACC(0);
             __builtin_amdgcn_s_barrier();
+            P8_ACC(1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -226,23 +284,35 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
                     for (int tn = 0; tn < 2; ++tn) acc[MA0 + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[tn][ks], a1[tm][ks], acc[MA0 + tm][tn], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            P8_ACC(2);
             __builtin_amdgcn_s_barrier();
+            P8_ACC(3);
         }
         // ---- tile done: re-align the two groups, convert + store (no barriers inside), stagger again
+        P8_STAMP();                                 // 2 + 3i: K loop of tile i done (wave 0)
         if (wr == 0) __builtin_amdgcn_s_barrier();
+        P8_STAMP();                                 // 3 + 3i: groups re-aligned
         const int nvt = c_vt + nblk;
         const bool more = nvt < g.total_tiles;
         nt256_epilogue<OutT, EPI, MT>(g, g.p[c_pi], lds + P8_EPI_OFF, wave, lane, c_m0, c_n0, wr, wc, acc, []() {});
+        P8_STAMP();                                 // 4 + 3i: epilogue issued (stores may still be in flight)
         if (!more) break;
         c_vt = nvt;
         locate_compute(nvt);
         if (wr == 1) __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing may land in LDS after this block has released it
+    P8_STAMP();                                     // last: everything drained
+#ifdef P8_STAMPS
+    if ((wave == 0 || wave == 4) && lane == 0) {
+        unsigned long long* q = g_p8_stamps + 256 * 32 * 2 + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 4;
+        q[0] = iv[0]; q[1] = iv[1]; q[2] = iv[2]; q[3] = iv[3];
+    }
+#endif
 }
 
 bool gemm_nt8p_eligible(const GemmGroup& g) {
-    static const int env = []() { const char* e = getenv("RGQA_NT8P"); return e ? atoi(e) : 0; }();
+    static const int env = []() { const char* e = getenv("RGQA_NT8P"); return e ? atoi(e) : 1; }();     // default on
     const int mode = g_rgqa_nt8p >= 0 ? g_rgqa_nt8p : env;
     if (mode <= 0) return false;
     for (int i = 0; i < g.count; ++i)
@@ -250,11 +320,11 @@ bool gemm_nt8p_eligible(const GemmGroup& g) {
     return true;
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, int BAL>
 static int launch8p(GemmGroup& g, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<bf16_t, EPI, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<bf16_t, EPI, MT, BAL>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
         attr_set = true;
     }
     gemm_group_finalize(g, 32 * MT, TN);
@@ -263,18 +333,27 @@ static int launch8p(GemmGroup& g, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     ncu &= ~7; if (ncu < 8) ncu = 8;
     const int grid = g.total_tiles < ncu ? g.total_tiles : ncu;
-    hipLaunchKernelGGL((gemm_nt8p_kernel<bf16_t, EPI, MT>), dim3(grid), dim3(T256_THREADS), P8_LDS, s, g);
+    hipLaunchKernelGGL((gemm_nt8p_kernel<bf16_t, EPI, MT, BAL>), dim3(grid), dim3(T256_THREADS), P8_LDS, s, g);
     RGQA_LAUNCH_CHECK("gemm_nt8p_kernel");
     return RGQA_OK;
 }
 
 template <int EPI>
 static int launch8p_mt(GemmGroup& g, int mt, hipStream_t s) {
+#ifdef P8_AB_BUILD      // lab builds carry both read schedules (g_rgqa_nt8p == 3 selects the balanced one)
+    if (g_rgqa_nt8p == 3)
+        switch (mt) {
+            case 8: return launch8p<EPI, 8, 1>(g, s);
+            case 7: return launch8p<EPI, 7, 1>(g, s);
+            case 6: return launch8p<EPI, 6, 1>(g, s);
+            default: return launch8p<EPI, 5, 1>(g, s);
+        }
+#endif
     switch (mt) {
-        case 8: return launch8p<EPI, 8>(g, s);
-        case 7: return launch8p<EPI, 7>(g, s);
-        case 6: return launch8p<EPI, 6>(g, s);
-        default: return launch8p<EPI, 5>(g, s);
+        case 8: return launch8p<EPI, 8, 0>(g, s);
+        case 7: return launch8p<EPI, 7, 0>(g, s);
+        case 6: return launch8p<EPI, 6, 0>(g, s);
+        default: return launch8p<EPI, 5, 0>(g, s);
     }
 }
 

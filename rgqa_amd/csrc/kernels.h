@@ -111,6 +111,7 @@ int k_bertadam(const AdamArgs& a, hipStream_t s);
 struct TransDesc { long src_off, dst_off; int N, K, ld_dst, tile_start; };
 int k_cast_transpose(const void* src, int src_is_bf16, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s);
 int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+int k_sum_bf16_parts(const void* parts, size_t stride, int nparts, float* dst, size_t n, hipStream_t s);
 
 // ---- misc.hip
 // RoI-mixup gather (gqa_mixup_vis.py:134-181): rows [B,2B) of feats/boxes built from partner + positive rows

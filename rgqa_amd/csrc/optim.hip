@@ -102,6 +102,36 @@ int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
     return RGQA_OK;
 }
 
+// Data-parallel exchange (rgqa_amd/parallel.py): dst[i] = sum_r f32(parts[r * stride + i]), r ascending (f32 accumulation of the
+// bf16 gradient shards every rank received for the range it owns - deterministic, unlike an in-network bf16 reduction)
+__global__ __launch_bounds__(256) void sum_bf16_parts_kernel(const bf16_t* __restrict__ parts, size_t stride, int nparts, float* __restrict__ dst, size_t n) {
+    const size_t nv = n >> 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < nparts; ++r) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(parts + (size_t)r * stride + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+        store4(dst + i * 8, acc); store4(dst + i * 8 + 4, acc + 4);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+        const size_t i = (nv << 3) + threadIdx.x;
+        float a = 0.f;
+        for (int r = 0; r < nparts; ++r) a += (float)parts[(size_t)r * stride + i];
+        dst[i] = a;
+    }
+}
+int k_sum_bf16_parts(const void* parts, size_t stride, int nparts, float* dst, size_t n, hipStream_t s) {
+    if (n == 0) return RGQA_OK;
+    RGQA_REQUIRE(((uintptr_t)parts % 16) == 0 && ((uintptr_t)dst % 16) == 0 && (stride % 8) == 0, "sum_bf16_parts: 16-byte alignment / stride %% 8 required");
+    size_t nb = (n / 8 + 255) / 256;
+    int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
+    hipLaunchKernelGGL(sum_bf16_parts_kernel, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(parts), stride, nparts, dst, n);
+    RGQA_LAUNCH_CHECK("sum_bf16_parts_kernel");
+    return RGQA_OK;
+}
+
 // Batched cast + transpose of every linear weight: dst[k][n] = bf16(src[n][k]); TRANSPOSE_TILE^2 (64x64) tiles through LDS:
 // float4 reads of 256-B row pieces, 8-B writes of full 128-B destination lines (the 32x32 / 2-B-store version ran at 58 % of
 // the copy's byte floor).

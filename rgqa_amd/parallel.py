@@ -1,18 +1,29 @@
-"""Data parallelism: one process per GPU, gradients of the flat arena all-reduced over RCCL/xGMI
-(torch.distributed backend "nccl" == RCCL on ROCm; "gloo" in the CPU / single-GPU tests).
+"""Data parallelism: one process per GPU, the gradient arena exchanged over RCCL/xGMI (torch.distributed backend "nccl" == RCCL
+on ROCm; "gloo" in the CPU / single-GPU tests).
 
-Replaces the reference's single-process nn.DataParallel (lxrt/entry.py:102-103): samples are independent through the
-whole forward, so each rank runs its own shard and the only exchange is a SUM all-reduce of the
-gradient arena per step, with the 1/world average folded into the optimizer kernel's grad_prescale.
+Replaces the reference's single-process nn.DataParallel (lxrt/entry.py:102-103): samples are independent through the whole
+forward, so each rank runs its own shard of the batch and the only exchange per step is the gradient arena.
+Three modes (`make_exchange`, env RGQA_DP_MODE):
 
-The exchange overlaps with backward: the engine finalises the arena range by range (head first, embeddings last) and
-records an event per range; buckets of adjacent ranges are all-reduced from a side stream that waits on those events,
-so only the last bucket (embeddings + visual embedding, ~125 MB) is exposed. xGMI is point-to-point, so buckets are
-kept large (>= ~64 MB). Parameters of the final x-layer's visn branch never receive gradients in mode 'x' and are in no
-bucket (a DDP that waited for them would hang; exchanging them would waste 28 MB per step)."""
+  allreduce        f32 SUM all-reduce of the live arena ranges (819 MB), buckets of >= 64 MB issued from a side stream as backward
+                   finalises them; every rank then clips and runs BertAdam over the whole arena (round 1).
+  allreduce_bf16   the same exchange with a bf16 payload (410 MB): cast -> SUM all-reduce -> back to f32.
+  sharded          (default) reduce-scatter as ONE all-to-all per chunk with a bf16 payload: rank r receives every rank's bf16 copy
+                   of the 1/N range it owns and accumulates them in f32 in rank order (rgqa_sum_bf16_parts: deterministic, no
+                   bf16 running sum); clip + BertAdam then touch only that 1/N (sum(g^2) of the shards is one scalar
+                   all-reduce), and the updated bf16 weights are all-gathered into every rank's forward copy.  On the 8-GPU xGMI
+                   mesh an all-to-all uses all 7 links of a GPU at once, the wire carries 2 x 7/8 x 410 MB per GPU per step
+                   instead of 2 x 7/8 x 819 MB, and the optimizer's 6 GB of HBM traffic shrinks 8x.  The f32 master copy of a
+                   range is current only on its owner: `gather_master()` refreshes all of them (checkpoints, state_dict).
+
+The dead range (x_layers.<last>.visn_*: never receives gradients in mode 'x') is in no bucket.  The exchange entry points
+return immediately; ordering is by streams and events, never by host synchronisation."""
+import ctypes as C
 import os
 
 import torch
+
+from ._lib import check, ptr
 
 
 def bucket_ranges(ranges, bucket_elems):
@@ -44,35 +55,232 @@ def merge_segments(segs, min_elems):
     return sorted(done, key=lambda c: c[2])
 
 
+def shard_layout(ranges, world, chunk_elems, align=8):
+    """The sharded mode's partition of the live arena: every (a, b) range is cut into chunks of at most chunk_elems elements,
+    every chunk into `world` parts of S = ceil(len / world / align) * align elements (the last parts of a ragged chunk are
+    short or empty).  Returns [(a, b, S)]; rank r owns [a + r*S, min(a + (r+1)*S, b)) of each chunk."""
+    out = []
+    for a, b in bucket_ranges(ranges, chunk_elems):
+        n = b - a
+        s = -(-n // world)
+        s = -(-s // align) * align
+        out.append((a, b, s))
+    return out
+
+
+def owned(chunk, rank):
+    a, b, s = chunk
+    lo = min(a + rank * s, b)
+    return lo, min(lo + s, b)
+
+
+class _HipOps:
+    """The exchange's local arithmetic on the engine's device, through the C ABI."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    @staticmethod
+    def _s():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def cast_bf16(self, dst, src):
+        check(self.lib.rgqa_cast_bf16(ptr(src), ptr(dst), src.numel(), self._s()))
+
+    def sum_parts(self, dst, parts, stride, nparts):
+        check(self.lib.rgqa_sum_bf16_parts(ptr(parts), stride, nparts, ptr(dst), dst.numel(), self._s()))
+
+
 class GradAllReduce:
-    def __init__(self, engine, dist, bucket_mb=64, overlap=None):
-        self.e, self.dist = engine, dist
+    """modes 'allreduce' / 'allreduce_bf16'"""
+
+    def __init__(self, engine, dist, bucket_mb=64, overlap=None, bf16=False, ops=None):
+        self.e, self.dist, self.bf16 = engine, dist, bf16
+        self.ops = ops if ops is not None else _HipOps(engine.lib)
         if overlap is None:
             overlap = os.environ.get("RGQA_DP_OVERLAP", "1") != "0"
         self.overlap = overlap and hasattr(engine, "grad_segments")
         if self.overlap:
             self.buckets = merge_segments(engine.grad_segments(), bucket_mb * (1 << 20) // 4)
-            self.side = None
         else:
             self.buckets = [(a, b, -1) for a, b in bucket_ranges(engine.live_ranges(), 256 * (1 << 20) // 4)]
+        self.side = None
+        self._stage = None
+
+    def describe(self):
+        return "%s, %d buckets, %s" % ("allreduce_bf16" if self.bf16 else "allreduce", len(self.buckets), "overlapped with backward" if self.overlap else "after backward")
+
+    def _reduce_bucket(self, g, a, b):
+        dist = self.dist
+        if not self.bf16:
+            return dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True), None
+        st = self._stage[a:b]
+        self.ops.cast_bf16(st, g[a:b])
+        return dist.all_reduce(st, op=dist.ReduceOp.SUM, async_op=True), (a, b)
 
     def all_reduce(self, grads=None):
         """Call right after the engine's backward returned (its work is enqueued, not necessarily finished)."""
         g = self.e.grads if grads is None else grads
-        dist = self.dist
         if hasattr(self.e, "invalidate_segment_sumsq"):
             self.e.invalidate_segment_sumsq()          # the norm must come from the REDUCED gradients
-        if not self.overlap or not g.is_cuda:
-            hs = [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b, _ in self.buckets]
-            for h in hs:
-                h.wait()
-            return
-        if self.side is None:
-            self.side = torch.cuda.Stream(device=g.device)
+        if self.bf16 and self._stage is None:
+            self._stage = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device)
         hs = []
-        for a, b, ev in self.buckets:
-            with torch.cuda.stream(self.side):
-                self.e.wait_grad_event(ev, self.side)
-                hs.append(dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True))
-        for h in hs:
+        if not self.overlap or not g.is_cuda:
+            hs = [self._reduce_bucket(g, a, b) for a, b, _ in self.buckets]
+        else:
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=g.device)
+            for a, b, ev in self.buckets:
+                with torch.cuda.stream(self.side):
+                    self.e.wait_grad_event(ev, self.side)
+                    hs.append(self._reduce_bucket(g, a, b))
+        for h, back in hs:
             h.wait()        # the CURRENT stream waits for the collective; no host synchronisation
+            if back is not None:
+                g[back[0]:back[1]].copy_(self._stage[back[0]:back[1]])
+
+    exchange = all_reduce
+
+    def step(self, lr_t, **kw):
+        """clip + BertAdam over the whole (identical) arena on every rank"""
+        self.e.adam_step(lr_t, grad_prescale=1.0 / self.dist.get_world_size(), **kw)
+
+    def gather_master(self):
+        pass
+
+
+class ShardedExchange:
+    """mode 'sharded' (module docstring).  exchange(): bf16 all-to-all reduce-scatter with f32 accumulation at the owner;
+    step(): sharded clip + BertAdam, bf16 weight all-gather, transposed-copy refresh."""
+
+    def __init__(self, engine, dist, chunk_mb=256, ops=None):
+        self.e, self.dist = engine, dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.ops = ops if ops is not None else _HipOps(engine.lib)
+        self.chunks = shard_layout(engine.live_ranges(), self.world, chunk_mb * (1 << 20) // 2)
+        self.smax = max(s for _, _, s in self.chunks)
+        self._send = self._recv = self._sumsq = self._sqws = None
+        backend = dist.get_backend()
+        self._host_staged = backend != "nccl"      # rehearsal on one device over gloo: collectives run on host copies
+        self.lp = engine.precision == "bf16"
+
+    def describe(self):
+        return "sharded: bf16 all-to-all reduce-scatter + sharded BertAdam + %s weight all-gather, %d chunk(s) of <= %d MB" % (
+            "bf16" if self.lp else "f32", len(self.chunks), self.smax * self.world * 2 >> 20)
+
+    # -- collectives (RCCL on device tensors; host-staged under gloo, where device tensors are not supported by every op)
+    def _a2a(self, recv, send):
+        if self._host_staged and send.is_cuda:
+            r, s = torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
+            self.dist.all_to_all_single(r, s)
+            recv.copy_(r)
+        else:
+            self.dist.all_to_all_single(recv, send)
+
+    def _ag(self, out, inp):
+        if self._host_staged and inp.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(o, inp.cpu())
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, inp)
+
+    def exchange(self, grads=None):
+        """After backward: leaves, in the gradient arena, the SUM over ranks of the ranges this rank owns (other ranges keep the
+        local gradients and are not read again)."""
+        g = self.e.grads if grads is None else grads
+        W, S = self.world, self.smax
+        if hasattr(self.e, "invalidate_segment_sumsq"):
+            self.e.invalidate_segment_sumsq()
+        if self._send is None:
+            self._send = torch.zeros(W * S, dtype=torch.bfloat16, device=g.device)
+            self._recv = torch.zeros(W * S, dtype=torch.bfloat16, device=g.device)
+        for a, b, s in self.chunks:
+            n = b - a
+            send, recv = self._send[:W * s], self._recv[:W * s]
+            self.ops.cast_bf16(send[:n], g[a:b])            # part r of the chunk at send[r*s : (r+1)*s]; the ragged tail is never read
+            self._a2a(recv, send)
+            lo, hi = owned((a, b, s), self.rank)
+            if hi > lo:
+                self.ops.sum_parts(g[lo:hi], recv, s, W)    # f32 accumulation in rank order
+
+    all_reduce = exchange
+
+    def step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, clip=True):
+        e, W = self.e, self.world
+        dev = e.grads.device
+        if e.adam_m is None:
+            e.adam_m = torch.zeros_like(e.params)        # only the owned ranges are ever touched (288 GB HBM: no need to compact)
+            e.adam_v = torch.zeros_like(e.params)
+        if self._sumsq is None:
+            self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._sqws = torch.zeros(2048, dtype=torch.float32, device=dev)
+        mine = [owned(c, self.rank) for c in self.chunks]
+        mine = [(lo, hi) for lo, hi in mine if hi > lo]
+        lib = e.lib
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev.type == "cuda" else None
+        if clip:
+            self._sumsq.zero_()
+            for lo, hi in mine:
+                self._local_sumsq(lo, hi, s)
+            if self._host_staged and self._sumsq.is_cuda:
+                t = self._sumsq.cpu()
+                self.dist.all_reduce(t)
+                self._sumsq.copy_(t)
+            else:
+                self.dist.all_reduce(self._sumsq)        # sum over ranks of the shards' sum(g^2) = the global norm^2
+        for lo, hi in mine:
+            self._local_adam(lo, hi, lr_t, b1, b2, eps, weight_decay, clip, max_norm, 1.0 / W, s)
+        # updated weights -> every rank's forward copy
+        wts = e.params_lp if self.lp else e.params
+        for a, b, sz in self.chunks:
+            n = b - a
+            lo, hi = owned((a, b, sz), self.rank)
+            if n == W * sz:
+                self._ag(wts[a:b], wts[lo:hi])            # in place: part r of the output is this rank's own input
+            else:                                           # ragged chunk: through a padded buffer
+                buf = self._recv[:W * sz] if self.lp else torch.empty(W * sz, dtype=wts.dtype, device=dev)
+                mine_pad = self._send[:sz] if self.lp else torch.zeros(sz, dtype=wts.dtype, device=dev)
+                if hi > lo:
+                    mine_pad[:hi - lo].copy_(wts[lo:hi])
+                self._ag(buf, mine_pad)
+                wts[a:b].copy_(buf[:n])
+        if self.lp:
+            check(lib.rgqa_engine_sync_transposed(e.h, s))
+
+    def _local_sumsq(self, lo, hi, s):
+        e = self.e
+        check(e.lib.rgqa_grad_sumsq(ptr(e.grads[lo:hi]), hi - lo, ptr(self._sqws), ptr(self._sumsq), 1, s))
+
+    def _local_adam(self, lo, hi, lr_t, b1, b2, eps, wd, clip, max_norm, prescale, s):
+        e = self.e
+        lp = ptr(e.params_lp[lo:hi]) if self.lp else None
+        check(e.lib.rgqa_bertadam_step(ptr(e.params[lo:hi]), ptr(e.grads[lo:hi]), ptr(e.adam_m[lo:hi]), ptr(e.adam_v[lo:hi]), lp, hi - lo,
+                                       lr_t, b1, b2, eps, wd, ptr(self._sumsq) if clip else None, max_norm, prescale, s))
+
+    def gather_master(self):
+        """All-gathers the f32 master weights (each range is current only on its owner): before state_dict() / checkpoints."""
+        p = self.e.params
+        for a, b, sz in self.chunks:
+            n = b - a
+            lo, hi = owned((a, b, sz), self.rank)
+            if n == self.world * sz:
+                self._ag(p[a:b], p[lo:hi])
+            else:
+                buf = torch.empty(self.world * sz, dtype=p.dtype, device=p.device)
+                mine_pad = torch.zeros(sz, dtype=p.dtype, device=p.device)
+                if hi > lo:
+                    mine_pad[:hi - lo].copy_(p[lo:hi])
+                self._ag(buf, mine_pad)
+                p[a:b].copy_(buf[:n])
+
+
+def make_exchange(engine, dist, mode=None, **kw):
+    """mode: 'sharded' (default), 'allreduce', 'allreduce_bf16'; env RGQA_DP_MODE overrides the default."""
+    mode = mode or os.environ.get("RGQA_DP_MODE", "sharded")
+    if mode == "sharded":
+        return ShardedExchange(engine, dist, **kw)
+    if mode in ("allreduce", "allreduce_bf16"):
+        return GradAllReduce(engine, dist, bf16=(mode == "allreduce_bf16"), **kw)
+    raise ValueError("RGQA_DP_MODE must be sharded, allreduce or allreduce_bf16 (got %r)" % mode)
