@@ -63,9 +63,18 @@ class LXRTEncoder(nn.Module):
         self._native = None
 
     def multi_gpu(self):
-        """The reference wraps the inner model in single-process nn.DataParallel (:102-103). Here data parallelism is
-        one process per GPU with RCCL gradient all-reduce (rgqa_amd.parallel, launched with torch.distributed.run); in a
-        single process this is a no-op."""
+        """The reference wraps the inner model in single-process nn.DataParallel (:102-103).  Here data parallelism is one process
+        per GPU (torchrun / torch.distributed.run): once the default process group exists, every backward of this module averages
+        its gradient arena over the ranks (RCCL all-reduce, rgqa_amd.parallel) and every rank draws its own dropout stream; give
+        the DataLoader a DistributedSampler.  In a single process nothing can be parallelised: say so."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            print("rgqa: data parallel over %d processes (rank %d): gradients are averaged in backward()" % (dist.get_world_size(), dist.get_rank()))
+        elif torch.cuda.is_available() and torch.cuda.device_count() > 1:
+            import warnings
+            warnings.warn("rgqa: multi_gpu() in a single process uses ONE of the %d visible GPUs; launch one process per GPU with "
+                          "`python -m torch.distributed.run --nproc-per-node N ...` and call torch.distributed.init_process_group('nccl') "
+                          "for data parallelism" % torch.cuda.device_count())
         return None
 
     @property

@@ -226,6 +226,14 @@ class ArenaBinding(object):
                 p.grad = e.view(e.grads, sp)
 
 
+def _dp_rank_world():
+    """(rank, world) of the default process group, (0, 1) when torch.distributed is not in use"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 class _EngineFunction(torch.autograd.Function):
     """Autograd boundary: forward and backward of the whole encoder (+ optional fused answer head) are single engine
     calls; parameter gradients are written straight into the gradient arena that the parameters' .grad view."""
@@ -258,6 +266,16 @@ class _EngineFunction(torch.autograd.Function):
         dboxes = torch.empty(ctx.in_shapes[1][0] * ctx.in_shapes[1][1], ctx.in_shapes[1][2], dtype=torch.float32, device=e.device) if want_b else None
         if want_f or want_b:
             e.set_input_grads(dfeats, dboxes)
+        # Data parallelism for the unchanged trainers (tasks/gqa_conf.py:111-112 `--multiGPU`, lxrt/entry.py:102-103): with
+        # torch.distributed initialised (torchrun, one process per GPU) every backward averages the gradient arena over the ranks
+        # before clip_grad_norm_ / BertAdam.step see it - the incoming gradient is scaled by 1/world, the arena SUM-all-reduced.
+        rank, world = _dp_rank_world()
+        if world > 1:
+            if acc:
+                raise RuntimeError("rgqa: gradient accumulation over several backward() calls is not supported under data parallelism "
+                                   "(the exchange would count the earlier contributions again): call zero_grad() before every backward")
+            dlogits = None if dlogits is None else dlogits * (1.0 / world)
+            dpooled = None if dpooled is None else dpooled * (1.0 / world)
         try:
             two = ctx.want_logits and dlogits is not None and dpooled is not None and bool((dpooled != 0).any())
             if two and (want_f or want_b):
@@ -272,6 +290,8 @@ class _EngineFunction(torch.autograd.Function):
         finally:
             if want_f or want_b:
                 e.set_input_grads(None, None)
+        if world > 1:
+            owner._dp_exchange().all_reduce()
         b.attach_grads()
         return (None, None, dfeats.view(ctx.in_shapes[0]) if want_f else None, dboxes.view(ctx.in_shapes[1]) if want_b else None, None, None, None, None)
 
@@ -364,6 +384,16 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         else:
             b.ensure(device)
 
+    def _dp_exchange(self):
+        """The gradient exchange of this module's engine (rgqa_amd.parallel; RGQA_DP_MODE=allreduce_bf16 halves the payload)."""
+        ex = self.__dict__.get("_dp_ex")
+        if ex is None or ex.e is not self._binding.engine:
+            import torch.distributed as dist
+            from ..parallel import GradAllReduce
+            ex = GradAllReduce(self._binding.engine, dist, bf16=os.environ.get("RGQA_DP_MODE", "allreduce") == "allreduce_bf16")
+            self.__dict__["_dp_ex"] = ex
+        return ex
+
     def _engine_forward(self, feats, boxes, ids, mask, seg, train):
         b = self._binding
         self._ready(feats.device)
@@ -372,7 +402,8 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         e.ensure_shape(B, ids.shape[1], O)
         b.sync_if_stale()
         if self._seed_base is None:
-            self._seed_base = int(torch.initial_seed()) & 0x7FFFFFFFFFFF
+            # data parallel (one process per GPU): every rank needs its own dropout stream although all of them seed torch alike
+            self._seed_base = (int(torch.initial_seed()) + 1000003 * _dp_rank_world()[0]) & 0x7FFFFFFFFFFF
         self._fwd_counter += 1
         lengths = self.__dict__.pop("_pending_lengths", None)
         return e.forward(feats, boxes, ids, mask, seg, train=train, seed=self._seed_base + 7919 * self._fwd_counter, lengths=lengths)

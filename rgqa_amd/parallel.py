@@ -96,7 +96,7 @@ class GradAllReduce:
 
     def __init__(self, engine, dist, bucket_mb=64, overlap=None, bf16=False, ops=None):
         self.e, self.dist, self.bf16 = engine, dist, bf16
-        self.ops = ops if ops is not None else _HipOps(engine.lib)
+        self.ops = ops if ops is not None else (_HipOps(engine.lib) if bf16 else None)
         if overlap is None:
             overlap = os.environ.get("RGQA_DP_OVERLAP", "1") != "0"
         self.overlap = overlap and hasattr(engine, "grad_segments")
@@ -218,7 +218,6 @@ class ShardedExchange:
             self._sqws = torch.zeros(2048, dtype=torch.float32, device=dev)
         mine = [owned(c, self.rank) for c in self.chunks]
         mine = [(lo, hi) for lo, hi in mine if hi > lo]
-        lib = e.lib
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev.type == "cuda" else None
         if clip:
             self._sumsq.zero_()
@@ -246,8 +245,12 @@ class ShardedExchange:
                     mine_pad[:hi - lo].copy_(wts[lo:hi])
                 self._ag(buf, mine_pad)
                 wts[a:b].copy_(buf[:n])
+        self._after_weights(s)
+
+    # -- local arithmetic (HIP, through the C ABI)
+    def _after_weights(self, s):
         if self.lp:
-            check(lib.rgqa_engine_sync_transposed(e.h, s))
+            check(self.e.lib.rgqa_engine_sync_transposed(self.e.h, s))     # dgrad operand: transposed bf16 copies, from the gathered bf16 arena
 
     def _local_sumsq(self, lo, hi, s):
         e = self.e

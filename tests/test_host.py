@@ -221,22 +221,73 @@ def test_dropin_model_surface(golden_dir, monkeypatch):
         M.BertConfig(3.5)
 
 
+class _TorchOps:
+    """the exchange's two local kernels (rgqa_cast_bf16, rgqa_sum_bf16_parts) restated with torch for the CPU rehearsal"""
+
+    def cast_bf16(self, dst, src):
+        dst.copy_(src)
+
+    def sum_parts(self, dst, parts, stride, nparts):
+        acc = torch.zeros_like(dst)
+        for r in range(nparts):
+            acc += parts[r * stride:r * stride + dst.numel()].float()
+        dst.copy_(acc)
+
+
+def _fake_engine(n, rank, precision):
+    base = (torch.arange(n) % 64).float()
+    return types.SimpleNamespace(grads=base * (rank + 1), params=torch.ones(n), params_lp=torch.ones(n, dtype=torch.bfloat16), adam_m=None, adam_v=None,
+                                 precision=precision, live_ranges=lambda: [(0, 296), (360, n)], lib=None, h=None)
+
+
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
-    from rgqa_amd.parallel import GradAllReduce
+    from rgqa_amd.parallel import GradAllReduce, ShardedExchange
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     n = 1000
-    eng = types.SimpleNamespace(grads=torch.arange(n, dtype=torch.float32) * (rank + 1), live_ranges=lambda: [(0, 300), (364, n)])
-    GradAllReduce(eng, dist, bucket_mb=1).all_reduce()
-    q.put((rank, eng.grads.clone()))
+    out = {}
+    for name, bf16 in (("allreduce", False), ("allreduce_bf16", True)):
+        eng = _fake_engine(n, rank, "f32")
+        GradAllReduce(eng, dist, bucket_mb=1, bf16=bf16, ops=_TorchOps()).all_reduce()
+        out[name] = eng.grads.numpy().copy()
+
+    class CpuSharded(ShardedExchange):      # the two HIP calls of step() restated with torch; everything else is the product code
+        def _local_sumsq(self, lo, hi, s):
+            self._sumsq += (self.e.grads[lo:hi] ** 2).sum()
+
+        def _local_adam(self, lo, hi, lr_t, b1, b2, eps, wd, clip, max_norm, prescale, s):
+            e = self.e
+            e.params[lo:hi] -= lr_t * prescale * e.grads[lo:hi]
+            e.params_lp[lo:hi] = e.params[lo:hi].bfloat16()
+
+        def _after_weights(self, s):
+            pass
+
+    for prec in ("bf16", "f32"):
+        eng = _fake_engine(n, rank, prec)
+        local = eng.grads.clone()
+        ex = CpuSharded(eng, dist, ops=_TorchOps())
+        ex.chunks = __import__("rgqa_amd.parallel", fromlist=["shard_layout"]).shard_layout(eng.live_ranges(), world, 256)    # several chunks, two of them ragged
+        ex.smax = max(c[2] for c in ex.chunks)
+        ex.exchange()
+        mine = [__import__("rgqa_amd.parallel", fromlist=["owned"]).owned(c, rank) for c in ex.chunks]
+        ex.step(0.5)
+        ex.gather_master()
+        out["sharded_" + prec] = dict(grads=eng.grads.numpy().copy(), local=local.numpy().copy(), mine=mine, params=eng.params.numpy().copy(),
+                                      params_lp=eng.params_lp.float().numpy().copy(), sumsq=float(ex._sumsq), chunks=ex.chunks)
+    q.put((rank, out))
     dist.destroy_process_group()
 
 
-def test_gradient_allreduce_gloo_world2():
-    """DP exchange on CPU/gloo, world_size 2: live ranges are summed across ranks, the dead range is left alone."""
+def test_gradient_exchange_modes_gloo_world2():
+    """DP exchange on CPU/gloo, world_size 2: all-reduce (f32 and bf16 payload) sums the live ranges and leaves the
+    dead range alone; the sharded mode leaves each rank the SUM over its own 1/N of every chunk (ragged chunks included), takes the
+    global norm from one scalar all-reduce, and after step() every rank holds the same updated weights."""
     import torch.multiprocessing as mp
-    from rgqa_amd.parallel import bucket_ranges
+    from rgqa_amd.parallel import bucket_ranges, shard_layout, owned
     assert bucket_ranges([(0, 10), (20, 25)], 4) == [(0, 4), (4, 8), (8, 10), (20, 24), (24, 25)]
+    assert shard_layout([(0, 100)], 4, 64) == [(0, 64, 16), (64, 100, 16)]
+    assert [owned((64, 100, 16), r) for r in range(4)] == [(64, 80), (80, 96), (96, 100), (100, 100)]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
@@ -252,11 +303,34 @@ def test_gradient_allreduce_gloo_world2():
             if p.is_alive():
                 p.terminate()
     assert all(p.exitcode == 0 for p in procs)
-    base = torch.arange(1000, dtype=torch.float32)
+    n = 1000
+    base = (torch.arange(n) % 64).float()
+    live = torch.zeros(n, dtype=torch.bool)
+    live[:296] = True
+    live[360:] = True
     for r in range(2):
-        g = res[r]
-        assert torch.equal(g[:300], base[:300] * 3) and torch.equal(g[364:], base[364:] * 3)
-        assert torch.equal(g[300:364], base[300:364] * (r + 1))
+        for mode in ("allreduce", "allreduce_bf16"):
+            g = torch.from_numpy(res[r][mode])
+            assert torch.equal(g[live], base[live] * 3), mode
+            assert torch.equal(g[~live], base[~live] * (r + 1)), mode
+        for prec in ("bf16", "f32"):
+            o = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in res[r]["sharded_" + prec].items()}
+            assert len(o["chunks"]) == 5 and any((b - a) != 2 * s for a, b, s in o["chunks"])
+            own = torch.zeros(n, dtype=torch.bool)
+            for lo, hi in o["mine"]:
+                own[lo:hi] = True
+            assert torch.equal(o["grads"][own], base[own] * 3)                 # reduced where this rank is the owner
+            assert torch.equal(o["grads"][~own], o["local"][~own])             # untouched elsewhere (dead range included)
+            assert abs(o["sumsq"] - float(((base[live] * 3) ** 2).sum())) < 1e-3 * o["sumsq"]
+            want = torch.ones(n)
+            want[live] -= 0.5 * 0.5 * 3 * base[live]
+            assert torch.equal(o["params"], want)                               # after gather_master every rank has every range
+            if prec == "bf16":
+                assert torch.equal(o["params_lp"][live], want[live].bfloat16().float())
+    for prec in ("bf16", "f32"):
+        own0 = set(map(tuple, res[0]["sharded_" + prec]["mine"]))
+        own1 = set(map(tuple, res[1]["sharded_" + prec]["mine"]))
+        assert not (own0 & own1)
 
 
 def test_bench_launches_its_own_ranks_when_no_launcher_is_present():
