@@ -111,14 +111,16 @@ def test_gqa_model_bf16_forward_and_grads(env, golden_dir):
     m.eval()
     with torch.no_grad():
         lg0 = m(feats.cuda(), boxes.cuda(), SENTS)
-    assert not lg0.requires_grad and float((lg0.cpu() - lg_r).abs().max()) < 6e-2
+    print("drop-in bf16: logits max err %.3e" % float((lg0.cpu() - lg_r).abs().max()))
+    assert not lg0.requires_grad and float((lg0.cpu() - lg_r).abs().max()) < 1.3e-2      # observed 6.4e-3
     lg = m(feats.cuda(), boxes.cuda(), SENTS)
     assert lg.requires_grad and torch.equal(lg, lg0)
     loss = torch.nn.functional.binary_cross_entropy_with_logits(lg, target.cuda()) * lg.size(1)
     loss.backward()
     w = "lxrt_encoder.model.bert.encoder.x_layers.0.visual_attention.att.query.weight"
     g = dict(m.named_parameters())[w].grad.cpu()
-    assert float((g - Pr[w].grad).norm() / Pr[w].grad.norm()) < 8e-2
+    print("drop-in bf16: grad rel err %.3e" % float((g - Pr[w].grad).norm() / Pr[w].grad.norm()))
+    assert float((g - Pr[w].grad).norm() / Pr[w].grad.norm()) < 3e-2       # observed 1.4e-2
     # gradient accumulation: a second backward without zero_grad doubles the gradient
     lg2 = m(feats.cuda(), boxes.cuda(), SENTS)
     (torch.nn.functional.binary_cross_entropy_with_logits(lg2, target.cuda()) * lg2.size(1)).backward()

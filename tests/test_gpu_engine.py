@@ -99,11 +99,11 @@ def oracle_run(cfgd, b, want_grads=True):
     return lg.detach(), pl.detach(), loss.item(), P
 
 
-@pytest.mark.parametrize("precision,tol,gtol", [("f32", 1e-4, 2e-3), ("bf16", 6e-2, 8e-2)])
+@pytest.mark.parametrize("precision,tol,gtol", [("f32", 1e-4, 2e-3), ("bf16", 1.5e-2, 3.5e-2)])    # bf16 observed: logits 7.6e-3, worst tensor 1.7e-2
 def test_medium_config_vs_oracle(precision, tol, gtol):
     """head size 64 / dims multiple of 64, so the bf16 MFMA kernels are the ones exercised.
-    bf16 tolerance: bf16 has 8 mantissa bits; through 7 blocks logits (|z|~1) land within 6e-2 abs, gradients within
-    8% relative Frobenius error per tensor."""
+    bf16 tolerance (2x observed): bf16 has 8 significant bits; through 7 blocks logits (|z|~1) land within 1.5e-2 abs, gradients within
+    3.5% relative Frobenius error per tensor."""
     B, T, O = 6, 12, 10
     b = synth.synth_batch(B, T, O=O, F=MED["feat_dim"], NA=MED["num_answers"], vocab=MED["vocab_size"], seed=5, min_len=2)
     lg_r, pl_r, loss_r, Pr = oracle_run(MED, b)
@@ -112,9 +112,11 @@ def test_medium_config_vs_oracle(precision, tol, gtol):
     e.ensure_shape(B, T, O)
     e.sync_weights()
     lg, pl = run(e, d)
-    assert float((lg.cpu() - lg_r).abs().max()) < tol
+    lerr = float((lg.cpu() - lg_r).abs().max())
+    assert lerr < tol
     loss = e.loss_backward(d["target"])
     assert abs(loss.item() - loss_r) < tol * 50
+    gworst = 0.0
     for sp in e.specs:
         got = e.view(e.grads, sp).cpu()
         ref = Pr[sp.name].grad
@@ -124,20 +126,125 @@ def test_medium_config_vs_oracle(precision, tol, gtol):
         den = float(ref.norm())
         if den < 1e-8:
             continue
+        gworst = max(gworst, float((got - ref).norm()) / den)
         assert float((got - ref).norm()) / den < gtol, (sp.name, float((got - ref).norm()) / den)
+    _report("medium config %s vs oracle" % precision, logits_max=lerr, worst_tensor_rel=gworst)
 
 
-def test_bf16_full_config_logits():
-    """bf16 operands on the real architecture (B=4): logits within 5e-2 abs of the f32 golden logits (|z| ~ 1)."""
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g2_full_T20.npz"))
+def _report(tag, **kv):
+    """observed errors go to stdout (pytest -s) and to gpurun_out/parity_observed.txt: every bf16 tolerance below is <= 2x what is printed"""
+    line = tag + ": " + ", ".join("%s %.3e" % (k, v) for k, v in kv.items())
+    print(line)
+    try:
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "parity_observed.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def _grad_sample_errors(e, names, counts, samples):
+    """per-tensor relative error of the gradient entries the golden fixture sampled: (worst tensor, its name, error over all samples)"""
+    byname = {sp.name: sp for sp in e.specs}
+    off, worst, wname, num, den = 0, 0.0, "", 0.0, 0.0
+    for k, n in zip(names, counts):
+        gr = e.view(e.grads, byname[k]).float().cpu().numpy().reshape(-1)
+        ref = samples[off:off + n]
+        off += n
+        got = gr[sample_idx(k, gr.size)]
+        d, r = float(np.linalg.norm(got - ref)), float(np.linalg.norm(ref))
+        num += d * d
+        den += r * r
+        if r > 1e-6 * max(1.0, float(np.abs(gr).max())) and d / r > worst:
+            worst, wname = d / r, k
+    return worst, wname, (num / max(den, 1e-30)) ** 0.5
+
+
+@pytest.mark.parametrize("T", [20, 30])
+def test_bf16_full_config_vs_golden(golden_dir, T):
+    """The benchmarked precision on the real 9/5/5 architecture (B=4) against the reference's own outputs (G2): logits, pooled,
+    loss, gradient norm and the sampled gradients of all 439 live tensors.  bf16 operands (8 significant bits) through 19 blocks."""
+    g = np.load(os.path.join(golden_dir, "g2_full_T%d.npz" % T))
     e = make_engine(FULL, "bf16")
-    b = dev(full_batch(20))
-    e.ensure_shape(4, 20, 36)
+    b = dev(full_batch(T))
+    e.ensure_shape(4, T, 36)
     e.sync_weights()
-    lg, _ = run(e, b)
+    lg, pl = run(e, b)
     err = np.abs(lg.cpu().numpy() - g["logits"])
-    assert err.max() < 5e-2, err.max()
-    assert err.mean() < 1e-2, err.mean()
+    perr = np.abs(pl.cpu().numpy() - g["pooled"])
+    loss = e.loss_backward(b["target"]).item()
+    gn = e.grad_norm().item()
+    worst, wname, overall = _grad_sample_errors(e, g["grad_names"].tolist(), g["grad_counts"].tolist(), g["grad_samples"])
+    _report("bf16 full B=4 T=%d vs G2" % T, logits_max=err.max(), logits_mean=err.mean(), pooled_max=perr.max(), loss_rel=abs(loss - g["loss"]) / abs(g["loss"]),
+            grad_norm_rel=abs(gn - g["grad_norm"]) / g["grad_norm"], grad_samples_rel=overall, worst_tensor_rel=worst)
+    print("   worst tensor:", wname)
+    # tolerances = 2x the errors observed on MI355X (T=20 / T=30): logits max 3.8e-2 / 4.5e-2, mean 8.2e-3, pooled max 2.2e-2 / 2.7e-2,
+    # loss 1.2e-4 / 2.8e-5 rel, gradient norm 2.6e-4 / 3.3e-4 rel, all sampled gradient entries 8.9e-3 / 8.5e-3 rel, worst tensor 5.8e-2 / 4.1e-2
+    assert err.max() < 9e-2 and err.mean() < 1.6e-2, (err.max(), err.mean())
+    assert perr.max() < 5.4e-2, perr.max()
+    assert abs(loss - g["loss"]) < 2.4e-4 * abs(g["loss"])
+    assert abs(gn - g["grad_norm"]) < 6.6e-4 * g["grad_norm"]
+    assert overall < 1.8e-2, overall
+    assert worst < 0.115, (wname, worst)
+
+
+_B256 = {}
+
+
+def _b256_oracle():
+    """config 3 at size: B=256, T=20, the oracle's forward + backward on the host (once per session, ~30 s)"""
+    if not _B256:
+        import time
+        b = synth.synth_batch(256, 20, seed=777)
+        t0 = time.time()
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+        lg, pl, loss, P = oracle_run(FULL, b)
+        gsq = sum(float((p.grad.double() ** 2).sum()) for p in P.values() if p.grad is not None)
+        _B256.update(b=b, logits=lg.numpy(), pooled=pl.numpy(), loss=loss, grad_norm=gsq ** 0.5,
+                     grads={k: p.grad.numpy().reshape(-1)[sample_idx(k, p.grad.numel())].copy() for k, p in P.items() if p.grad is not None})
+        print("oracle B=256 fwd+bwd on the host: %.1f s" % (time.time() - t0))
+    return _B256
+
+
+@pytest.mark.parametrize("layout", ["packed", "padded"])
+def test_bf16_cfg3_b256_fwd_bwd_vs_oracle(layout):
+    """BASELINE config 3 at its real size (B=256, T=20, bf16, dropout off for parity): one forward + backward against the CPU
+    oracle - the split-K visual-projection wgrad, the 256-row wgrad tiles with contraction tails and the persistent / phase-
+    interleaved NT tiles only exist at this size.  Both language layouts (packed rows = what bench.py runs; padded = the reference's)."""
+    o = _b256_oracle()
+    b = o["b"]
+    e = make_engine(FULL, "bf16")
+    d = dev(b)
+    e.ensure_shape(256, 20, 36)
+    e.sync_weights()
+    lengths = np.ascontiguousarray(b["lengths"], dtype=np.int32) if layout == "packed" else None
+    lg, pl = e.forward(d["feats"], d["boxes"], d["input_ids"], d["input_mask"], d["segment_ids"], train=False, seed=0, lengths=lengths)
+    err = np.abs(lg.cpu().numpy() - o["logits"])
+    loss = e.loss_backward(d["target"]).item()
+    gn = e.grad_norm().item()
+    byname = {sp.name: sp for sp in e.specs}
+    num = den = 0.0
+    worst, wname = 0.0, ""
+    for k, ref in o["grads"].items():
+        gr = e.view(e.grads, byname[k]).float().cpu().numpy().reshape(-1)
+        got = gr[sample_idx(k, gr.size)]
+        dd, rr = float(np.linalg.norm(got - ref)), float(np.linalg.norm(ref))
+        num += dd * dd
+        den += rr * rr
+        if rr > 1e-6 * max(1.0, float(np.abs(gr).max())) and dd / rr > worst:
+            worst, wname = dd / rr, k
+    overall = (num / den) ** 0.5
+    _report("bf16 full B=256 T=20 %s vs oracle" % layout, logits_max=err.max(), logits_mean=err.mean(), loss_rel=abs(loss - o["loss"]) / abs(o["loss"]),
+            grad_norm_rel=abs(gn - o["grad_norm"]) / o["grad_norm"], grad_samples_rel=overall, worst_tensor_rel=worst)
+    print("   worst tensor:", wname)
+    assert len(o["grads"]) == 439
+    # tolerances = 2x observed (identical for both layouts): logits max 4.45e-2, mean 7.75e-3, loss 2.6e-6 rel, gradient norm 6.2e-5 rel,
+    # sampled gradient entries 6.2e-3 rel, worst tensor (word embeddings) 2.4e-2
+    assert err.max() < 8.9e-2 and err.mean() < 1.55e-2, (err.max(), err.mean())
+    assert abs(loss - o["loss"]) < 6e-6 * abs(o["loss"])
+    assert abs(gn - o["grad_norm"]) < 1.3e-4 * o["grad_norm"]
+    assert overall < 1.25e-2, overall
+    assert worst < 4.8e-2, (wname, worst)
 
 
 def test_dropout_train_mode_is_deterministic_and_consistent():
@@ -457,7 +564,7 @@ SWEEP = [   # (B, T, O, l, x, r, heads, hidden, answers, packed)
 ]
 
 
-@pytest.mark.parametrize("precision,tol,gtol", [("f32", 2e-4, 3e-3), ("bf16", 8e-2, 1e-1)])
+@pytest.mark.parametrize("precision,tol,gtol", [("f32", 2e-4, 3e-3), ("bf16", 2e-2, 4.5e-2)])     # bf16 observed: logits <= 1.0e-2, worst tensor <= 2.2e-2
 @pytest.mark.parametrize("shape", SWEEP, ids=lambda s: "B%dT%dO%d_l%dx%dr%d_h%d" % (s[0], s[1], s[2], s[3], s[4], s[5], s[6]))
 def test_shape_sweep_vs_oracle(shape, precision, tol, gtol):
     """Edge shapes of the engine (single sample, no l- or r-layers, T beyond two query tiles, 2-token questions, 64 RoIs, answer
@@ -473,10 +580,12 @@ def test_shape_sweep_vs_oracle(shape, precision, tol, gtol):
     e.sync_weights()
     lens = b["lengths"].astype(np.int32) if packed else None
     lg, pl = e.forward(d["feats"], d["boxes"], d["input_ids"], d["input_mask"], d["segment_ids"], lengths=lens)
-    assert float((lg.cpu() - lg_r).abs().max()) < tol * max(1.0, float(lg_r.abs().max()))
+    lerr = float((lg.cpu() - lg_r).abs().max())
+    assert lerr < tol * max(1.0, float(lg_r.abs().max()))
     assert float((pl.cpu() - pl_r).abs().max()) < tol
     loss = e.loss_backward(d["target"])
     assert abs(loss.item() - loss_r) < 50 * tol * max(1.0, abs(loss_r))
+    gworst = 0.0
     for sp in e.specs:
         got = e.view(e.grads, sp).cpu()
         ref = Pr[sp.name].grad
@@ -487,7 +596,9 @@ def test_shape_sweep_vs_oracle(shape, precision, tol, gtol):
         if den < 1e-8:      # mathematically zero gradients (key biases: softmax is shift-invariant): rounding noise only
             assert float(got.norm()) < 1e-3 * gtol, sp.name
             continue
+        gworst = max(gworst, float((got - ref).norm()) / den)
         assert float((got - ref).norm()) / den < gtol, (sp.name, float((got - ref).norm()) / den)
+    _report("shape sweep %s %s vs oracle" % ("B%dT%dO%d_l%dx%dr%d_h%d" % shape[:7], precision), logits_max=lerr, worst_tensor_rel=gworst)
 
 
 def test_training_converges_bf16_like_f32():
