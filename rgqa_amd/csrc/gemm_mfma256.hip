@@ -477,11 +477,7 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
     // bench.py, profiles/r02_*): 256- and 224-row tiles tie (+-1 %, +4 % for the DGELU dgrad), 192-row tiles gain 2-6 %, and the
     // single-round 160-row launches lose 12 % to the deep-ring kernel, which has 104 KiB in flight.  Default (RGQA_NT8P=1): 192-row
     // tiles only; 2 = every launch of 160..256-row tiles (what a cold / large-K caller wants); 0 = never.
-    if (mt >= 5 && gemm_nt8p_eligible(g)) {
-        static const int env = []() { const char* e = getenv("RGQA_NT8P"); return e ? atoi(e) : 1; }();
-        const int mode = g_rgqa_nt8p >= 0 ? g_rgqa_nt8p : env;
-        if (mode >= 2 || mt == 6) return launch_gemm_nt8p_bf16(g, mt, s);
-    }
+    if (mt >= 5 && gemm_nt8p_eligible(g) && (g_rgqa_nt8p >= 2 || mt == 6)) return launch_gemm_nt8p_bf16(g, mt, s);
     return launch256_epi(g, mt, s);
 }
 

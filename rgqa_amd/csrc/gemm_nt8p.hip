@@ -29,7 +29,15 @@
 #define P8_EPI_OFF 131072
 #define P8_LDS (P8_EPI_OFF + 8 * 4096)
 
-#define P8_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define P8_WAIT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define P8_WAIT(n) P8_WAIT_(n)
+#define P8_WAITV() do { if (P8_SPLIT) P8_WAIT_(9); else P8_WAIT(P8_INFLIGHT); } while (0)      /* split issue: the current unit has one instruction out */
+#ifndef P8_DEFAULT_VARIANT
+#define P8_DEFAULT_VARIANT 0
+#endif
+#ifndef P8_INFLIGHT      // LDS-DMA instructions a wave may leave in flight at a wait: 10 = 5 units (the schedule's maximum); lab builds lower it
+#define P8_INFLIGHT 10
+#endif
 #define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // diagnostic build only (tools/lab/stamp_lab.cpp defines P8_STAMPS and g_p8_stamps): wave 0 of every block stamps the shader
@@ -40,7 +48,11 @@ __device__ unsigned long long* g_p8_stamps;     // [blocks][32][2]
         q_[0] = __builtin_amdgcn_s_memtime(); q_[1] = __builtin_amdgcn_s_memrealtime(); } ++n_stamp; } while (0)
 // interval accounting (waves 0 and 4): cycles from interval start to "my part is done" (work) and from there to the barrier's release (wait)
 #define P8_T() __builtin_amdgcn_s_memtime()
+#ifdef P8_STAMPS_FINE   // 16 s_memtime per K-tile: slows the loop by ~30 %, read the RATIOS only
 #define P8_ACC(slot) do { const unsigned long long n_ = P8_T(); iv[slot] += n_ - t_prev; t_prev = n_; } while (0)
+#else
+#define P8_ACC(slot) do { } while (0)
+#endif
 #else
 #define P8_STAMP() do { } while (0)
 #define P8_ACC(slot) do { } while (0)
@@ -52,8 +64,11 @@ int g_rgqa_nt8p = -1;    // rgqa_debug_set key 7: 2 = every eligible launch of 1
 // (8 + 8, 8 + 4 or 4 + 4; the short ones run with the upper lanes masked off), so every unit costs every wave two vmcnt slots
 template <int RW> struct P8Split { static constexpr int R1 = RW >= 12 ? 8 : 4; static constexpr int R2 = RW - R1; };
 
-template <typename OutT, int EPI, int MT, int P8_BALANCED>
+template <typename OutT, int EPI, int MT, int VARIANT>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup g) {
+    // VARIANT 0: both LDS-DMA instructions of a phase's unit go out in its read interval; 1: as 0 with the fragment reads balanced
+    // over the phases; 2: one in the read interval, one between the two halves of the phase's MFMAs
+    constexpr bool P8_BALANCED = VARIANT == 1, P8_SPLIT = VARIANT == 2;
     constexpr int MA0 = (MT + 1) / 2, MA1 = MT / 2, TM = 32 * MT;
     constexpr int RW0 = 4 * MA0, RW1 = 4 * MA1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -112,18 +127,19 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
         const int nvt = i_vt + nblk;
         if (nvt < g.total_tiles) { i_vt = nvt; i_kt = 0; locate_issue(nvt); }
     };
-    auto issue_a = [&](int u, unsigned dst) {
+    // which: 0 = the unit's first instruction, 1 = its second, 2 = both
+    auto issue_a = [&](int u, unsigned dst, int which) {
         if (u == 0) {
-            if (P8Split<RW0>::R1 == 8 || lrow < P8Split<RW0>::R1) dma16o(aoff[0][0], sA, dst + (RW0 * wave) * 128);
-            if (P8Split<RW0>::R2 == 8 || lrow < P8Split<RW0>::R2) dma16o(aoff[0][1], sA, dst + (RW0 * wave + P8Split<RW0>::R1) * 128);
+            if (which != 1 && (P8Split<RW0>::R1 == 8 || lrow < P8Split<RW0>::R1)) dma16o(aoff[0][0], sA, dst + (RW0 * wave) * 128);
+            if (which != 0 && (P8Split<RW0>::R2 == 8 || lrow < P8Split<RW0>::R2)) dma16o(aoff[0][1], sA, dst + (RW0 * wave + P8Split<RW0>::R1) * 128);
         } else {
-            if (P8Split<RW1>::R1 == 8 || lrow < P8Split<RW1>::R1) dma16o(aoff[1][0], sA, dst + (RW1 * wave) * 128);
-            if (P8Split<RW1>::R2 == 8 || lrow < P8Split<RW1>::R2) dma16o(aoff[1][1], sA, dst + (RW1 * wave + P8Split<RW1>::R1) * 128);
+            if (which != 1 && (P8Split<RW1>::R1 == 8 || lrow < P8Split<RW1>::R1)) dma16o(aoff[1][0], sA, dst + (RW1 * wave) * 128);
+            if (which != 0 && (P8Split<RW1>::R2 == 8 || lrow < P8Split<RW1>::R2)) dma16o(aoff[1][1], sA, dst + (RW1 * wave + P8Split<RW1>::R1) * 128);
         }
     };
-    auto issue_w = [&](int u, unsigned dst) {
-        dma16o(woff[u][0], sW, dst + wave * 1024);
-        dma16o(woff[u][1], sW, dst + (wave + 8) * 1024);
+    auto issue_w = [&](int u, unsigned dst, int which) {
+        if (which != 1) dma16o(woff[u][0], sW, dst + wave * 1024);
+        if (which != 0) dma16o(woff[u][1], sW, dst + (wave + 8) * 1024);
     };
 
     // ---- compute cursor
@@ -150,10 +166,10 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
     // ---- prologue: units 0..6 of the stream
     locate_issue(i_vt);
     locate_compute(c_vt);
-    issue_a(0, lds0 + 0 * P8_UNIT); issue_w(0, lds0 + 1 * P8_UNIT); issue_w(1, lds0 + 2 * P8_UNIT); issue_a(1, lds0 + 3 * P8_UNIT);
+    issue_a(0, lds0 + 0 * P8_UNIT, 2); issue_w(0, lds0 + 1 * P8_UNIT, 2); issue_w(1, lds0 + 2 * P8_UNIT, 2); issue_a(1, lds0 + 3 * P8_UNIT, 2);
     advance();
-    issue_a(0, lds0 + P8_BUF + 0 * P8_UNIT); issue_w(0, lds0 + P8_BUF + 1 * P8_UNIT); issue_w(1, lds0 + P8_BUF + 2 * P8_UNIT);
-    P8_WAIT(10);                                    // U0, U1 of K-tile 0 have landed (this wave's pieces)
+    issue_a(0, lds0 + P8_BUF + 0 * P8_UNIT, 2); issue_w(0, lds0 + P8_BUF + 1 * P8_UNIT, 2); issue_w(1, lds0 + P8_BUF + 2 * P8_UNIT, 2);
+    P8_WAITV();                                    // U0, U1 of K-tile 0 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     P8_STAMP();                                     // 1: first units landed
     if (wr == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run one interval behind waves 0-3
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
             const unsigned cur = lds0 + b * P8_BUF, oth = lds0 + (b ^ 1) * P8_BUF;
             bf16x8 a1[MA1][2], w0[2][2], w1[2][2];
             // ---------------- phase 1: quadrant (0,0)
-            issue_a(1, oth + 3 * P8_UNIT);          // U3 of K-tile vk+1
+            issue_a(1, oth + 3 * P8_UNIT, P8_SPLIT ? 0 : 2);          // U3 of K-tile vk+1
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) a0[tm][ks] = lda(buf, 0, tm, ks);
             }
-            P8_WAIT(10);                            // U2 of this K-tile
+            P8_WAITV();                            // U2 of this K-tile
             P8_LGKM0();
             __builtin_amdgcn_sched_barrier(0);
             P8_ACC(0);
@@ -196,11 +212,13 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
             P8_ACC(1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks) {
+                if (P8_SPLIT && ks == 1) { __builtin_amdgcn_sched_barrier(0); issue_a(1, oth + 3 * P8_UNIT, 1); __builtin_amdgcn_sched_barrier(0); }      // the unit's second half, behind 8 MFMAs
 #pragma unroll
                 for (int tm = 0; tm < MA0; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[tn][ks], a0[tm][ks], acc[tm][tn], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             P8_ACC(2);
@@ -208,12 +226,12 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
             P8_ACC(3);
             // ---------------- phase 2: quadrant (0,1)
             advance();
-            issue_a(0, cur + 0 * P8_UNIT);          // U0 of K-tile vk+2
+            issue_a(0, cur + 0 * P8_UNIT, P8_SPLIT ? 0 : 2);          // U0 of K-tile vk+2
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) w1[tn][ks] = ldw(buf, 1, tn, ks);
-            P8_WAIT(10);                            // U3 of this K-tile
+            P8_WAITV();                            // U3 of this K-tile
             P8_LGKM0();
             __builtin_amdgcn_sched_barrier(0);
             P8_ACC(0);
@@ -221,23 +239,25 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
             P8_ACC(1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks) {
+                if (P8_SPLIT && ks == 1) { __builtin_amdgcn_sched_barrier(0); issue_a(0, cur + 0 * P8_UNIT, 1); __builtin_amdgcn_sched_barrier(0); }      // the unit's second half, behind 8 MFMAs
 #pragma unroll
                 for (int tm = 0; tm < MA0; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) acc[tm][2 + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[tn][ks], a0[tm][ks], acc[tm][2 + tn], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             P8_ACC(2);
             __builtin_amdgcn_s_barrier();
             P8_ACC(3);
             // ---------------- phase 3: quadrant (1,1)
-            issue_w(0, cur + 1 * P8_UNIT);          // U1 of K-tile vk+2
+            issue_w(0, cur + 1 * P8_UNIT, P8_SPLIT ? 0 : 2);          // U1 of K-tile vk+2
 #pragma unroll
             for (int tm = 0; tm < MA1; ++tm)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) a1[tm][ks] = lda(buf, 1, tm, ks);
-            if (P8_BALANCED) P8_WAIT(10);           // U0 of K-tile vk+1 (read in phase 4)
+            if (P8_BALANCED) P8_WAITV();           // U0 of K-tile vk+1 (read in phase 4)
             P8_LGKM0();
             __builtin_amdgcn_sched_barrier(0);
             P8_ACC(0);
@@ -245,19 +265,21 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
             P8_ACC(1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks) {
+                if (P8_SPLIT && ks == 1) { __builtin_amdgcn_sched_barrier(0); issue_w(0, cur + 1 * P8_UNIT, 1); __builtin_amdgcn_sched_barrier(0); }      // the unit's second half, behind 8 MFMAs
 #pragma unroll
                 for (int tm = 0; tm < MA1; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) acc[MA0 + tm][2 + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[tn][ks], a1[tm][ks], acc[MA0 + tm][2 + tn], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             P8_ACC(2);
             __builtin_amdgcn_s_barrier();
             P8_ACC(3);
             // ---------------- phase 4: quadrant (1,0)
-            issue_w(1, cur + 2 * P8_UNIT);          // U2 of K-tile vk+2
-            P8_WAIT(10);                            // U0, U1 of K-tile vk+1 (balanced: U1; U0 was waited for in phase 3)
+            issue_w(1, cur + 2 * P8_UNIT, P8_SPLIT ? 0 : 2);          // U2 of K-tile vk+2
+            P8_WAITV();                            // U0, U1 of K-tile vk+1 (balanced: U1; U0 was waited for in phase 3)
             // P8_BALANCED spreads the fragment reads 4 / 4 / 8 / 8 over the phases instead of 12 / 4 / 8 / 0.  Measured (tools/lab, A/B in one
             // process): no gain, -1..+7 % - the read intervals are long because of the two LDS-DMA issues (~100-180 cycles each
             // beside fragment reads), not because of phase 1's read burst; kept for A/B builds only (-DP8_AB_BUILD).
@@ -277,11 +299,13 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
             P8_ACC(1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks) {
+                if (P8_SPLIT && ks == 1) { __builtin_amdgcn_sched_barrier(0); issue_w(1, cur + 2 * P8_UNIT, 1); __builtin_amdgcn_sched_barrier(0); }      // the unit's second half, behind 8 MFMAs
 #pragma unroll
                 for (int tm = 0; tm < MA1; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) acc[MA0 + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[tn][ks], a1[tm][ks], acc[MA0 + tm][tn], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             P8_ACC(2);
@@ -312,9 +336,9 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
 }
 
 bool gemm_nt8p_eligible(const GemmGroup& g) {
-    static const int env = []() { const char* e = getenv("RGQA_NT8P"); return e ? atoi(e) : 1; }();     // default on
-    const int mode = g_rgqa_nt8p >= 0 ? g_rgqa_nt8p : env;
-    if (mode <= 0) return false;
+    static const int env = []() { const char* e = getenv("RGQA_NT8P"); return e ? atoi(e) : 1; }();     // default: mode 1
+    if (g_rgqa_nt8p < 0) g_rgqa_nt8p = env;
+    if (g_rgqa_nt8p <= 0) return false;
     for (int i = 0; i < g.count; ++i)
         if (g.p[i].K < 2 * TK || (g.p[i].K % TK) != 0) return false;
     return true;
@@ -340,20 +364,22 @@ static int launch8p(GemmGroup& g, hipStream_t s) {
 
 template <int EPI>
 static int launch8p_mt(GemmGroup& g, int mt, hipStream_t s) {
-#ifdef P8_AB_BUILD      // lab builds carry both read schedules (g_rgqa_nt8p == 3 selects the balanced one)
-    if (g_rgqa_nt8p == 3)
+#ifdef P8_AB_BUILD      // lab builds carry every schedule variant: g_rgqa_nt8p == 3 balanced reads, 4 = split LDS-DMA issue
+    if (g_rgqa_nt8p == 3 || g_rgqa_nt8p == 4) {
+        const bool bal = g_rgqa_nt8p == 3;
         switch (mt) {
-            case 8: return launch8p<EPI, 8, 1>(g, s);
-            case 7: return launch8p<EPI, 7, 1>(g, s);
-            case 6: return launch8p<EPI, 6, 1>(g, s);
-            default: return launch8p<EPI, 5, 1>(g, s);
+            case 8: return bal ? launch8p<EPI, 8, 1>(g, s) : launch8p<EPI, 8, 2>(g, s);
+            case 7: return bal ? launch8p<EPI, 7, 1>(g, s) : launch8p<EPI, 7, 2>(g, s);
+            case 6: return bal ? launch8p<EPI, 6, 1>(g, s) : launch8p<EPI, 6, 2>(g, s);
+            default: return bal ? launch8p<EPI, 5, 1>(g, s) : launch8p<EPI, 5, 2>(g, s);
         }
+    }
 #endif
     switch (mt) {
-        case 8: return launch8p<EPI, 8, 0>(g, s);
-        case 7: return launch8p<EPI, 7, 0>(g, s);
-        case 6: return launch8p<EPI, 6, 0>(g, s);
-        default: return launch8p<EPI, 5, 0>(g, s);
+        case 8: return launch8p<EPI, 8, P8_DEFAULT_VARIANT>(g, s);
+        case 7: return launch8p<EPI, 7, P8_DEFAULT_VARIANT>(g, s);
+        case 6: return launch8p<EPI, 6, P8_DEFAULT_VARIANT>(g, s);
+        default: return launch8p<EPI, 5, P8_DEFAULT_VARIANT>(g, s);
     }
 }
 

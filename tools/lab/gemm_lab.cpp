@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
             for (int c = 0; c < 2; ++c) { double t = bench(c == 1); if (t < t_auto[c]) t_auto[c] = t; }
             for (int k = 0; k < 4; ++k) {
                 rgqa_debug_set(1, mts[k]);
-                rgqa_debug_set(7, getenv("LAB_AB") ? 3 : 0);
+                rgqa_debug_set(7, getenv("LAB_AB") ? atoi(getenv("LAB_AB")) : 0);
                 for (int c = 0; c < 2; ++c) { double t = bench(c == 1); if (rep == 0 || t < t_old[k][c]) t_old[k][c] = t; }
                 if (rep == 0) grab(ref, ref2);
                 rgqa_debug_set(7, 2);
