@@ -239,29 +239,23 @@ def main():
     lengths = None if (args.padded or args.butd) else np.ascontiguousarray(np.tile(b["lengths"], 2 if args.mixup else 1), dtype=np.int32)
     MB = B                       # rows the model sees per step
     if args.mixup:
-        import ctypes as C
-        from rgqa_amd._lib import check, ptr
+        from rgqa_amd.mixup import RoIMixup
         MB = 2 * B
-        rs = np.random.RandomState(777 + rank)
-        dev = {k: torch.cat([v, torch.zeros_like(v)], 0).contiguous() for k, v in dev.items()}
-        dev["input_ids"][B:] = dev["input_ids"][:B]          # sent = sent + sent (gqa_mixup_vis.py:181)
-        dev["input_mask"][B:] = dev["input_mask"][:B]
+        import random as _random
+        _random.seed(777 + rank)
+        np.random.seed(777 + rank)
+        mixer = RoIMixup("mixup_v1", alpha=1.0, beta=5.0)       # run/gqa_mixup_vis_finetune.bash: mixup_v1, Beta(1, 5)
+        img_ids = list(range(B))                                  # every synthetic sample is its own image
+        loader = {k: dev[k] for k in ("feats", "boxes", "target")}
+        ids2 = torch.cat([dev["input_ids"], dev["input_ids"]], 0).contiguous()       # sent = sent + sent (gqa_mixup_vis.py:181)
+        mask2 = torch.cat([dev["input_mask"], dev["input_mask"]], 0).contiguous()
+        seg2 = torch.cat([dev["segment_ids"], dev["segment_ids"]], 0).contiguous()
 
         def mixup_batch():
-            """host draws exactly as the reference (partner != self, prop ~ Beta(1,5), int(prop*36) shuffled RoI indices),
-            then ONE device gather + target scaling (rgqa_mixup_gather / rgqa_scale_rows)."""
-            partner = (np.arange(B) + rs.randint(1, B, size=B)) % B
-            prop = rs.beta(1.0, 5.0, size=B)
-            take = np.zeros((B, O), dtype=np.uint8)
-            for j in range(B):
-                take[j, rs.permutation(O)[: int(prop[j] * O)]] = 1
-            pg = torch.from_numpy(partner.astype(np.int32)).cuda(non_blocking=True)
-            tg = torch.from_numpy(take).cuda(non_blocking=True)
-            sg = torch.from_numpy(prop.astype(np.float32)).cuda(non_blocking=True)
-            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            check(e.lib.rgqa_mixup_gather(ptr(dev["feats"]), ptr(dev["boxes"]), ptr(pg), ptr(tg), B, O, 2048, 0, st))
-            check(e.lib.rgqa_scale_rows(ptr(dev["target"]), ptr(sg), B, dev["target"].shape[1], dev["target"].stride(0), B, st))
-            return pg, tg, sg
+            """the reference's host draws (partner != own image, prop ~ Beta(1,5), int(prop*36) shuffled RoI indices), then ONE
+            device gather + target scaling (rgqa_amd.mixup)"""
+            f2, b2, t2 = mixer(loader["feats"], loader["boxes"], loader["target"], img_ids)
+            dev.update(feats=f2, boxes=b2, target=t2, input_ids=ids2, input_mask=mask2, segment_ids=seg2)
     e.ensure_shape(MB, T, O)
     e.sync_weights()
     comm = make_exchange(e, dist) if world > 1 else None      # RGQA_DP_MODE: sharded (default) | allreduce | allreduce_bf16
@@ -273,7 +267,7 @@ def main():
     def step(exchange=True):
         i = state["step"]
         if args.mixup:
-            state["keep"] = mixup_batch()
+            mixup_batch()
         e.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=True, seed=4321 + rank + 1000003 * i, lengths=state["lengths"])
         e.loss_backward(dev["target"])
         lr_t = 1e-5 * warmup_linear(i / t_total, 0.1)

@@ -164,7 +164,15 @@ int rgqa_sum_bf16_parts(const void* parts_bf16, size_t part_stride, int nparts, 
  * the positive sample). Writes rows [B,2B). */
 int rgqa_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uint8_t* take_pos, int B, int O,
                       int F, int mode_v3, void* stream);
-/* target[B+j,:] = target[j,:] * prop[j]   (mixup_v1 / v3 soft targets, gqa_mixup_vis.py:170-171) */
+/* 'perturb' (gqa_mixup_vis.py:124-133): rows [B,2B) = the features again; boxes[B+j][o] = boxes[j][perm[o]], perm [O] i32 = the
+ * batch's one torch.randperm draw.  (targets of the second half are zero: the caller's buffer.) */
+int rgqa_mixup_perturb(float* feats, float* boxes, const int32_t* perm, int B, int O, int F, void* stream);
+/* 'weighted_sum_v1/v2' (gqa_mixup_vis.py:217-244): feats[B+j] = feats[j] * prop[j] + feats[partner[j]] * one_minus_prop[j], each product
+ * rounded to f32 before the sum (bit-identical to the reference's torch expression); one_minus_prop[j] = (float)(1.0 - prop_double);
+ * boxes[B+j] = boxes[j]. */
+int rgqa_mixup_weighted_sum(float* feats, float* boxes, const int32_t* partner, const float* prop, const float* one_minus_prop,
+                            int B, int O, int F, void* stream);
+/* target[B+j,:] = target[j,:] * prop[j]   (mixup_v1 / v3 / weighted_sum_v1 soft targets, gqa_mixup_vis.py:170-171, 233-234) */
 int rgqa_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, void* stream);
 
 /* ---- input path: a staged batch from the binary feature store -> engine inputs, on the device ----------

@@ -318,6 +318,58 @@ def gen_mixup():
         z[mode + ".prop"] = np.array(draws["prop"], dtype=np.float64)
         z[mode + ".perm"] = np.stack(draws["idx"])
         assert len(ns["sent"]) == 2 * B
+    # the other two batch constructions of the same trainer: 'perturb' (:124-133) and 'weighted_sum_v1/v2' (:217-244), executed
+    # the same way (the reference's own statements, RNG draws recorded)
+    p0 = next(i for i, l in enumerate(lines) if "if args.mixup_mode == 'perturb':" in l)
+    p1 = next(i for i, l in enumerate(lines) if i > p0 and "target = torch.cat([target, torch.zeros_like(target)], 0)" in l)
+    body_p = textwrap.dedent("\n".join(lines[p0 + 1:p1 + 1]))
+    w0 = next(i for i, l in enumerate(lines) if "elif args.mixup_mode.startswith('weighted_sum'):" in l)
+    w1 = next(i for i, l in enumerate(lines) if i > w0 and "sent = sent + sent" in l)
+    body_w = textwrap.dedent("\n".join(lines[w0 + 1:w1 + 1]))
+    feats = torch.from_numpy(synth.uniform("mix.f", (B, O, Fd), 0, 1))
+    boxes = torch.from_numpy(synth.uniform("mix.b", (B, O, 4), 0, 1))
+    target = torch.from_numpy(synth.uniform("mix.t", (B, NA), 0, 1))
+    perm_rec = {}
+    real_randperm = torch.randperm
+
+    def randperm(n):
+        r = real_randperm(n)
+        perm_rec["perm"] = r.numpy().copy()
+        return r
+    torch.manual_seed(9595)
+    ns = dict(args=types.SimpleNamespace(mixup_mode="perturb"), feats=feats, boxes=boxes, target=target, sent=["s"] * B,
+              torch=types.SimpleNamespace(randperm=randperm, cat=torch.cat, zeros_like=torch.zeros_like))
+    exec(body_p, ns)
+    z["perturb.feats"], z["perturb.boxes"], z["perturb.target"] = ns["feats"].numpy(), ns["boxes"].numpy(), ns["target"].numpy()
+    z["perturb.perm"] = perm_rec["perm"]
+    assert len(ns["sent"]) == 2 * B
+    for mode in ("weighted_sum_v1", "weighted_sum_v2"):
+        ques_id = ["q%d" % i for i in range(B)]
+        img = {"q0": "A", "q1": "B", "q2": "A", "q3": "C", "q4": "D", "q5": "B"}
+
+        class DS2:
+            id2datum = {q: {"img_id": img[q]} for q in ques_id}
+        draws = {"partner": [], "prop": []}
+        pend = {}
+        random.seed(4242)
+
+        def choice2(seq):
+            r = random.Random.choice(random._inst, seq)
+            pend["last"] = seq.index(r)
+            return r
+
+        def rnd():
+            draws["partner"].append(pend["last"])
+            p = random.Random.random(random._inst)
+            draws["prop"].append(p)
+            return p
+        ns = dict(args=types.SimpleNamespace(mixup_mode=mode), dset=DS2, ques_id=ques_id, feats=feats, boxes=boxes, target=target,
+                  sent=["s"] * B, torch=torch, random=types.SimpleNamespace(choice=choice2, random=rnd))
+        exec(body_w, ns)
+        z[mode + ".feats"], z[mode + ".boxes"], z[mode + ".target"] = ns["feats"].numpy(), ns["boxes"].numpy(), ns["target"].numpy()
+        z[mode + ".partner"] = np.array(draws["partner"])
+        z[mode + ".prop"] = np.array(draws["prop"], dtype=np.float64)
+        assert len(ns["sent"]) == 2 * B
     np.savez_compressed(os.path.join(OUT, "g5_mixup.npz"), **z)
     print("g5 ok")
 

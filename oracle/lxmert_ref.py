@@ -281,6 +281,30 @@ def roi_mixup(feats, boxes, target, partner, prop, idx_lists, mode="mixup_v1"):
             torch.cat([target, torch.stack(pt, 0)], 0))
 
 
+def perturb_batch(feats, boxes, target, perm):
+    """'perturb' batch construction (tasks/gqa_mixup_vis.py:124-133): the second half repeats the features with the boxes of every
+    sample permuted by ONE random permutation of the RoIs (`perm` = the torch.randperm draw) and all-zero targets."""
+    perm = torch.as_tensor(perm, dtype=torch.long)
+    return (feats.repeat(2, 1, 1), torch.cat([boxes, boxes[:, perm, :]], 0), torch.cat([target, torch.zeros_like(target)], 0))
+
+
+def weighted_sum_batch(feats, boxes, target, partner, prop, mode="weighted_sum_v1"):
+    """'weighted_sum_v1/v2' (tasks/gqa_mixup_vis.py:217-244): second half = feat_pos * prop + feat_neg * (1 - prop) with
+    prop = random.random() (a Python float: each product is rounded to f32 before the sum), boxes repeated, targets scaled by
+    prop (v1) or zero (v2)."""
+    pf, pt = [], []
+    for j in range(feats.shape[0]):
+        p = float(prop[j])
+        pf.append(feats[j] * p + feats[int(partner[j])] * (1 - p))
+        if mode == "weighted_sum_v1":
+            pt.append(target[j] * p)
+        elif mode == "weighted_sum_v2":
+            pt.append(target[j] * 0)
+        else:
+            raise ValueError(mode)
+    return (torch.cat([feats, torch.stack(pf, 0)], 0), boxes.repeat(2, 1, 1), torch.cat([target, torch.stack(pt, 0)], 0))
+
+
 def clip_grad_norm(grads, max_norm):
     """torch.nn.utils.clip_grad_norm_(params, 5.) semantics (tasks/gqa_conf.py:201): global L2 norm over
     grads that are not None, scale by max_norm/(norm+1e-6) when that is < 1. Returns the norm."""

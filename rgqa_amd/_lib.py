@@ -54,6 +54,8 @@ SIGNATURES = {
     "rgqa_cast_bf16": [_vp, _vp, _sz, _vp],
     "rgqa_sum_bf16_parts": [_vp, _sz, _i, _vp, _sz, _vp],
     "rgqa_mixup_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "rgqa_mixup_perturb": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "rgqa_mixup_weighted_sum": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "rgqa_scale_rows": [_vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rgqa_op_linear_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],

@@ -191,6 +191,14 @@ int rgqa_mixup_gather(float* feats, float* boxes, const int32_t* partner, const 
     RGQA_REQUIRE(feats && boxes && partner && take_pos, "mixup_gather: null argument");
     return k_mixup_gather(feats, boxes, partner, take_pos, B, O, F, mode_v3, S(stream));
 }
+int rgqa_mixup_perturb(float* feats, float* boxes, const int32_t* perm, int B, int O, int F, void* stream) {
+    RGQA_REQUIRE(feats && boxes && perm, "mixup_perturb: null argument");
+    return k_mixup_perturb(feats, boxes, perm, B, O, F, S(stream));
+}
+int rgqa_mixup_weighted_sum(float* feats, float* boxes, const int32_t* partner, const float* prop, const float* one_minus_prop, int B, int O, int F, void* stream) {
+    RGQA_REQUIRE(feats && boxes && partner && prop && one_minus_prop, "mixup_weighted_sum: null argument");
+    return k_mixup_weighted_sum(feats, boxes, partner, prop, one_minus_prop, B, O, F, S(stream));
+}
 int rgqa_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, void* stream) {
     RGQA_REQUIRE(target && prop, "scale_rows: null argument");
     return k_scale_rows(target, prop, B, NA, ld, row0, S(stream));

@@ -123,6 +123,8 @@ int k_batch_prepare(const void* feats_in, int feats_f16, float* feats_out, const
 int k_score_rows(const float* logits, int ld, int B, int NA, float temperature, int k, float* max_score, int64_t* label, float* energy,
                  float* topk_val, int64_t* topk_idx, float* topk_energy, hipStream_t s);
 int k_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uint8_t* take_pos /*[B,O]*/, int B, int O, int F, int mode_v3, hipStream_t s);
+int k_mixup_perturb(float* feats, float* boxes, const int32_t* perm, int B, int O, int F, hipStream_t s);
+int k_mixup_weighted_sum(float* feats, float* boxes, const int32_t* partner, const float* p, const float* q, int B, int O, int F, hipStream_t s);
 int k_scale_rows(float* target, const float* prop, int B, int NA, int ld, int row0, hipStream_t s);
 template <typename T> int k_fill_rows(T* dst, int ld, const T* src, int lds, int rows, int cols, hipStream_t s);
 template <typename T> int k_cast_pad(const float* src, int lds, T* dst, int ldd, int rows, int cols, float scale, hipStream_t s);

@@ -25,6 +25,47 @@ int k_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uin
     return RGQA_OK;
 }
 
+// 'perturb' (gqa_mixup_vis.py:124-133): rows [B,2B) = the features again, boxes[B+j][o] = boxes[j][perm[o]] (one permutation for the batch)
+__global__ __launch_bounds__(256) void mixup_perturb_kernel(float* __restrict__ feats, float* __restrict__ boxes, const int32_t* __restrict__ perm, int B, int O, int F) {
+    const int j = blockIdx.x / O, o = blockIdx.x % O;
+    const float* sf = feats + ((size_t)j * O + o) * F;
+    float* df = feats + ((size_t)(B + j) * O + o) * F;
+    for (int c = threadIdx.x; c < (F >> 2); c += 256) reinterpret_cast<float4*>(df)[c] = reinterpret_cast<const float4*>(sf)[c];
+    if (threadIdx.x < 4) boxes[((size_t)(B + j) * O + o) * 4 + threadIdx.x] = boxes[((size_t)j * O + perm[o]) * 4 + threadIdx.x];
+}
+int k_mixup_perturb(float* feats, float* boxes, const int32_t* perm, int B, int O, int F, hipStream_t s) {
+    RGQA_REQUIRE(F % 4 == 0 && B > 0 && O > 0, "mixup_perturb: bad shape");
+    hipLaunchKernelGGL(mixup_perturb_kernel, dim3(B * O), dim3(256), 0, s, feats, boxes, perm, B, O, F);
+    RGQA_LAUNCH_CHECK("mixup_perturb_kernel");
+    return RGQA_OK;
+}
+
+// 'weighted_sum' (gqa_mixup_vis.py:217-244): feats[B+j] = feats[j] * p[j] + feats[partner[j]] * q[j], every product rounded to f32
+// before the sum as torch does (__fmul_rn / __fadd_rn: no fused multiply-add); q[j] = f32(1 - prop) is formed on the host in double
+// like the reference's Python expression; boxes repeated
+__global__ __launch_bounds__(256) void mixup_wsum_kernel(float* __restrict__ feats, float* __restrict__ boxes, const int32_t* __restrict__ partner,
+                                                         const float* __restrict__ p, const float* __restrict__ q, int B, int O, int F) {
+    const int j = blockIdx.x / O, o = blockIdx.x % O;
+    const float pj = p[j], qj = q[j];
+    const float4* sp = reinterpret_cast<const float4*>(feats + ((size_t)j * O + o) * F);
+    const float4* sn = reinterpret_cast<const float4*>(feats + ((size_t)partner[j] * O + o) * F);
+    float4* df = reinterpret_cast<float4*>(feats + ((size_t)(B + j) * O + o) * F);
+    for (int c = threadIdx.x; c < (F >> 2); c += 256) {
+        const float4 a = sp[c], b = sn[c];
+        float4 r;
+        r.x = __fadd_rn(__fmul_rn(a.x, pj), __fmul_rn(b.x, qj)); r.y = __fadd_rn(__fmul_rn(a.y, pj), __fmul_rn(b.y, qj));
+        r.z = __fadd_rn(__fmul_rn(a.z, pj), __fmul_rn(b.z, qj)); r.w = __fadd_rn(__fmul_rn(a.w, pj), __fmul_rn(b.w, qj));
+        df[c] = r;
+    }
+    if (threadIdx.x < 4) boxes[((size_t)(B + j) * O + o) * 4 + threadIdx.x] = boxes[((size_t)j * O + o) * 4 + threadIdx.x];
+}
+int k_mixup_weighted_sum(float* feats, float* boxes, const int32_t* partner, const float* p, const float* q, int B, int O, int F, hipStream_t s) {
+    RGQA_REQUIRE(F % 4 == 0 && B > 0 && O > 0, "mixup_weighted_sum: bad shape");
+    hipLaunchKernelGGL(mixup_wsum_kernel, dim3(B * O), dim3(256), 0, s, feats, boxes, partner, p, q, B, O, F);
+    RGQA_LAUNCH_CHECK("mixup_wsum_kernel");
+    return RGQA_OK;
+}
+
 // target[row0 + j][:] = target[j][:] * prop[j]
 __global__ void scale_rows_kernel(float* __restrict__ target, const float* __restrict__ prop, int NA, int ld, int row0) {
     const int j = blockIdx.x;

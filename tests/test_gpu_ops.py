@@ -317,3 +317,33 @@ def test_mixup_gather_vs_golden(lib, golden_dir, mode):
     assert np.array_equal(feats.cpu().numpy(), g[mode + ".feats"])
     assert np.array_equal(boxes.cpu().numpy(), g[mode + ".boxes"])
     np.testing.assert_allclose(target.cpu().numpy(), g[mode + ".target"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["perturb", "mixup_v1", "mixup_v2", "mixup_v3", "weighted_sum_v1", "weighted_sum_v2"])
+def test_roi_mixup_entry_vs_golden(golden_dir, mode):
+    """rgqa_amd.mixup.RoIMixup (the product entry for gqa_mixup_vis.py:117-259) on the reference's recorded draws: every batch
+    construction of the trainer, bit for bit (G5)."""
+    from rgqa_amd import synth
+    from rgqa_amd.mixup import RoIMixup
+    g = np.load(os.path.join(golden_dir, "g5_mixup.npz"))
+    B, O, Fd, NA = 6, 36, 8, 5
+    feats = torch.from_numpy(synth.uniform("mix.f", (B, O, Fd), 0, 1)).cuda()
+    boxes = torch.from_numpy(synth.uniform("mix.b", (B, O, 4), 0, 1)).cuda()
+    target = torch.from_numpy(synth.uniform("mix.t", (B, NA), 0, 1)).cuda()
+    if mode == "perturb":
+        draws = dict(perm=g["perturb.perm"])
+    elif mode.startswith("mixup"):
+        take = np.zeros((B, O), dtype=np.uint8)
+        for j in range(B):
+            take[j, g[mode + ".perm"][j][: int(g[mode + ".prop"][j] * O)]] = 1
+        draws = dict(partner=g[mode + ".partner"], prop=g[mode + ".prop"], take=take)
+    else:
+        draws = dict(partner=g[mode + ".partner"], prop=g[mode + ".prop"])
+    f2, b2, t2 = RoIMixup(mode, 1.0, 5.0)(feats, boxes, target, ["A", "B", "A", "C", "D", "B"], draws=draws)
+    assert np.array_equal(f2.cpu().numpy(), g[mode + ".feats"])
+    assert np.array_equal(b2.cpu().numpy(), g[mode + ".boxes"])
+    assert np.array_equal(t2.cpu().numpy(), g[mode + ".target"])
+    # own draws: the host loop terminates, partners have another image, shapes double
+    f3, b3, t3 = RoIMixup(mode, 1.0, 5.0)(feats, boxes, target, ["A", "B", "A", "C", "D", "B"])
+    assert f3.shape == (2 * B, O, Fd) and b3.shape == (2 * B, O, 4) and t3.shape == (2 * B, NA)
+    assert torch.equal(f3[:B], feats) and torch.equal(t3[:B], target)

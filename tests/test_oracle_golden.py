@@ -137,6 +137,23 @@ def test_g5_mixup(golden_dir, mode):
     np.testing.assert_allclose(t.numpy(), g[mode + ".target"], rtol=1e-6)
 
 
+def test_g5_perturb_and_weighted_sum(golden_dir):
+    """the other batch constructions of gqa_mixup_vis.py (:124-133, :217-244) against the reference's own statements (G5)"""
+    g = np.load(os.path.join(golden_dir, "g5_mixup.npz"))
+    B, O, Fd, NA = 6, 36, 8, 5
+    feats = torch.from_numpy(synth.uniform("mix.f", (B, O, Fd), 0, 1))
+    boxes = torch.from_numpy(synth.uniform("mix.b", (B, O, 4), 0, 1))
+    target = torch.from_numpy(synth.uniform("mix.t", (B, NA), 0, 1))
+    f, b, t = R.perturb_batch(feats, boxes, target, g["perturb.perm"])
+    for got, key in ((f, "feats"), (b, "boxes"), (t, "target")):
+        np.testing.assert_array_equal(got.numpy(), g["perturb." + key])
+    for mode in ("weighted_sum_v1", "weighted_sum_v2"):
+        f, b, t = R.weighted_sum_batch(feats, boxes, target, g[mode + ".partner"], g[mode + ".prop"], mode)
+        np.testing.assert_array_equal(f.numpy(), g[mode + ".feats"])
+        np.testing.assert_array_equal(b.numpy(), g[mode + ".boxes"])
+        np.testing.assert_array_equal(t.numpy(), g[mode + ".target"])
+
+
 def test_bce_and_uq_column():
     """G6: BCE x NA with an all-zero (pseudo-UQ) row and the dropped UQ column (gqa_conf.py:153,197-198)."""
     z = torch.from_numpy(synth.uniform("bce.z", (4, 7), -3, 3))
