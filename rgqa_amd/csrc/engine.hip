@@ -1,5 +1,7 @@
 // Engine implementation: parameter table, workspace plan, forward and backward launch sequences.
 #include "engine.h"
+
+int g_rgqa_cls_tail = -1;   // rgqa_debug_set key 8: 1 / 0 = last language FFN on the [CLS] rows only / on every row; -1 = env RGQA_CLS_TAIL (default on)
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -314,7 +316,7 @@ public:
         ws_used = 0;
         stages.clear();
         maskf = take<float>(RlC);
-        lens_dev = take<int>(B); cu_dev = take<int>(B + 1); row_src_dev = take<int>(RlC); cls_rows = take<T>((size_t)B * H);
+        lens_dev = take<int>(B); cu_dev = take<int>(B + 1); row_src_dev = take<int>(RlC); cls_rows = take<T>((size_t)B * H); tail_x = take<T>((size_t)B * H); tail_dx = take<T>((size_t)B * H);
         emb_out = take<T>((size_t)RC * H); emb_z = take<T>((size_t)RlC * H); emb_mean = take<float>(RlC); emb_rstd = take<float>(RlC);
         zf = take<T>((size_t)Rv * H); visn_stats = take<float>((size_t)Rv * 4);
         feats_lp = LP ? take<T>((size_t)Rv * cfg.feat_dim) : nullptr;   // bf16 copy of the RoI features: read by visn_fc forward AND its wgrad
@@ -411,7 +413,7 @@ public:
         wpart = LP ? take<float>(wpart_elems) : nullptr;
         tdesc = take<TransDesc>(n_tdesc + 1);
     }
-    int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr;
+    int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr; T* tail_x = nullptr; T* tail_dx = nullptr; T* pool_in = nullptr;
     // UNITER (arch 2): ONE sequence per sample, [text tokens ; image regions], laid out as the engine's language modality with
     // Tn = Tt + Oi rows per sample (packed: real text tokens + Oi) and no vision modality; only the embedding front-end differs.
     bool joint = false; int Tt = 0, Oi = 0, jstate = 0, n_text = 0;      // jstate: index arrays built for 1 = padded / 2 = packed rows
@@ -574,6 +576,14 @@ public:
 // CK + HIP-event timing of the call under profiling (non-GEMM kernels: they count towards the per-block times)
 #define CKP(cat, x) do { prof_begin((cat), 0.0, 0.0, s); int _r = (x); prof_end(s); if (_r) return _r; } while (0)
 
+    // The pooler reads only token 0 of the final language output (modeling.py:575-581) and nothing else reads that output in mode
+    // 'x': the FFN sub-block of the LAST cross-modality layer runs on the B [CLS] rows only (gathered in, kept compact: rows 0..B-1
+    // of the stage buffers), forward and backward.  RGQA_CLS_TAIL=0 computes every row as the reference does.
+    bool cls_tail(const Stage& st) const {
+        static const bool env_on = []() { const char* e = getenv("RGQA_CLS_TAIL"); return !(e && e[0] == '0'); }();
+        const bool on = g_rgqa_cls_tail < 0 ? env_on : g_rgqa_cls_tail != 0;       // rgqa_debug_set key 8 (tests: both paths in one process)
+        return on && cfg.arch == 0 && st.kind == ST_FFN && st.last_dead && st.active[0] && !st.active[1] && &st == &stages.back();
+    }
     int seg_rows(int m) const { return m == 0 ? Rl : Rv; }
     int seg_len(int m) const { return m == 0 ? Tn : O; }
 
@@ -582,6 +592,17 @@ public:
     int forward_stage(Stage& st, const int* cu, hipStream_t s) {
         const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh;
         const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
+        if (st.kind == ST_FFN && cls_tail(st)) {
+            GemmGroup g; gg_init(g);
+            CKP(PC_OTHER, k_gather_rows<T>((const T*)st.sb[0].x_in, H, cu, Tn, tail_x, H, B, H, s));      // the [CLS] row of every sample
+            add_fwd(g, tail_x, H, st.ffn[0]->up, 0, I, st.sb[0].h, I, B, EPI_GELU, nullptr, 0, st.sb[0].hpre, 0);
+            CK(run_fwd(g, s));
+            gg_init(g); g.drop = drop_base(pd);
+            add_fwd(g, st.sb[0].h, I, st.ffn[0]->down, 0, H, st.sb[0].z, H, B, EPI_RESID_DROP, tail_x, H, nullptr, st.site + 1);
+            CK(run_fwd(g, s));
+            CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.ffn[0]->ln.w, P + st.ffn[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, B, H, cfg.ln_eps, s));
+            return RGQA_OK;
+        }
         if (st.kind == ST_FFN) {
             GemmGroup g; gg_init(g);
             for (int m = 0; m < 2; ++m) if (st.active[m])
@@ -785,8 +806,10 @@ public:
         prof_block = PB_HEAD;
         {
             GemmGroup g; gg_init(g);
-            CKP(PC_OTHER, k_gather_rows<T>((const T*)lang_final, H, cu, Tn, cls_rows, H, B, H, s));     // the [CLS] row of every sample
-            add_fwd(g, cls_rows, H, mp.pooler, 0, H, pooled, H, B, EPI_TANH, nullptr, 0, nullptr, 0);
+            pool_in = cls_rows;
+            if (!stages.empty() && cls_tail(stages.back())) pool_in = (T*)lang_final;      // already the B compact [CLS] rows
+            else CKP(PC_OTHER, k_gather_rows<T>((const T*)lang_final, H, cu, Tn, cls_rows, H, B, H, s));     // the [CLS] row of every sample
+            add_fwd(g, pool_in, H, mp.pooler, 0, H, pooled, H, B, EPI_TANH, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s));
             gg_init(g);
             add_fwd(g, pooled, H, mp.head0, 0, 2 * H, h1, 2 * H, B, EPI_GELU, nullptr, 0, h1pre, 0);
@@ -876,7 +899,7 @@ public:
         GemmGroup g;
         CKP(PC_OTHER, colsum_bias(gp1, H, mp.pooler, 0, H, B, accumulate, s));
         const int* cu = fwd_varlen ? cu_dev : nullptr;
-        gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, cls_rows, H, B, accumulate); CK(run_wgrad(g, s));
+        gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, pool_in, H, B, accumulate); CK(run_wgrad(g, s));
         // gradient w.r.t. the final hidden states: zero except the [CLS] rows of lang
         // Gradient w.r.t. the current stage's output, one pointer per modality: a stage moves only the modalities it computes to
         // the other buffer, so a modality that merely passes through (vision under the language-only layers) stays where it is
@@ -896,7 +919,8 @@ public:
         };
         CK(rgqa_check_hip(hipMemsetAsync(dyp[0], 0, (size_t)R * H * sizeof(T), s), "zero dy"));
         gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, gp2, H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
-        CKP(PC_OTHER, k_scatter_rows<T>(gp2, H, dyp[0], H, cu, Tn, B, H, s));
+        const bool tail = !stages.empty() && cls_tail(stages.back());
+        if (!tail) CKP(PC_OTHER, k_scatter_rows<T>(gp2, H, dyp[0], H, cu, Tn, B, H, s));     // tail: the last FFN stage takes gp2 [B,H] as it is
         seg_cursor = 0;
         CK(mark_segment(s));     // head + pooler gradients are final
 
@@ -911,6 +935,23 @@ public:
             const bool cross = st.kind == ST_ATT_CROSS;
             const bool shared_all = cross && st.active[1];
             auto rowp = [&](T* base, int m, int width) { return base + (size_t)(m == 0 ? 0 : Rl) * width; };
+            if (st.kind == ST_FFN && tail && si == (int)stages.size() - 1) {
+                // B compact [CLS] rows: LayerNorm / FFN backward on them, then the input gradient goes back to the [CLS] rows of a zeroed buffer
+                const FfnP& f = *st.ffn[0];
+                DropCfg d = drop_site(pd, st.site + 1);
+                CKP(PC_LN, k_ln_bwd<T>(gp2, H, (T*)st.sb[0].z, H, P + f.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b,
+                               accumulate, B, H, d, nodrop, 1.0f, s));
+                T* gzm = d.thresh ? gzd : gz;
+                gg_init(g); add_dgrad(g, gzm, H, f.down, 0, H, gh, I, B, EPI_DGELU, st.sb[0].hpre, I); CK(run_dgrad(g, s));
+                add_wgrad(wg, gzm, H, f.down, 0, H, st.sb[0].h, I, B, accumulate);
+                add_wgrad(wg, gh, I, f.up, 0, I, tail_x, H, B, accumulate, true);
+                gg_init(g); add_dgrad(g, gh, I, f.up, 0, I, tail_dx, H, B, EPI_ADD, gz, H); CK(run_dgrad(g, s));
+                CK(rgqa_check_hip(hipMemsetAsync(dxp[0], 0, (size_t)Rl * H * sizeof(T), s), "zero tail dx"));
+                CKP(PC_OTHER, k_scatter_rows<T>(tail_dx, H, dxp[0], H, cu, Tn, B, H, s));
+                { T* t = dyp[0]; dyp[0] = dxp[0]; dxp[0] = t; }
+                if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
+                continue;
+            }
             if (st.kind == ST_FFN) {
                 const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && dyp[1] == dyp[0] + (size_t)Rl * H;
                 if (both) {
@@ -1150,6 +1191,7 @@ public:
             const bool visn = nm.find("_visn") != std::string::npos;
             RGQA_REQUIRE(!(visn && i == cfg.x_layers - 1), "get_activation: %s is the dead branch in mode 'x' and is not computed", name);
             stage_out(2 * nlr + 3 * i + 2, visn ? 1 : 0);
+            if (!visn && i == cfg.x_layers - 1 && cls_tail(stages.back())) n = (size_t)B * H;      // only the B [CLS] rows exist (compact)
         }
         RGQA_REQUIRE(src != nullptr, "get_activation: unknown activation '%s'", name);
         RGQA_REQUIRE(cap >= n, "get_activation: buffer too small (%zu < %zu)", cap, n);

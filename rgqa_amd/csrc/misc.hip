@@ -41,10 +41,11 @@ int k_mixup_perturb(float* feats, float* boxes, const int32_t* perm, int B, int 
 }
 
 // 'weighted_sum' (gqa_mixup_vis.py:217-244): feats[B+j] = feats[j] * p[j] + feats[partner[j]] * q[j], every product rounded to f32
-// before the sum as torch does (__fmul_rn / __fadd_rn: no fused multiply-add); q[j] = f32(1 - prop) is formed on the host in double
+// before the sum as torch does (fp contraction off: no fused multiply-add); q[j] = f32(1 - prop) is formed on the host in double
 // like the reference's Python expression; boxes repeated
 __global__ __launch_bounds__(256) void mixup_wsum_kernel(float* __restrict__ feats, float* __restrict__ boxes, const int32_t* __restrict__ partner,
                                                          const float* __restrict__ p, const float* __restrict__ q, int B, int O, int F) {
+#pragma clang fp contract(off)      // hipcc's __fmul_rn / __fadd_rn are plain operators: without this the sum becomes an FMA
     const int j = blockIdx.x / O, o = blockIdx.x % O;
     const float pj = p[j], qj = q[j];
     const float4* sp = reinterpret_cast<const float4*>(feats + ((size_t)j * O + o) * F);

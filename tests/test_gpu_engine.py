@@ -45,6 +45,10 @@ def test_f32_small_vs_golden(golden_dir, T):
         if name == "x1_visn":
             continue   # dead branch in mode 'x' (SURVEY.md §8 A11): not computed
         ref = g[k]
+        if name == "x1_lang":      # final language output: only its [CLS] rows are consumed (pooler) and computed
+            got = e.activation(name, ref.shape[0]).cpu().numpy()
+            np.testing.assert_allclose(got, ref[:, 0, :], rtol=0, atol=1e-4, err_msg=name)
+            continue
         got = e.activation(name, ref.shape[0] * ref.shape[1]).cpu().numpy().reshape(ref.shape)
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4, err_msg=name)
     loss = e.loss_backward(b["target"])
@@ -475,16 +479,64 @@ def test_varlen_matches_padded(precision, ltol, gtol):
     # packed activations are the valid rows of the padded ones
     n = int(lengths.sum())
     rows = np.concatenate([np.arange(T * i, T * i + lengths[i]) for i in range(B)])
-    a1 = e.activation("x1_lang", n).cpu().numpy()
+    a1 = e.activation("x0_lang", n).cpu().numpy()
+    c1 = e.activation("x1_lang", B).cpu().numpy()            # the final language output exists for the [CLS] rows only
     e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"])
-    a0 = e.activation("x1_lang", B * T).cpu().numpy()[rows]
+    a0 = e.activation("x0_lang", B * T).cpu().numpy()[rows]
+    c0 = e.activation("x1_lang", B).cpu().numpy()
     np.testing.assert_allclose(a1, a0, rtol=0, atol=(1e-4 if precision == "f32" else 0.1))
+    np.testing.assert_allclose(c1, c0, rtol=0, atol=(1e-4 if precision == "f32" else 0.1))
     lg2, pl2, loss2, g2 = run_pass(None)
     assert torch.equal(lg2, lg0) and torch.equal(pl2, pl0)
     first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
     for sp in e.specs:
         if sp.offset >= first:
             assert torch.equal(g2[sp.name], g0[sp.name]), sp.name
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("train", [False, True])
+def test_cls_only_tail_matches_full_rows(precision, train):
+    """Only token 0 of the last language FFN is consumed (modeling.py:575-581): running that sub-block on the B [CLS] rows
+    (default) gives the logits and every gradient of the all-rows computation (rgqa_debug_set key 8 = 0), in both layouts.  Train
+    mode runs with attention dropout only: the hidden-dropout draws of the tail's own site are indexed by the row number inside the
+    launch, which the compact layout changes (any draw is a valid dropout mask; it is the same in forward and backward)."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    B, T, O = 6, 12, 7
+    raw = synth.synth_batch(B, T, O=O, F=MED["feat_dim"], NA=MED["num_answers"], vocab=MED["vocab_size"], seed=33, min_len=2)
+    b = dev(raw)
+    lens = raw["lengths"].astype(np.int32)
+    from rgqa_amd.engine import Engine
+    e = Engine(precision=precision, hidden_dropout=0.0, attn_dropout=0.1 if train else 0.0, **MED).allocate("cuda")
+    for sp in e.specs:
+        e.view(e.params, sp).copy_(torch.from_numpy(synth.fill_value(sp.name, sp.shape)))
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    res = {}
+    try:
+        for mode in (0, 1):
+            assert L.rgqa_debug_set(8, mode) == 0
+            for packed in (False, True):
+                lg, _ = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=train, seed=5, lengths=lens if packed else None)
+                lg = lg.clone()
+                loss = e.loss_backward(b["target"]).item()
+                res[(mode, packed)] = (lg, loss, _grads_by_name(e))
+    finally:
+        L.rgqa_debug_set(8, -1)
+    tol = 1e-6       # observed: logits identical, gradients within 1.2e-7 of their largest entry (different GEMM tile shapes / row counts)
+    for packed in (False, True):
+        lg0, loss0, g0 = res[(0, packed)]
+        lg1, loss1, g1 = res[(1, packed)]
+        assert float((lg1 - lg0).abs().max()) <= tol * max(1.0, float(lg0.abs().max()))
+        assert abs(loss1 - loss0) <= tol * max(1.0, abs(loss0))
+        worst = 0.0
+        for name, ref in g0.items():
+            den = float(ref.abs().max())
+            if den > 0:
+                worst = max(worst, float((g1[name] - ref).abs().max()) / den)
+        _report("cls tail vs all rows %s train=%s packed=%s" % (precision, train, packed), logits_max=float((lg1 - lg0).abs().max()), grad_rel_max=worst)
+        assert worst <= 1e-6
 
 
 @pytest.mark.parametrize("T", [5, 8])
