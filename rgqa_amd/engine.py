@@ -258,6 +258,7 @@ class Engine:
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
+        if getattr(self, "_sumsq", None) is None:        # (the sharded data-parallel optimizer may have created the moments already)
             self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._sq_ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
         s = _stream()
