@@ -183,9 +183,12 @@ def main():
     ap.add_argument("--mixup", action="store_true",
                     help="BASELINE config 4: RoI-mixup finetune (gqa_mixup_vis.py:134-181): every loader batch is doubled on the device "
                          "(mixup_v1, Beta(1,5)); the model sees 2x rows per QA pair; value still counts loader QA pairs")
+    ap.add_argument("--lean", action="store_true", help="only the warm-up and timed steps (no padded-layout / exchange-free legs, no live kernel timing, no CPU baseline): what runs under rocprofv3")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)          # CPU rehearsal of the N-rank launch path
     ap.add_argument("--launch-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.lean:
+        args.no_cpu_baseline, args.profile_steps = True, 0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))     # before any torch.cuda / HIP call
@@ -317,11 +320,11 @@ def main():
     # diagnostics outside the timed region (every rank takes part): the step without the gradient exchange -> what the exchange
     # costs beyond what backward hides; the reference's padded layout (all B*T token positions computed)
     exposed_comm_ms = None
-    if dist is not None:
+    if dist is not None and not args.lean:
         n2 = max(3, min(args.steps, 10))
         exposed_comm_ms = round(ms - timed_leg(n2, exchange=False), 3)
     padded_leg = None
-    if lengths is not None and not (args.butd or args.uniter or args.mixup):
+    if lengths is not None and not (args.butd or args.uniter or args.mixup or args.lean):
         n2 = max(3, min(args.steps, 10))
         state["lengths"] = None
         for _ in range(2):

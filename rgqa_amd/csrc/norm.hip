@@ -2,6 +2,7 @@
 // reference lxrt/modeling.py:261) forward / backward, one 64-lane wave per row, f32 statistics.
 // HBM-bound: algorithmic bytes per row = N * (sizeof(T) in + sizeof(T) out) forward.
 #include "kernels.h"
+#include <type_traits>
 
 #define LN_MAXV 8  // up to 8 vec4 chunks per lane -> N <= 2048 (NV = chunks per lane, compile-time)
 
@@ -49,6 +50,56 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
         }
     }
     if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+}
+
+// bf16 rows with N = 256 * NC columns (768, 1536): HALF a wave per row, every access a full 16 bytes per lane (the 8-byte bf16x4 accesses
+// of the generic kernel run at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).  Lane l of a half owns the 8-column chunks l, l + 32, ...
+int g_rgqa_ln16 = -1;      // rgqa_debug_set key 9: 0 = generic kernels only, 1 / -1 = 16-byte kernels where they apply
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int NC>
+__global__ __launch_bounds__(256) void ln_fwd16_kernel(const bf16_t* __restrict__ x, int ldx, const float* gamma, const float* beta, bf16_t* __restrict__ y, int ldy,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int M, float eps, int split,
+                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2) {
+    constexpr int N = 256 * NC;
+    const int hl = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= M) return;                                   // a whole half-wave leaves: the shuffles below stay inside a half
+    if (row >= split) { gamma = gamma2; beta = beta2; }
+    bf16x8 raw[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) raw[i] = *reinterpret_cast<const bf16x8*>(x + (size_t)row * ldx + (hl + 32 * i) * 8);
+    float v[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[i][j] = (float)raw[i][j]; s += v[i][j]; }
+    const float mu = half_sum(s) * (1.0f / (float)N);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
+    const float rs = rsqrtf(half_sum(q) * (1.0f / (float)N) + eps);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = (hl + 32 * i) * 8;
+        float g[8], b[8];
+        load4(gamma + c, g); load4(gamma + c + 4, g + 4);
+        load4(beta + c, b); load4(beta + c + 4, b + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((v[i][j] - mu) * rs * g[j] + b[j]);
+        *reinterpret_cast<bf16x8*>(y + (size_t)row * ldy + c) = o;
+    }
+    if (hl == 0) {
         if (mean) mean[row] = mu;
         if (rstd) rstd[row] = rs;
     }
@@ -192,6 +243,9 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const LnBwdSeg<T
     }
 }
 
+// (A 16-byte-access variant of the backward kernel - lane l owning the 8-column chunks l and 64 + l - needs 48 column accumulators per lane
+// and spills at the 128-VGPR budget of a 16-wave block: 52 us against 24 us per launch, tools/lab/ln_lab.  Not kept.)
+
 // out[q][n*stride] (+)= sum_blk part[blk][q][n] for q < nq (null output pointers are skipped).
 // Block = 16 columns (4 lanes x float4) x 64 partial groups: every thread sums nblk/64 float4 partials (fixed order ->
 // bit-reproducible), then the 64 group sums are folded in a fixed order through LDS.  N % 4 == 0.
@@ -261,6 +315,14 @@ int k_ln_fwd2(const T* x, int ldx, const float* gamma, const float* beta, const 
               int M, int N, float eps, hipStream_t s) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: N=%d must be a multiple of 4 and <= %d", N, LN_MAXV * 256);
     if (M <= 0) return RGQA_OK;
+    if (std::is_same<T, bf16_t>::value && g_rgqa_ln16 != 0 && (N == 768 || N == 1536) && ldx % 8 == 0 && ldy % 8 == 0 &&
+        ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0) {
+        const bf16_t* xb = reinterpret_cast<const bf16_t*>(x); bf16_t* yb = reinterpret_cast<bf16_t*>(y);
+        if (N == 768) hipLaunchKernelGGL(ln_fwd16_kernel<3>, dim3(cdiv(M, 8)), dim3(256), 0, s, xb, ldx, gamma, beta, yb, ldy, mean, rstd, M, eps, split, gamma2, beta2);
+        else hipLaunchKernelGGL(ln_fwd16_kernel<6>, dim3(cdiv(M, 8)), dim3(256), 0, s, xb, ldx, gamma, beta, yb, ldy, mean, rstd, M, eps, split, gamma2, beta2);
+        RGQA_LAUNCH_CHECK("ln_fwd16_kernel");
+        return RGQA_OK;
+    }
 #define LN_FWD(NVV) hipLaunchKernelGGL((ln_fwd_kernel<T, NVV>), dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, split, gamma2, beta2)
     const int nvl = cdiv(N / 4, 64);
     if (nvl <= 1) LN_FWD(1); else if (nvl == 2) LN_FWD(2); else if (nvl == 3) LN_FWD(3); else if (nvl == 4) LN_FWD(4);

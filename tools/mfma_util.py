@@ -5,7 +5,7 @@ import collections, csv, json, sys
 
 
 def family(k):
-    if "gemm_nt256" in k or "gemm_nt_kernel" in k:
+    if "gemm_nt" in k:
         return "gemm_nt"
     if "gemm_tn" in k:
         return "gemm_tn"
