@@ -29,7 +29,7 @@ def main(path, steps, out_md):
         c["calls"] += int(r["Calls"])
     with open(out_md, "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats summary (%d bench steps incl. warm-up)\n\n" % steps)
-        f.write("source: `%s`; command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0`\n\n" % path)
+        f.write("source: `%s`; command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --lean`\n\n" % path)
         f.write("Sum of kernel durations per step: **%.3f ms** (kernels of the side stream - the deferred weight-gradient GEMMs - run BESIDE the main "
                 "stream's LayerNorm/attention/dgrad kernels, so durations overlap in time and a kernel that waits for CUs shows a longer span: the sum "
                 "exceeds the measured step time; `bench.py`'s live HIP-event figures are taken with the side stream folded into the main one)\n\n## categories (as in bench.py)\n\n| category | launches/step | ms/step | avg launch us | share |\n|---|---|---|---|---|\n" % (tot / 1e6 / steps))
