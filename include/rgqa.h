@@ -117,6 +117,13 @@ int rgqa_engine_get_cross_attention(rgqa_engine* e, int layer, int direction, fl
  * then not read and language activations returned by get_activation are the packed rows. NULL / n = 0 restores the
  * padded layout (the default after bind). The array is consumed before the call returns. */
 int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n);
+/* Optimizer / forward pipelining.  A training loop may run clip + BertAdam (lxrt/optimization.py:101-180) of step t on a side stream,
+ * range by range in arena (= forward) order, and let the forward pass of step t+1 start as soon as the ranges it reads first are
+ * done.  Three hipEvent_t handles (any may be NULL = nothing to wait for), kept until replaced: every following forward waits for
+ * ev_first before its first kernel (embeddings + language / vision layers: arena range [0, first cross-modality parameter)), for
+ * ev_cross before the first cross-modality layer (the rest: cross-modality layers, pooler, head), and every following backward for
+ * ev_all (all of the above plus the transposed bf16 copies the dgrad GEMMs read).  LXMERT engine (arch 0) only. */
+int rgqa_engine_set_weight_events(rgqa_engine* e, void* ev_first, void* ev_cross, void* ev_all);
 /* Input gradients for the FOLLOWING backward calls (the reference's ODIN scorer differentiates w.r.t. the RoI features and boxes,
  * tasks/gqa_odin.py:97-121): dfeats [B*O, feat_dim] f32, dboxes [B*O, pos_dim] f32 device buffers, either may be NULL (not computed,
  * the default). */

@@ -139,6 +139,13 @@ int rgqa_engine_set_input_grads(rgqa_engine* e, float* dfeats, float* dboxes) {
     return e->impl->set_input_grads(dfeats, dboxes);
 }
 
+int rgqa_engine_set_weight_events(rgqa_engine* e, void* ev_first, void* ev_cross, void* ev_all) {
+    NEED(e);
+    e->impl->wev_first = reinterpret_cast<hipEvent_t>(ev_first);
+    e->impl->wev_cross = reinterpret_cast<hipEvent_t>(ev_cross);
+    e->impl->wev_all = reinterpret_cast<hipEvent_t>(ev_all);
+    return RGQA_OK;
+}
 int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n) {
     NEED(e);
     return e->impl->set_lengths(lengths, n);

@@ -751,6 +751,7 @@ public:
             fwd_varlen = varlen;
         }
         const int* cu = fwd_varlen ? cu_dev : nullptr;
+        if (wev_first) RGQA_HIP(hipStreamWaitEvent(s, wev_first, 0));      // embeddings + single-modality layers updated (rgqa_engine_set_weight_events)
         if (joint) CK(forward_joint_embeddings(feats, boxes, ids, seg, mask, s));
         else {
         if (!fwd_varlen) CKP(PC_OTHER, k_make_mask(mask, maskf, Rl, s));
@@ -779,9 +780,11 @@ public:
             RGQA_HIP(hipEventRecord(ev_v[0], s));          // embeddings done
             RGQA_HIP(hipStreamWaitEvent(s_v, ev_v[0], 0));
         }
+        bool cross_waited = false;
         for (size_t si = 0; si < stages.size(); ++si) {
             Stage& st = stages[si];
             prof_block = si < n_lr_stages ? PB_LR : PB_X;
+            if (si >= n_lr_stages && !cross_waited) { if (wev_cross) RGQA_HIP(hipStreamWaitEvent(s, wev_cross, 0)); cross_waited = true; }
             if (st.kind == ST_ATT_CROSS && x0_needed && !gathered) {
                 if (x0_src[0] && Rl > 0) CK(rgqa_check_hip(hipMemcpyAsync(x0, x0_src[0], (size_t)Rl * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather lang"));
                 if (x0_src[1]) CK(rgqa_check_hip(hipMemcpyAsync(x0 + (size_t)Rl * H, x0_src[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather visn"));
@@ -804,6 +807,7 @@ public:
         }
         // ---- BertPooler (modeling.py:575-581) + answer head (gqa_model.py:22-27)
         prof_block = PB_HEAD;
+        if (!cross_waited && wev_cross) RGQA_HIP(hipStreamWaitEvent(s, wev_cross, 0));
         {
             GemmGroup g; gg_init(g);
             pool_in = cls_rows;
@@ -833,6 +837,7 @@ public:
         RGQA_REQUIRE(G != nullptr, "loss_backward: no gradient arena bound");
         // BCE on the f32 logits; dlogits written as f32 into `logits`' sibling then cast+padded to T
         prof_block = PB_HEAD;
+        if (wev_all) RGQA_HIP(hipStreamWaitEvent(s, wev_all, 0));          // every weight copy (the transposed dgrad operands included) is final
         float* dl32 = part;   // scratch [B, NAp] f32
         CKP(PC_OTHER, k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, cfg.num_answers, NAp, grad_scale, s));
         if (loss_out) CK(rgqa_check_hip(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s), "loss copy"));
@@ -842,6 +847,7 @@ public:
     int backward(const float* dl, int ldd, int accumulate, hipStream_t s) override {
         RGQA_REQUIRE(have_fwd, "backward: no forward pass recorded");
         RGQA_REQUIRE(G != nullptr && dl != nullptr, "backward: null gradient arena / dlogits");
+        if (wev_all) RGQA_HIP(hipStreamWaitEvent(s, wev_all, 0));
         CKP(PC_OTHER, k_cast_pad<T>(dl, ldd, dlogits, NAp, B, cfg.num_answers, 1.0f, s));
         return backward_impl(accumulate, s);
     }

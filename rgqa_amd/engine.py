@@ -252,9 +252,17 @@ class Engine:
         n = self.arena_elems
         return [(0, b), (e, n)] if e > b else [(0, n)]
 
-    def adam_step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, grad_prescale=1.0, clip=True):
+    def cross_offset(self):
+        """arena offset of the first cross-modality parameter: [0, offset) = embeddings + language / vision layers"""
+        offs = [sp.offset for sp in self.specs if ".x_layers." in sp.name]
+        return min(offs) if offs else None
+
+    def adam_step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, grad_prescale=1.0, clip=True, pipeline=False):
         """clip_grad_norm_(params, max_norm) + BertAdam.step over every parameter that receives a gradient
-        (gqa_conf.py:201-202); then refreshes the bf16 weight copies."""
+        (gqa_conf.py:201-202); then refreshes the bf16 weight copies.
+        pipeline=True (LXMERT engine): the update runs on a side stream in forward order - first the ranges the next forward pass
+        reads first - and the next forward / backward wait for exactly the ranges they need (rgqa_engine_set_weight_events), so most
+        of the optimizer's 6 GB of HBM traffic runs beside the next step's embedding and single-modality layers.  Same results."""
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
@@ -269,13 +277,40 @@ class Engine:
             for i, (a, b) in enumerate(rngs):
                 check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
         self._seg_sumsq_valid = False
-        for a, b in rngs:
+
+        def update(a, b, st):
             lp = ptr(self.params_lp[a:b]) if self.precision == "bf16" else None     # the kernel re-casts the bf16 copy in the same pass
             check(self.lib.rgqa_bertadam_step(ptr(self.params[a:b]), ptr(self.grads[a:b]), ptr(self.adam_m[a:b]), ptr(self.adam_v[a:b]),
                                               lp, b - a, lr_t, b1, b2, eps, weight_decay, ptr(self._sumsq) if clip else None,
-                                              max_norm, grad_prescale, s))
-        if self.precision == "bf16":
-            check(self.lib.rgqa_engine_sync_transposed(self.h, s))
+                                              max_norm, grad_prescale, st))
+
+        x0 = self.cross_offset() if (pipeline and self.cfg.arch == 0) else None
+        if x0 is None:
+            for a, b in rngs:
+                update(a, b, s)
+            if self.precision == "bf16":
+                check(self.lib.rgqa_engine_sync_transposed(self.h, s))
+            return
+        if getattr(self, "_opt_stream", None) is None:
+            self._opt_stream = torch.cuda.Stream(device=self.device)
+            self._opt_events = [torch.cuda.Event() for _ in range(3)]
+        cur = torch.cuda.current_stream()
+        self._opt_stream.wait_stream(cur)                  # gradients + clip norm are final
+        ev_first, ev_cross, ev_all = self._opt_events
+        with torch.cuda.stream(self._opt_stream):
+            so = C.c_void_p(self._opt_stream.cuda_stream)
+            first = [(max(a, 0), min(b, x0)) for a, b in rngs if a < x0]
+            rest = [(max(a, x0), b) for a, b in rngs if b > x0]
+            for a, b in first:
+                update(a, b, so)
+            ev_first.record(self._opt_stream)
+            for a, b in rest:
+                update(a, b, so)
+            ev_cross.record(self._opt_stream)
+            if self.precision == "bf16":
+                check(self.lib.rgqa_engine_sync_transposed(self.h, so))
+            ev_all.record(self._opt_stream)
+        check(self.lib.rgqa_engine_set_weight_events(self.h, C.c_void_p(ev_first.cuda_event), C.c_void_p(ev_cross.cuda_event), C.c_void_p(ev_all.cuda_event)))
 
     def grad_norm(self):
         """Global L2 norm of the live gradient ranges (what clip_grad_norm_ measures, gqa_conf.py:201) as a device scalar."""

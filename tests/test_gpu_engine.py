@@ -762,3 +762,36 @@ def test_full_size_batch_independence_and_roi_permutation():
     permuted = e.forward(feats_p, boxes_p, b["input_ids"], b["input_mask"], b["segment_ids"], lengths=lens)[0]
     assert float((permuted - full).abs().max()) <= 3e-2 * scale
     assert float((permuted - full).abs().mean()) <= 3e-3 * scale
+
+
+def test_pipelined_optimizer_matches_inline():
+    """Engine.adam_step(pipeline=True): BertAdam on a side stream in forward order, the next forward / backward waiting on per-range
+    events (rgqa_engine_set_weight_events).  One step from identical state: every parameter outside the three embedding tables (whose
+    gradients are f32 atomic scatter-adds: order-dependent last bits in ANY two runs) and both bf16 copies come out bit-identical to
+    the in-line optimizer; over four train-mode steps the two runs stay as close as two in-line runs do."""
+    B, T, O = 64, 20, 36
+    b = dev(synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=15, min_len=3))
+
+    def train(pipe, steps):
+        e = make_engine(FULL, "bf16", dropout=0.1)
+        e.ensure_shape(B, T, O)
+        e.sync_weights()
+        for step in range(steps):
+            run(e, b, True, 100 + step)
+            e.loss_backward(b["target"])
+            e.adam_step(1e-4, max_norm=5.0, pipeline=pipe)
+        lg, _ = run(e, b, False, 0)          # waits for the pipelined update of the ranges it reads
+        torch.cuda.synchronize()
+        first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
+        return e.params.clone(), e.params_lp.clone(), e.params_lp_t.clone(), lg.clone(), first
+
+    p0, lp0, lpt0, lg0, first = train(False, 1)
+    p1, lp1, lpt1, lg1, _ = train(True, 1)
+    assert torch.equal(p0[first:], p1[first:]) and torch.equal(lp0[first:], lp1[first:]) and torch.equal(lpt0[first:], lpt1[first:])
+    assert torch.allclose(p0[:first], p1[:first], rtol=0, atol=2.1e-4)          # one BertAdam step of lr 1e-4 moves an element by <= 3.2e-4
+    assert float((lg0 - lg1).abs().max()) < 5e-2
+    a = train(False, 4)
+    bb = train(False, 4)
+    c = train(True, 4)
+    spread = float((a[0] - bb[0]).abs().max())                  # run-to-run spread of the in-line optimizer (the atomics)
+    assert float((a[0] - c[0]).abs().max()) <= max(2.0 * spread, 1e-6)
