@@ -45,7 +45,7 @@ int k_mixup_perturb(float* feats, float* boxes, const int32_t* perm, int B, int 
 // like the reference's Python expression; boxes repeated
 __global__ __launch_bounds__(256) void mixup_wsum_kernel(float* __restrict__ feats, float* __restrict__ boxes, const int32_t* __restrict__ partner,
                                                          const float* __restrict__ p, const float* __restrict__ q, int B, int O, int F) {
-#pragma clang fp contract(off)      // hipcc's __fmul_rn / __fadd_rn are plain operators: without this the sum becomes an FMA
+#pragma clang fp contract(off)      // without this the sum becomes an FMA (one rounding instead of torch's three)
     const int j = blockIdx.x / O, o = blockIdx.x % O;
     const float pj = p[j], qj = q[j];
     const float4* sp = reinterpret_cast<const float4*>(feats + ((size_t)j * O + o) * F);
@@ -54,8 +54,10 @@ __global__ __launch_bounds__(256) void mixup_wsum_kernel(float* __restrict__ fea
     for (int c = threadIdx.x; c < (F >> 2); c += 256) {
         const float4 a = sp[c], b = sn[c];
         float4 r;
-        r.x = __fadd_rn(__fmul_rn(a.x, pj), __fmul_rn(b.x, qj)); r.y = __fadd_rn(__fmul_rn(a.y, pj), __fmul_rn(b.y, qj));
-        r.z = __fadd_rn(__fmul_rn(a.z, pj), __fmul_rn(b.z, qj)); r.w = __fadd_rn(__fmul_rn(a.w, pj), __fmul_rn(b.w, qj));
+        // plain operators under the pragma above (the __fmul_rn / __fadd_rn wrappers are inlined WITH the header's contraction setting)
+        const float ax = a.x * pj, ay = a.y * pj, az = a.z * pj, aw = a.w * pj;
+        const float bx = b.x * qj, by = b.y * qj, bz = b.z * qj, bw = b.w * qj;
+        r.x = ax + bx; r.y = ay + by; r.z = az + bz; r.w = aw + bw;
         df[c] = r;
     }
     if (threadIdx.x < 4) boxes[((size_t)(B + j) * O + o) * 4 + threadIdx.x] = boxes[((size_t)j * O + o) * 4 + threadIdx.x];
