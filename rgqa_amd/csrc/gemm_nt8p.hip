@@ -32,6 +32,17 @@
 #define P8_WAIT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define P8_WAIT(n) P8_WAIT_(n)
 #define P8_WAITV() do { if (P8_SPLIT) P8_WAIT_(9); else P8_WAIT(P8_INFLIGHT); } while (0)      /* split issue: the current unit has one instruction out */
+// lab-only ablations of the K loop (results are garbage): P8_ABLATE bit 0 = no LDS-DMA in the loop, bit 1 = no fragment reads,
+// bit 2 = no MFMAs.  tools/lab/stamp_lab builds one binary per value.
+#ifndef P8_ABLATE
+#define P8_ABLATE 0
+#endif
+#if P8_ABLATE & 4
+__device__ __forceinline__ f32x4 p8_no_mfma(bf16x8 a, bf16x8 b, f32x4 c) { asm volatile("" :: "v"(a), "v"(b)); return c; }
+#define P8_MFMA(a, b, c, x, y, z) p8_no_mfma(a, b, c)
+#else
+#define P8_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#endif
 #ifndef P8_DEFAULT_VARIANT
 #define P8_DEFAULT_VARIANT 0
 #endif
@@ -128,7 +139,9 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
         if (nvt < g.total_tiles) { i_vt = nvt; i_kt = 0; locate_issue(nvt); }
     };
     // which: 0 = the unit's first instruction, 1 = its second, 2 = both
+    bool in_loop = false;
     auto issue_a = [&](int u, unsigned dst, int which) {
+        if ((P8_ABLATE & 1) && in_loop) return;
         if (u == 0) {
             if (which != 1 && (P8Split<RW0>::R1 == 8 || lrow < P8Split<RW0>::R1)) dma16o(aoff[0][0], sA, dst + (RW0 * wave) * 128);
             if (which != 0 && (P8Split<RW0>::R2 == 8 || lrow < P8Split<RW0>::R2)) dma16o(aoff[0][1], sA, dst + (RW0 * wave + P8Split<RW0>::R1) * 128);
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
         }
     };
     auto issue_w = [&](int u, unsigned dst, int which) {
+        if ((P8_ABLATE & 1) && in_loop) return;
         if (which != 1) dma16o(woff[u][0], sW, dst + wave * 1024);
         if (which != 0) dma16o(woff[u][1], sW, dst + (wave + 8) * 1024);
     };
@@ -157,9 +171,11 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
     // fragment addresses inside a K-tile buffer (unit order in LDS: U0, U1, U2, U3)
     const int a_row0 = wr * (16 * MA0) + fr, a_row1 = wr * (16 * MA1) + fr, w_row = wc * 32 + fr;
     auto lda = [&](const unsigned char* buf, int sub, int tm, int ks) {
+        if (P8_ABLATE & 2) { bf16x8 z; for (int j = 0; j < 8; ++j) z[j] = (bf16_t)(float)(lane + tm + ks + sub); asm volatile("" : "+v"(z)); return z; }
         return *reinterpret_cast<const bf16x8*>(buf + (sub ? 3 * P8_UNIT : 0) + off256((sub ? a_row1 : a_row0) + tm * 16, ks * 4 + fq));
     };
     auto ldw = [&](const unsigned char* buf, int sub, int tn, int ks) {
+        if (P8_ABLATE & 2) { bf16x8 z; for (int j = 0; j < 8; ++j) z[j] = (bf16_t)(float)(lane + tn + ks + sub); asm volatile("" : "+v"(z)); return z; }
         return *reinterpret_cast<const bf16x8*>(buf + (1 + sub) * P8_UNIT + off256(w_row + tn * 16, ks * 4 + fq));
     };
 
@@ -174,6 +190,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
     P8_STAMP();                                     // 1: first units landed
     if (wr == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run one interval behind waves 0-3
 
+    in_loop = true;
     int vk = 0;                                     // K-tiles consumed so far (buffer = vk & 1)
     for (;;) {
         f32x4 acc[MT][4];
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
 #pragma unroll
                 for (int tm = 0; tm < MA0; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[tn][ks], a0[tm][ks], acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = P8_MFMA(w0[tn][ks], a0[tm][ks], acc[tm][tn], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -244,7 +261,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
 #pragma unroll
                 for (int tm = 0; tm < MA0; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) acc[tm][2 + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[tn][ks], a0[tm][ks], acc[tm][2 + tn], 0, 0, 0);
+                    for (int tn = 0; tn < 2; ++tn) acc[tm][2 + tn] = P8_MFMA(w1[tn][ks], a0[tm][ks], acc[tm][2 + tn], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
 #pragma unroll
                 for (int tm = 0; tm < MA1; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) acc[MA0 + tm][2 + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[tn][ks], a1[tm][ks], acc[MA0 + tm][2 + tn], 0, 0, 0);
+                    for (int tn = 0; tn < 2; ++tn) acc[MA0 + tm][2 + tn] = P8_MFMA(w1[tn][ks], a1[tm][ks], acc[MA0 + tm][2 + tn], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -304,7 +321,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
 #pragma unroll
                 for (int tm = 0; tm < MA1; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) acc[MA0 + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[tn][ks], a1[tm][ks], acc[MA0 + tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < 2; ++tn) acc[MA0 + tm][tn] = P8_MFMA(w0[tn][ks], a1[tm][ks], acc[MA0 + tm][tn], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
