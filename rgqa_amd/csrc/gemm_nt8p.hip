@@ -33,7 +33,7 @@
 #define P8_WAIT(n) P8_WAIT_(n)
 #define P8_WAITV() do { if (P8_SPLIT) P8_WAIT_(9); else P8_WAIT(P8_INFLIGHT); } while (0)      /* split issue: the current unit has one instruction out */
 // lab-only ablations of the K loop (results are garbage): P8_ABLATE bit 0 = no LDS-DMA in the loop, bit 1 = no fragment reads,
-// bit 2 = no MFMAs.  tools/lab/stamp_lab builds one binary per value.
+// bit 2 = no MFMAs, bit 3 = the W units fetched by plain global_load_dwordx4 into registers instead of LDS-DMA.  tools/lab/stamp_lab builds one binary per value.
 #ifndef P8_ABLATE
 #define P8_ABLATE 0
 #endif
@@ -152,6 +152,12 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt8p_kernel(const GemmGroup
     };
     auto issue_w = [&](int u, unsigned dst, int which) {
         if ((P8_ABLATE & 1) && in_loop) return;
+        if ((P8_ABLATE & 8) && in_loop) {      // lab: the W half of the operand traffic as plain vector loads into (discarded) registers
+            uint4 t0, t1;
+            if (which != 1) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t0) : "v"(woff[u][0]), "s"(sW) : "memory");
+            if (which != 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t1) : "v"(woff[u][1]), "s"(sW) : "memory");
+            return;
+        }
         if (which != 1) dma16o(woff[u][0], sW, dst + wave * 1024);
         if (which != 0) dma16o(woff[u][1], sW, dst + (wave + 8) * 1024);
     };
