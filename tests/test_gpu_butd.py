@@ -44,18 +44,23 @@ def test_butd_vs_reference_golden(golden_dir, precision, tol, gtol):
     m.eval()
     logits, att = m(feat, pos, BUTD_SENTS, attention=True)
     assert att.shape == (len(BUTD_SENTS), 36, 1)
+    print("butd %s: logits max err %.3e, att max err %.3e" % (precision, np.abs(logits.detach().cpu().numpy() - g["logits"]).max(), np.abs(att.cpu().numpy() - g["att"]).max()))
     np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=0, atol=tol)
     np.testing.assert_allclose(att.cpu().numpy(), g["att"], rtol=0, atol=tol / 4)
     loss = torch.nn.BCEWithLogitsLoss()(logits, target) * logits.size(1)
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=50 * tol / 15)
     loss.backward()
+    wn = ws = 0.0
     for k, p in m.named_parameters():
         gr = p.grad.cpu().numpy()
         ref_norm = float(g["gnorm." + k])
+        wn = max(wn, abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - ref_norm) / max(ref_norm, 1e-12))
+        ws = max(ws, float(np.abs(gr.reshape(-1)[sample_idx(k, gr.size)] - g["gsamp." + k]).max() / max(np.abs(g["gsamp." + k]).max(), 1e-6)))
         assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - ref_norm) <= gtol * ref_norm + 1e-7, k
         ref = g["gsamp." + k]
         got = gr.reshape(-1)[sample_idx(k, gr.size)]
         assert np.abs(got - ref).max() <= 3 * gtol * max(np.abs(ref).max(), 1e-6) + 1e-7, k
+    print("butd %s: worst gradient-norm rel err %.3e, worst sampled-entry err / max %.3e, loss rel %.3e" % (precision, wn, ws, abs(loss.item() - g["loss"]) / abs(g["loss"])))
     assert float(dict(m.named_parameters())["w_emb.emb.weight"].grad[-1].abs().max()) == 0.0
 
 

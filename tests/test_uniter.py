@@ -123,8 +123,11 @@ def test_engine_full_config_vs_golden(golden_dir, prec, packed):
     lg, pl = e.forward(b["feats"], b["pos7"], b["input_ids"], b["input_mask"], b["segment_ids"], lengths=lens)
     err = np.abs(lg.cpu().numpy() - g["logits"]).max()
     assert err <= (1e-3 if prec == "f32" else 6e-2), err
+    perr = np.abs(pl.cpu().numpy() - g["pooled"]).max()
     np.testing.assert_allclose(pl.cpu().numpy(), g["pooled"], rtol=0, atol=2e-4 if prec == "f32" else 3e-2)
     loss = e.loss_backward(b["target"])
+    print("uniter full %s packed=%s: logits max %.3e pooled max %.3e loss rel %.3e grad norm rel %.3e" % (prec, packed, err, perr, abs(loss.item() - g["loss"]) / abs(g["loss"]),
+          abs(e.grad_norm().item() - g["grad_norm"]) / g["grad_norm"]))
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4 if prec == "f32" else 2e-3)
     np.testing.assert_allclose(e.grad_norm().item(), g["grad_norm"], rtol=1e-3 if prec == "f32" else 3e-2)
     if prec == "f32":
