@@ -48,7 +48,8 @@ int rgqa_version(void);
  * key 3: perf ablation of the NT LDS-DMA kernel, results are garbage: 1 = no operand DMA in the K loop, 2 = no LDS reads / MFMAs, 5 = as 2 with twice the DMA bytes in flight;
  * key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots;
  * key 7: phase-interleaved NT kernel: 0 never, 1 192-row tiles (default), 2 every 160..256-row launch; key 8: 0 computes the last
- * language FFN on every row (as the reference), 1 on the [CLS] rows only (default), -1 = environment) */
+ * language FFN on every row (as the reference), 1 on the [CLS] rows only (default), -1 = environment; key 9: 0 = generic LayerNorm kernels only;
+ * key 10: 0 = every LayerNorm backward folds its column sums at once on the main stream, 1 (default) = once per layer beside the layer's wgrad launch) */
 int rgqa_debug_set(int key, int value);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over

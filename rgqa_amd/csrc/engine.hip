@@ -143,6 +143,8 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 }
 
 // ============================================================================ engine
+#define LNPART_BLOCKS 1536     // per layer: <= 3 LayerNorm-backward launches of <= 512 blocks
+int g_rgqa_ln_defer = -1;      // rgqa_debug_set key 10: 0 = every LayerNorm backward finalises its column sums at once on the main stream; 1 / -1 = once per layer, with the layer's wgrad launch
 int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
 
 template <typename T>
@@ -175,6 +177,7 @@ public:
     T *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
     bool ln_merge = !(getenv("RGQA_LN_MERGE") && getenv("RGQA_LN_MERGE")[0] == '0');   // one LayerNorm launch over [language | vision] rows
     float* wpart = nullptr; size_t wpart_elems = 0;
+    float* lnpart_s[2] = {nullptr, nullptr}; FinDefer fin; int fin_accumulate = 0;   // LayerNorm-backward column sums of the open layer (finalised with its wgrad launch)
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
     void* lang_final = nullptr;
     std::vector<TransDesc> tdesc_host;
@@ -225,6 +228,7 @@ public:
     int flush_wgrad(GemmGroup& wg, int par, hipStream_t s) {
         static const bool serial = getenv("RGQA_WGRAD_SERIAL") != nullptr;
         if (serial || g_rgqa_wgrad_serial || profiling) {
+            if (int r = fin_flush(fin, fin_accumulate, s)) return r;
             if (int r = run_wgrad(wg, s)) return r;
             gg_init(wg);
             return mark_segment(s);
@@ -238,6 +242,7 @@ public:
         }
         RGQA_HIP(hipEventRecord(ev_chain[par], s));
         RGQA_HIP(hipStreamWaitEvent(s_w, ev_chain[par], 0));
+        if (int r = fin_flush(fin, fin_accumulate, s_w)) return r;
         if (int r = run_wgrad(wg, s_w)) return r;
         gg_init(wg);
         if (int r = mark_segment(s_w)) return r;
@@ -398,6 +403,7 @@ public:
         gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
+        for (int par = 0; par < 2; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
         sumsq_ws_segs = (int)grad_segs.size(); sumsq_ws = take<float>((size_t)sumsq_ws_segs * 1024);
         if (joint) {
             const size_t ni = (size_t)B * Oi, nt = (size_t)B * Tt;
@@ -936,7 +942,12 @@ public:
         for (int si = (int)stages.size() - 1; si >= 0; --si) {
             Stage& st = stages[si];
             prof_block = si < n_lr_stages ? PB_LR : PB_X;
-            if (!layer_open) { CK(wait_wgrad(par, s)); layer_open = true; }     // first stage (in backward order) of a layer
+            if (!layer_open) {     // first stage (in backward order) of a layer
+                CK(wait_wgrad(par, s)); layer_open = true;
+                fin_accumulate = accumulate;
+                static const bool defer_env = !(getenv("RGQA_LN_DEFER") && getenv("RGQA_LN_DEFER")[0] == '0');
+                if (g_rgqa_ln_defer < 0 ? defer_env : g_rgqa_ln_defer != 0) fin.begin(lnpart_s[par], LNPART_BLOCKS, H); else fin.begin(nullptr, 0, 0);
+            }
             T* gz = gz_s[par][st.slot]; T* gzd = gzd_s[par][st.slot]; T* gqkv = gqkv_s[par][st.slot]; T* gh = gh_s[par][st.slot];
             const bool cross = st.kind == ST_ATT_CROSS;
             const bool shared_all = cross && st.active[1];
@@ -946,7 +957,7 @@ public:
                 const FfnP& f = *st.ffn[0];
                 DropCfg d = drop_site(pd, st.site + 1);
                 CKP(PC_LN, k_ln_bwd<T>(gp2, H, (T*)st.sb[0].z, H, P + f.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b,
-                               accumulate, B, H, d, nodrop, 1.0f, s));
+                               accumulate, B, H, d, nodrop, 1.0f, s, &fin));
                 T* gzm = d.thresh ? gzd : gz;
                 gg_init(g); add_dgrad(g, gzm, H, f.down, 0, H, gh, I, B, EPI_DGELU, st.sb[0].hpre, I); CK(run_dgrad(g, s));
                 add_wgrad(wg, gzm, H, f.down, 0, H, st.sb[0].h, I, B, accumulate);
@@ -964,13 +975,13 @@ public:
                     const FfnP &f0 = *st.ffn[0], &f1 = *st.ffn[1];
                     CKP(PC_LN, k_ln_bwd2<T>(dyp[0], H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
                                             Rl, P + f0.ln.w, G + f0.ln.w, G + f0.ln.b, G + f0.down.b, drop_site(pd, st.site + 1),
-                                            Rv, P + f1.ln.w, G + f1.ln.w, G + f1.ln.b, G + f1.down.b, drop_site(pd, st.site + 5), s));
+                                            Rv, P + f1.ln.w, G + f1.ln.w, G + f1.ln.b, G + f1.down.b, drop_site(pd, st.site + 5), s, &fin));
                 }
                 for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const FfnP& f = *st.ffn[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
                     CKP(PC_LN, k_ln_bwd<T>(dyp[m], H, (T*)st.sb[m].z, H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
-                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s));
+                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s, &fin));
                 }
                 T* gzm = drop_base(pd).thresh ? gzd : gz;
                 gg_init(g);
@@ -997,7 +1008,7 @@ public:
                 DropCfg d = drop_site(pd, st.site + 1);
                 CK(adjacent());
                 CKP(PC_LN, k_ln_bwd<T>(dyp[0], H, (T*)st.sb[0].z, H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
-                               G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, R, H, d, nodrop, 1.0f, s));
+                               G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, R, H, d, nodrop, 1.0f, s, &fin));
                 gg_init(g); add_dgrad(g, gzm, H, ap.o, 0, H, gctx, H, R, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
             } else {
                 const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && dyp[1] == dyp[0] + (size_t)Rl * H;
@@ -1005,13 +1016,13 @@ public:
                     const AttP &a0 = *st.att[0], &a1 = *st.att[1];
                     CKP(PC_LN, k_ln_bwd2<T>(dyp[0], H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
                                             Rl, P + a0.ln.w, G + a0.ln.w, G + a0.ln.b, G + a0.o.b, drop_site(pd, st.site + 1),
-                                            Rv, P + a1.ln.w, G + a1.ln.w, G + a1.ln.b, G + a1.o.b, drop_site(pd, st.site + 5), s));
+                                            Rv, P + a1.ln.w, G + a1.ln.w, G + a1.ln.b, G + a1.o.b, drop_site(pd, st.site + 5), s, &fin));
                 }
                 for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const AttP& ap = *st.att[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
                     CKP(PC_LN, k_ln_bwd<T>(dyp[m], H, (T*)st.sb[m].z, H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
-                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s));
+                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s, &fin));
                 }
                 gg_init(g);
                 for (int m = 0; m < 2; ++m) if (st.active[m])
@@ -1077,6 +1088,8 @@ public:
             if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
         }
         prof_block = PB_LR;
+        CK(fin_flush(fin, fin_accumulate, s));
+        fin.begin(nullptr, 0, 0);
         CK(run_wgrad(wg, s));
         // `par` is now the OLDER gradient-buffer set (its weight-gradient launch precedes the first layer's on the side stream):
         // join it here - its qkv buffer becomes the split-K scratch below - and let the first layer's weight gradients, still

@@ -5,10 +5,22 @@
 #include "gemm.h"
 
 // ---- norm.hip
-#define FIN_MAXQ 10
+#define FIN_MAXQ 24
 struct FinOut { float* p[FIN_MAXQ]; int stride[FIN_MAXQ]; int qsrc[FIN_MAXQ], b0[FIN_MAXQ], b1[FIN_MAXQ]; };   // qsrc / b0 / b1: filled by k_colsum_finalize, or by the caller of _ranges
 int k_colsum_finalize(const float* part, int nblk, int nq, int N, const FinOut& fo, int accumulate, hipStream_t s);
 int k_colsum_finalize_ranges(const float* part, int nq_part, int nout, int N, const FinOut& fo, int accumulate, hipStream_t s);
+// Deferred finalisation of LayerNorm-backward column sums (dgamma / dbeta / the producing GEMM's bias gradient): the backward kernels of one
+// encoder layer park their per-block partials behind each other in `base` (3 quantities per block, width N) and append their outputs here;
+// ONE colsum_finalize launch folds them all, on whichever stream the owner chooses (fin_flush) - nothing downstream on the main stream reads them.
+struct FinDefer {
+    float* base = nullptr; int cap_blocks = 0, N = 0;       // partials region: cap_blocks * 3 * N floats
+    int blk = 0, nout = 0; FinOut fo = {};
+    void begin(float* b, int cap, int n) { base = b; cap_blocks = cap; N = n; blk = 0; nout = 0; fo = FinOut{}; }
+    bool room(int nblk, int outs, int n) const { return base != nullptr && n == N && blk + nblk <= cap_blocks && nout + outs <= FIN_MAXQ; }
+    float* take(int nblk) { float* q = base + (size_t)blk * 3 * N; blk += nblk; return q; }
+    void add(float* out, int qsrc, int b0, int b1) { if (out) { fo.p[nout] = out; fo.stride[nout] = 1; fo.qsrc[nout] = qsrc; fo.b0[nout] = b0; fo.b1[nout] = b1; ++nout; } }
+};
+int fin_flush(FinDefer& d, int accumulate, hipStream_t s);
 template <typename T>
 int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s);
 // rows [0, split) use (gamma, beta), rows [split, M) use (gamma2, beta2): two modules' LayerNorms over adjacent row ranges in one launch
@@ -19,12 +31,13 @@ int ln_bwd_blocks(int M, int N);
 // part: workspace of ln_bwd_blocks(M,N)*3*N floats (or null: no column sums). dzd may be null.
 template <typename T>
 int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, const float* mean, const float* rstd, T* dz, T* dzd, int lddz,
-             float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s);
+             float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s,
+             FinDefer* defer = nullptr);
 // two adjacent row segments of the same buffers (language | vision), each with its own module parameters, gradients and dropout site
 template <typename T>
 int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, const float* rstd, T* dz, T* dzd, int lddz, float* part, int N, int accumulate,
               int M0, const float* gamma0, float* dgamma0, float* dbeta0, float* dbias0, DropCfg drop0,
-              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s);
+              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s, FinDefer* defer = nullptr);
 // out[n] (+)= sum_m x[m][n]; part: workspace of 256*N floats
 template <typename T>
 int k_colsum(const T* x, int ldx, float* part, float* out, int accumulate, int M, int N, hipStream_t s);

@@ -352,13 +352,21 @@ static int ln_bwd_launch(const LnBwdSeg<T>& a, const LnBwdSeg<T>& b, int nblk0, 
 
 template <typename T>
 int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, const float* mean, const float* rstd, T* dz, T* dzd, int lddz,
-             float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s) {
+             float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s,
+             FinDefer* defer) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256, "layernorm bwd: N=%d unsupported", N);
     if (M <= 0) return RGQA_OK;
     const int nblk = ln_bwd_blocks(M, N);
+    if (part && defer && !defer->room(nblk, 3, N)) defer = nullptr;
+    const int blk0 = defer ? defer->blk : 0;
+    if (part && defer) part = defer->take(nblk);
     LnBwdSeg<T> a; a.dy = dy; a.z = z; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.dz = dz; a.dzd = dzd; a.M = M; a.drop = drop; a.drop_in = drop_in;
     int r = ln_bwd_launch<T>(a, a, nblk, nblk, lddy, ldz, lddz, part, N, dy_scale, s);
     if (r) return r;
+    if (part && defer) {
+        defer->add(dgamma, 0, blk0, blk0 + nblk); defer->add(dbeta, 1, blk0, blk0 + nblk); defer->add(dbias, 2, blk0, blk0 + nblk);
+        return RGQA_OK;
+    }
     if (part) {
         FinOut fo = {};
         fo.p[0] = dgamma; fo.p[1] = dbeta; fo.p[2] = dbias;
@@ -367,12 +375,18 @@ int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, con
     }
     return RGQA_OK;
 }
+int fin_flush(FinDefer& d, int accumulate, hipStream_t s) {
+    if (d.nout == 0) return RGQA_OK;
+    int r = k_colsum_finalize_ranges(d.base, 3, d.nout, d.N, d.fo, accumulate, s);
+    d.blk = 0; d.nout = 0; d.fo = FinOut{};
+    return r;
+}
 
 // two adjacent row segments (rows [0,M0) and [M0, M0+M1) of the same buffers, different modules) in one launch + one finalize
 template <typename T>
 int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, const float* rstd, T* dz, T* dzd, int lddz, float* part, int N, int accumulate,
               int M0, const float* gamma0, float* dgamma0, float* dbeta0, float* dbias0, DropCfg drop0,
-              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s) {
+              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s, FinDefer* defer) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256 && part != nullptr && M0 > 0 && M1 > 0, "layernorm bwd2: bad arguments (N=%d)", N);
     const DropCfg nodrop = make_drop(0.f, 0, 0);
     int nb0 = ln_bwd_blocks(M0, N), nb1 = ln_bwd_blocks(M1, N);
@@ -382,10 +396,17 @@ int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, con
     a.dy = dy; a.z = z; a.gamma = gamma0; a.mean = mean; a.rstd = rstd; a.dz = dz; a.dzd = drop0.thresh ? dzd : nullptr; a.M = M0; a.drop = drop0; a.drop_in = nodrop;
     b.dy = dy + (size_t)M0 * lddy; b.z = z + (size_t)M0 * ldz; b.gamma = gamma1; b.mean = mean + M0; b.rstd = rstd + M0;
     b.dz = dz + (size_t)M0 * lddz; b.dzd = drop1.thresh ? dzd + (size_t)M0 * lddz : nullptr; b.M = M1; b.drop = drop1; b.drop_in = nodrop;
+    if (defer && !defer->room(nb0 + nb1, 6, N)) defer = nullptr;
+    const int blk0 = defer ? defer->blk : 0;
+    if (defer) part = defer->take(nb0 + nb1);
     int r = ln_bwd_launch<T>(a, b, nb0, nb0 + nb1, lddy, ldz, lddz, part, N, 1.0f, s);
     if (r) return r;
-    FinOut fo = {};
     float* outs[6] = {dgamma0, dbeta0, dbias0, dgamma1, dbeta1, dbias1};
+    if (defer) {
+        for (int q = 0; q < 6; ++q) defer->add(outs[q], q % 3, blk0 + (q < 3 ? 0 : nb0), blk0 + (q < 3 ? nb0 : nb0 + nb1));
+        return RGQA_OK;
+    }
+    FinOut fo = {};
     for (int q = 0; q < 6; ++q) { fo.p[q] = outs[q]; fo.stride[q] = 1; fo.qsrc[q] = q % 3; fo.b0[q] = q < 3 ? 0 : nb0; fo.b1[q] = q < 3 ? nb0 : nb0 + nb1; }
     return k_colsum_finalize_ranges(part, 3, 6, N, fo, accumulate, s);
 }
@@ -406,9 +427,9 @@ template int k_ln_fwd2<float>(const float*, int, const float*, const float*, con
 template int k_ln_fwd2<bf16_t>(const bf16_t*, int, const float*, const float*, const float*, const float*, int, bf16_t*, int, float*, float*, int, int, float, hipStream_t);
 template int k_ln_fwd<float>(const float*, int, const float*, const float*, float*, int, float*, float*, int, int, float, hipStream_t);
 template int k_ln_fwd<bf16_t>(const bf16_t*, int, const float*, const float*, bf16_t*, int, float*, float*, int, int, float, hipStream_t);
-template int k_ln_bwd2<float>(const float*, int, const float*, int, const float*, const float*, float*, float*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t);
-template int k_ln_bwd2<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, bf16_t*, bf16_t*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t);
-template int k_ln_bwd<float>(const float*, int, const float*, int, const float*, const float*, const float*, float*, float*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t);
-template int k_ln_bwd<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, bf16_t*, bf16_t*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t);
+template int k_ln_bwd2<float>(const float*, int, const float*, int, const float*, const float*, float*, float*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
+template int k_ln_bwd2<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, bf16_t*, bf16_t*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
+template int k_ln_bwd<float>(const float*, int, const float*, int, const float*, const float*, const float*, float*, float*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*);
+template int k_ln_bwd<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, bf16_t*, bf16_t*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*);
 template int k_colsum<float>(const float*, int, float*, float*, int, int, int, hipStream_t);
 template int k_colsum<bf16_t>(const bf16_t*, int, float*, float*, int, int, int, hipStream_t);
