@@ -49,7 +49,8 @@ int rgqa_version(void);
  * key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots;
  * key 7: phase-interleaved NT kernel: 0 never, 1 192-row tiles (default), 2 every 160..256-row launch; key 8: 0 computes the last
  * language FFN on every row (as the reference), 1 on the [CLS] rows only (default), -1 = environment; key 9: 0 = generic LayerNorm kernels only;
- * key 10: 0 = every LayerNorm backward folds its column sums at once on the main stream, 1 (default) = once per layer beside the layer's wgrad launch) */
+ * key 10: 0 = every LayerNorm backward folds its column sums at once on the main stream, 1 (default) = once per layer beside the layer's wgrad launch;
+ * key 11: deferred wgrad launches cut after a layer's attention block (0) or after every FFN stage (1, default), -1 = environment RGQA_WGRAD_PHASE) */
 int rgqa_debug_set(int key, int value);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over

@@ -24,6 +24,7 @@ extern int g_rgqa_nt8p;
 extern int g_rgqa_cls_tail;
 extern int g_rgqa_ln16;
 extern int g_rgqa_ln_defer;
+extern int g_rgqa_wgrad_phase;
 // debug / A-B knobs: key 0 = force the 128x128 GEMM kernel; key 1 = force the LDS-DMA kernel's MT (0 = auto)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -37,6 +38,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 8) { g_rgqa_cls_tail = value; return RGQA_OK; }
     if (key == 9) { g_rgqa_ln16 = value; return RGQA_OK; }
     if (key == 10) { g_rgqa_ln_defer = value; return RGQA_OK; }
+    if (key == 11) { g_rgqa_wgrad_phase = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }

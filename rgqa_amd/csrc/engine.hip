@@ -145,6 +145,9 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 // ============================================================================ engine
 #define LNPART_BLOCKS 1536     // per layer: <= 3 LayerNorm-backward launches of <= 512 blocks
 int g_rgqa_ln_defer = -1;      // rgqa_debug_set key 10: 0 = every LayerNorm backward finalises its column sums at once on the main stream; 1 / -1 = once per layer, with the layer's wgrad launch
+int g_rgqa_wgrad_phase = -1;   // rgqa_debug_set key 11: where a layer's deferred wgrad GEMMs are launched: 0 = after the layer's last stage in backward order (its attention
+                               // block), 1 = after every FFN stage (the launch then holds the attention wgrads of the layer above and this layer's FFN wgrads, and runs
+                               // beside this layer's LayerNorm / attention kernels instead of beside the next layer's FFN GEMMs: -0.08 ms per step); -1 = env RGQA_WGRAD_PHASE (layer | ffn, default ffn)
 int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
 
 template <typename T>
@@ -225,13 +228,13 @@ public:
     // Launches the collected weight-gradient GEMMs of one layer on the side stream, ordered after everything the main
     // stream has enqueued for that layer; records the DP segment event there (the segment is final once both the main
     // stream's bias / LayerNorm gradients and these GEMMs are done).
-    int flush_wgrad(GemmGroup& wg, int par, hipStream_t s) {
+    int flush_wgrad(GemmGroup& wg, int par, hipStream_t s, bool layer_done = true) {
         static const bool serial = getenv("RGQA_WGRAD_SERIAL") != nullptr;
         if (serial || g_rgqa_wgrad_serial || profiling) {
             if (int r = fin_flush(fin, fin_accumulate, s)) return r;
             if (int r = run_wgrad(wg, s)) return r;
             gg_init(wg);
-            return mark_segment(s);
+            return layer_done ? mark_segment(s) : RGQA_OK;
         }
         if (s_w == nullptr) {
             RGQA_HIP(hipStreamCreateWithFlags(&s_w, hipStreamNonBlocking));
@@ -245,7 +248,7 @@ public:
         if (int r = fin_flush(fin, fin_accumulate, s_w)) return r;
         if (int r = run_wgrad(wg, s_w)) return r;
         gg_init(wg);
-        if (int r = mark_segment(s_w)) return r;
+        if (layer_done) if (int r = mark_segment(s_w)) return r;
         RGQA_HIP(hipEventRecord(ev_wdone[par], s_w));
         wdone_valid[par] = true;
         return RGQA_OK;
@@ -361,7 +364,7 @@ public:
             Stage& f = new_stage(ST_FFN, al, av);
             if (al) f.ffn[0] = &mp.l_ffn[i];
             if (av) f.ffn[1] = &mp.r_ffn[i];
-            f.slot = 1; f.layer_first = 0;
+            f.slot = 2; f.layer_first = 0;      // not 1: with RGQA_WGRAD_PHASE=ffn a launch period spans [self-attention (slot 1) of the first x-layer, this FFN]
         }
         // the cross-modality layers need [lang; visn] contiguous: copy-free when both chains end in one stage,
         // otherwise the engine gathers them into x0 (one row copy of the shorter chain's output)
@@ -939,6 +942,16 @@ public:
         // ---- encoder stages in reverse; weight-gradient GEMMs are collected per layer and launched once
         GemmGroup wg; gg_init(wg);
         int par = 0; bool layer_open = false;
+        static const bool phase_env = !(getenv("RGQA_WGRAD_PHASE") != nullptr && getenv("RGQA_WGRAD_PHASE")[0] == 'l');     // default: ffn
+        const bool phase_ffn = g_rgqa_wgrad_phase < 0 ? phase_env : g_rgqa_wgrad_phase != 0;
+        int flushes = 0;
+        // phase_ffn: the first launch holds the last layer's FFN only (no layer is complete yet); every later one completes the layer above
+        auto flush_after = [&](const Stage& st) { return phase_ffn ? st.kind == ST_FFN : st.layer_first != 0; };
+        auto flush_layer = [&](hipStream_t ss) -> int {
+            int r = flush_wgrad(wg, par, ss, !phase_ffn || flushes > 0);
+            ++flushes; par ^= 1; layer_open = false;
+            return r;
+        };
         for (int si = (int)stages.size() - 1; si >= 0; --si) {
             Stage& st = stages[si];
             prof_block = si < n_lr_stages ? PB_LR : PB_X;
@@ -966,7 +979,7 @@ public:
                 CK(rgqa_check_hip(hipMemsetAsync(dxp[0], 0, (size_t)Rl * H * sizeof(T), s), "zero tail dx"));
                 CKP(PC_OTHER, k_scatter_rows<T>(tail_dx, H, dxp[0], H, cu, Tn, B, H, s));
                 { T* t = dyp[0]; dyp[0] = dxp[0]; dxp[0] = t; }
-                if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
+                if (flush_after(st)) CK(flush_layer(s));
                 continue;
             }
             if (st.kind == ST_FFN) {
@@ -998,7 +1011,7 @@ public:
                 CK(run_dgrad(g, s));
                 // an inactive modality's gradient passes through untouched: its pointers simply do not move
                 for (int m = 0; m < 2; ++m) if (st.active[m]) { T* t = dyp[m]; dyp[m] = dxp[m]; dxp[m] = t; }
-                if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
+                if (flush_after(st)) CK(flush_layer(s));
                 continue;
             }
             // ---- attention stage backward
@@ -1085,9 +1098,10 @@ public:
             CK(run_dgrad(g, s));
             // a cross stage writes both modalities' input gradients (the dead last layer too: vision keys / values are live)
             for (int m = 0; m < 2; ++m) if (st.active[m] || cross) { T* t = dyp[m]; dyp[m] = dxp[m]; dxp[m] = t; }
-            if (st.layer_first) { CK(flush_wgrad(wg, par, s)); par ^= 1; layer_open = false; }
+            if (flush_after(st)) CK(flush_layer(s));
         }
         prof_block = PB_LR;
+        if (phase_ffn && layer_open) CK(flush_layer(s));        // the first layer's attention wgrads: the only launch nothing of the encoder runs beside
         CK(fin_flush(fin, fin_accumulate, s));
         fin.begin(nullptr, 0, 0);
         CK(run_wgrad(wg, s));

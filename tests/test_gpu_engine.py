@@ -321,6 +321,42 @@ def test_side_stream_wgrad_matches_serial():
         assert torch.equal(grads(0), ref)
 
 
+def test_wgrad_launch_phase_is_bit_identical():
+    """Where the deferred weight-gradient launches are cut (rgqa_debug_set key 11: 0 = after a layer's attention block, 1 = after every FFN
+    stage, so that a launch runs beside LayerNorm / attention kernels) changes only the grouping: every gradient is bit-identical, on the
+    side stream and on the main stream, full architecture (two-modality, language-only and cross-modality layers), packed rows."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    B, T, O = 32, 20, 36
+    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=15, min_len=3)
+    b = dev(raw)
+    lens = raw["lengths"].astype(np.int32)
+    e = make_engine(FULL, "bf16", dropout=0.1)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
+
+    def grads(phase, serial, packed):
+        assert L.rgqa_debug_set(11, phase) == 0 and L.rgqa_debug_set(2, serial) == 0
+        try:
+            e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=41, lengths=lens if packed else None)
+            e.loss_backward(b["target"])
+            gn = e.grad_norm().item()
+            torch.cuda.synchronize()
+            return e.grads[first:].clone(), gn
+        finally:
+            L.rgqa_debug_set(11, -1)
+            L.rgqa_debug_set(2, 0)
+
+    for packed in (True, False):
+        ref, gn_ref = grads(0, 1, packed)
+        assert float(ref.abs().max()) > 0
+        for phase, serial in ((1, 1), (1, 0), (0, 0), (1, 0)):
+            g, gn = grads(phase, serial, packed)
+            assert torch.equal(g, ref), (packed, phase, serial)
+            assert gn == gn_ref          # the per-segment sum of squares is taken when a segment's last gradient is final
+
+
 def test_merged_layernorm_matches_per_modality(monkeypatch):
     """Stages where both modalities run their own module share one LayerNorm launch (forward and backward) over the
     adjacent [language | vision] rows; RGQA_LN_MERGE=0 keeps one launch per modality. Same arithmetic per row and the same
