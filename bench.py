@@ -266,7 +266,7 @@ def main():
         e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
     t_total = 10000
     # BertAdam of step t on a side stream, in forward order, beside the first layers of step t+1 (Engine.adam_step(pipeline=True))
-    opt_pipeline = world == 1 and not (args.butd or args.uniter) and os.environ.get("RGQA_OPT_PIPELINE", "0") == "1"     # measured: 12.50 vs 12.57 ms - the update's blocks and the persistent GEMM blocks cannot share a CU (registers), so nothing overlaps; opt-in
+    opt_pipeline = {"1": True, "bg": "background"}.get(os.environ.get("RGQA_OPT_PIPELINE", "0"), False) if (world == 1 and not (args.butd or args.uniter)) else False     # measured: 12.50 vs 12.57 ms - the update's blocks and the persistent GEMM blocks cannot share a CU (registers), so nothing overlaps; opt-in
     state = dict(step=0, lengths=lengths)
 
     def step(exchange=True):

@@ -50,7 +50,9 @@ int rgqa_version(void);
  * key 7: phase-interleaved NT kernel: 0 never, 1 192-row tiles (default), 2 every 160..256-row launch; key 8: 0 computes the last
  * language FFN on every row (as the reference), 1 on the [CLS] rows only (default), -1 = environment; key 9: 0 = generic LayerNorm kernels only;
  * key 10: 0 = every LayerNorm backward folds its column sums at once on the main stream, 1 (default) = once per layer beside the layer's wgrad launch;
- * key 11: deferred wgrad launches cut after a layer's attention block (0) or after every FFN stage (1, default), -1 = environment RGQA_WGRAD_PHASE) */
+ * key 11: deferred wgrad launches cut after a layer's attention block (0) or after every FFN stage (1, default), -1 = environment RGQA_WGRAD_PHASE;
+ * key 12: persistent forward / dgrad GEMMs draw their tiles by ticket: 0 = fixed walk, N = yes with the first N blocks on a fixed first tile, -1 = env RGQA_NT_TICKETS;
+ * key 13: N > 0 confines the optimizer / transposed-copy kernels launched next to N CUs (one 1024-thread block each), 0 = whole chip) */
 int rgqa_debug_set(int key, int value);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over
@@ -126,6 +128,9 @@ int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n);
  * ev_cross before the first cross-modality layer (the rest: cross-modality layers, pooler, head), and every following backward for
  * ev_all (all of the above plus the transposed bf16 copies the dgrad GEMMs read).  LXMERT engine (arch 0) only. */
 int rgqa_engine_set_weight_events(rgqa_engine* e, void* ev_first, void* ev_cross, void* ev_all);
+/* finer grain: events[k] (hipEvent_t, may be null or repeated) = the parameters of gradient segment k (rgqa_engine_grad_segment's event id) are updated;
+ * the next forward passes wait for events[k] right before the first kernel that reads segment k.  n = 0 clears them. */
+int rgqa_engine_set_segment_weight_events(rgqa_engine* e, void* const* events, int n);
 /* Input gradients for the FOLLOWING backward calls (the reference's ODIN scorer differentiates w.r.t. the RoI features and boxes,
  * tasks/gqa_odin.py:97-121): dfeats [B*O, feat_dim] f32, dboxes [B*O, pos_dim] f32 device buffers, either may be NULL (not computed,
  * the default). */

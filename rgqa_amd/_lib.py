@@ -42,6 +42,7 @@ SIGNATURES = {
     "rgqa_engine_get_cross_attention": [_vp, _i, _i, _vp, _sz, _vp],
     "rgqa_engine_set_lengths": [_vp, _vp, _i],
     "rgqa_engine_set_weight_events": [_vp, _vp, _vp, _vp],
+    "rgqa_engine_set_segment_weight_events": [_vp, _vp, _i],
     "rgqa_engine_set_input_grads": [_vp, _vp, _vp],
     "rgqa_engine_set_grad_sumsq_slots": [_vp, _vp, _i],
     "rgqa_engine_num_grad_segments": [_vp, C.POINTER(_i)],

@@ -25,6 +25,8 @@ extern int g_rgqa_cls_tail;
 extern int g_rgqa_ln16;
 extern int g_rgqa_ln_defer;
 extern int g_rgqa_wgrad_phase;
+extern int g_rgqa_nt_tickets;
+extern int g_rgqa_narrow_cus;
 // debug / A-B knobs: key 0 = force the 128x128 GEMM kernel; key 1 = force the LDS-DMA kernel's MT (0 = auto)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -39,6 +41,8 @@ int rgqa_debug_set(int key, int value) {
     if (key == 9) { g_rgqa_ln16 = value; return RGQA_OK; }
     if (key == 10) { g_rgqa_ln_defer = value; return RGQA_OK; }
     if (key == 11) { g_rgqa_wgrad_phase = value; return RGQA_OK; }
+    if (key == 12) { g_rgqa_nt_tickets = value; return RGQA_OK; }
+    if (key == 13) { g_rgqa_narrow_cus = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }
@@ -148,6 +152,12 @@ int rgqa_engine_set_weight_events(rgqa_engine* e, void* ev_first, void* ev_cross
     e->impl->wev_first = reinterpret_cast<hipEvent_t>(ev_first);
     e->impl->wev_cross = reinterpret_cast<hipEvent_t>(ev_cross);
     e->impl->wev_all = reinterpret_cast<hipEvent_t>(ev_all);
+    return RGQA_OK;
+}
+int rgqa_engine_set_segment_weight_events(rgqa_engine* e, void* const* events, int n) {
+    NEED(e);
+    e->impl->wev_seg.clear();
+    for (int i = 0; i < n && events != nullptr; ++i) e->impl->wev_seg.push_back(reinterpret_cast<hipEvent_t>(events[i]));
     return RGQA_OK;
 }
 int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n) {

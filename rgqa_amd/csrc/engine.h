@@ -42,6 +42,7 @@ struct Stage {
     int last_dead;             // 1: visn side is the dead branch of the final x-layer
     int slot;                  // stage index within its layer (selects the per-stage gradient buffers)
     int layer_first;           // 1: first stage of a layer in forward order (deferred wgrads are launched after it in backward)
+    int seg_event;             // event id of the layer's gradient segment (build_grad_segments): also indexes the per-segment weight events
 };
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's live roofline figures).
@@ -113,6 +114,8 @@ public:
     // per-sample real token counts for the following forward passes (packed language rows); null: padded layout
     // optimizer / forward pipelining (rgqa_engine_set_weight_events): events the NEXT passes wait for before they read parameters
     hipEvent_t wev_first = nullptr, wev_cross = nullptr, wev_all = nullptr;
+    // finer: one event per gradient segment (index = the segment's event id), waited for before the layer's first kernel of a forward pass
+    std::vector<hipEvent_t> wev_seg;
     virtual int set_lengths(const int* lens, int n) { (void)lens; (void)n; rgqa_set_error("set_lengths: not supported by this engine"); return RGQA_ERR_ARG; }
 };
 

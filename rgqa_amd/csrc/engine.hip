@@ -143,11 +143,15 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 }
 
 // ============================================================================ engine
+#define SCHED_SLOTS 1024
 #define LNPART_BLOCKS 1536     // per layer: <= 3 LayerNorm-backward launches of <= 512 blocks
 int g_rgqa_ln_defer = -1;      // rgqa_debug_set key 10: 0 = every LayerNorm backward finalises its column sums at once on the main stream; 1 / -1 = once per layer, with the layer's wgrad launch
 int g_rgqa_wgrad_phase = -1;   // rgqa_debug_set key 11: where a layer's deferred wgrad GEMMs are launched: 0 = after the layer's last stage in backward order (its attention
                                // block), 1 = after every FFN stage (the launch then holds the attention wgrads of the layer above and this layer's FFN wgrads, and runs
                                // beside this layer's LayerNorm / attention kernels instead of beside the next layer's FFN GEMMs: -0.08 ms per step); -1 = env RGQA_WGRAD_PHASE (layer | ffn, default ffn)
+int g_rgqa_nt_tickets = -1;    // rgqa_debug_set key 12: persistent forward / dgrad GEMMs hand out their tiles by ticket (GemmGroup::sched): 0 = no (fixed walk), N > 0 = yes, with
+                               // the first N blocks of a launch starting on a fixed tile (N >= 256: all of them); -1 = env RGQA_NT_TICKETS (default 0)
+extern int g_rgqa_nt_static_blocks;
 int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
 
 template <typename T>
@@ -181,6 +185,7 @@ public:
     bool ln_merge = !(getenv("RGQA_LN_MERGE") && getenv("RGQA_LN_MERGE")[0] == '0');   // one LayerNorm launch over [language | vision] rows
     float* wpart = nullptr; size_t wpart_elems = 0;
     float* lnpart_s[2] = {nullptr, nullptr}; FinDefer fin; int fin_accumulate = 0;   // LayerNorm-backward column sums of the open layer (finalised with its wgrad launch)
+    int* sched_pool = nullptr; int sched_cursor = 0;       // one zeroed ticket word per persistent GEMM launch of a step (SCHED_SLOTS, 64 B apart)
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
     void* lang_final = nullptr;
     std::vector<TransDesc> tdesc_host;
@@ -360,10 +365,11 @@ public:
             Stage& a = new_stage(ST_ATT_SELF, al, av);
             if (al) a.att[0] = &mp.l_att[i];
             if (av) a.att[1] = &mp.r_att[i];
-            a.slot = 0; a.layer_first = 1;
+            a.slot = 0; a.layer_first = 1; a.seg_event = 1 + cfg.x_layers + (nlr - 1 - i);
             Stage& f = new_stage(ST_FFN, al, av);
             if (al) f.ffn[0] = &mp.l_ffn[i];
             if (av) f.ffn[1] = &mp.r_ffn[i];
+            f.seg_event = a.seg_event;
             f.slot = 2; f.layer_first = 0;      // not 1: with RGQA_WGRAD_PHASE=ffn a launch period spans [self-attention (slot 1) of the first x-layer, this FFN]
         }
         // the cross-modality layers need [lang; visn] contiguous: copy-free when both chains end in one stage,
@@ -382,11 +388,11 @@ public:
         for (int i = 0; i < cfg.x_layers; ++i) {
             const bool last = (i == cfg.x_layers - 1);
             Stage& c = new_stage(ST_ATT_CROSS, true, !last);
-            c.att[0] = c.att[1] = &mp.x_cross[i]; c.last_dead = last; c.slot = 0; c.layer_first = 1;
+            c.att[0] = c.att[1] = &mp.x_cross[i]; c.last_dead = last; c.slot = 0; c.layer_first = 1; c.seg_event = 1 + (cfg.x_layers - 1 - i);
             Stage& a = new_stage(ST_ATT_SELF, true, !last);
-            a.att[0] = &mp.x_latt[i]; a.att[1] = &mp.x_vatt[i]; a.last_dead = last; a.slot = 1; a.layer_first = 0;
+            a.att[0] = &mp.x_latt[i]; a.att[1] = &mp.x_vatt[i]; a.last_dead = last; a.slot = 1; a.layer_first = 0; a.seg_event = c.seg_event;
             Stage& f = new_stage(ST_FFN, true, !last);
-            f.ffn[0] = &mp.x_lffn[i]; f.ffn[1] = &mp.x_vffn[i]; f.last_dead = last; f.slot = 2; f.layer_first = 0;
+            f.ffn[0] = &mp.x_lffn[i]; f.ffn[1] = &mp.x_vffn[i]; f.last_dead = last; f.slot = 2; f.layer_first = 0; f.seg_event = c.seg_event;
         }
         lang_final = cur[0];
         visn_final = cur[1];
@@ -407,6 +413,7 @@ public:
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
         for (int par = 0; par < 2; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
+        sched_pool = take<int>((size_t)SCHED_SLOTS * 16);
         sumsq_ws_segs = (int)grad_segs.size(); sumsq_ws = take<float>((size_t)sumsq_ws_segs * 1024);
         if (joint) {
             const size_t ni = (size_t)B * Oi, nt = (size_t)B * Tt;
@@ -550,9 +557,25 @@ public:
             bytes += sizeof(T) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
         }
     }
+    static int nt_tickets() {
+        static const int env = []() { const char* e = getenv("RGQA_NT_TICKETS"); return e ? atoi(e) : 0; }();
+        return g_rgqa_nt_tickets < 0 ? env : g_rgqa_nt_tickets;
+    }
+    // forward() zeroes the pool once; every GEMM launch of the step (forward and backward) takes the next word
+    int sched_reset(hipStream_t s) {
+        sched_cursor = 0;
+        if (nt_tickets() > 0 && sched_pool != nullptr) RGQA_HIP(hipMemsetAsync(sched_pool, 0, (size_t)SCHED_SLOTS * 16 * sizeof(int), s));
+        return RGQA_OK;
+    }
+    void sched_assign(GemmGroup& g) {
+        const int n = nt_tickets();
+        g.sched = nullptr;
+        if (n > 0 && sched_pool != nullptr && sched_cursor < SCHED_SLOTS && !profiling) { g.sched = sched_pool + (size_t)(sched_cursor++) * 16; g_rgqa_nt_static_blocks = n; }
+    }
     int run_fwd(GemmGroup& g, hipStream_t s, int out_f32 = 0, int a_f32 = 0) {
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = a_f32;
+        sched_assign(g);
         double f, b; gemm_work(g, f, b);
         prof_begin(PC_GEMM_NT, f, b, s);
         int r = LP ? launch_gemm_nt_bf16(g, out_f32, s) : launch_gemm_f32(g, 0, 0, s);
@@ -561,6 +584,7 @@ public:
     }
     int run_dgrad(GemmGroup& g, hipStream_t s) {
         if (g.count == 0) return RGQA_OK;
+        sched_assign(g);
         double f, b; gemm_work(g, f, b);
         prof_begin(PC_GEMM_NT, f, b, s);
         int r = LP ? launch_gemm_nt_bf16(g, 0, s) : launch_gemm_f32(g, 0, 1, s);
@@ -760,6 +784,13 @@ public:
             fwd_varlen = varlen;
         }
         const int* cu = fwd_varlen ? cu_dev : nullptr;
+        CK(sched_reset(s));
+        hipEvent_t seg_waited = nullptr;
+        auto wait_seg = [&](int id) -> int {      // weights of gradient segment `id` are updated (rgqa_engine_set_segment_weight_events)
+            if (id >= 0 && id < (int)wev_seg.size() && wev_seg[id] != nullptr && wev_seg[id] != seg_waited) { RGQA_HIP(hipStreamWaitEvent(s, wev_seg[id], 0)); seg_waited = wev_seg[id]; }
+            return RGQA_OK;
+        };
+        CK(wait_seg(n_seg_events - 1));           // embeddings, visual feature projection
         if (wev_first) RGQA_HIP(hipStreamWaitEvent(s, wev_first, 0));      // embeddings + single-modality layers updated (rgqa_engine_set_weight_events)
         if (joint) CK(forward_joint_embeddings(feats, boxes, ids, seg, mask, s));
         else {
@@ -794,6 +825,7 @@ public:
             Stage& st = stages[si];
             prof_block = si < n_lr_stages ? PB_LR : PB_X;
             if (si >= n_lr_stages && !cross_waited) { if (wev_cross) RGQA_HIP(hipStreamWaitEvent(s, wev_cross, 0)); cross_waited = true; }
+            if (st.layer_first) CK(wait_seg(st.seg_event));
             if (st.kind == ST_ATT_CROSS && x0_needed && !gathered) {
                 if (x0_src[0] && Rl > 0) CK(rgqa_check_hip(hipMemcpyAsync(x0, x0_src[0], (size_t)Rl * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather lang"));
                 if (x0_src[1]) CK(rgqa_check_hip(hipMemcpyAsync(x0 + (size_t)Rl * H, x0_src[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather visn"));
@@ -817,6 +849,7 @@ public:
         // ---- BertPooler (modeling.py:575-581) + answer head (gqa_model.py:22-27)
         prof_block = PB_HEAD;
         if (!cross_waited && wev_cross) RGQA_HIP(hipStreamWaitEvent(s, wev_cross, 0));
+        CK(wait_seg(0));                          // pooler + head
         {
             GemmGroup g; gg_init(g);
             pool_in = cls_rows;

@@ -44,6 +44,8 @@ struct GemmGroup {
     const void* zeros;  // TN LDS-DMA kernel: >= 16 zero bytes on the device (source of the contraction tail's A rows)
     void* tn_scratch;   // TN LDS-DMA kernel, host side only: f32 scratch for split-contraction partials (null: no splitting)
     size_t tn_scratch_bytes;
+    int* sched;         // persistent NT kernel: a ZEROED device word of the caller = this launch's tile-ticket counter (null: every block walks tiles blockIdx, +grid, ...)
+    int sched_static;   // set by the launcher: blocks below it start on tile blockIdx, tickets hand out the tiles from it on
     DropCfg drop;
     GemmProblem p[GEMM_MAX_PROBLEMS];
 };

@@ -81,6 +81,7 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
 
 // EPI is a compile-time constant: the generic (run-time switched) epilogue inlined 32x stops the compiler from
 // unrolling the accumulator loops and pushes the 128 accumulators into scratch.
+int g_rgqa_nt_static_blocks = 0;   // with a ticket counter (GemmGroup::sched), blocks below this start on a fixed tile and the rest are spares (0 = all of them fixed); set by the engine (RGQA_NT_TICKETS / rgqa_debug_set key 12)
 template <typename OutT, int EPI, int MT>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -147,7 +148,27 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     };
 
     const int fr = lane & 15, fq = lane >> 4;
+    // Tile order.  Static: block b walks tiles b, b + grid, ...  With a ticket counter (g.sched, zeroed by the caller): blocks below
+    // g.sched_static start on tile b, every further tile is the next ticket - a block that reaches its CU late (another stream's
+    // kernel holds it) then takes fewer tiles instead of finishing its fixed share long after the others; with sched_static < grid the
+    // blocks above it are spares that only run if a CU is free while tickets remain.  The ticket for the tile after this one is requested
+    // at the top of the K loop (one lane, returned long before the loop ends) and handed to the eight waves through the first word of
+    // each wave's PRIVATE epilogue scratch, written before the barrier that ends the loop: no extra barrier, no extra LDS.
+    const bool dyn = PERSIST && g.sched != nullptr;
+    constexpr int EPI_WAVE_BYTES = PERSIST ? NT256_TP(MT) * 4096 : 0;
     int vt = blockIdx.x;
+    if (dyn && (int)blockIdx.x >= g.sched_static) {       // spare block: first tile by ticket, too (block-uniform)
+        if (tid == 0) {
+            int t0;        // (inline asm: hipcc's rewrite of a uniform atomic leaves the LDS-DMA statements below with a vector M0 operand)
+            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(t0) : "v"(g.sched), "v"(1) : "memory");
+#pragma unroll
+            for (int w = 0; w < 8; ++w) *reinterpret_cast<int*>(lds + EPI_OFF + w * EPI_WAVE_BYTES) = t0;
+        }
+        __syncthreads();
+        vt = g.sched_static + __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(lds + EPI_OFF + wave * EPI_WAVE_BYTES));
+        __syncthreads();
+        if (vt >= g.total_tiles) return;
+    }
     locate(vt);
     issue(0, 0);
     bool pre1 = false;      // K-step 1 of the current tile was already issued (behind the previous tile's epilogue)
@@ -157,6 +178,11 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Issued from inline asm and NOT waited for here (hipcc would turn a builtin atomic on a uniform address into an atomic followed by
+        // s_waitcnt vmcnt(0), a 2-us stall per tile): the value is read after the K loop, whose first step waits for vmcnt(0).
+        // tools/check_ticket_isa.py verifies on the compiled code that nothing touches the register in between.
+        int ticket = 0;
+        if (dyn && tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(ticket) : "v"(g.sched), "v"(1) : "memory");
 
         for (int kt = 0; kt < nkt; ++kt) {
             const int st = kt & 1;
@@ -169,9 +195,13 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             if (g.ablate == 2 || g.ablate == 5) continue;
             nt256_kstep<MT>(a, w, wm, wn, fr, fq, acc);
         }
+        if (dyn && tid == 0) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) *reinterpret_cast<int*>(lds + EPI_OFF + w * EPI_WAVE_BYTES) = ticket;
+        }
         __syncthreads();   // every wave is done with the operand stages: they may be refilled (PERSIST) or reused as scratch
         const int cpi = pi, cm0 = m0, cn0 = n0;
-        const int nvt = vt + (int)gridDim.x;
+        const int nvt = dyn ? g.sched_static + __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(lds + EPI_OFF + wave * EPI_WAVE_BYTES)) : vt + (int)gridDim.x;
         const bool more = PERSIST && nvt < g.total_tiles;
         nt256_epilogue<OutT, EPI, MT>(g, g.p[cpi], lds + EPI_OFF, wave, lane, cm0, cn0, wm, wn, acc, [&]() {
             if (more) {
@@ -367,6 +397,9 @@ static int launch256(GemmGroup& g, hipStream_t s) {
     int grid = g.total_tiles;
     static const bool nonpersist = getenv("RGQA_NT_NONPERSIST") != nullptr;   // experiment: one tile per block, hardware dispatch order
     if (NT256_PERSIST(MT) && !nonpersist && grid > rgqa_num_cus()) grid = rgqa_num_cus();     // one persistent block per CU
+    if (grid == g.total_tiles) g.sched = nullptr;          // one tile per block anyway
+    g.sched_static = grid;
+    if (g.sched != nullptr && g_rgqa_nt_static_blocks > 0 && g_rgqa_nt_static_blocks < grid) g.sched_static = g_rgqa_nt_static_blocks;
     hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI, MT>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
     RGQA_LAUNCH_CHECK("gemm_nt256_kernel");
     return RGQA_OK;
@@ -425,6 +458,8 @@ static int tuned_mt(GemmGroup& g, int model_mt, hipStream_t s) {
     const int cand[6] = {8, 7, 6, 5, 4, 2};
     float best[6] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     bool ok = true;
+    int* const sched_saved = g.sched;
+    g.sched = nullptr;                 // the timing launches must not draw this launch's tile tickets
     for (int round = 0; round < 4 && ok; ++round)
         for (int c = 0; c < 6 && ok; ++c) {
             ok = hipEventRecord(e0, s) == hipSuccess && launch256_epi(g, cand[c], s) == RGQA_OK && hipEventRecord(e1, s) == hipSuccess &&
@@ -433,6 +468,7 @@ static int tuned_mt(GemmGroup& g, int model_mt, hipStream_t s) {
             if (ok && round > 0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best[c]) best[c] = ms;   // round 0 warms up
         }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    g.sched = sched_saved;
     int mt = model_mt;
     if (ok) {
         int bi = 0;

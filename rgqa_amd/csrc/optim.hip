@@ -40,6 +40,29 @@ int k_sumsq(const float* g, size_t n, float* partial, float* out_sumsq, int accu
     return RGQA_OK;
 }
 
+__device__ __forceinline__ void adam_update4(const AdamArgs& a, float coef, float p[4], const float g[4], float m[4], float v[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float gg = g[j] * coef;
+        m[j] = m[j] * a.b1 + (1.f - a.b1) * gg;              // optimization.py:142
+        v[j] = v[j] * a.b2 + (1.f - a.b2) * gg * gg;         // :143
+        float u = m[j] / (sqrtf(v[j]) + a.eps);              // :144 (no bias correction, :175-178)
+        u += a.wd * p[j];                                    // :153-154 (every parameter)
+        p[j] -= a.lr_t * u;                                  // :170-171
+    }
+}
+// the n % 4 trailing elements
+__device__ __forceinline__ void adam_tail(const AdamArgs& a, float coef, size_t nv) {
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const size_t i = (nv << 2) + threadIdx.x;
+        const float gg = a.g[i] * coef;
+        float m = a.m[i] * a.b1 + (1.f - a.b1) * gg, v = a.v[i] * a.b2 + (1.f - a.b2) * gg * gg;
+        float u = m / (sqrtf(v) + a.eps) + a.wd * a.p[i];
+        a.p[i] -= a.lr_t * u; a.m[i] = m; a.v[i] = v;
+        if (a.p_lp) reinterpret_cast<bf16_t*>(a.p_lp)[i] = (bf16_t)a.p[i];
+    }
+}
+
 __global__ __launch_bounds__(256) void bertadam_kernel(const AdamArgs a) {
     // clip coefficient exactly as torch's clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied when < 1
     float coef = a.grad_prescale;
@@ -52,32 +75,94 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const AdamArgs a) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
         float p[4], g[4], m[4], v[4];
         load4(a.p + i * 4, p); load4(a.g + i * 4, g); load4(a.m + i * 4, m); load4(a.v + i * 4, v);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gg = g[j] * coef;
-            m[j] = m[j] * a.b1 + (1.f - a.b1) * gg;              // optimization.py:142
-            v[j] = v[j] * a.b2 + (1.f - a.b2) * gg * gg;         // :143
-            float u = m[j] / (sqrtf(v[j]) + a.eps);              // :144 (no bias correction, :175-178)
-            u += a.wd * p[j];                                    // :153-154 (every parameter)
-            p[j] -= a.lr_t * u;                                  // :170-171
-        }
+        adam_update4(a, coef, p, g, m, v);
         store4(a.p + i * 4, p); store4(a.m + i * 4, m); store4(a.v + i * 4, v);
         if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + i * 4, p);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
-        const size_t i = (nv << 2) + threadIdx.x;
-        const float gg = a.g[i] * coef;
-        float m = a.m[i] * a.b1 + (1.f - a.b1) * gg, v = a.v[i] * a.b2 + (1.f - a.b2) * gg * gg;
-        float u = m / (sqrtf(v) + a.eps) + a.wd * a.p[i];
-        a.p[i] -= a.lr_t * u; a.m[i] = m; a.v[i] = v;
-        if (a.p_lp) reinterpret_cast<bf16_t*>(a.p_lp)[i] = (bf16_t)a.p[i];
+    adam_tail(a, coef, nv);
+}
+
+// The same update confined to gridDim.x CUs: 1024-thread blocks that each claim more than half of a CU's LDS (so two never share a
+// CU), two groups of four 16-byte loads in flight per lane.  Used when the update runs on a side stream BESIDE the next forward
+// pass (Engine.adam_step(pipeline="background")): the persistent GEMM blocks of that pass need whole CUs (all registers, 128 KiB of
+// LDS) - an update spread over every CU starves them until it has drained, one that owns a quarter of the chip leaves them the rest.
+#define NARROW_THREADS 1024
+#define NARROW_LDS (84 * 1024)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+// NT: non-temporal accesses (streamed once: keep the 6 GB of optimizer state out of the caches the forward pass beside it lives in)
+template <bool NT> __device__ __forceinline__ void ld4(const float* p, float v[4]) {
+    const f32x4v t = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p)) : *reinterpret_cast<const f32x4v*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <bool NT> __device__ __forceinline__ void st4(float* p, const float v[4]) {
+    const f32x4v t = {v[0], v[1], v[2], v[3]};
+    if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(p)); else *reinterpret_cast<f32x4v*>(p) = t;
+}
+template <bool NT, int UNROLL>
+__global__ __launch_bounds__(NARROW_THREADS) void bertadam_narrow_kernel(const AdamArgs a) {
+    extern __shared__ unsigned char narrow_pad[];
+    float coef = a.grad_prescale;
+    if (a.sumsq) {
+        const float norm = sqrtf(*a.sumsq) * a.grad_prescale;
+        const float c = a.max_norm / (norm + 1e-6f);
+        if (c < 1.f) coef *= c;
     }
+    const size_t nv = a.n >> 2, stride = (size_t)gridDim.x * NARROW_THREADS;
+    size_t i = (size_t)blockIdx.x * NARROW_THREADS + threadIdx.x;
+    auto one = [&](size_t k) {
+        float p[4], g[4], m[4], v[4];
+        ld4<NT>(a.p + k * 4, p); ld4<NT>(a.g + k * 4, g); ld4<NT>(a.m + k * 4, m); ld4<NT>(a.v + k * 4, v);
+        adam_update4(a, coef, p, g, m, v);
+        st4<NT>(a.p + k * 4, p); st4<NT>(a.m + k * 4, m); st4<NT>(a.v + k * 4, v);
+        if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + k * 4, p);      // the forward pass reads this copy next: cached
+    };
+    if (UNROLL == 2) {
+        for (; i + stride < nv; i += 2 * stride) {
+            const size_t i2 = i + stride;
+            float p[4], g[4], m[4], v[4], p2[4], g2[4], m2[4], v2[4];
+            ld4<NT>(a.p + i * 4, p); ld4<NT>(a.g + i * 4, g); ld4<NT>(a.m + i * 4, m); ld4<NT>(a.v + i * 4, v);
+            ld4<NT>(a.p + i2 * 4, p2); ld4<NT>(a.g + i2 * 4, g2); ld4<NT>(a.m + i2 * 4, m2); ld4<NT>(a.v + i2 * 4, v2);
+            adam_update4(a, coef, p, g, m, v);
+            st4<NT>(a.p + i * 4, p); st4<NT>(a.m + i * 4, m); st4<NT>(a.v + i * 4, v);
+            if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + i * 4, p);
+            adam_update4(a, coef, p2, g2, m2, v2);
+            st4<NT>(a.p + i2 * 4, p2); st4<NT>(a.m + i2 * 4, m2); st4<NT>(a.v + i2 * 4, v2);
+            if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + i2 * 4, p2);
+        }
+    }
+    for (; i < nv; i += stride) one(i);
+    adam_tail(a, coef, nv);
+}
+
+int g_rgqa_narrow_cus = 0;     // rgqa_debug_set key 13: > 0 = the optimizer / weight-copy kernels launched next stay on that many CUs (one 1024-thread block each)
+static int narrow_blocks() {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bertadam_narrow_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bertadam_narrow_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bertadam_narrow_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bertadam_narrow_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
+        attr = true;
+    }
+    return g_rgqa_narrow_cus;
 }
 
 int k_bertadam(const AdamArgs& a, hipStream_t s) {
     if (a.n == 0) return RGQA_OK;
     RGQA_REQUIRE(((uintptr_t)a.p % 16) == 0 && ((uintptr_t)a.g % 16) == 0 && ((uintptr_t)a.m % 16) == 0 && ((uintptr_t)a.v % 16) == 0, "bertadam: 16-byte alignment required");
     size_t nb = (a.n / 4 + 255) / 256;
+    if (const int ncu = narrow_blocks(); ncu > 0 && nb > (size_t)ncu * 4) {
+        static const int variant = []() { const char* e = getenv("RGQA_ADAM_NARROW_VARIANT"); return e ? atoi(e) : 3; }();     // bit 0: non-temporal, bit 1: two groups of loads in flight
+        switch (variant & 3) {
+            case 0: hipLaunchKernelGGL((bertadam_narrow_kernel<false, 1>), dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, a); break;
+            case 1: hipLaunchKernelGGL((bertadam_narrow_kernel<true, 1>), dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, a); break;
+            case 2: hipLaunchKernelGGL((bertadam_narrow_kernel<false, 2>), dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, a); break;
+            default: hipLaunchKernelGGL((bertadam_narrow_kernel<true, 2>), dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, a); break;
+        }
+        RGQA_LAUNCH_CHECK("bertadam_narrow_kernel");
+        return RGQA_OK;
+    }
     int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
     hipLaunchKernelGGL(bertadam_kernel, dim3(nblk), dim3(256), 0, s, a);
     RGQA_LAUNCH_CHECK("bertadam_kernel");
@@ -135,17 +220,16 @@ int k_sum_bf16_parts(const void* parts, size_t stride, int nparts, float* dst, s
 // Batched cast + transpose of every linear weight: dst[k][n] = bf16(src[n][k]); TRANSPOSE_TILE^2 (64x64) tiles through LDS:
 // float4 reads of 256-B row pieces, 8-B writes of full 128-B destination lines (the 32x32 / 2-B-store version ran at 58 % of
 // the copy's byte floor).
+// one 64 x 64 tile `t` by 256 threads (ltid), in two phases around a workgroup barrier of the caller
 template <typename S>
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc) {
+__device__ __forceinline__ void transpose_tile_load(const S* __restrict__ src, const TransDesc* __restrict__ desc, int ndesc, int t, float (*tile)[TRANSPOSE_TILE + 1], int ltid, TransDesc& d, int& n0, int& k0) {
     constexpr int TT = TRANSPOSE_TILE;
-    __shared__ float tile[TT][TT + 1];
     int lo = 0, hi = ndesc - 1;
-    const int t = blockIdx.x;
     while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (desc[mid].tile_start <= t) lo = mid; else hi = mid - 1; }
-    const TransDesc d = desc[lo];
+    d = desc[lo];
     const int lt = t - d.tile_start, tk = cdiv(d.K, TT);
-    const int n0 = (lt / tk) * TT, k0 = (lt % tk) * TT;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 threads x 4 elements per 64-wide row, 16 rows per pass
+    n0 = (lt / tk) * TT; k0 = (lt % tk) * TT;
+    const int tx = ltid & 15, ty = ltid >> 4;      // 16 threads x 4 elements per 64-wide row, 16 rows per pass
     const bool k4 = (d.K & 3) == 0;
 #pragma unroll
     for (int r = 0; r < TT / 16; ++r) {
@@ -159,7 +243,10 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) tile[ty + r * 16][tx * 4 + j] = v[j];
     }
-    __syncthreads();
+}
+__device__ __forceinline__ void transpose_tile_store(bf16_t* __restrict__ dst, const TransDesc& d, int n0, int k0, float (*tile)[TRANSPOSE_TILE + 1], int ltid) {
+    constexpr int TT = TRANSPOSE_TILE;
+    const int tx = ltid & 15, ty = ltid >> 4;
     const bool n4 = (d.ld_dst & 3) == 0;
 #pragma unroll
     for (int r = 0; r < TT / 16; ++r) {
@@ -173,9 +260,45 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict
         else { for (int j = 0; j < 4; ++j) if (n + j < d.ld_dst) dp[j] = (bf16_t)v[j]; }
     }
 }
+template <typename S>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc) {
+    __shared__ float tile[TRANSPOSE_TILE][TRANSPOSE_TILE + 1];
+    TransDesc d; int n0, k0;
+    transpose_tile_load<S>(src, desc, ndesc, blockIdx.x, tile, threadIdx.x, d, n0, k0);
+    __syncthreads();
+    transpose_tile_store(dst, d, n0, k0, tile, threadIdx.x);
+}
+// confined to gridDim.x CUs (see bertadam_narrow_kernel): four 256-thread groups per block, each walking its own tiles
+template <typename S>
+__global__ __launch_bounds__(NARROW_THREADS) void cast_transpose_narrow_kernel(const S* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char narrow_lds[];
+    const int sub = threadIdx.x >> 8, ltid = threadIdx.x & 255;
+    float (*tile)[TRANSPOSE_TILE + 1] = reinterpret_cast<float (*)[TRANSPOSE_TILE + 1]>(narrow_lds) + sub * TRANSPOSE_TILE;
+    const int step = (int)gridDim.x * 4;
+    for (int base = 0; base < total_tiles; base += step) {        // block-uniform trip count: every thread reaches both barriers
+        const int t = base + (int)blockIdx.x * 4 + sub;
+        TransDesc d; int n0 = 0, k0 = 0;
+        if (t < total_tiles) transpose_tile_load<S>(src, desc, ndesc, t, tile, ltid, d, n0, k0);
+        __syncthreads();
+        if (t < total_tiles) transpose_tile_store(dst, d, n0, k0, tile, ltid);
+        __syncthreads();
+    }
+}
 // src: the f32 master weights, or (src_is_bf16) their bf16 copy at the same element offsets - half the bytes to read, same result
 int k_cast_transpose(const void* src, int src_is_bf16, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s) {
     if (ndesc <= 0 || total_tiles <= 0) return RGQA_OK;
+    if (const int ncu = narrow_blocks(); ncu > 0 && total_tiles > ncu * 16) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cast_transpose_narrow_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cast_transpose_narrow_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
+            attr = true;
+        }
+        if (src_is_bf16) hipLaunchKernelGGL(cast_transpose_narrow_kernel<bf16_t>, dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc, total_tiles);
+        else hipLaunchKernelGGL(cast_transpose_narrow_kernel<float>, dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, reinterpret_cast<const float*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc, total_tiles);
+        RGQA_LAUNCH_CHECK("cast_transpose_narrow_kernel");
+        return RGQA_OK;
+    }
     if (src_is_bf16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc);
     else hipLaunchKernelGGL(cast_transpose_kernel<float>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const float*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc);
     RGQA_LAUNCH_CHECK("cast_transpose_kernel");

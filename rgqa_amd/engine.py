@@ -4,6 +4,7 @@ torch is plumbing only here: it owns device memory (arenas, workspace, I/O tenso
 Every tensor operation of the hot path happens inside librgqa_hip.so.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -284,6 +285,8 @@ class Engine:
                                               lp, b - a, lr_t, b1, b2, eps, weight_decay, ptr(self._sumsq) if clip else None,
                                               max_norm, grad_prescale, st))
 
+        if pipeline == "background" and self.cfg.arch == 0:
+            return self._adam_background(update, rngs, s)
         x0 = self.cross_offset() if (pipeline and self.cfg.arch == 0) else None
         if x0 is None:
             for a, b in rngs:
@@ -311,6 +314,56 @@ class Engine:
                 check(self.lib.rgqa_engine_sync_transposed(self.h, so))
             ev_all.record(self._opt_stream)
         check(self.lib.rgqa_engine_set_weight_events(self.h, C.c_void_p(ev_first.cuda_event), C.c_void_p(ev_cross.cuda_event), C.c_void_p(ev_all.cuda_event)))
+
+    def _adam_background(self, update, rngs, s):
+        """pipeline="background": the update of everything but the first layers runs on a side stream on RGQA_OPT_CUS CUs (default 64;
+        kernels of 1024-thread blocks that own a CU each, rgqa_debug_set key 13) BESIDE the next forward pass, gradient segment by
+        gradient segment in forward order, and that pass waits for each layer's event right before it reads the layer
+        (rgqa_engine_set_segment_weight_events).  The embeddings + the first RGQA_OPT_HEAD_LAYERS layers (default 1) are updated on the
+        caller's stream, whole chip, first: the forward pass needs them at once.  Same arithmetic per element, same results."""
+        ncu = int(os.environ.get("RGQA_OPT_CUS", "64"))
+        head_layers = int(os.environ.get("RGQA_OPT_HEAD_LAYERS", "1"))
+        group = max(1, int(os.environ.get("RGQA_OPT_GROUP", "1")))        # layers per event
+        segs = self.grad_segments()
+        n_ev = max(ev for _, _, ev in segs) + 1
+        by_ev = {}
+        for a, b, ev in segs:
+            by_ev.setdefault(ev, []).append((a, b))
+        order = sorted(by_ev, reverse=True)                   # forward order: embeddings, l/r layers, x layers, pooler + head
+        if getattr(self, "_opt_stream", None) is None:
+            self._opt_stream = torch.cuda.Stream(device=self.device)
+            self._opt_events = [torch.cuda.Event() for _ in range(3)]
+        if getattr(self, "_seg_wevents", None) is None or len(self._seg_wevents) != n_ev:
+            self._seg_wevents = [torch.cuda.Event() for _ in range(n_ev)]
+        cur = torch.cuda.current_stream()
+        self._opt_stream.wait_stream(cur)                     # gradients + clip norm are final
+        head, rest = order[:1 + head_layers], order[1 + head_layers:]
+        for ev in head:                                       # exposed part, whole chip
+            for a, b in by_ev[ev]:
+                update(a, b, s)
+        table = (C.c_void_p * n_ev)()
+        ev_all = self._opt_events[2]
+        with torch.cuda.stream(self._opt_stream):
+            so = C.c_void_p(self._opt_stream.cuda_stream)
+            check(self.lib.rgqa_debug_set(13, ncu))
+            try:
+                for k in range(0, len(rest), group):
+                    chunk = rest[k:k + group]
+                    for ev in chunk:
+                        for a, b in by_ev[ev]:
+                            update(a, b, so)
+                    e = self._seg_wevents[chunk[-1]]
+                    e.record(self._opt_stream)
+                    for ev in chunk:
+                        table[ev] = e.cuda_event
+                if self.precision == "bf16":
+                    self._opt_stream.wait_stream(cur)         # the transposed copies also cover the ranges updated on the caller's stream
+                    check(self.lib.rgqa_engine_sync_transposed(self.h, so))
+            finally:
+                check(self.lib.rgqa_debug_set(13, 0))
+            ev_all.record(self._opt_stream)
+        check(self.lib.rgqa_engine_set_segment_weight_events(self.h, table, n_ev))
+        check(self.lib.rgqa_engine_set_weight_events(self.h, None, None, C.c_void_p(ev_all.cuda_event)))
 
     def grad_norm(self):
         """Global L2 norm of the live gradient ranges (what clip_grad_norm_ measures, gqa_conf.py:201) as a device scalar."""

@@ -357,6 +357,41 @@ def test_wgrad_launch_phase_is_bit_identical():
             assert gn == gn_ref          # the per-segment sum of squares is taken when a segment's last gradient is final
 
 
+def test_ticket_scheduled_gemm_tiles_are_bit_identical():
+    """Persistent forward / dgrad GEMMs can hand out their tiles by ticket (rgqa_debug_set key 12: N = the first N blocks of a launch start on a
+    fixed tile, the rest are spares that only draw tickets) instead of the fixed walk b, b + grid, ...: which block computes a tile
+    changes nothing in the tile, so logits and every gradient are bit-identical - B = 128 so that the FFN / QKV launches have more tiles than
+    the chip has CUs."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    B, T, O = 128, 20, 36
+    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=17, min_len=3)
+    b = dev(raw)
+    lens = raw["lengths"].astype(np.int32)
+    e = make_engine(FULL, "bf16", dropout=0.1)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
+
+    def run_mode(n):
+        assert L.rgqa_debug_set(12, n) == 0
+        try:
+            lg, _ = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=43, lengths=lens)
+            lg = lg.clone()
+            e.loss_backward(b["target"])
+            torch.cuda.synchronize()
+            return lg, e.grads[first:].clone()
+        finally:
+            L.rgqa_debug_set(12, -1)
+
+    lg0, g0 = run_mode(0)
+    assert float(g0.abs().max()) > 0
+    for n in (256, 200, 64, 256):
+        lg, g = run_mode(n)
+        assert torch.equal(lg, lg0), n
+        assert torch.equal(g, g0), n
+
+
 def test_merged_layernorm_matches_per_modality(monkeypatch):
     """Stages where both modalities run their own module share one LayerNorm launch (forward and backward) over the
     adjacent [language | vision] rows; RGQA_LN_MERGE=0 keeps one launch per modality. Same arithmetic per row and the same
@@ -847,15 +882,27 @@ def test_full_size_batch_independence_and_roi_permutation():
     assert float((permuted - full).abs().mean()) <= 3e-3 * scale
 
 
-def test_pipelined_optimizer_matches_inline():
+@pytest.mark.parametrize("mode", [True, "background"])
+def test_pipelined_optimizer_matches_inline(mode, monkeypatch):
     """Engine.adam_step(pipeline=True): BertAdam on a side stream in forward order, the next forward / backward waiting on per-range
-    events (rgqa_engine_set_weight_events).  One step from identical state: every parameter outside the three embedding tables (whose
+    events (rgqa_engine_set_weight_events); pipeline="background": the update confined to a few CUs (here 48, with the ticket-scheduled
+    GEMMs that tolerate the missing CUs), per-layer events (rgqa_engine_set_segment_weight_events).  One step from identical state: every parameter outside the three embedding tables (whose
     gradients are f32 atomic scatter-adds: order-dependent last bits in ANY two runs) and both bf16 copies come out bit-identical to
     the in-line optimizer; over four train-mode steps the two runs stay as close as two in-line runs do."""
+    from rgqa_amd import _lib
+    L = _lib.load()
     B, T, O = 64, 20, 36
     b = dev(synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=15, min_len=3))
+    monkeypatch.setenv("RGQA_OPT_CUS", "48")
 
     def train(pipe, steps):
+        L.rgqa_debug_set(12, 200 if pipe == "background" else -1)
+        try:
+            return train_(pipe, steps)
+        finally:
+            L.rgqa_debug_set(12, -1)
+
+    def train_(pipe, steps):
         e = make_engine(FULL, "bf16", dropout=0.1)
         e.ensure_shape(B, T, O)
         e.sync_weights()
@@ -869,12 +916,16 @@ def test_pipelined_optimizer_matches_inline():
         return e.params.clone(), e.params_lp.clone(), e.params_lp_t.clone(), lg.clone(), first
 
     p0, lp0, lpt0, lg0, first = train(False, 1)
-    p1, lp1, lpt1, lg1, _ = train(True, 1)
+    p1, lp1, lpt1, lg1, _ = train(mode, 1)
     assert torch.equal(p0[first:], p1[first:]) and torch.equal(lp0[first:], lp1[first:]) and torch.equal(lpt0[first:], lpt1[first:])
     assert torch.allclose(p0[:first], p1[:first], rtol=0, atol=2.1e-4)          # one BertAdam step of lr 1e-4 moves an element by <= 3.2e-4
     assert float((lg0 - lg1).abs().max()) < 5e-2
     a = train(False, 4)
     bb = train(False, 4)
-    c = train(True, 4)
-    spread = float((a[0] - bb[0]).abs().max())                  # run-to-run spread of the in-line optimizer (the atomics)
-    assert float((a[0] - c[0]).abs().max()) <= max(2.0 * spread, 1e-6)
+    c = train(mode, 4)
+    # run-to-run spread of the in-line optimizer: the embedding tables' atomic scatter-adds, which BertAdam's m / sqrt(v) amplifies for elements
+    # with tiny gradients.  Two in-line runs under identical timing often reproduce the same order (spread 0 .. 3e-5 observed); a run whose
+    # kernels are scheduled differently need not, so the floor is the observed 2.7e-5 with margin - still 5x below what ONE step moves an
+    # element (3.2e-4), i.e. far below what a forward pass reading a layer's weights before their update would cause.
+    spread = float((a[0] - bb[0]).abs().max())
+    assert float((a[0] - c[0]).abs().max()) <= max(2.0 * spread, 6e-5)
