@@ -52,7 +52,9 @@ int rgqa_version(void);
  * key 10: 0 = every LayerNorm backward folds its column sums at once on the main stream, 1 (default) = once per layer beside the layer's wgrad launch;
  * key 11: deferred wgrad launches cut after a layer's attention block (0) or after every FFN stage (1, default), -1 = environment RGQA_WGRAD_PHASE;
  * key 12: persistent forward / dgrad GEMMs draw their tiles by ticket: 0 = fixed walk, N = yes with the first N blocks on a fixed first tile, -1 = env RGQA_NT_TICKETS;
- * key 13: N > 0 confines the optimizer / transposed-copy kernels launched next to N CUs (one 1024-thread block each), 0 = whole chip) */
+ * key 13: N > 0 confines the optimizer / transposed-copy kernels launched next to N CUs (one 1024-thread block each), 0 = whole chip;
+ * key 14: 1 = dgrad GEMMs read the weight as stored ([K,N] operand form), 0 = its transposed bf16 copy, -1 = env RGQA_DGRAD_NN (an engine created with
+ * RGQA_DGRAD_NN=1 writes no transposed copy for modules whose dgrads all qualify and keeps the [K,N] form for them) */
 int rgqa_debug_set(int key, int value);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over
@@ -228,6 +230,11 @@ int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int
  * NULL when the epilogue does not use them.  Kernel parity tests and tools/lab only. */
 int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const void* aux, void* C, void* C2, int M, int N,
                       int K, int lda, int ldw, int ldc, int ldaux, int epilogue, float drop_p, void* stream);
+/* bf16: C[M,N] = epilogue(A[M,K] B[K,N]) with B stored [K,N] row-major (the dgrad GEMM reading a weight [out,in] as it is stored - replaces
+ * the transposed-copy operand of the reference's autograd matmul, torch.nn.functional.linear backward); epilogue 0 none, 4 x*aux, 5 x+aux,
+ * 7 x*(1-aux^2), 10 relu/dropout gradient; K % 64 == 0, N % 8 == 0.  Kernel parity tests. */
+int rgqa_op_matmul_nn(const void* A, const void* B, const void* aux, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+                      int epilogue, void* stream);
 /* C[M,N] f32 = A[K,M]^T B[K,N]   (wgrad form); dtype of A and B */
 int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int dtype, void* stream);

@@ -27,6 +27,7 @@ extern int g_rgqa_ln_defer;
 extern int g_rgqa_wgrad_phase;
 extern int g_rgqa_nt_tickets;
 extern int g_rgqa_narrow_cus;
+extern int g_rgqa_dgrad_nn;
 // debug / A-B knobs: key 0 = force the 128x128 GEMM kernel; key 1 = force the LDS-DMA kernel's MT (0 = auto)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -43,6 +44,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 11) { g_rgqa_wgrad_phase = value; return RGQA_OK; }
     if (key == 12) { g_rgqa_nt_tickets = value; return RGQA_OK; }
     if (key == 13) { g_rgqa_narrow_cus = value; return RGQA_OK; }
+    if (key == 14) { g_rgqa_dgrad_nn = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }
@@ -248,6 +250,15 @@ int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const voi
     GemmProblem& p = g.p[0];
     p.A = A; p.B = W; p.C = C; p.C2 = C2; p.bias = bias; p.aux = aux; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.ldaux = ldaux;
     p.epi = epilogue; p.drop_site = 17u;
+    return launch_gemm_nt_bf16(g, 0, S(stream));
+}
+// bf16, B stored [K, N] (the dgrad form on the weight as it is): C[M,N] = epilogue(A[M,K] B[K,N]); epilogue in {0, 4, 5, 7, 10}; K % 64 == 0, N % 8 == 0
+int rgqa_op_matmul_nn(const void* A, const void* B, const void* aux, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int epilogue, void* stream) {
+    RGQA_REQUIRE(K % 64 == 0 && K >= 64 && N % 8 == 0 && ldb >= N, "op_matmul_nn: K=%d must be a multiple of 64, N=%d of 8", K, N);
+    GemmGroup g; memset(&g, 0, sizeof g);
+    g.count = 1; g.b_kn = 1; g.drop = make_drop(0.f, 0, 0);
+    GemmProblem& p = g.p[0];
+    p.A = A; p.B = B; p.C = C; p.aux = aux; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.epi = epilogue;
     return launch_gemm_nt_bf16(g, 0, S(stream));
 }
 int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {

@@ -152,6 +152,7 @@ int g_rgqa_wgrad_phase = -1;   // rgqa_debug_set key 11: where a layer's deferre
 int g_rgqa_nt_tickets = -1;    // rgqa_debug_set key 12: persistent forward / dgrad GEMMs hand out their tiles by ticket (GemmGroup::sched): 0 = no (fixed walk), N > 0 = yes, with
                                // the first N blocks of a launch starting on a fixed tile (N >= 256: all of them); -1 = env RGQA_NT_TICKETS (default 0)
 extern int g_rgqa_nt_static_blocks;
+int g_rgqa_dgrad_nn = -1;      // rgqa_debug_set key 14: 1 = dgrad GEMMs read the weight as stored (no transposed copy), 0 = the transposed bf16 copy, -1 = env RGQA_DGRAD_NN
 int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
 
 template <typename T>
@@ -286,13 +287,18 @@ public:
 
     void build_transpose_table() {
         // every [out,in] linear weight gets a transposed low-precision copy at the same arena offset
-        auto add = [&](const Lin& l) {
+        nn_only = LP && dgrad_nn_env();
+        auto add = [&](const Lin& l, int row_block = 0) {
+            // row_block: the smallest block of weight rows a dgrad of this module contracts (0: always the whole module; the fused q|k|v
+            // projection: its q block).  With nn_only only modules with a contraction that is not a multiple of 64 keep a transposed copy
+            // (the answer head's last layer, 1842 rows).
+            if (nn_only && dgrad_nn_shape(l, l.out) && (row_block == 0 || row_block % 64 == 0)) return;
             TransDesc d; d.src_off = (long)l.w; d.dst_off = (long)l.w; d.N = l.out; d.K = l.in; d.ld_dst = l.ldt; d.tile_start = tdesc_tiles;
             tdesc_tiles += cdiv(l.ldt, TRANSPOSE_TILE) * cdiv(l.in, TRANSPOSE_TILE);
             tdesc_host.push_back(d);
         };
         add(mp.visn_fc);
-        auto addatt = [&](const AttP& a) { add(a.qkv); add(a.o); };
+        auto addatt = [&](const AttP& a) { add(a.qkv, a.qkv.out / 3); add(a.o); };
         auto addffn = [&](const FfnP& f) { add(f.up); add(f.down); };
         for (auto& a : mp.l_att) addatt(a);
         for (auto& f : mp.l_ffn) addffn(f);
@@ -533,11 +539,28 @@ public:
         p.aux = aux; p.ldaux = ldaux; p.epi = epi; p.drop_site = site;
     }
     // dx[rows, in] = dy[rows, cols] @ W[wrow0 : wrow0+cols, :]      ; DGRAD
+    // dgrad straight from the [out, in] weight (NN form): contraction a whole number of K-steps, rows 16-byte aligned
+    static bool dgrad_nn_env() {
+        static const bool env = getenv("RGQA_DGRAD_NN") != nullptr && getenv("RGQA_DGRAD_NN")[0] == '1';
+        return env;
+    }
+    // nn_only (RGQA_DGRAD_NN=1 when the engine was created): the transposed copy of a weight whose dgrads can all take the [K,N] form is
+    // never written (build_transpose_table), so those dgrads take it whatever rgqa_debug_set key 14 says later
+    bool nn_only = false;
+    bool dgrad_mixed = false;      // a group mixing [K,N] and [N,K] weight operands was built (never for the encoder's layer shapes): run_dgrad refuses it
+    static bool dgrad_nn_shape(const Lin& l, int wrows) { return wrows % 64 == 0 && wrows >= 64 && l.in % 8 == 0 && l.in >= 64; }
+    bool dgrad_nn(const Lin& l, int wrows) const {
+        const bool on = nn_only || (g_rgqa_dgrad_nn < 0 ? dgrad_nn_env() : g_rgqa_dgrad_nn != 0);
+        return on && dgrad_nn_shape(l, wrows);
+    }
     void add_dgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, void* dx, int lddx, int M, int epi, const void* aux, int ldaux) {
         GemmProblem& p = g.p[g.count++];
         memset(&p, 0, sizeof p);
         p.A = dy; p.lda = lddy; p.M = M; p.N = l.in; p.C = dx; p.ldc = lddx;
-        if (LP) { p.B = PbT + l.w + wrow0; p.ldb = l.ldt; p.K = (wrow0 + wrows == l.out) ? (int)rup(wrows, 64) : wrows; if (p.K > l.ldt - wrow0) p.K = l.ldt - wrow0; }   // the transposed copy and dy are zero-padded up to ldt = round_up(out, 64): a whole number of K-steps for the LDS-DMA kernel
+        if (LP && dgrad_nn(l, wrows) && (g.count == 1 || g.b_kn)) {
+            // the weight as stored, [out, in]: rows wrow0 .. wrow0 + wrows are the contraction, no transposed copy involved (gemm.h b_kn)
+            g.b_kn = 1; p.B = Pb + l.w + (size_t)wrow0 * l.in; p.ldb = l.in; p.K = wrows;
+        } else if (LP) { if (g.b_kn) dgrad_mixed = true; p.B = PbT + l.w + wrow0; p.ldb = l.ldt; p.K = (wrow0 + wrows == l.out) ? (int)rup(wrows, 64) : wrows; if (p.K > l.ldt - wrow0) p.K = l.ldt - wrow0; }   // the transposed copy and dy are zero-padded up to ldt = round_up(out, 64): a whole number of K-steps for the LDS-DMA kernel
         else { p.B = P + l.w + (size_t)wrow0 * l.in; p.ldb = l.in; p.K = wrows; }
         p.aux = aux; p.ldaux = ldaux; p.epi = epi;
     }
@@ -584,6 +607,7 @@ public:
     }
     int run_dgrad(GemmGroup& g, hipStream_t s) {
         if (g.count == 0) return RGQA_OK;
+        RGQA_REQUIRE(!dgrad_mixed, "dgrad: one grouped launch mixes stored and transposed weight operands");
         sched_assign(g);
         double f, b; gemm_work(g, f, b);
         prof_begin(PC_GEMM_NT, f, b, s);

@@ -40,6 +40,7 @@ struct GemmGroup {
     int count;
     int total_tiles;
     int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
+    int b_kn;           // NT LDS-DMA kernels only: every problem's B operand is stored [K, N] row-major (ldb = row pitch) instead of [N, K]: C = A B.  K % 64 == 0
     int ablate;         // perf ablation (rgqa_debug_set key 3; results are garbage): 1 = no operand DMA in the K loop, 2 = no LDS reads / MFMAs
     const void* zeros;  // TN LDS-DMA kernel: >= 16 zero bytes on the device (source of the contraction tail's A rows)
     void* tn_scratch;   // TN LDS-DMA kernel, host side only: f32 scratch for split-contraction partials (null: no splitting)

@@ -144,3 +144,23 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
         }
     }
 }
+
+// ---- row-major-over-the-contraction LDS images (wgrad operands; the weight operand of the NN dgrad): 32-byte granule swizzle + transposed fragment reads
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+__device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <int PITCH>
+__device__ __forceinline__ bf16x8 tr_frag_dma(const unsigned char* tile, int r0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row = r0 + 8 * g + q;
+    const int ch = (c0 >> 3) + (p >> 1);
+    const int sw = tn_f(row) << 1;      // identical for row and row + 4
+    const unsigned char* a1 = tile + row * PITCH + ((ch ^ sw) << 4) + 8 * (p & 1);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(a1));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(a1 + 4 * PITCH));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}

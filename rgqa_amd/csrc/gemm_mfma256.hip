@@ -38,14 +38,21 @@ int g_rgqa_no_deep = 0;  // rgqa_debug_set key 5: 1 = never use the deep-ring si
 #ifndef RGQA_TN_PIPE
 #define RGQA_TN_PIPE 3
 #endif
-template <int MT>
+// NN: the W stage is a [64 contraction rows][256 columns] image (the weight as stored, [out, in], serves dgrad without a transposed copy):
+// its fragments come through ds_read_b64_tr_b16 like the wgrad kernel's
+template <int MT, bool NN>
 __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsigned char* w, int wm, int wn, int fr, int fq, f32x4 (&acc)[MT][4]) {
+    const int lane_ = fq * 16 + fr;
+    auto ldw = [&](int half, int t) -> bf16x8 {
+        if constexpr (NN) return tr_frag_dma<TN * 2>(w, half * 32, wn * 64 + t * 16, lane_);
+        else return *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, half * 4 + fq));
+    };
 #if RGQA_NT_PIPE
     constexpr int PD = RGQA_NT_PIPE, NF = 2 * MT;
     auto lda = [&](int i) { return *reinterpret_cast<const bf16x8*>(a + off256(wm * (16 * MT) + (i % MT) * 16 + fr, (i / MT) * 4 + fq)); };
     bf16x8 xw[2][4], ring[PD];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) xw[0][t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, fq));
+    for (int t = 0; t < 4; ++t) xw[0][t] = ldw(0, t);
 #pragma unroll
     for (int i = 0; i < PD; ++i) ring[i] = lda(i);
 #pragma unroll
@@ -57,7 +64,7 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
         if (i + PD < NF) ring[i % PD] = lda(i + PD);
         if (s == 0 && tm == MT - 1 - (MT > 2 ? 2 : 0)) {          // second half's W fragments, two fragments of lead
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xw[1][t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, 4 + fq));
+            for (int t = 0; t < 4; ++t) xw[1][t] = ldw(1, t);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -66,7 +73,7 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
     for (int s = 0; s < 2; ++s) {
         bf16x8 xw[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xw[t] = *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, s * 4 + fq));
+        for (int t = 0; t < 4; ++t) xw[t] = ldw(s, t);
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm) {
             const bf16x8 xa = *reinterpret_cast<const bf16x8*>(a + off256(wm * (16 * MT) + tm * 16 + fr, s * 4 + fq));
@@ -82,7 +89,7 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
 // EPI is a compile-time constant: the generic (run-time switched) epilogue inlined 32x stops the compiler from
 // unrolling the accumulator loops and pushes the 128 accumulators into scratch.
 int g_rgqa_nt_static_blocks = 0;   // with a ticket counter (GemmGroup::sched), blocks below this start on a fixed tile and the rest are spares (0 = all of them fixed); set by the engine (RGQA_NT_TICKETS / rgqa_debug_set key 12)
-template <typename OutT, int EPI, int MT>
+template <typename OutT, int EPI, int MT, bool NN = false>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr bool PERSIST = NT256_PERSIST(MT);
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     const int lch_w[2] = {(lane & 7) ^ (lrow >> 1), (lane & 7) ^ (4 + (lrow >> 1))};
     const bf16_t* asrc[AG];
     const bf16_t* wsrc[4];
+    size_t wstep = TK;      // W source advance per K-step: TK elements along a row (NT) or TK rows (NN)
     int pi = 0, m0 = 0, n0 = 0, nkt = 0;
     // tile id -> problem, tile origin and this lane's DMA source rows
     auto locate = [&](int vt) {
@@ -117,10 +125,21 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             int am = m0 + (i * 8 + wave) * 8 + lrow; if (am > P.M - 1) am = P.M - 1;   // clamp: rows past the edge are never stored
             asrc[i] = A + (size_t)am * P.lda + lch_a * 8;
         }
+        if constexpr (NN) {
+            wstep = (size_t)TK * P.ldb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > P.N - 1) wn_ = P.N - 1;
-            wsrc[i] = W + (size_t)wn_ * P.ldb + lch_w[i & 1] * 8;
+            for (int i = 0; i < 4; ++i) {      // piece = 2 contraction rows x 256 columns; source columns un-swizzled per lane, clamped in-bounds (columns past N are never stored)
+                const int row = (wave * 4 + i) * 2 + (lane >> 5);
+                int col = n0 + (((lane & 31) ^ (tn_f(row) << 1)) << 3);
+                if (col > P.ldb - 8) col = P.ldb - 8;
+                wsrc[i] = W + (size_t)row * P.ldb + col;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > P.N - 1) wn_ = P.N - 1;
+                wsrc[i] = W + (size_t)wn_ * P.ldb + lch_w[i & 1] * 8;
+            }
         }
     };
     // LDS ring depth 2. Measured alternatives on these shapes (round 1): 3 stages for MT <= 4 lost 10..20 % (MT2 loses its
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
         for (int i = 0; i < AG; ++i)
             if ((MT & 1) == 0 || i * 8 + wave < NAG) dma16(asrc[i] + kt * TK, base + (i * 8 + wave) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * TK, base + A_BYTES + (wave * 4 + i) * 1024);
+        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * wstep, base + A_BYTES + (wave * 4 + i) * 1024);
     };
 
     const int fr = lane & 15, fq = lane >> 4;
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             const unsigned char* w = a + A_BYTES;
             if (g.ablate == 5 && kt + 1 < nkt) issue(st, kt + 1);      // DMA-only with twice the bytes in flight: latency- or bandwidth-bound?
             if (g.ablate == 2 || g.ablate == 5) continue;
-            nt256_kstep<MT>(a, w, wm, wn, fr, fq, acc);
+            nt256_kstep<MT, NN>(a, w, wm, wn, fr, fq, acc);
         }
         if (dyn && tid == 0) {
 #pragma unroll
@@ -222,7 +241,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
 // costs a full L2/MALL round trip (~1 us) whatever the MFMA work.  One tile per block, so the whole 160 KiB of LDS can hold
 // the ring: NS = 4 slots for MT = 2 (40 KiB each) - three K-steps in flight under counted vmcnt waits; the epilogue scratch
 // aliases the ring once the last step has been consumed.  (Written for any MT <= 5 / NS; only <MT 2, NS 4> is instantiated.)
-template <typename OutT, int EPI, int MT, int NS>
+template <typename OutT, int EPI, int MT, int NS, bool NN = false>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TM = 32 * MT, A_BYTES = TM * TK * 2, STAGE_BYTES = A_BYTES + TN * TK * 2, AG = (MT + 1) / 2, NAG = 4 * MT;
@@ -251,10 +270,22 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
         int am = m0 + (i * 8 + wave) * 8 + lrow; if (am > P.M - 1) am = P.M - 1;
         asrc[i] = A + (size_t)am * P.lda + lch_a * 8;
     }
+    size_t wstep = TK;
+    if constexpr (NN) {
+        wstep = (size_t)TK * P.ldb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > P.N - 1) wn_ = P.N - 1;
-        wsrc[i] = W + (size_t)wn_ * P.ldb + lch_w[i & 1] * 8;
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 2 + (lane >> 5);
+            int col = n0 + (((lane & 31) ^ (tn_f(row) << 1)) << 3);
+            if (col > P.ldb - 8) col = P.ldb - 8;
+            wsrc[i] = W + (size_t)row * P.ldb + col;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > P.N - 1) wn_ = P.N - 1;
+            wsrc[i] = W + (size_t)wn_ * P.ldb + lch_w[i & 1] * 8;
+        }
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int kt) {
@@ -263,7 +294,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
         for (int i = 0; i < AG; ++i)
             if (i * 8 + wave < NAG) dma16(asrc[i] + kt * TK, base + (i * 8 + wave) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * TK, base + A_BYTES + (wave * 4 + i) * 1024);
+        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * wstep, base + A_BYTES + (wave * 4 + i) * 1024);
     };
     // wait until at most `slots` of my slots (my_a + 4 DMA instructions each) are still in flight
     auto wait_keep = [&](int slots) {
@@ -294,7 +325,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
         if (kt + NS - 1 < nkt) issue(kt + NS - 1);      // refills slot (kt-1) % NS
         const unsigned char* a = lds + (kt % NS) * STAGE_BYTES;
         const unsigned char* w = a + A_BYTES;
-        nt256_kstep<MT>(a, w, wm, wn, fr, fq, acc);
+        nt256_kstep<MT, NN>(a, w, wm, wn, fr, fq, acc);
     }
     __syncthreads();   // the ring is dead: reuse it as the epilogue's transpose scratch
     nt256_epilogue<OutT, EPI, MT>(g, P, lds, wave, lane, m0, n0, wm, wn, acc, []() {});
@@ -355,12 +386,12 @@ bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
     return tiles >= min_tiles;
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, bool NN>
 static int launch256(GemmGroup& g, hipStream_t s) {
     constexpr int LDS_BYTES = NT256_LDS(MT);
     static bool attr_set = false;
     if (!attr_set) {
-        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<bf16_t, EPI, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<bf16_t, EPI, MT, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     gemm_group_finalize(g, 32 * MT, TN);
@@ -386,10 +417,10 @@ static int launch256(GemmGroup& g, hipStream_t s) {
             constexpr int LDS_D = NSD * (32 * MT * TK * 2 + TN * TK * 2);
             static bool attr_set_d = false;
             if (!attr_set_d) {
-                RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<bf16_t, EPI, MT, NSD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
+                RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<bf16_t, EPI, MT, NSD, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
                 attr_set_d = true;
             }
-            hipLaunchKernelGGL((gemm_nt256d_kernel<bf16_t, EPI, MT, NSD>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, g);
+            hipLaunchKernelGGL((gemm_nt256d_kernel<bf16_t, EPI, MT, NSD, NN>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, g);
             RGQA_LAUNCH_CHECK("gemm_nt256d_kernel");
             return RGQA_OK;
         }
@@ -400,25 +431,35 @@ static int launch256(GemmGroup& g, hipStream_t s) {
     if (grid == g.total_tiles) g.sched = nullptr;          // one tile per block anyway
     g.sched_static = grid;
     if (g.sched != nullptr && g_rgqa_nt_static_blocks > 0 && g_rgqa_nt_static_blocks < grid) g.sched_static = g_rgqa_nt_static_blocks;
-    hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI, MT>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI, MT, NN>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
     RGQA_LAUNCH_CHECK("gemm_nt256_kernel");
     return RGQA_OK;
 }
 
-template <int EPI>
+template <int EPI, bool NN = false>
 static int launch256_mt(GemmGroup& g, int mt, hipStream_t s) {
     switch (mt) {
-        case 8: return launch256<EPI, 8>(g, s);
-        case 7: return launch256<EPI, 7>(g, s);
-        case 6: return launch256<EPI, 6>(g, s);
-        case 5: return launch256<EPI, 5>(g, s);
-        case 4: return launch256<EPI, 4>(g, s);
-        default: return launch256<EPI, 2>(g, s);
+        case 8: return launch256<EPI, 8, NN>(g, s);
+        case 7: return launch256<EPI, 7, NN>(g, s);
+        case 6: return launch256<EPI, 6, NN>(g, s);
+        case 5: return launch256<EPI, 5, NN>(g, s);
+        case 4: return launch256<EPI, 4, NN>(g, s);
+        default: return launch256<EPI, 2, NN>(g, s);
     }
 }
 
 int g_rgqa_force_mt = 0;
 static int launch256_epi(GemmGroup& g, int mt, hipStream_t s) {
+    if (g.b_kn) {       // B operand stored [K, N] (dgrad on the weight as it is): the epilogues a dgrad uses
+        switch (g.p[0].epi) {
+            case EPI_BIAS: return launch256_mt<EPI_BIAS, true>(g, mt, s);
+            case EPI_DGELU: return launch256_mt<EPI_DGELU, true>(g, mt, s);
+            case EPI_ADD: return launch256_mt<EPI_ADD, true>(g, mt, s);
+            case EPI_DTANH: return launch256_mt<EPI_DTANH, true>(g, mt, s);
+            case EPI_DRELU_DROP: return launch256_mt<EPI_DRELU_DROP, true>(g, mt, s);
+            default: rgqa_set_error("gemm: no [K,N]-operand kernel for epilogue %d", g.p[0].epi); return RGQA_ERR_ARG;
+        }
+    }
     switch (g.p[0].epi) {
         case EPI_BIAS: return launch256_mt<EPI_BIAS>(g, mt, s);
         case EPI_GELU: return launch256_mt<EPI_GELU>(g, mt, s);
@@ -513,7 +554,7 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
     // bench.py, profiles/r02_*): 256- and 224-row tiles tie (+-1 %, +4 % for the DGELU dgrad), 192-row tiles gain 2-6 %, and the
     // single-round 160-row launches lose 12 % to the deep-ring kernel, which has 104 KiB in flight.  Default (RGQA_NT8P=1): 192-row
     // tiles only; 2 = every launch of 160..256-row tiles (what a cold / large-K caller wants); 0 = never.
-    if (mt >= 5 && gemm_nt8p_eligible(g) && (g_rgqa_nt8p >= 2 || mt == 6)) return launch_gemm_nt8p_bf16(g, mt, s);
+    if (mt >= 5 && !g.b_kn && gemm_nt8p_eligible(g) && (g_rgqa_nt8p >= 2 || mt == 6)) return launch_gemm_nt8p_bf16(g, mt, s);
     return launch256_epi(g, mt, s);
 }
 
@@ -527,25 +568,6 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
 // dispatcher balances the unequal (lang / visn / shared) problems of one launch over the 256 CUs.
 #define WM 128
 #define WN 256
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
-
-__device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
-
-template <int PITCH>
-__device__ __forceinline__ bf16x8 tr_frag_dma(const unsigned char* tile, int r0, int c0, int lane) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const int row = r0 + 8 * g + q;
-    const int ch = (c0 >> 3) + (p >> 1);
-    const int sw = tn_f(row) << 1;      // identical for row and row + 4
-    const unsigned char* a1 = tile + row * PITCH + ((ch ^ sw) << 4) + 8 * (p & 1);
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(a1));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(a1 + 4 * PITCH));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-
 // MTW = 16-row m-tiles per wave (2 waves along M): output tile WMV = 32*MTW rows x 256 columns.
 //   MTW = 4: 128 x 256, 3-slot ring (48 KiB per K-step per CU);  MTW = 8: 256 x 256, 2 slots of 64 KiB: twice the MFMAs per
 //   DMA byte.  The loop is bound by what the LDS-DMA path delivers per CU (~50 GB/s), not by the MFMAs, so the taller tile

@@ -392,6 +392,40 @@ def test_ticket_scheduled_gemm_tiles_are_bit_identical():
         assert torch.equal(g, g0), n
 
 
+@pytest.mark.parametrize("cfgname,B", [("MED", 6), ("FULL", 128)])
+def test_dgrad_from_stored_weight_is_bit_identical(cfgname, B):
+    """rgqa_debug_set key 14 = 1: the input-gradient GEMMs read the weight as stored, [out, in] (contraction rows staged as a row-major
+    LDS image, fragments by transposed LDS reads) instead of the transposed bf16 copy: the same operand values in the same MFMA order, so
+    every gradient is bit-identical - hidden size 128 (small tiles, deep-ring kernel) and the full architecture at B = 128 (persistent
+    kernel, more tiles than CUs), packed and padded rows."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    cfgd = MED if cfgname == "MED" else FULL
+    T, O = (12, 7) if cfgname == "MED" else (20, 36)
+    raw = synth.synth_batch(B, T, O=O, F=cfgd["feat_dim"], NA=cfgd["num_answers"], vocab=cfgd["vocab_size"], seed=19, min_len=2)
+    b = dev(raw)
+    lens = raw["lengths"].astype(np.int32)
+    e = make_engine(cfgd, "bf16", dropout=0.1)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
+
+    def grads(nn, packed):
+        assert L.rgqa_debug_set(14, nn) == 0
+        try:
+            e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=47, lengths=lens if packed else None)
+            e.loss_backward(b["target"])
+            torch.cuda.synchronize()
+            return e.grads[first:].clone()
+        finally:
+            L.rgqa_debug_set(14, -1)
+
+    for packed in (True, False):
+        ref = grads(0, packed)
+        assert float(ref.abs().max()) > 0
+        assert torch.equal(grads(1, packed), ref), packed
+
+
 def test_merged_layernorm_matches_per_modality(monkeypatch):
     """Stages where both modalities run their own module share one LayerNorm launch (forward and backward) over the
     adjacent [language | vision] rows; RGQA_LN_MERGE=0 keeps one launch per modality. Same arithmetic per row and the same

@@ -178,6 +178,28 @@ def test_matmul_tn_exact_integers(lib, M, N, K):
     assert torch.equal(Cc, A.float().t() @ Bm.float())
 
 
+@pytest.mark.parametrize("M,N,K", [(6, 128, 256), (70, 128, 384), (300, 768, 768), (3140, 768, 3072), (9216, 3072, 768), (12356, 768, 2304), (5000, 1536, 1536), (257, 520, 128)])
+def test_matmul_nn_exact_integers_and_vs_nt(lib, M, N, K):
+    """C = A[M,K] B[K,N] with B stored [K,N] (the dgrad GEMM on the stored weight): exact on small integers, and bit-identical to the NT kernels
+    fed the transposed copy of B (same operand values, same MFMA order) on random data - every tile height the launcher picks for these shapes."""
+    A = ((torch.arange(M * K).reshape(M, K) * 5 + 1) % 7 - 3).float().cuda().bfloat16()
+    Bm = ((torch.arange(K * N).reshape(K, N) * 3 + 2) % 5 - 2).float().cuda().bfloat16()
+    Cc = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ck(lib.rgqa_op_matmul_nn(P(A), P(Bm), None, P(Cc), M, N, K, K, N, N, 0, 0, S()))
+    ref = (A.float() @ Bm.float()).bfloat16()
+    assert torch.equal(Cc, ref)
+    A = rnd(M, K, seed=14).bfloat16()
+    Bm = rnd(K, N, seed=15).bfloat16()
+    aux = rnd(M, N, seed=16).bfloat16()
+    for epi in (0, 5):
+        c_nn = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        c_nt = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        ck(lib.rgqa_op_matmul_nn(P(A), P(Bm), P(aux) if epi else None, P(c_nn), M, N, K, K, N, N, N, epi, S()))
+        Bt = Bm.t().contiguous()
+        ck(lib.rgqa_op_linear_ex(P(A), P(Bt), None, P(aux) if epi else None, P(c_nt), None, M, N, K, K, K, N, N, epi, 0.0, S()))
+        assert torch.equal(c_nn, c_nt), epi
+
+
 def test_matmul_tn_f32(lib):
     M, N, K = 70, 52, 33
     A, Bm = rnd(K, M, seed=1), rnd(K, N, seed=2)
