@@ -54,7 +54,9 @@ int rgqa_version(void);
  * key 12: persistent forward / dgrad GEMMs draw their tiles by ticket: 0 = fixed walk, N = yes with the first N blocks on a fixed first tile, -1 = env RGQA_NT_TICKETS;
  * key 13: N > 0 confines the optimizer / transposed-copy kernels launched next to N CUs (one 1024-thread block each), 0 = whole chip;
  * key 14: 1 = dgrad GEMMs read the weight as stored ([K,N] operand form), 0 = its transposed bf16 copy, -1 = env RGQA_DGRAD_NN (an engine created with
- * RGQA_DGRAD_NN=1 writes no transposed copy for modules whose dgrads all qualify and keeps the [K,N] form for them) */
+ * RGQA_DGRAD_NN=1 writes no transposed copy for modules whose dgrads all qualify and keeps the [K,N] form for them);
+ * key 15: 1 = the attention backward kernel that recomputes the probabilities in its key-major pass, 0 (default) = the one that parks dS / dropout(P)
+ * in LDS, -1 = env RGQA_ATTN_BWD_TWO_PASS) */
 int rgqa_debug_set(int key, int value);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over

@@ -24,13 +24,14 @@ __device__ __forceinline__ bf16x8 ldfrag(const bf16_t* base, int row, int nrows,
     return *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + s * 32 + g * 8);
 }
 // transposed fragment: element jj = tile[ (jj<4 ? r0a : r0b) + 4*g + (jj&3) ][ c0 + (lane&15) ]
+template <int PITCH = ROWB>
 __device__ __forceinline__ bf16x8 trfrag(const unsigned char* tile, int r0a, int r0b, bool has_b, int c0, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const unsigned char* a1 = tile + (r0a + 4 * g + q) * ROWB + (c0 + 4 * p) * 2;
+    const unsigned char* a1 = tile + (r0a + 4 * g + q) * PITCH + (c0 + 4 * p) * 2;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
     bf16x4 hi = {0, 0, 0, 0};
     if (has_b) {
-        const unsigned char* a2 = tile + (r0b + 4 * g + q) * ROWB + (c0 + 4 * p) * 2;
+        const unsigned char* a2 = tile + (r0b + 4 * g + q) * PITCH + (c0 + 4 * p) * 2;
         hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a2);
     }
     bf16x8 r;
@@ -328,6 +329,182 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     }
 }
 
+// ============================================================================ backward, probabilities computed once
+// Same products, but the key-major pass no longer recomputes S, the softmax, the dropout draws and dP: the query-major pass parks
+// dS[q][key] and Pd[q][key] (bf16, exactly the values it feeds its own dQ MFMAs / the values the key-major pass would recompute) in two
+// row-major LDS images, and the key-major pass fetches them as MFMA B operands with the transposed reads it already uses for Q^T and
+// dO^T.  The kernel is instruction-issue bound (SQ_ACTIVE_INST_ANY 0.36 per wave at two waves per SIMD): the key-major pass shrinks
+// from ~2200 to ~800 instructions.  dS takes the K image's place once every dQ is done (held packed in registers until then); the Pd
+// image is the only new LDS (pitch NKT * 32 + 16 bytes).
+template <int NQT, int NKT>
+__global__ __launch_bounds__(64) void attn_bwd1_mfma_kernel(const AttnArgs a) {
+    constexpr int P2 = NKT * 32 + 16;                  // pitch of the [query][key] images
+    constexpr int KS_BYTES = NKT * 16 * ROWB > NQT * 16 * P2 ? NKT * 16 * ROWB : NQT * 16 * P2;
+    __shared__ __attribute__((aligned(16))) unsigned char ks_[KS_BYTES];     // K image; after the query-major pass: dS[q][key]
+    __shared__ __attribute__((aligned(16))) unsigned char qs_[NQT * 16 * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char os_[NQT * 16 * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char pd_[NQT * 16 * P2];  // Pd[q][key] = dropout(P)
+    const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    ATTN_SAMPLE_ROWS(a, b)
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + q0 * a.ldq + h * 64;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + k0 * a.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + k0 * a.ldv + h * 64;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + q0 * a.lddo + h * 64;
+    const float* lse = a.lse + ((size_t)b * a.nh + h) * a.Lq;
+    // ONE global-load phase: every operand fragment (both passes use the same 16-B-per-lane row pieces), the log-sum-exp and
+    // the key mask are requested back to back; the three LDS images the transposed reads need are then written from those
+    // registers.  (The first version re-read K/Q/dO from global for the images and again per pass: ~6 dependent L2/HBM
+    // round trips on a 1-wave block.)
+    bf16x8 kf[NKT][2], vf[NKT][2], qf[NQT][2], of[NQT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { kf[kt][s] = ldfrag(K, kt * 16 + fr, Lk, a.ldk, s, g); vf[kt][s] = ldfrag(V, kt * 16 + fr, Lk, a.ldv, s, g); }
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { qf[qt][s] = ldfrag(Q, qt * 16 + fr, Lq, a.ldq, s, g); of[qt][s] = ldfrag(dO, qt * 16 + fr, Lq, a.lddo, s, g); }
+    float lse_t[NQT], mk[NKT][4];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        lse_t[qt] = qt * 16 + fr < Lq ? lse[qt * 16 + fr] : 0.f;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(ks_ + (kt * 16 + fr) * ROWB + s * 64 + g * 16) = kf[kt][s];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            *reinterpret_cast<bf16x8*>(qs_ + (qt * 16 + fr) * ROWB + s * 64 + g * 16) = qf[qt][s];
+            *reinterpret_cast<bf16x8*>(os_ + (qt * 16 + fr) * ROWB + s * 64 + g * 16) = of[qt][s];
+        }
+    __syncthreads();
+    DropCfg dc = a.drop; dc.seed_hi ^= a.drop_site;
+    const uint32_t idx0 = (uint32_t)((b * a.nh + h) * a.Lq) * (uint32_t)a.Lk;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NKS = (NKT + 1) / 2, NQS = (NQT + 1) / 2;
+
+    // ---------------- pass T: lane = query, registers = keys  ->  dQ; Pd -> pd_, dS held packed
+    bf16x4 dsh[NQT][NKT];
+    {
+        bf16_t* dQ = reinterpret_cast<bf16_t*>(a.dq) + q0 * a.lddq + h * 64;
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            const int q = qt * 16 + fr;
+            const bf16x8 qf0 = qf[qt][0], qf1 = qf[qt][1];
+            const bf16x8 of0 = of[qt][0], of1 = of[qt][1];
+            const float lq = lse_t[qt];
+            f32x4 pp[NKT], dpp[NKT];
+            float delta = 0.f;
+            unsigned char* pdrow = pd_ + q * P2 + 8 * g;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
+                s4 = MFMA(kf[kt][0], qf0, s4); s4 = MFMA(kf[kt][1], qf1, s4);
+                dp4 = MFMA(vf[kt][0], of0, dp4); dp4 = MFMA(vf[kt][1], of1, dp4);
+                float keep4[4] = {1.f, 1.f, 1.f, 1.f};
+                {
+                    const uint32_t idx = idx0 + (uint32_t)(q * a.Lk + kt * 16 + 4 * g);
+                    if ((a.Lk & 1) == 0) drop_apply_vec<4>(dc, idx, keep4);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) keep4[r] = drop_apply(dc, idx + (uint32_t)r, 1.0f);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = q < Lq ? __expf(s4[r] * a.scale + mk[kt][r] - lq) : 0.f;
+                    const float keep = keep4[r];
+                    const float dp = dp4[r] * keep;
+                    delta += p * dp;
+                    s4[r] = p; dp4[r] = dp;
+                    keep4[r] = p * keep;               // Pd
+                }
+                pp[kt] = s4; dpp[kt] = dp4;
+                {
+                    bf16x4 pk;
+                    pk[0] = (bf16_t)keep4[0]; pk[1] = (bf16_t)keep4[1]; pk[2] = (bf16_t)keep4[2]; pk[3] = (bf16_t)keep4[3];
+                    *reinterpret_cast<bf16x4*>(pdrow + kt * 32) = pk;      // keys kt*16 + 4g .. +3 of query row q
+                }
+            }
+            delta += __shfl_xor(delta, 16, 64);
+            delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pp[kt][r] = pp[kt][r] * (dpp[kt][r] - delta) * a.scale;   // dS^T
+                dsh[qt][kt][0] = (bf16_t)pp[kt][0]; dsh[qt][kt][1] = (bf16_t)pp[kt][1]; dsh[qt][kt][2] = (bf16_t)pp[kt][2]; dsh[qt][kt][3] = (bf16_t)pp[kt][3];
+            }
+            // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const bf16x8 ka = trfrag(ks_, 2 * ks * 16, (2 * ks + 1) * 16, 2 * ks + 1 < NKT, dt * 16, lane);
+                    const bf16x8 db = pack8(pp[2 * ks], (2 * ks + 1 < NKT) ? pp[(2 * ks + 1 < NKT) ? 2 * ks + 1 : 0] : zero4);
+                    o = MFMA(ka, db, o);
+                }
+                if (q < Lq) {
+                    float v[4] = {o[0], o[1], o[2], o[3]};
+                    store4(dQ + (size_t)q * a.lddq + dt * 16 + 4 * g, v);
+                }
+            }
+        }
+    }
+    __syncthreads();   // every dQ product has read the K image
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) *reinterpret_cast<bf16x4*>(ks_ + (qt * 16 + fr) * P2 + kt * 32 + 8 * g) = dsh[qt][kt];
+    __syncthreads();
+    // ---------------- pass N: lane = key  ->  dK, dV from the parked dS / Pd
+    {
+        bf16_t* dK = reinterpret_cast<bf16_t*>(a.dk) + k0 * a.lddk + h * 64;
+        bf16_t* dV = reinterpret_cast<bf16_t*>(a.dv) + k0 * a.lddv + h * 64;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const int key = kt * 16 + fr;
+            bf16x8 dsb[NQS], pdb[NQS];
+#pragma unroll
+            for (int qs = 0; qs < NQS; ++qs) {
+                const bool two = 2 * qs + 1 < NQT;
+                dsb[qs] = trfrag<P2>(ks_, 2 * qs * 16, (2 * qs + 1) * 16, two, kt * 16, lane);     // element jj = dS[q(jj)][key]
+                pdb[qs] = trfrag<P2>(pd_, 2 * qs * 16, (2 * qs + 1) * 16, two, kt * 16, lane);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 ok = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int qs = 0; qs < NQS; ++qs) {
+                    const bool two = 2 * qs + 1 < NQT;
+                    const bf16x8 qa = trfrag(qs_, 2 * qs * 16, (2 * qs + 1) * 16, two, dt * 16, lane);
+                    const bf16x8 oa = trfrag(os_, 2 * qs * 16, (2 * qs + 1) * 16, two, dt * 16, lane);
+                    ok = MFMA(qa, dsb[qs], ok);   // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+                    ov = MFMA(oa, pdb[qs], ov);   // dV^T[d][key] = sum_q dO^T[d][q] Pd[q][key]
+                }
+                if (key < Lk) {
+                    float v1[4] = {ok[0], ok[1], ok[2], ok[3]}, v2[4] = {ov[0], ov[1], ov[2], ov[3]};
+                    store4(dK + (size_t)key * a.lddk + dt * 16 + 4 * g, v1);
+                    store4(dV + (size_t)key * a.lddv + dt * 16 + 4 * g, v2);
+                }
+            }
+        }
+    }
+}
+
+int g_rgqa_attn_bwd_two_pass = -1;   // rgqa_debug_set key 15: 1 = attn_bwd_mfma_kernel (probabilities recomputed in the key-major pass), 0 = attn_bwd1_mfma_kernel, -1 = env RGQA_ATTN_BWD_TWO_PASS
 // ============================================================================ host side
 static int mfma_check(const AttnArgs& a, bool bwd) {
     RGQA_REQUIRE(a.dh == 64, "mfma attention: head size must be 64 (got %d)", a.dh);
@@ -378,7 +555,9 @@ int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s) {
     if (r) return r;
     const int nqt = cdiv(a.Lq, 16), nkt = cdiv(a.Lk, 16);
     dim3 grid(a.B * a.nh);
-    DISPATCH_TILES(attn_bwd_mfma_kernel, nqt, nkt)
+    static const bool env2 = getenv("RGQA_ATTN_BWD_TWO_PASS") != nullptr;       // the kernel that recomputes the probabilities in the key-major pass
+    if (g_rgqa_attn_bwd_two_pass < 0 ? env2 : g_rgqa_attn_bwd_two_pass != 0) { DISPATCH_TILES(attn_bwd_mfma_kernel, nqt, nkt) }
+    else { DISPATCH_TILES(attn_bwd1_mfma_kernel, nqt, nkt) }
     RGQA_LAUNCH_CHECK("attn_bwd_mfma_kernel");
     return RGQA_OK;
 }

@@ -28,6 +28,7 @@ extern int g_rgqa_wgrad_phase;
 extern int g_rgqa_nt_tickets;
 extern int g_rgqa_narrow_cus;
 extern int g_rgqa_dgrad_nn;
+extern int g_rgqa_attn_bwd_two_pass;
 // debug / A-B knobs: key 0 = force the 128x128 GEMM kernel; key 1 = force the LDS-DMA kernel's MT (0 = auto)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -45,6 +46,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 12) { g_rgqa_nt_tickets = value; return RGQA_OK; }
     if (key == 13) { g_rgqa_narrow_cus = value; return RGQA_OK; }
     if (key == 14) { g_rgqa_dgrad_nn = value; return RGQA_OK; }
+    if (key == 15) { g_rgqa_attn_bwd_two_pass = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }

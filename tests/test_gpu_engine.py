@@ -825,8 +825,12 @@ def test_training_converges_bf16_like_f32():
             e.adam_step(2e-3 * (x / 0.1 if x < 0.1 else max((x - 1.0) / (0.1 - 1.0), 0.0)), max_norm=5.0)
         assert all(np.isfinite(losses)), precision
         curves[precision] = losses
-        assert np.mean(losses[-5:]) < np.mean(losses[:3]) / 3.0, (precision, losses[:3], losses[-5:])
-    f, h = np.mean(curves["f32"][-10:]), np.mean(curves["bf16"][-10:])
+        # medians: once the toy model has memorised the batch, an occasional dropout mask (hidden + attention dropout together) sends the
+        # train-mode loss of ONE step from 3.6 to 70..140 and back - a property of that mask on those weights, reproduced exactly by the
+        # f32 engine from the same weights and seed in both layouts and absent in eval mode (measured in round 2); which step it
+        # hits depends on the last bits of the trajectory, so a mean over the final steps is not a stable statistic
+        assert np.median(losses[-9:]) < np.median(losses[:3]) / 3.0, (precision, losses[:3], losses[-9:])
+    f, h = np.median(curves["f32"][-11:]), np.median(curves["bf16"][-11:])
     assert abs(f - h) < 0.35 * max(f, h), (f, h)
 
 

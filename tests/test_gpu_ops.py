@@ -269,6 +269,34 @@ def test_attention_fwd_bwd(lib, dtype, impl, B, nh, L, dh):
         np.testing.assert_allclose(dqkv.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,nh,L", [(2, 12, 36), (4, 12, 20), (2, 12, 30), (1, 2, 64), (3, 12, 7)])
+def test_attention_bwd_single_pass_matches_two_pass(lib, B, nh, L):
+    """attn_bwd1_mfma_kernel (default: dS and dropout(P) parked in LDS by the query-major pass and fetched by the key-major pass) against
+    attn_bwd_mfma_kernel (rgqa_debug_set key 15 = 1: the key-major pass recomputes them): the same products on the same bf16 operand values
+    up to how the compiler contracts the softmax arithmetic in the two kernels and how the two MFMA orientations round a score, so the bound
+    is a bf16 ulp of an operand's effect - the observed differences are printed (pytest -s)."""
+    dh = 64
+    H = nh * dh
+    qkv = rnd(B * L, 3 * H, seed=17).bfloat16()
+    lens = torch.tensor([max(1, L - 3 * i) for i in range(B)])
+    mask = ((torch.arange(L)[None, :] >= lens[:, None]).float() * -10000.0).cuda()
+    dout = rnd(B * L, H, seed=18).bfloat16()
+    out = torch.empty(B * L, H, dtype=torch.bfloat16, device="cuda"); lse = torch.empty(B, nh, L, device="cuda")
+    ck(lib.rgqa_op_attention(P(qkv), P(mask), P(out), P(lse), B, nh, L, dh, 1, 1, S()))
+    res = []
+    try:
+        for two_pass in (1, 0):
+            assert lib.rgqa_debug_set(15, two_pass) == 0
+            dqkv = torch.zeros_like(qkv)
+            ck(lib.rgqa_op_attention_bwd(P(qkv), P(mask), P(lse), P(dout), P(dqkv), B, nh, L, dh, 1, 1, S()))
+            res.append(dqkv.float().view(B * L, 3, H))
+    finally:
+        lib.rgqa_debug_set(15, -1)
+    ds = [float((res[0][:, i] - res[1][:, i]).abs().max()) / float(res[0][:, i].abs().max()) for i in range(3)]
+    print("attn bwd single-pass vs two-pass B=%d nh=%d L=%d: max |d| / max |ref|  dQ %.2e dK %.2e dV %.2e" % (B, nh, L, ds[0], ds[1], ds[2]))
+    assert max(ds) < 8e-3, ds
+
+
 def test_bce(lib):
     B, NA = 5, 1842
     z, t = rnd(B, NA, seed=1, scale=2.0), (rnd(B, NA, seed=2) > 1.5).float()
