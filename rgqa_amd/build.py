@@ -14,6 +14,10 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "lib", "librgqa_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + os.environ.get("RGQA_EXTRA_HIPCC_FLAGS", "").split()
+# Per-file additions.  attn_mfma.hip: MFMA results straight into VGPRs - hipcc otherwise parks the small accumulators of these one-wave kernels in
+# AGPRs and copies every one out with v_accvgpr_read (216 of 3197 instructions in attn_bwd1<3,3>, a kernel at the instruction-issue limit);
+# with the flag that kernel also fits three waves per SIMD (164 registers instead of 158 + 16).
+PER_FILE_FLAGS = {"attn_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _newest_header():
@@ -26,7 +30,7 @@ def _compile(src, force):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= _newest_header()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -40,6 +44,7 @@ def source_digest():
     for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
