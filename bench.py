@@ -104,6 +104,19 @@ def cpu_baseline(T, sample_b, iters, warm=2, extra=True):
     return out
 
 
+_JSON_FD = None
+
+
+def emit_json(obj):
+    """the one stdout line of a run (see main(): fd 1 itself is routed to stderr while the ranks run)"""
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_JSON_FD, line)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this parent - which never touches the GPU, so nothing
     that has initialised HIP is ever exec'd or forked - starts N fresh rank processes of this same command line with
@@ -161,7 +174,7 @@ def launch_check(world, rank, fail_rank):
     else:
         seen = 1
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "n_ranks_seen": seen, "sum": float(t.item())}), flush=True)
+        emit_json({"launch_check": True, "n_gpus": world, "n_ranks_seen": seen, "sum": float(t.item())})
     if world > 1:
         dist.destroy_process_group()
 
@@ -195,6 +208,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries the ONE JSON line and nothing else: native libraries (gloo / RCCL rendezvous banners, HIP runtime notes) write to
+    # file descriptor 1 behind Python's back, so every rank sends fd 1 to stderr now and rank 0 emits its line through the saved descriptor
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.launch_check:
@@ -413,7 +432,7 @@ def main():
                     tf = xb["flops"] / (xb["ms"] * 1e-3) / 1e12
                     out["cross_attention_block"] = {"ms_per_step": round(xb["ms"] / args.profile_steps, 3), "gflop_per_step": round(xb["flops"] / args.profile_steps / 1e9, 1),
                                                     "achieved": round(tf, 1), "unit": "TFLOP/s", "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
-        print(json.dumps(out), flush=True)
+        emit_json(out)
     if dist is not None:
         dist.destroy_process_group()
 
