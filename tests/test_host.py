@@ -350,6 +350,16 @@ def test_bench_launches_its_own_ranks_when_no_launcher_is_present():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_ticket_atomic_result_is_not_touched_before_the_wait():
+    """The persistent NT GEMM requests its next tile ticket with an inline-asm atomic whose result hipcc believes valid at once; the kernel
+    reads it only after the K loop's first `s_waitcnt vmcnt(0)`.  tools/check_ticket_isa.py compiles the file to gfx950 assembly and checks
+    every instantiation: no instruction may read or write the result register between the atomic and that wait."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_ticket_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 violations" in r.stdout and not r.stdout.startswith("0 ticket")
+
+
 def test_synth_batch_contract():
     from rgqa_amd import synth
     b = synth.synth_batch(8, 20, seed=1)
