@@ -143,6 +143,11 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 }
 
 // ============================================================================ engine
+// Gradient-buffer sets of the deferred wgrad launches: launch period k uses set k % wgrad_sets().  Two sets let the main stream run ONE period
+// ahead of the side stream; behind the cross-modality layers the four language-only layers have short chains, and the main stream then
+// sat 0.17 ms per step waiting for the set of two periods ago (profiles/r02_timeline_b256.txt); with four it runs on and the side stream
+// catches up beside the longer chains of the paired layers that follow.
+#define NPAR 4
 #define SCHED_SLOTS 1024
 #define LNPART_BLOCKS 1536     // per layer: <= 3 LayerNorm-backward launches of <= 512 blocks
 int g_rgqa_ln_defer = -1;      // rgqa_debug_set key 10: 0 = every LayerNorm backward finalises its column sums at once on the main stream; 1 / -1 = once per layer, with the layer's wgrad launch
@@ -176,16 +181,16 @@ public:
     T *pooled = nullptr, *h1pre = nullptr, *h1 = nullptr, *h2 = nullptr; float *hd_mean = nullptr, *hd_rstd = nullptr;
     float* logits = nullptr; T* dlogits = nullptr; float* loss_dev = nullptr;
     T *gA = nullptr, *gB = nullptr, *gctx = nullptr;
-    T *gz_s[2][3] = {}, *gzd_s[2][3] = {}, *gqkv_s[2][3] = {}, *gh_s[2][3] = {};   // [layer parity][stage slot]
+    T *gz_s[NPAR][3] = {}, *gzd_s[NPAR][3] = {}, *gqkv_s[NPAR][3] = {}, *gh_s[NPAR][3] = {};   // [ring position of the launch period][stage slot]
     hipStream_t s_v = nullptr; hipEvent_t ev_v[2] = {nullptr, nullptr};   // vision chain of the single-modality layers (forward, experiment)
     hipStream_t s_w = nullptr;                 // side stream: the deferred weight-gradient GEMMs of a layer run beside the next layer's chain
-    hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_wdone[2] = {nullptr, nullptr};
-    bool wdone_valid[2] = {false, false};
+    hipEvent_t ev_chain[NPAR] = {}, ev_wdone[NPAR] = {};
+    bool wdone_valid[NPAR] = {};
     T* gemb = nullptr;
     T *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
     bool ln_merge = !(getenv("RGQA_LN_MERGE") && getenv("RGQA_LN_MERGE")[0] == '0');   // one LayerNorm launch over [language | vision] rows
     float* wpart = nullptr; size_t wpart_elems = 0;
-    float* lnpart_s[2] = {nullptr, nullptr}; FinDefer fin; int fin_accumulate = 0;   // LayerNorm-backward column sums of the open layer (finalised with its wgrad launch)
+    float* lnpart_s[NPAR] = {}; FinDefer fin; int fin_accumulate = 0;   // LayerNorm-backward column sums of the open layer (finalised with its wgrad launch)
     int* sched_pool = nullptr; int sched_cursor = 0;       // one zeroed ticket word per persistent GEMM launch of a step (SCHED_SLOTS, 64 B apart)
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
     void* lang_final = nullptr;
@@ -244,7 +249,7 @@ public:
         }
         if (s_w == nullptr) {
             RGQA_HIP(hipStreamCreateWithFlags(&s_w, hipStreamNonBlocking));
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NPAR; ++i) {
                 RGQA_HIP(hipEventCreateWithFlags(&ev_chain[i], hipEventDisableTiming));
                 RGQA_HIP(hipEventCreateWithFlags(&ev_wdone[i], hipEventDisableTiming));
             }
@@ -257,6 +262,21 @@ public:
         if (layer_done) if (int r = mark_segment(s_w)) return r;
         RGQA_HIP(hipEventRecord(ev_wdone[par], s_w));
         wdone_valid[par] = true;
+        return RGQA_OK;
+    }
+    static int wgrad_sets() {
+        static const int n = []() { const char* e = getenv("RGQA_WGRAD_SETS"); int v = e ? atoi(e) : NPAR; return v < 2 ? 2 : (v > NPAR ? NPAR : v); }();
+        return n;
+    }
+    // every launch on the side stream has joined `s` (the side stream is in order: the newest event covers the older ones); `next` = the set the
+    // next period would use
+    int join_wgrad(int next, hipStream_t s) {
+        const int n = wgrad_sets();
+        for (int k = 1; k <= n; ++k) {
+            const int p = (next + n - k) % n;          // newest first
+            if (wdone_valid[p]) { RGQA_HIP(hipStreamWaitEvent(s, ev_wdone[p], 0)); break; }
+        }
+        for (int p = 0; p < NPAR; ++p) wdone_valid[p] = false;
         return RGQA_OK;
     }
     // the main stream must not overwrite a gradient-buffer set while an older wgrad launch still reads it
@@ -410,7 +430,7 @@ public:
         // deferred into ONE grouped launch (432-504 tiles: fills the 256 CUs), so their operands must outlive the stage
         // ... and two such sets (layer parity): layer i's wgrad launch reads its set on the side stream while layer i-1
         // already overwrites the other one on the main stream
-        for (int par = 0; par < 2; ++par)
+        for (int par = 0; par < NPAR; ++par)
             for (int k = 0; k < 3; ++k) {
                 gz_s[par][k] = take<T>((size_t)RC * H); gzd_s[par][k] = take<T>((size_t)RC * H);
                 gqkv_s[par][k] = take<T>((size_t)RC * 3 * H); gh_s[par][k] = take<T>((size_t)RC * I);
@@ -418,7 +438,7 @@ public:
         gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
-        for (int par = 0; par < 2; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
+        for (int par = 0; par < NPAR; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
         sched_pool = take<int>((size_t)SCHED_SLOTS * 16);
         sumsq_ws_segs = (int)grad_segs.size(); sumsq_ws = take<float>((size_t)sumsq_ws_segs * 1024);
         if (joint) {
@@ -1006,7 +1026,7 @@ public:
         auto flush_after = [&](const Stage& st) { return phase_ffn ? st.kind == ST_FFN : st.layer_first != 0; };
         auto flush_layer = [&](hipStream_t ss) -> int {
             int r = flush_wgrad(wg, par, ss, !phase_ffn || flushes > 0);
-            ++flushes; par ^= 1; layer_open = false;
+            ++flushes; par = (par + 1) % wgrad_sets(); layer_open = false;
             return r;
         };
         for (int si = (int)stages.size() - 1; si >= 0; --si) {
@@ -1167,11 +1187,11 @@ public:
         // running on the side stream, overlap the embedding backward; they are joined at the end.
         static const bool late_join = !(getenv("RGQA_WGRAD_LATE_JOIN") && getenv("RGQA_WGRAD_LATE_JOIN")[0] == '0');
         CK(wait_wgrad(par, s));
-        if (!late_join) CK(wait_wgrad(par ^ 1, s));
+        if (!late_join) CK(join_wgrad(par, s));
         prof_block = PB_EMBED;
         if (joint) {
             CK(backward_joint_embeddings(dyp[0], accumulate, s));
-            CK(wait_wgrad(par ^ 1, s));
+            CK(join_wgrad(par, s));
             CK(mark_segment(s));
             return RGQA_OK;
         }
@@ -1226,7 +1246,7 @@ public:
                 CK(r);
             }
         }
-        CK(wait_wgrad(par ^ 1, s));      // everything on the side stream has joined the caller's stream before backward returns
+        CK(join_wgrad(par, s));      // everything on the side stream has joined the caller's stream before backward returns
         CK(mark_segment(s));     // embeddings + visual embedding
         return RGQA_OK;
     }
