@@ -63,31 +63,6 @@ __device__ __forceinline__ void adam_tail(const AdamArgs& a, float coef, size_t 
     }
 }
 
-__global__ __launch_bounds__(256) void bertadam_kernel(const AdamArgs a) {
-    // clip coefficient exactly as torch's clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied when < 1
-    float coef = a.grad_prescale;
-    if (a.sumsq) {
-        const float norm = sqrtf(*a.sumsq) * a.grad_prescale;
-        const float c = a.max_norm / (norm + 1e-6f);
-        if (c < 1.f) coef *= c;
-    }
-    const size_t nv = a.n >> 2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
-        float p[4], g[4], m[4], v[4];
-        load4(a.p + i * 4, p); load4(a.g + i * 4, g); load4(a.m + i * 4, m); load4(a.v + i * 4, v);
-        adam_update4(a, coef, p, g, m, v);
-        store4(a.p + i * 4, p); store4(a.m + i * 4, m); store4(a.v + i * 4, v);
-        if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + i * 4, p);
-    }
-    adam_tail(a, coef, nv);
-}
-
-// The same update confined to gridDim.x CUs: 1024-thread blocks that each claim more than half of a CU's LDS (so two never share a
-// CU), two groups of four 16-byte loads in flight per lane.  Used when the update runs on a side stream BESIDE the next forward
-// pass (Engine.adam_step(pipeline="background")): the persistent GEMM blocks of that pass need whole CUs (all registers, 128 KiB of
-// LDS) - an update spread over every CU starves them until it has drained, one that owns a quarter of the chip leaves them the rest.
-#define NARROW_THREADS 1024
-#define NARROW_LDS (84 * 1024)
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 // NT: non-temporal accesses (streamed once: keep the 6 GB of optimizer state out of the caches the forward pass beside it lives in)
@@ -99,6 +74,35 @@ template <bool NT> __device__ __forceinline__ void st4(float* p, const float v[4
     const f32x4v t = {v[0], v[1], v[2], v[3]};
     if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(p)); else *reinterpret_cast<f32x4v*>(p) = t;
 }
+// NT: non-temporal 16-byte accesses for the streamed-once f32 state (p, g, m, v in; p, m, v out): 6 GB per step that would otherwise wash
+// through the 256 MB Infinity Cache and displace what the next forward pass re-reads; the bf16 weight copy, which that pass reads, stays a
+// normal store.  In situ (tools/ab_bench.sh, three interleaved rounds): 11.64 vs 11.84 ms per step.
+template <bool NT>
+__global__ __launch_bounds__(256) void bertadam_kernel(const AdamArgs a) {
+    // clip coefficient exactly as torch's clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied when < 1
+    float coef = a.grad_prescale;
+    if (a.sumsq) {
+        const float norm = sqrtf(*a.sumsq) * a.grad_prescale;
+        const float c = a.max_norm / (norm + 1e-6f);
+        if (c < 1.f) coef *= c;
+    }
+    const size_t nv = a.n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        float p[4], g[4], m[4], v[4];
+        ld4<NT>(a.p + i * 4, p); ld4<NT>(a.g + i * 4, g); ld4<NT>(a.m + i * 4, m); ld4<NT>(a.v + i * 4, v);
+        adam_update4(a, coef, p, g, m, v);
+        st4<NT>(a.p + i * 4, p); st4<NT>(a.m + i * 4, m); st4<NT>(a.v + i * 4, v);
+        if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + i * 4, p);
+    }
+    adam_tail(a, coef, nv);
+}
+
+// The same update confined to gridDim.x CUs: 1024-thread blocks that each claim more than half of a CU's LDS (so two never share a
+// CU), two groups of four 16-byte loads in flight per lane.  Used when the update runs on a side stream BESIDE the next forward
+// pass (Engine.adam_step(pipeline="background")): the persistent GEMM blocks of that pass need whole CUs (all registers, 128 KiB of
+// LDS) - an update spread over every CU starves them until it has drained, one that owns a quarter of the chip leaves them the rest.
+#define NARROW_THREADS 1024
+#define NARROW_LDS (84 * 1024)
 template <bool NT, int UNROLL>
 __global__ __launch_bounds__(NARROW_THREADS) void bertadam_narrow_kernel(const AdamArgs a) {
     extern __shared__ unsigned char narrow_pad[];
@@ -163,8 +167,10 @@ int k_bertadam(const AdamArgs& a, hipStream_t s) {
         RGQA_LAUNCH_CHECK("bertadam_narrow_kernel");
         return RGQA_OK;
     }
+    static const bool nt = []() { const char* e = getenv("RGQA_ADAM_NT"); return !(e != nullptr && e[0] == '0'); }();     // default on
     int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
-    hipLaunchKernelGGL(bertadam_kernel, dim3(nblk), dim3(256), 0, s, a);
+    if (nt) hipLaunchKernelGGL(bertadam_kernel<true>, dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(bertadam_kernel<false>, dim3(nblk), dim3(256), 0, s, a);
     RGQA_LAUNCH_CHECK("bertadam_kernel");
     return RGQA_OK;
 }
@@ -244,7 +250,7 @@ __device__ __forceinline__ void transpose_tile_load(const S* __restrict__ src, c
         for (int j = 0; j < 4; ++j) tile[ty + r * 16][tx * 4 + j] = v[j];
     }
 }
-__device__ __forceinline__ void transpose_tile_store(bf16_t* __restrict__ dst, const TransDesc& d, int n0, int k0, float (*tile)[TRANSPOSE_TILE + 1], int ltid) {
+__device__ __forceinline__ void transpose_tile_store(bf16_t* __restrict__ dst, const TransDesc& d, int n0, int k0, float (*tile)[TRANSPOSE_TILE + 1], int ltid, bool nt) {
     constexpr int TT = TRANSPOSE_TILE;
     const int tx = ltid & 15, ty = ltid >> 4;
     const bool n4 = (d.ld_dst & 3) == 0;
@@ -256,17 +262,22 @@ __device__ __forceinline__ void transpose_tile_store(bf16_t* __restrict__ dst, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = tile[tx * 4 + j][ty + r * 16];
         bf16_t* dp = dst + d.dst_off + (size_t)k * d.ld_dst + n;
-        if (n4 && n + 4 <= d.ld_dst) store4(dp, v);
+        if (n4 && n + 4 <= d.ld_dst) {
+            if (nt) {       // the transposed copy is read by a backward pass milliseconds later: do not let it displace cached data now
+                bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+                __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(dp));
+            } else store4(dp, v);
+        }
         else { for (int j = 0; j < 4; ++j) if (n + j < d.ld_dst) dp[j] = (bf16_t)v[j]; }
     }
 }
 template <typename S>
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc) {
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc, int nt) {
     __shared__ float tile[TRANSPOSE_TILE][TRANSPOSE_TILE + 1];
     TransDesc d; int n0, k0;
     transpose_tile_load<S>(src, desc, ndesc, blockIdx.x, tile, threadIdx.x, d, n0, k0);
     __syncthreads();
-    transpose_tile_store(dst, d, n0, k0, tile, threadIdx.x);
+    transpose_tile_store(dst, d, n0, k0, tile, threadIdx.x, nt != 0);
 }
 // confined to gridDim.x CUs (see bertadam_narrow_kernel): four 256-thread groups per block, each walking its own tiles
 template <typename S>
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(NARROW_THREADS) void cast_transpose_narrow_kernel(c
         TransDesc d; int n0 = 0, k0 = 0;
         if (t < total_tiles) transpose_tile_load<S>(src, desc, ndesc, t, tile, ltid, d, n0, k0);
         __syncthreads();
-        if (t < total_tiles) transpose_tile_store(dst, d, n0, k0, tile, ltid);
+        if (t < total_tiles) transpose_tile_store(dst, d, n0, k0, tile, ltid, true);
         __syncthreads();
     }
 }
@@ -299,8 +310,9 @@ int k_cast_transpose(const void* src, int src_is_bf16, void* dst_bf16, const Tra
         RGQA_LAUNCH_CHECK("cast_transpose_narrow_kernel");
         return RGQA_OK;
     }
-    if (src_is_bf16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc);
-    else hipLaunchKernelGGL(cast_transpose_kernel<float>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const float*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc);
+    const int ntf = 0;       // (non-temporal stores of the transposed copy, of the wgrad output, of gelu' and non-temporal loads in the gradient norm: +-0 in situ, 11.73 vs 11.69 ms; only the optimizer's state streams pay, RGQA_ADAM_NT)
+    if (src_is_bf16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc, ntf);
+    else hipLaunchKernelGGL(cast_transpose_kernel<float>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const float*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc, ntf);
     RGQA_LAUNCH_CHECK("cast_transpose_kernel");
     return RGQA_OK;
 }
