@@ -18,10 +18,12 @@
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 #define ROWB 144  // LDS row pitch in bytes for a [rows][64] bf16 image (128 + 16: spreads 8 consecutive rows over banks)
 
+// Rows past the sample's length are read from its LAST valid row instead of being zero-filled under a branch (4 v_mov + an exec-mask
+// branch per fragment: 8-9 % of these kernels' instructions): whatever such a row holds is finite and only ever multiplies a probability
+// that is exactly 0 (masked key: exp(-inf); query row past Lq: forced to 0 in the backward kernels, never stored in the forward one).
 __device__ __forceinline__ bf16x8 ldfrag(const bf16_t* base, int row, int nrows, int ld, int s, int g) {
-    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row >= nrows) return z;
-    return *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + s * 32 + g * 8);
+    const int r = row < nrows ? row : nrows - 1;
+    return *reinterpret_cast<const bf16x8*>(base + (size_t)r * ld + s * 32 + g * 8);
 }
 // transposed fragment: element jj = tile[ (jj<4 ? r0a : r0b) + 4*g + (jj&3) ][ c0 + (lane&15) ]
 template <int PITCH = ROWB>
