@@ -284,8 +284,6 @@ def main():
     if world == 1 and not args.butd and os.environ.get("RGQA_SEG_SUMSQ", "1") != "0":
         e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
     t_total = 10000
-    # BertAdam of step t on a side stream, in forward order, beside the first layers of step t+1 (Engine.adam_step(pipeline=True))
-    opt_pipeline = {"1": True, "bg": "background"}.get(os.environ.get("RGQA_OPT_PIPELINE", "0"), False) if (world == 1 and not (args.butd or args.uniter)) else False     # measured: 12.50 vs 12.57 ms - the update's blocks and the persistent GEMM blocks cannot share a CU (registers), so nothing overlaps; opt-in
     state = dict(step=0, lengths=lengths)
 
     def step(exchange=True):
@@ -299,7 +297,7 @@ def main():
             comm.exchange()
             comm.step(lr_t, max_norm=5.0)
         else:       # single GPU, or the collective-free legs after the timed region (local gradients, whole arena)
-            e.adam_step(lr_t, max_norm=5.0, grad_prescale=1.0 / world, pipeline=opt_pipeline)
+            e.adam_step(lr_t, max_norm=5.0, grad_prescale=1.0 / world)
         state["step"] = i + 1
 
     def fence():

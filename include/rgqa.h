@@ -20,8 +20,12 @@
 extern "C" {
 #endif
 
-#define RGQA_PRECISION_F32 0   /* exact-f32 operands: logits within 1e-3 of the reference CPU path */
-#define RGQA_PRECISION_BF16 1  /* bf16 MFMA operands, f32 accumulate / statistics: throughput path */
+#define RGQA_PRECISION_F32 0    /* exact-f32 FMA arithmetic on the vector ALU: the on-device numerical reference (slow) */
+#define RGQA_PRECISION_BF16 1   /* bf16 MFMA operands, f32 accumulate / statistics: BASELINE config 3's mode; its logits are OUTSIDE
+                                   the 1e-3 bound (bf16 rounding through 19 blocks, ~5e-2) */
+#define RGQA_PRECISION_BF16X3 2 /* split-f32 ("bf16x3"): every activation / weight operand a bf16 pair hi + lo (16-17 significant bits),
+                                   products on the bf16 matrix pipe as hi*hi + hi*lo + lo*hi with f32 accumulation: the fast path whose
+                                   logits stay within 1e-3 of the reference CPU path (lxrt/modeling.py:309-346 is f32 end to end) */
 
 typedef struct rgqa_config {
     int32_t vocab_size, hidden, heads, inter, max_pos, type_vocab; /* BertConfig, lxrt/modeling.py:172-258 */
@@ -43,20 +47,10 @@ typedef struct rgqa_engine rgqa_engine;
 
 const char* rgqa_last_error_string(void);
 int rgqa_version(void);
-/* debug / A-B knobs (key 0: 1 forces the 128x128 GEMM kernel everywhere; key 1: forces the NT M-tile;
- * key 2: 1 runs the deferred weight-gradient launches on the main stream instead of the side stream;
- * key 3: perf ablation of the NT LDS-DMA kernel, results are garbage: 1 = no operand DMA in the K loop, 2 = no LDS reads / MFMAs, 5 = as 2 with twice the DMA bytes in flight;
- * key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots;
- * key 7: phase-interleaved NT kernel: 0 never, 1 192-row tiles (default), 2 every 160..256-row launch; key 8: 0 computes the last
- * language FFN on every row (as the reference), 1 on the [CLS] rows only (default), -1 = environment; key 9: 0 = generic LayerNorm kernels only;
- * key 10: 0 = every LayerNorm backward folds its column sums at once on the main stream, 1 (default) = once per layer beside the layer's wgrad launch;
- * key 11: deferred wgrad launches cut after a layer's attention block (0) or after every FFN stage (1, default), -1 = environment RGQA_WGRAD_PHASE;
- * key 12: persistent forward / dgrad GEMMs draw their tiles by ticket: 0 = fixed walk, N = yes with the first N blocks on a fixed first tile, -1 = env RGQA_NT_TICKETS;
- * key 13: N > 0 confines the optimizer / transposed-copy kernels launched next to N CUs (one 1024-thread block each), 0 = whole chip;
- * key 14: 1 = dgrad GEMMs read the weight as stored ([K,N] operand form), 0 = its transposed bf16 copy, -1 = env RGQA_DGRAD_NN (an engine created with
- * RGQA_DGRAD_NN=1 writes no transposed copy for modules whose dgrads all qualify and keeps the [K,N] form for them);
- * key 15: 1 = the attention backward kernel that recomputes the probabilities in its key-major pass, 0 (default) = the one that parks dS / dropout(P)
- * in LDS, -1 = env RGQA_ATTN_BWD_TWO_PASS) */
+/* test switches: key 0: 1 forces the 128x128 register-staged GEMM kernels everywhere; key 1: forces the NT tile height (16-row
+ * m-tiles per wave: 2, 4..8; 0 = cost model); key 2: 1 runs the deferred weight-gradient launches on the caller's stream instead of
+ * the side stream; key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots; key 8: 0 computes
+ * the last language FFN on every row (as the reference does), 1 on the [CLS] rows only (default), -1 = environment RGQA_CLS_TAIL. */
 int rgqa_debug_set(int key, int value);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over
@@ -84,8 +78,10 @@ int rgqa_engine_param_info(const rgqa_engine* e, int index, char* name, size_t n
 /* element range [begin,end) of the parameters that never receive gradients in mode 'x' */
 int rgqa_engine_dead_range(const rgqa_engine* e, size_t* begin, size_t* end);
 int rgqa_engine_workspace_bytes(rgqa_engine* e, int B, int T, int O, size_t* out);
-/* params / grads: f32 arenas of arena_elems; params_lp / params_lp_t: bf16 arenas of arena_elems (may be null in
- * f32 precision); workspace: ws_bytes of scratch.  Must be called again when B, T or O change. */
+/* params / grads: f32 arenas of arena_elems; params_lp / params_lp_t: the operand copies of the linear weights and their
+ * transposes at the same element offsets - bf16 arenas of arena_elems in bf16 precision, 4-byte-per-element split-f32 arenas
+ * (128-byte aligned) in bf16x3 precision, may be null in f32 precision; workspace: ws_bytes of scratch.  Must be called again
+ * when B, T or O change. */
 int rgqa_engine_bind(rgqa_engine* e, float* params, float* grads, void* params_lp, void* params_lp_t,
                      void* workspace, size_t ws_bytes, int B, int T, int O);
 /* refresh the low-precision weight copies from the f32 master arena (after load_state_dict / external updates) */
@@ -125,16 +121,6 @@ int rgqa_engine_get_cross_attention(rgqa_engine* e, int layer, int direction, fl
  * then not read and language activations returned by get_activation are the packed rows. NULL / n = 0 restores the
  * padded layout (the default after bind). The array is consumed before the call returns. */
 int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n);
-/* Optimizer / forward pipelining.  A training loop may run clip + BertAdam (lxrt/optimization.py:101-180) of step t on a side stream,
- * range by range in arena (= forward) order, and let the forward pass of step t+1 start as soon as the ranges it reads first are
- * done.  Three hipEvent_t handles (any may be NULL = nothing to wait for), kept until replaced: every following forward waits for
- * ev_first before its first kernel (embeddings + language / vision layers: arena range [0, first cross-modality parameter)), for
- * ev_cross before the first cross-modality layer (the rest: cross-modality layers, pooler, head), and every following backward for
- * ev_all (all of the above plus the transposed bf16 copies the dgrad GEMMs read).  LXMERT engine (arch 0) only. */
-int rgqa_engine_set_weight_events(rgqa_engine* e, void* ev_first, void* ev_cross, void* ev_all);
-/* finer grain: events[k] (hipEvent_t, may be null or repeated) = the parameters of gradient segment k (rgqa_engine_grad_segment's event id) are updated;
- * the next forward passes wait for events[k] right before the first kernel that reads segment k.  n = 0 clears them. */
-int rgqa_engine_set_segment_weight_events(rgqa_engine* e, void* const* events, int n);
 /* Input gradients for the FOLLOWING backward calls (the reference's ODIN scorer differentiates w.r.t. the RoI features and boxes,
  * tasks/gqa_odin.py:97-121): dfeats [B*O, feat_dim] f32, dboxes [B*O, pos_dim] f32 device buffers, either may be NULL (not computed,
  * the default). */
@@ -168,7 +154,8 @@ int rgqa_engine_profile_blocks(rgqa_engine* e, double* ms, double* flops, int nb
  * BertAdam.step (lxrt/optimization.py:101-180) over arena ranges. */
 int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws /* >= 1024 f32 */, float* sumsq_out,
                     int accumulate, void* stream);
-int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp /* bf16 copy or null */, size_t n,
+int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp /* operand copy or null */,
+                       int lp_split /* 0: p_lp is bf16, 1: split f32 (bf16x3 precision) */, size_t n,
                        float lr_t, float b1, float b2, float eps, float weight_decay,
                        const float* sumsq /* device scalar or null */, float max_norm, float grad_prescale, void* stream);
 
@@ -177,6 +164,10 @@ int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp 
  * rgqa_sum_bf16_parts: dst[i] = sum over r < nparts of f32(parts[r * part_stride + i]), r ascending: the f32 accumulation,
  * at the rank that owns the range, of the bf16 shards it received from every rank (part_stride % 8 == 0). */
 int rgqa_cast_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+/* split-f32 storage (bf16x3 precision; layout in rgqa_amd/csrc/common.h): dst slot i = (hi, lo) of src[i]; dst 128-byte aligned, 4 bytes
+ * per element; and back: dst[i] = hi + lo.  n % 32 == 0.  Used by the kernel parity tests to build / read operands. */
+int rgqa_split_f32(const float* src, void* dst_split, size_t n, void* stream);
+int rgqa_unsplit_f32(const void* src_split, float* dst, size_t n, void* stream);
 int rgqa_sum_bf16_parts(const void* parts_bf16, size_t part_stride, int nparts, float* dst, size_t n, void* stream);
 
 /* ---- batch construction: replaces the host loop of RoI-mixup (tasks/gqa_mixup_vis.py:134-181).
@@ -224,19 +215,15 @@ int rgqa_score_rows(const float* logits, int ld, int B, int NA, float temperatur
                     void* stream);
 
 /* ---- stand-alone operators (unit parity tests; the engine calls the same kernels internally) ------------- */
-/* C[M,N] = A[M,K] W[N,K]^T + bias, epilogue 0 none / 1 gelu / 2 tanh; dtype 0 f32, 1 bf16 (A, W, C all dtype) */
+/* dtype of the stand-alone operators: 0 f32, 1 bf16, 2 split f32 (every activation / weight operand in the split layout, ld % 32 == 0).
+ * C[M,N] = A[M,K] W[N,K]^T + bias, epilogue 0 none / 1 gelu / 2 tanh (A, W, C all dtype) */
 int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
                    int ldc, int epilogue, int dtype, void* stream);
-/* bf16 only, any epilogue of the grouped NT GEMM (rgqa_amd/csrc/gemm.h GemmEpi: 0 bias, 1 gelu (+ C2 = gelu'), 2 tanh,
+/* bf16 (dtype 1) or split f32 (dtype 2), any epilogue of the grouped NT GEMM (rgqa_amd/csrc/gemm.h GemmEpi: 0 bias, 1 gelu (+ C2 = gelu'), 2 tanh,
  * 3 dropout(x)+aux, 4 x*aux, 5 x+aux, 7 x*(1-aux^2), 8 relu, 9 dropout(relu), 10 relu/dropout gradient); aux / C2 may be
  * NULL when the epilogue does not use them.  Kernel parity tests and tools/lab only. */
 int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const void* aux, void* C, void* C2, int M, int N,
-                      int K, int lda, int ldw, int ldc, int ldaux, int epilogue, float drop_p, void* stream);
-/* bf16: C[M,N] = epilogue(A[M,K] B[K,N]) with B stored [K,N] row-major (the dgrad GEMM reading a weight [out,in] as it is stored - replaces
- * the transposed-copy operand of the reference's autograd matmul, torch.nn.functional.linear backward); epilogue 0 none, 4 x*aux, 5 x+aux,
- * 7 x*(1-aux^2), 10 relu/dropout gradient; K % 64 == 0, N % 8 == 0.  Kernel parity tests. */
-int rgqa_op_matmul_nn(const void* A, const void* B, const void* aux, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
-                      int epilogue, void* stream);
+                      int K, int lda, int ldw, int ldc, int ldaux, int epilogue, float drop_p, int dtype, void* stream);
 /* C[M,N] f32 = A[K,M]^T B[K,N]   (wgrad form); dtype of A and B */
 int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int dtype, void* stream);
@@ -245,7 +232,7 @@ int rgqa_op_layernorm(const void* x, const float* gamma, const float* beta, void
 int rgqa_op_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                           void* dx, float* dgamma, float* dbeta, float* ws /* 512*3*N f32 */, int M, int N, int dtype,
                           void* stream);
-/* fused attention core on a packed QKV buffer [B*L, 3*nh*dh] (self-attention), impl 0 generic / 1 MFMA (bf16 only) */
+/* fused attention core on a packed QKV buffer [B*L, 3*nh*dh] (self-attention), impl 0 generic / 1 MFMA (bf16 and split f32) */
 int rgqa_op_attention(const void* qkv, const float* mask /* [B,L] additive or null */, void* out, float* lse, int B,
                       int nh, int L, int dh, int dtype, int impl, void* stream);
 int rgqa_op_attention_bwd(const void* qkv, const float* mask, const float* lse, const void* dout, void* dqkv, int B,

@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librgqa_hip.so")
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 
 
 class Config(C.Structure):
@@ -41,8 +41,6 @@ SIGNATURES = {
     "rgqa_engine_get_activation": [_vp, C.c_char_p, _vp, _sz, _vp],
     "rgqa_engine_get_cross_attention": [_vp, _i, _i, _vp, _sz, _vp],
     "rgqa_engine_set_lengths": [_vp, _vp, _i],
-    "rgqa_engine_set_weight_events": [_vp, _vp, _vp, _vp],
-    "rgqa_engine_set_segment_weight_events": [_vp, _vp, _i],
     "rgqa_engine_set_input_grads": [_vp, _vp, _vp],
     "rgqa_engine_set_grad_sumsq_slots": [_vp, _vp, _i],
     "rgqa_engine_num_grad_segments": [_vp, C.POINTER(_i)],
@@ -52,17 +50,18 @@ SIGNATURES = {
     "rgqa_engine_profile_read": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _i],
     "rgqa_engine_profile_blocks": [_vp, _vp, _vp, _i],
     "rgqa_grad_sumsq": [_vp, _sz, _vp, _vp, _i, _vp],
-    "rgqa_bertadam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _f, _f, _vp],
+    "rgqa_bertadam_step": [_vp, _vp, _vp, _vp, _vp, _i, _sz, _f, _f, _f, _f, _f, _vp, _f, _f, _vp],
     "rgqa_cast_bf16": [_vp, _vp, _sz, _vp],
+    "rgqa_split_f32": [_vp, _vp, _sz, _vp],
+    "rgqa_unsplit_f32": [_vp, _vp, _sz, _vp],
     "rgqa_sum_bf16_parts": [_vp, _sz, _i, _vp, _sz, _vp],
     "rgqa_mixup_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_mixup_perturb": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "rgqa_mixup_weighted_sum": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "rgqa_scale_rows": [_vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "rgqa_op_linear_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "rgqa_op_linear_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "rgqa_op_matmul_tn": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "rgqa_op_matmul_nn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rgqa_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
     "rgqa_op_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "rgqa_op_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -86,8 +85,6 @@ def load():
     # torch bundles its own libamdhip64.so.7; it must be the HIP runtime already resident when our library is
     # mapped, otherwise the process ends up with two runtimes and torch's device pointers / streams mean nothing to ours
     import torch  # noqa: F401
-    global LIB_PATH
-    LIB_PATH = os.environ.get("RGQA_LIB", LIB_PATH)          # A/B of differently built kernels (tools/ab_bench.sh)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("rgqa_amd: %s not found. Build it with `python -m rgqa_amd.build` "
                            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)

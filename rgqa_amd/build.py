@@ -17,7 +17,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-res
 # Per-file additions.  attn_mfma.hip: MFMA results straight into VGPRs - hipcc otherwise parks the small accumulators of these one-wave kernels in
 # AGPRs and copies every one out with v_accvgpr_read (216 of 3197 instructions in attn_bwd1<3,3>, a kernel at the instruction-issue limit);
 # with the flag that kernel also fits three waves per SIMD (164 registers instead of 158 + 16).
-PER_FILE_FLAGS = {"attn_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+PER_FILE_FLAGS = {"attn_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attn_x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _newest_header():

@@ -20,10 +20,10 @@ __global__ __launch_bounds__(64) void attn_fwd_ref_kernel(const AttnArgs a) {
     const T* k = reinterpret_cast<const T*>(a.k) + k0 * a.ldk + h * dh;
     const T* v = reinterpret_cast<const T*>(a.v) + k0 * a.ldv + h * dh;
     const int tid = threadIdx.x;
-    for (int x = tid; x < Lq * dh; x += 64) Qs[(x / dh) * dp + x % dh] = to_f32(q[(size_t)(x / dh) * a.ldq + x % dh]);
+    for (int x = tid; x < Lq * dh; x += 64) Qs[(x / dh) * dp + x % dh] = ld_elem(q + (size_t)(x / dh) * a.ldq + x % dh);
     for (int x = tid; x < Lk * dh; x += 64) {
-        Ks[(x / dh) * dp + x % dh] = to_f32(k[(size_t)(x / dh) * a.ldk + x % dh]);
-        Vs[(x / dh) * dp + x % dh] = to_f32(v[(size_t)(x / dh) * a.ldv + x % dh]);
+        Ks[(x / dh) * dp + x % dh] = ld_elem(k + (size_t)(x / dh) * a.ldk + x % dh);
+        Vs[(x / dh) * dp + x % dh] = ld_elem(v + (size_t)(x / dh) * a.ldv + x % dh);
     }
     __syncthreads();
     for (int x = tid; x < Lq * Lk; x += 64) {
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void attn_fwd_ref_kernel(const AttnArgs a) {
         const int i = x / dh, d = x % dh;
         float s = 0.f;
         for (int j = 0; j < Lk; ++j) s = fmaf(Ps[i * kp + j], Vs[j * dp + d], s);
-        o[(size_t)i * a.ldo + d] = from_f32<T>(s);
+        st_elem(o + (size_t)i * a.ldo + d, s);
     }
 }
 
@@ -76,12 +76,12 @@ __global__ __launch_bounds__(64) void attn_bwd_ref_kernel(const AttnArgs a) {
     const T* dO = reinterpret_cast<const T*>(a.dout) + q0 * a.lddo + h * dh;
     const int tid = threadIdx.x;
     for (int x = tid; x < Lq * dh; x += 64) {
-        Qs[(x / dh) * dp + x % dh] = to_f32(q[(size_t)(x / dh) * a.ldq + x % dh]);
-        Os[(x / dh) * dp + x % dh] = to_f32(dO[(size_t)(x / dh) * a.lddo + x % dh]);
+        Qs[(x / dh) * dp + x % dh] = ld_elem(q + (size_t)(x / dh) * a.ldq + x % dh);
+        Os[(x / dh) * dp + x % dh] = ld_elem(dO + (size_t)(x / dh) * a.lddo + x % dh);
     }
     for (int x = tid; x < Lk * dh; x += 64) {
-        Ks[(x / dh) * dp + x % dh] = to_f32(k[(size_t)(x / dh) * a.ldk + x % dh]);
-        Vs[(x / dh) * dp + x % dh] = to_f32(v[(size_t)(x / dh) * a.ldv + x % dh]);
+        Ks[(x / dh) * dp + x % dh] = ld_elem(k + (size_t)(x / dh) * a.ldk + x % dh);
+        Vs[(x / dh) * dp + x % dh] = ld_elem(v + (size_t)(x / dh) * a.ldv + x % dh);
     }
     __syncthreads();
     DropCfg dc = a.drop; dc.seed_hi ^= a.drop_site;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void attn_bwd_ref_kernel(const AttnArgs a) {
         const int i = x / dh, d = x % dh;
         float s = 0.f;
         for (int j = 0; j < Lk; ++j) s = fmaf(Ds[i * kp + j], Ks[j * dp + d], s);
-        dq[(size_t)i * a.lddq + d] = from_f32<T>(s);
+        st_elem(dq + (size_t)i * a.lddq + d, s);
     }
     for (int x = tid; x < Lk * dh; x += 64) {
         const int j = x / dh, d = x % dh;
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(64) void attn_bwd_ref_kernel(const AttnArgs a) {
             s1 = fmaf(Ds[i * kp + j], Qs[i * dp + d], s1);
             s2 = fmaf(Ps[i * kp + j], Os[i * dp + d], s2);
         }
-        dk[(size_t)j * a.lddk + d] = from_f32<T>(s1);
-        dv[(size_t)j * a.lddv + d] = from_f32<T>(s2);
+        st_elem(dk + (size_t)j * a.lddk + d, s1);
+        st_elem(dv + (size_t)j * a.lddv + d, s2);
     }
 }
 
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(const AttnArgs a, float*
     const T* q = reinterpret_cast<const T*>(a.q) + q0 * a.ldq + h * dh;
     const T* k = reinterpret_cast<const T*>(a.k) + k0 * a.ldk + h * dh;
     const int tid = threadIdx.x;
-    for (int x = tid; x < Lq * dh; x += 64) Qs[(x / dh) * dp + x % dh] = to_f32(q[(size_t)(x / dh) * a.ldq + x % dh]);
-    for (int x = tid; x < Lk * dh; x += 64) Ks[(x / dh) * dp + x % dh] = to_f32(k[(size_t)(x / dh) * a.ldk + x % dh]);
+    for (int x = tid; x < Lq * dh; x += 64) Qs[(x / dh) * dp + x % dh] = ld_elem(q + (size_t)(x / dh) * a.ldq + x % dh);
+    for (int x = tid; x < Lk * dh; x += 64) Ks[(x / dh) * dp + x % dh] = ld_elem(k + (size_t)(x / dh) * a.ldk + x % dh);
     __syncthreads();
     for (int x = tid; x < Lq * Lk; x += 64) {
         const int i = x / Lk, j = x % Lk;
@@ -220,8 +220,11 @@ int k_attn_probs(const AttnArgs& a, float* out, hipStream_t s) {
 }
 template int k_attn_probs<float>(const AttnArgs&, float*, hipStream_t);
 template int k_attn_probs<bf16_t>(const AttnArgs&, float*, hipStream_t);
+template int k_attn_probs<sf32>(const AttnArgs&, float*, hipStream_t);
 
 template int k_attn_fwd_ref<float>(const AttnArgs&, hipStream_t);
 template int k_attn_fwd_ref<bf16_t>(const AttnArgs&, hipStream_t);
+template int k_attn_fwd_ref<sf32>(const AttnArgs&, hipStream_t);
 template int k_attn_bwd_ref<float>(const AttnArgs&, hipStream_t);
 template int k_attn_bwd_ref<bf16_t>(const AttnArgs&, hipStream_t);
+template int k_attn_bwd_ref<sf32>(const AttnArgs&, hipStream_t);

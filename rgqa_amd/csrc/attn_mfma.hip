@@ -156,181 +156,6 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
     }
 }
 
-// ============================================================================ backward
-template <int NQT, int NKT>
-__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char ks_[NKT * 16 * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char qs_[NQT * 16 * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char os_[NQT * 16 * ROWB];
-    __shared__ __attribute__((aligned(16))) float delta_s[NQT * 16];
-    const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
-    ATTN_SAMPLE_ROWS(a, b)
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + q0 * a.ldq + h * 64;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + k0 * a.ldk + h * 64;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + k0 * a.ldv + h * 64;
-    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + q0 * a.lddo + h * 64;
-    const float* lse = a.lse + ((size_t)b * a.nh + h) * a.Lq;
-    // ONE global-load phase: every operand fragment (both passes use the same 16-B-per-lane row pieces), the log-sum-exp and
-    // the key mask are requested back to back; the three LDS images the transposed reads need are then written from those
-    // registers.  (The first version re-read K/Q/dO from global for the images and again per pass: ~6 dependent L2/HBM
-    // round trips on a 1-wave block.)
-    bf16x8 kf[NKT][2], vf[NKT][2], qf[NQT][2], of[NQT][2];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { kf[kt][s] = ldfrag(K, kt * 16 + fr, Lk, a.ldk, s, g); vf[kt][s] = ldfrag(V, kt * 16 + fr, Lk, a.ldv, s, g); }
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { qf[qt][s] = ldfrag(Q, qt * 16 + fr, Lq, a.ldq, s, g); of[qt][s] = ldfrag(dO, qt * 16 + fr, Lq, a.lddo, s, g); }
-    float lse_t[NQT], lse_n[NQT][4], mk[NKT][4], mkk[NKT];
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt) {
-        lse_t[qt] = qt * 16 + fr < Lq ? lse[qt * 16 + fr] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lse_n[qt][r] = qt * 16 + 4 * g + r < Lq ? lse[qt * 16 + 4 * g + r] : 0.f;
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + 4 * g + r;
-            mk[kt][r] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
-        }
-        const int key = kt * 16 + fr;
-        mkk[kt] = key < Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -INFINITY;
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(ks_ + (kt * 16 + fr) * ROWB + s * 64 + g * 16) = kf[kt][s];
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            *reinterpret_cast<bf16x8*>(qs_ + (qt * 16 + fr) * ROWB + s * 64 + g * 16) = qf[qt][s];
-            *reinterpret_cast<bf16x8*>(os_ + (qt * 16 + fr) * ROWB + s * 64 + g * 16) = of[qt][s];
-        }
-    __syncthreads();
-    DropCfg dc = a.drop; dc.seed_hi ^= a.drop_site;
-    const uint32_t idx0 = (uint32_t)((b * a.nh + h) * a.Lq) * (uint32_t)a.Lk;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int NKS = (NKT + 1) / 2, NQS = (NQT + 1) / 2;
-
-    // ---------------- pass T: lane = query, registers = keys  ->  delta[q], dQ
-    {
-        bf16_t* dQ = reinterpret_cast<bf16_t*>(a.dq) + q0 * a.lddq + h * 64;
-#pragma unroll
-        for (int qt = 0; qt < NQT; ++qt) {
-            const int q = qt * 16 + fr;
-            const bf16x8 qf0 = qf[qt][0], qf1 = qf[qt][1];
-            const bf16x8 of0 = of[qt][0], of1 = of[qt][1];
-            const float lq = lse_t[qt];
-            f32x4 pp[NKT], dpp[NKT];
-            float delta = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
-                s4 = MFMA(kf[kt][0], qf0, s4); s4 = MFMA(kf[kt][1], qf1, s4);
-                dp4 = MFMA(vf[kt][0], of0, dp4); dp4 = MFMA(vf[kt][1], of1, dp4);
-                float keep4[4] = {1.f, 1.f, 1.f, 1.f};
-                {
-                    const uint32_t idx = idx0 + (uint32_t)(q * a.Lk + kt * 16 + 4 * g);
-                    if ((a.Lk & 1) == 0) drop_apply_vec<4>(dc, idx, keep4);
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) keep4[r] = drop_apply(dc, idx + (uint32_t)r, 1.0f);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = q < Lq ? __expf(s4[r] * a.scale + mk[kt][r] - lq) : 0.f;
-                    const float keep = keep4[r];
-                    const float dp = dp4[r] * keep;
-                    delta += p * dp;
-                    s4[r] = p; dp4[r] = dp;
-                }
-                pp[kt] = s4; dpp[kt] = dp4;
-            }
-            delta += __shfl_xor(delta, 16, 64);
-            delta += __shfl_xor(delta, 32, 64);
-            if (g == 0) delta_s[qt * 16 + fr] = delta;
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pp[kt][r] = pp[kt][r] * (dpp[kt][r] - delta) * a.scale;   // dS^T
-            // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const bf16x8 ka = trfrag(ks_, 2 * ks * 16, (2 * ks + 1) * 16, 2 * ks + 1 < NKT, dt * 16, lane);
-                    const bf16x8 db = pack8(pp[2 * ks], (2 * ks + 1 < NKT) ? pp[(2 * ks + 1 < NKT) ? 2 * ks + 1 : 0] : zero4);
-                    o = MFMA(ka, db, o);
-                }
-                if (q < Lq) {
-                    float v[4] = {o[0], o[1], o[2], o[3]};
-                    store4(dQ + (size_t)q * a.lddq + dt * 16 + 4 * g, v);
-                }
-            }
-        }
-    }
-    __syncthreads();   // single-wave workgroup: orders the delta_s writes before the reads below
-    // ---------------- pass N: lane = key, registers = queries  ->  dK, dV
-    {
-        float dl[NQT][4];
-#pragma unroll
-        for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dl[qt][r] = delta_s[qt * 16 + 4 * g + r];
-        bf16_t* dK = reinterpret_cast<bf16_t*>(a.dk) + k0 * a.lddk + h * 64;
-        bf16_t* dV = reinterpret_cast<bf16_t*>(a.dv) + k0 * a.lddv + h * 64;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            const int key = kt * 16 + fr;
-            const bf16x8 kf0 = kf[kt][0], kf1 = kf[kt][1];
-            const bf16x8 vf0 = vf[kt][0], vf1 = vf[kt][1];
-            const float mkk_ = mkk[kt];
-            f32x4 dsn[NQT], pdn[NQT];
-#pragma unroll
-            for (int qt = 0; qt < NQT; ++qt) {
-                f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
-                s4 = MFMA(qf[qt][0], kf0, s4); s4 = MFMA(qf[qt][1], kf1, s4);      // S[q][key]: lane = key, regs = queries
-                dp4 = MFMA(of[qt][0], vf0, dp4); dp4 = MFMA(of[qt][1], vf1, dp4);  // dP[q][key]
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = qt * 16 + 4 * g + r;
-                    const float p = q < Lq ? __expf(s4[r] * a.scale + mkk_ - lse_n[qt][r]) : 0.f;
-                    const float keep = drop_apply(dc, idx0 + (uint32_t)(q * a.Lk + key), 1.0f);
-                    dsn[qt][r] = p * (dp4[r] * keep - dl[qt][r]) * a.scale;
-                    pdn[qt][r] = p * keep;
-                }
-            }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f32x4 ok = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int qs = 0; qs < NQS; ++qs) {
-                    const bool two = 2 * qs + 1 < NQT;
-                    const bf16x8 qa = trfrag(qs_, 2 * qs * 16, (2 * qs + 1) * 16, two, dt * 16, lane);
-                    const bf16x8 oa = trfrag(os_, 2 * qs * 16, (2 * qs + 1) * 16, two, dt * 16, lane);
-                    const bf16x8 dsb = pack8(dsn[2 * qs], two ? dsn[two ? 2 * qs + 1 : 0] : zero4);
-                    const bf16x8 pdb = pack8(pdn[2 * qs], two ? pdn[two ? 2 * qs + 1 : 0] : zero4);
-                    ok = MFMA(qa, dsb, ok);   // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
-                    ov = MFMA(oa, pdb, ov);   // dV^T[d][key] = sum_q dO^T[d][q] Pd[q][key]
-                }
-                if (key < Lk) {
-                    float v1[4] = {ok[0], ok[1], ok[2], ok[3]}, v2[4] = {ov[0], ov[1], ov[2], ov[3]};
-                    store4(dK + (size_t)key * a.lddk + dt * 16 + 4 * g, v1);
-                    store4(dV + (size_t)key * a.lddv + dt * 16 + 4 * g, v2);
-                }
-            }
-        }
-    }
-}
-
 // ============================================================================ backward, probabilities computed once
 // Same products, but the key-major pass no longer recomputes S, the softmax, the dropout draws and dP: the query-major pass parks
 // dS[q][key] and Pd[q][key] (bf16, exactly the values it feeds its own dQ MFMAs / the values the key-major pass would recompute) in two
@@ -506,7 +331,6 @@ __global__ __launch_bounds__(64) void attn_bwd1_mfma_kernel(const AttnArgs a) {
     }
 }
 
-int g_rgqa_attn_bwd_two_pass = -1;   // rgqa_debug_set key 15: 1 = attn_bwd_mfma_kernel (probabilities recomputed in the key-major pass), 0 = attn_bwd1_mfma_kernel, -1 = env RGQA_ATTN_BWD_TWO_PASS
 // ============================================================================ host side
 static int mfma_check(const AttnArgs& a, bool bwd) {
     RGQA_REQUIRE(a.dh == 64, "mfma attention: head size must be 64 (got %d)", a.dh);
@@ -557,9 +381,7 @@ int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s) {
     if (r) return r;
     const int nqt = cdiv(a.Lq, 16), nkt = cdiv(a.Lk, 16);
     dim3 grid(a.B * a.nh);
-    static const bool env2 = getenv("RGQA_ATTN_BWD_TWO_PASS") != nullptr;       // the kernel that recomputes the probabilities in the key-major pass
-    if (g_rgqa_attn_bwd_two_pass < 0 ? env2 : g_rgqa_attn_bwd_two_pass != 0) { DISPATCH_TILES(attn_bwd_mfma_kernel, nqt, nkt) }
-    else { DISPATCH_TILES(attn_bwd1_mfma_kernel, nqt, nkt) }
+    DISPATCH_TILES(attn_bwd1_mfma_kernel, nqt, nkt)
     RGQA_LAUNCH_CHECK("attn_bwd_mfma_kernel");
     return RGQA_OK;
 }

@@ -16,37 +16,15 @@ int rgqa_version(void) { return 100; }
 extern int g_rgqa_force_gemm128;
 extern int g_rgqa_force_mt;
 extern int g_rgqa_wgrad_serial;
-extern int g_rgqa_ablate;
 extern int g_rgqa_tn_mtw;
-extern int g_rgqa_tn_plan;
-extern int g_rgqa_no_deep;
-extern int g_rgqa_nt8p;
 extern int g_rgqa_cls_tail;
-extern int g_rgqa_ln16;
-extern int g_rgqa_ln_defer;
-extern int g_rgqa_wgrad_phase;
-extern int g_rgqa_nt_tickets;
-extern int g_rgqa_narrow_cus;
-extern int g_rgqa_dgrad_nn;
-extern int g_rgqa_attn_bwd_two_pass;
-// debug / A-B knobs: key 0 = force the 128x128 GEMM kernel; key 1 = force the LDS-DMA kernel's MT (0 = auto)
+// debug / test switches (include/rgqa.h)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
     if (key == 1) { g_rgqa_force_mt = value; return RGQA_OK; }
     if (key == 2) { g_rgqa_wgrad_serial = value; return RGQA_OK; }
-    if (key == 3) { g_rgqa_ablate = value; return RGQA_OK; }
     if (key == 4) { g_rgqa_tn_mtw = value; return RGQA_OK; }
-    if (key == 6) { g_rgqa_tn_plan = value; return RGQA_OK; }
-    if (key == 5) { g_rgqa_no_deep = value; return RGQA_OK; }
-    if (key == 7) { g_rgqa_nt8p = value; return RGQA_OK; }
     if (key == 8) { g_rgqa_cls_tail = value; return RGQA_OK; }
-    if (key == 9) { g_rgqa_ln16 = value; return RGQA_OK; }
-    if (key == 10) { g_rgqa_ln_defer = value; return RGQA_OK; }
-    if (key == 11) { g_rgqa_wgrad_phase = value; return RGQA_OK; }
-    if (key == 12) { g_rgqa_nt_tickets = value; return RGQA_OK; }
-    if (key == 13) { g_rgqa_narrow_cus = value; return RGQA_OK; }
-    if (key == 14) { g_rgqa_dgrad_nn = value; return RGQA_OK; }
-    if (key == 15) { g_rgqa_attn_bwd_two_pass = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }
@@ -76,7 +54,10 @@ int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out) {
     RGQA_REQUIRE(cfg->pos_dim >= 1 && cfg->pos_dim <= (cfg->arch == 2 ? 8 : 4), "engine_create: pos_dim %d unsupported", cfg->pos_dim);
     RGQA_REQUIRE(cfg->vocab_size > 0 && cfg->max_pos > 0 && cfg->type_vocab > 0 && cfg->num_answers > 0, "engine_create: empty table");
     RGQA_REQUIRE(cfg->l_layers >= 0 && cfg->x_layers >= 0 && cfg->r_layers >= 0, "engine_create: negative layer count");
-    RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16, "engine_create: unknown precision %d", cfg->precision);
+    RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16 || cfg->precision == RGQA_PRECISION_BF16X3, "engine_create: unknown precision %d", cfg->precision);
+    if (cfg->precision == RGQA_PRECISION_BF16X3)
+        RGQA_REQUIRE(cfg->arch == 0 && cfg->hidden % 64 == 0 && cfg->hidden / cfg->heads == 64 && cfg->inter % 32 == 0 && cfg->feat_dim % 32 == 0,
+                     "engine_create: bf16x3 precision needs the LXMERT engine with head size 64 and hidden / intermediate / feature sizes that are multiples of 32");
     RGQA_REQUIRE(cfg->hidden_dropout >= 0.f && cfg->hidden_dropout < 1.f && cfg->attn_dropout >= 0.f && cfg->attn_dropout < 1.f, "engine_create: dropout out of range");
     rgqa_engine* e = new (std::nothrow) rgqa_engine;
     if (!e) { rgqa_set_error("engine_create: out of host memory"); return RGQA_ERR_STATE; }
@@ -151,19 +132,6 @@ int rgqa_engine_set_input_grads(rgqa_engine* e, float* dfeats, float* dboxes) {
     return e->impl->set_input_grads(dfeats, dboxes);
 }
 
-int rgqa_engine_set_weight_events(rgqa_engine* e, void* ev_first, void* ev_cross, void* ev_all) {
-    NEED(e);
-    e->impl->wev_first = reinterpret_cast<hipEvent_t>(ev_first);
-    e->impl->wev_cross = reinterpret_cast<hipEvent_t>(ev_cross);
-    e->impl->wev_all = reinterpret_cast<hipEvent_t>(ev_all);
-    return RGQA_OK;
-}
-int rgqa_engine_set_segment_weight_events(rgqa_engine* e, void* const* events, int n) {
-    NEED(e);
-    e->impl->wev_seg.clear();
-    for (int i = 0; i < n && events != nullptr; ++i) e->impl->wev_seg.push_back(reinterpret_cast<hipEvent_t>(events[i]));
-    return RGQA_OK;
-}
 int rgqa_engine_set_lengths(rgqa_engine* e, const int32_t* lengths, int n) {
     NEED(e);
     return e->impl->set_lengths(lengths, n);
@@ -200,10 +168,10 @@ int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws, float* sums
     RGQA_REQUIRE(grads && partial_ws && sumsq_out, "grad_sumsq: null argument");
     return k_sumsq(grads, n, partial_ws, sumsq_out, accumulate, S(stream));
 }
-int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp, size_t n, float lr_t, float b1, float b2, float eps, float wd,
+int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp, int lp_split, size_t n, float lr_t, float b1, float b2, float eps, float wd,
                        const float* sumsq, float max_norm, float grad_prescale, void* stream) {
     RGQA_REQUIRE(p && g && m && v, "bertadam_step: null argument");
-    AdamArgs a; a.p = p; a.g = g; a.m = m; a.v = v; a.p_lp = p_lp; a.n = n; a.lr_t = lr_t; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;
+    AdamArgs a; a.p = p; a.g = g; a.m = m; a.v = v; a.p_lp = p_lp; a.lp_split = lp_split; a.n = n; a.lr_t = lr_t; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;
     a.sumsq = sumsq; a.max_norm = max_norm; a.grad_prescale = grad_prescale;
     return k_bertadam(a, S(stream));
 }
@@ -211,6 +179,20 @@ int rgqa_cast_bf16(const float* src, void* dst_bf16, size_t n, void* stream) {
     RGQA_REQUIRE(src && dst_bf16, "cast_bf16: null argument");
     RGQA_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst_bf16 % 8) == 0, "cast_bf16: src must be 16-byte, dst 8-byte aligned");
     return k_cast_bf16(src, dst_bf16, n, S(stream));
+}
+int rgqa_split_f32(const float* src, void* dst_split, size_t n, void* stream) {
+    RGQA_REQUIRE(src && dst_split && (n % 32) == 0 && (((uintptr_t)dst_split) & 127) == 0, "split_f32: n %% 32 and a 128-byte aligned destination required");
+    return k_cast_split(src, dst_split, n, S(stream));
+}
+int rgqa_unsplit_f32(const void* src_split, float* dst, size_t n, void* stream) {
+    RGQA_REQUIRE(src_split && dst && (n % 32) == 0 && (((uintptr_t)src_split) & 127) == 0, "unsplit_f32: n %% 32 and a 128-byte aligned source required");
+    if (n == 0) return RGQA_OK;
+    const size_t rows = (n + 32767) / 32768;           // rows of 32768 elements (whole lines), the last one shorter
+    for (size_t r = 0; r < rows; ++r) {
+        const size_t o = r * 32768, c = n - o < 32768 ? n - o : 32768;
+        if (int rc = k_to_f32<sf32>(reinterpret_cast<const sf32*>(src_split) + o, (int)c, dst + o, (int)c, 1, (int)c, S(stream))) return rc;
+    }
+    return RGQA_OK;
 }
 int rgqa_sum_bf16_parts(const void* parts_bf16, size_t part_stride, int nparts, float* dst, size_t n, void* stream) {
     RGQA_REQUIRE(parts_bf16 && dst && nparts >= 1, "sum_bf16_parts: bad argument");
@@ -240,11 +222,13 @@ int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int
     GemmProblem& p = g.p[0];
     p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.epi = epilogue;
     RGQA_REQUIRE(epilogue >= 0 && epilogue <= 2, "op_linear: epilogue must be 0..2");
+    if (dtype == 2) return launch_gemm_nt_x3(g, 0, S(stream));
     return dtype == 1 ? launch_gemm_nt_bf16(g, 0, S(stream)) : launch_gemm_f32(g, 0, 0, S(stream));
 }
-// bf16 only: every epilogue of the grouped NT GEMM on one problem (kernel parity tests, tools/lab).  epilogue = GemmEpi value.
+// bf16 / split f32: every epilogue of the grouped NT GEMM on one problem (kernel parity tests, tools/lab).  epilogue = GemmEpi value.
 int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const void* aux, void* C, void* C2, int M, int N, int K, int lda, int ldw, int ldc,
-                      int ldaux, int epilogue, float drop_p, void* stream) {
+                      int ldaux, int epilogue, float drop_p, int dtype, void* stream) {
+    RGQA_REQUIRE(dtype == 1 || dtype == 2, "op_linear_ex: dtype 1 (bf16) or 2 (split f32)");
     RGQA_REQUIRE(epilogue >= 0 && epilogue <= EPI_DRELU_DROP && epilogue != EPI_ACCUM, "op_linear_ex: bad epilogue %d", epilogue);
     RGQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "op_linear_ex: dropout out of range");
     GemmGroup g; memset(&g, 0, sizeof g);
@@ -252,31 +236,25 @@ int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const voi
     GemmProblem& p = g.p[0];
     p.A = A; p.B = W; p.C = C; p.C2 = C2; p.bias = bias; p.aux = aux; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.ldaux = ldaux;
     p.epi = epilogue; p.drop_site = 17u;
-    return launch_gemm_nt_bf16(g, 0, S(stream));
-}
-// bf16, B stored [K, N] (the dgrad form on the weight as it is): C[M,N] = epilogue(A[M,K] B[K,N]); epilogue in {0, 4, 5, 7, 10}; K % 64 == 0, N % 8 == 0
-int rgqa_op_matmul_nn(const void* A, const void* B, const void* aux, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int epilogue, void* stream) {
-    RGQA_REQUIRE(K % 64 == 0 && K >= 64 && N % 8 == 0 && ldb >= N, "op_matmul_nn: K=%d must be a multiple of 64, N=%d of 8", K, N);
-    GemmGroup g; memset(&g, 0, sizeof g);
-    g.count = 1; g.b_kn = 1; g.drop = make_drop(0.f, 0, 0);
-    GemmProblem& p = g.p[0];
-    p.A = A; p.B = B; p.C = C; p.aux = aux; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.epi = epilogue;
-    return launch_gemm_nt_bf16(g, 0, S(stream));
+    return dtype == 2 ? launch_gemm_nt_x3(g, 0, S(stream)) : launch_gemm_nt_bf16(g, 0, S(stream));
 }
 int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {
     GemmGroup g; memset(&g, 0, sizeof g);
     g.count = 1; g.drop = make_drop(0.f, 0, 0);
     GemmProblem& p = g.p[0];
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.epi = EPI_BIAS;
+    if (dtype == 2) return launch_gemm_tn_x3(g, S(stream));
     return dtype == 1 ? launch_gemm_tn_bf16(g, 1, S(stream)) : launch_gemm_f32(g, 1, 1, S(stream));
 }
 int rgqa_op_layernorm(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int N, float eps, int dtype, void* stream) {
+    if (dtype == 2) return k_ln_fwd<sf32>((const sf32*)x, N, gamma, beta, (sf32*)y, N, mean, rstd, M, N, eps, S(stream));
     if (dtype == 1) return k_ln_fwd<bf16_t>((const bf16_t*)x, N, gamma, beta, (bf16_t*)y, N, mean, rstd, M, N, eps, S(stream));
     return k_ln_fwd<float>((const float*)x, N, gamma, beta, (float*)y, N, mean, rstd, M, N, eps, S(stream));
 }
 int rgqa_op_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                           float* ws, int M, int N, int dtype, void* stream) {
     const DropCfg nd = make_drop(0.f, 0, 0);
+    if (dtype == 2) return k_ln_bwd<sf32>((const sf32*)dy, N, (const sf32*)x, N, gamma, mean, rstd, (sf32*)dx, nullptr, N, ws, dgamma, dbeta, nullptr, 0, M, N, nd, nd, 1.f, S(stream));
     if (dtype == 1) return k_ln_bwd<bf16_t>((const bf16_t*)dy, N, (const bf16_t*)x, N, gamma, mean, rstd, (bf16_t*)dx, nullptr, N, ws, dgamma, dbeta, nullptr, 0, M, N, nd, nd, 1.f, S(stream));
     return k_ln_bwd<float>((const float*)dy, N, (const float*)x, N, gamma, mean, rstd, (float*)dx, nullptr, N, ws, dgamma, dbeta, nullptr, 0, M, N, nd, nd, 1.f, S(stream));
 }
@@ -290,6 +268,7 @@ static void fill_attn(AttnArgs& a, const void* qkv, const float* mask, int B, in
 int rgqa_op_attention(const void* qkv, const float* mask, void* out, float* lse, int B, int nh, int L, int dh, int dtype, int impl, void* stream) {
     AttnArgs a; fill_attn(a, qkv, mask, B, nh, L, dh, dtype == 1 ? 2 : 4);
     a.out = out; a.ldo = nh * dh; a.lse = lse;
+    if (dtype == 2) return impl == 1 ? k_attn_fwd_x3(a, S(stream)) : k_attn_fwd_ref<sf32>(a, S(stream));
     if (dtype == 1) return impl == 1 ? k_attn_fwd_mfma(a, S(stream)) : k_attn_fwd_ref<bf16_t>(a, S(stream));
     return k_attn_fwd_ref<float>(a, S(stream));
 }
@@ -299,6 +278,7 @@ int rgqa_op_attention_bwd(const void* qkv, const float* mask, const float* lse, 
     const int H = nh * dh;
     a.lse = const_cast<float*>(lse); a.dout = dout; a.lddo = H;
     a.dq = dqkv; a.dk = (char*)dqkv + (size_t)H * esz; a.dv = (char*)dqkv + (size_t)2 * H * esz; a.lddq = a.lddk = a.lddv = 3 * H;
+    if (dtype == 2) return impl == 1 ? k_attn_bwd_x3(a, S(stream)) : k_attn_bwd_ref<sf32>(a, S(stream));
     if (dtype == 1) return impl == 1 ? k_attn_bwd_mfma(a, S(stream)) : k_attn_bwd_ref<bf16_t>(a, S(stream));
     return k_attn_bwd_ref<float>(a, S(stream));
 }

@@ -46,10 +46,79 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     *reinterpret_cast<bf16x4*>(p) = t;
 }
 
+// ---------------------------------------------------------------- split-f32 storage ("bf16x3" precision)
+// An f32 value x is kept as two bf16 numbers hi = bf16(x), lo = bf16(x - hi): hi + lo carries 16-17 significant bits
+// (relative error <= 2^-17) and products of such pairs are formed on the bf16 matrix pipe as hi*hi + hi*lo + lo*hi
+// (three MFMAs, f32 accumulate; the dropped lo*lo term is below 2^-16 relative).  Layout: rows of ld elements, ld % 32 == 0,
+// row starts 128-byte aligned; the 32 consecutive elements 32b .. 32b+31 of a row occupy ONE 128-byte line:
+// bytes [0,64) their 32 hi parts, bytes [64,128) their 32 lo parts.  A matrix operand therefore reads as a bf16 matrix
+// of 2*ld columns whose 64-column K-steps hold [32 hi | 32 lo] of 32 contraction elements: the LDS-DMA GEMM kernels
+// stage it unchanged and only their MFMA streams differ.  Storage is 4 bytes per element, so `sf32*` pointer arithmetic
+// in ELEMENTS addresses rows and 32-aligned columns exactly as `float*` would; inside a line the address of an
+// element's parts is decoded from the slot address itself (sf_hi): no base pointer is needed.
+struct sf32 { uint32_t slot; };      // one element slot; never read as a value
+__device__ __forceinline__ const unsigned char* sf_hi(const sf32* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    return reinterpret_cast<const unsigned char*>((a & ~(uintptr_t)127) + ((a & 127) >> 1));      // lo part: + 64
+}
+__device__ __forceinline__ unsigned char* sf_hi(sf32* p) { return const_cast<unsigned char*>(sf_hi(const_cast<const sf32*>(p))); }
+__device__ __forceinline__ void sf_split(float x, bf16_t& hi, bf16_t& lo) { hi = (bf16_t)x; lo = (bf16_t)(x - (float)hi); }
+__device__ __forceinline__ float sf_load1(const sf32* p) {
+    const unsigned char* h = sf_hi(p);
+    return (float)*reinterpret_cast<const bf16_t*>(h) + (float)*reinterpret_cast<const bf16_t*>(h + 64);
+}
+__device__ __forceinline__ void sf_store1(sf32* p, float x) {
+    unsigned char* h = sf_hi(p);
+    bf16_t a, b; sf_split(x, a, b);
+    *reinterpret_cast<bf16_t*>(h) = a; *reinterpret_cast<bf16_t*>(h + 64) = b;
+}
+// 4 consecutive elements, first index a multiple of 4
+__device__ __forceinline__ void load4(const sf32* p, float v[4]) {
+    const unsigned char* h = sf_hi(p);
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(h), b = *reinterpret_cast<const bf16x4*>(h + 64);
+    v[0] = (float)a[0] + (float)b[0]; v[1] = (float)a[1] + (float)b[1]; v[2] = (float)a[2] + (float)b[2]; v[3] = (float)a[3] + (float)b[3];
+}
+__device__ __forceinline__ void store4(sf32* p, const float v[4]) {
+    unsigned char* h = sf_hi(p);
+    bf16x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bf16_t x, y; sf_split(v[i], x, y); a[i] = x; b[i] = y; }
+    *reinterpret_cast<bf16x4*>(h) = a; *reinterpret_cast<bf16x4*>(h + 64) = b;
+}
+// 8 consecutive elements, first index a multiple of 8: two 16-byte accesses
+__device__ __forceinline__ void sf_load8(const sf32* p, float v[8]) {
+    const unsigned char* h = sf_hi(p);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(h), b = *reinterpret_cast<const bf16x8*>(h + 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i] + (float)b[i];
+}
+__device__ __forceinline__ void sf_store8(sf32* p, const float v[8]) {
+    unsigned char* h = sf_hi(p);
+    bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { bf16_t x, y; sf_split(v[i], x, y); a[i] = x; b[i] = y; }
+    *reinterpret_cast<bf16x8*>(h) = a; *reinterpret_cast<bf16x8*>(h + 64) = b;
+}
+// scalar element access for any activation type (the generic LDS / VALU kernels)
+__device__ __forceinline__ float ld_elem(const float* p) { return *p; }
+__device__ __forceinline__ float ld_elem(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ float ld_elem(const sf32* p) { return sf_load1(p); }
+__device__ __forceinline__ void st_elem(float* p, float x) { *p = x; }
+__device__ __forceinline__ void st_elem(bf16_t* p, float x) { *p = (bf16_t)x; }
+__device__ __forceinline__ void st_elem(sf32* p, float x) { sf_store1(p, x); }
+
 // raw (unconverted) 4-element loads: lets a kernel issue the next row's loads before it consumes the current row
 template <typename T> struct raw4;
 template <> struct raw4<float> { float4 v; };
 template <> struct raw4<bf16_t> { bf16x4 v; };
+template <> struct raw4<sf32> { bf16x4 h, l; };
+__device__ __forceinline__ void load_raw4(const sf32* p, raw4<sf32>& r) {
+    const unsigned char* a = sf_hi(p);
+    r.h = *reinterpret_cast<const bf16x4*>(a); r.l = *reinterpret_cast<const bf16x4*>(a + 64);
+}
+__device__ __forceinline__ void cvt_raw4(const raw4<sf32>& r, float v[4]) {
+    v[0] = (float)r.h[0] + (float)r.l[0]; v[1] = (float)r.h[1] + (float)r.l[1]; v[2] = (float)r.h[2] + (float)r.l[2]; v[3] = (float)r.h[3] + (float)r.l[3];
+}
 __device__ __forceinline__ void load_raw4(const float* p, raw4<float>& r) { r.v = *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void load_raw4(const bf16_t* p, raw4<bf16_t>& r) { r.v = *reinterpret_cast<const bf16x4*>(p); }
 __device__ __forceinline__ void cvt_raw4(const raw4<float>& r, float v[4]) { v[0] = r.v.x; v[1] = r.v.y; v[2] = r.v.z; v[3] = r.v.w; }

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict_
     const int t = src % Tn;
     const int64_t id = ids[src], sg = seg ? seg[src] : 0;
     for (int n = threadIdx.x; n < H; n += 256) {
-        const float g = to_f32(de[(size_t)row * H + n]);
+        const float g = ld_elem(de + (size_t)row * H + n);
         if (id != 0) atomicAdd(dword + (size_t)id * H + n, g);
         if (t != 0 || !pad0_all) atomicAdd(dpos + (size_t)t * H + n, g);
         if (sg != 0 || !pad0_all) atomicAdd(dtype + (size_t)sg * H + n, g);
@@ -118,5 +118,7 @@ int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s) {
 
 template int k_embed_fwd<float>(const int64_t*, const int64_t*, const int*, const int*, int, const float*, const float*, const float*, const float*, const float*, float*, int, float*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
 template int k_embed_fwd<bf16_t>(const int64_t*, const int64_t*, const int*, const int*, int, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, bf16_t*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
+template int k_embed_fwd<sf32>(const int64_t*, const int64_t*, const int*, const int*, int, const float*, const float*, const float*, const float*, const float*, sf32*, int, sf32*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
+template int k_embed_scatter<sf32>(const sf32*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, hipStream_t);
 template int k_embed_scatter<float>(const float*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, hipStream_t);
 template int k_embed_scatter<bf16_t>(const bf16_t*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, hipStream_t);

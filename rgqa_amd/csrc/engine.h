@@ -112,10 +112,6 @@ public:
     float* sumsq_slots = nullptr; float* sumsq_ws = nullptr; int sumsq_ws_segs = 0;
     virtual int set_input_grads(float* dfeats, float* dboxes) { (void)dfeats; (void)dboxes; rgqa_set_error("set_input_grads: not supported by this engine"); return RGQA_ERR_ARG; }
     // per-sample real token counts for the following forward passes (packed language rows); null: padded layout
-    // optimizer / forward pipelining (rgqa_engine_set_weight_events): events the NEXT passes wait for before they read parameters
-    hipEvent_t wev_first = nullptr, wev_cross = nullptr, wev_all = nullptr;
-    // finer: one event per gradient segment (index = the segment's event id), waited for before the layer's first kernel of a forward pass
-    std::vector<hipEvent_t> wev_seg;
     virtual int set_lengths(const int* lens, int n) { (void)lens; (void)n; rgqa_set_error("set_lengths: not supported by this engine"); return RGQA_ERR_ARG; }
 };
 

@@ -148,22 +148,29 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 // sat 0.17 ms per step waiting for the set of two periods ago (profiles/r02_timeline_b256.txt); with four it runs on and the side stream
 // catches up beside the longer chains of the paired layers that follow.
 #define NPAR 4
-#define SCHED_SLOTS 1024
 #define LNPART_BLOCKS 1536     // per layer: <= 3 LayerNorm-backward launches of <= 512 blocks
-int g_rgqa_ln_defer = -1;      // rgqa_debug_set key 10: 0 = every LayerNorm backward finalises its column sums at once on the main stream; 1 / -1 = once per layer, with the layer's wgrad launch
-int g_rgqa_wgrad_phase = -1;   // rgqa_debug_set key 11: where a layer's deferred wgrad GEMMs are launched: 0 = after the layer's last stage in backward order (its attention
-                               // block), 1 = after every FFN stage (the launch then holds the attention wgrads of the layer above and this layer's FFN wgrads, and runs
-                               // beside this layer's LayerNorm / attention kernels instead of beside the next layer's FFN GEMMs: -0.08 ms per step); -1 = env RGQA_WGRAD_PHASE (layer | ffn, default ffn)
-int g_rgqa_nt_tickets = -1;    // rgqa_debug_set key 12: persistent forward / dgrad GEMMs hand out their tiles by ticket (GemmGroup::sched): 0 = no (fixed walk), N > 0 = yes, with
-                               // the first N blocks of a launch starting on a fixed tile (N >= 256: all of them); -1 = env RGQA_NT_TICKETS (default 0)
-extern int g_rgqa_nt_static_blocks;
-int g_rgqa_dgrad_nn = -1;      // rgqa_debug_set key 14: 1 = dgrad GEMMs read the weight as stored (no transposed copy), 0 = the transposed bf16 copy, -1 = env RGQA_DGRAD_NN
 int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
 
 template <typename T>
 class Engine : public EngineBase {
 public:
-    static constexpr bool LP = !std::is_same<T, float>::value;
+    static constexpr bool LP = !std::is_same<T, float>::value;       // operand copies of the weights (direct + transposed) exist
+    static constexpr bool X3 = std::is_same<T, sf32>::value;         // split-f32 activations and operand copies (bf16x3 precision)
+    static int nt_gemm(GemmGroup& g, int out_f32, int trans_b, hipStream_t s) {
+        if constexpr (X3) return launch_gemm_nt_x3(g, out_f32, s);
+        else if constexpr (LP) return launch_gemm_nt_bf16(g, out_f32, s);
+        else return launch_gemm_f32(g, 0, trans_b, s);
+    }
+    static int tn_gemm(GemmGroup& g, hipStream_t s) {
+        if constexpr (X3) return launch_gemm_tn_x3(g, s);
+        else if constexpr (LP) return launch_gemm_tn_bf16(g, 1, s);
+        else return launch_gemm_f32(g, 1, 1, s);
+    }
+    // f32 -> the activation type of the LDS-DMA GEMM operands (the RoI features)
+    static int cast_lp(const float* src, T* dst, size_t n, hipStream_t s) {
+        if constexpr (X3) return k_cast_split(src, dst, n, s);
+        else return k_cast_bf16(src, dst, n, s);
+    }
     ModelParams mp;
     std::vector<Stage> stages;
     // bound memory
@@ -182,16 +189,13 @@ public:
     float* logits = nullptr; T* dlogits = nullptr; float* loss_dev = nullptr;
     T *gA = nullptr, *gB = nullptr, *gctx = nullptr;
     T *gz_s[NPAR][3] = {}, *gzd_s[NPAR][3] = {}, *gqkv_s[NPAR][3] = {}, *gh_s[NPAR][3] = {};   // [ring position of the launch period][stage slot]
-    hipStream_t s_v = nullptr; hipEvent_t ev_v[2] = {nullptr, nullptr};   // vision chain of the single-modality layers (forward, experiment)
     hipStream_t s_w = nullptr;                 // side stream: the deferred weight-gradient GEMMs of a layer run beside the next layer's chain
     hipEvent_t ev_chain[NPAR] = {}, ev_wdone[NPAR] = {};
     bool wdone_valid[NPAR] = {};
     T* gemb = nullptr;
     T *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
-    bool ln_merge = !(getenv("RGQA_LN_MERGE") && getenv("RGQA_LN_MERGE")[0] == '0');   // one LayerNorm launch over [language | vision] rows
-    float* wpart = nullptr; size_t wpart_elems = 0;
+    static constexpr bool ln_merge = true;   // one LayerNorm launch over [language | vision] rows
     float* lnpart_s[NPAR] = {}; FinDefer fin; int fin_accumulate = 0;   // LayerNorm-backward column sums of the open layer (finalised with its wgrad launch)
-    int* sched_pool = nullptr; int sched_cursor = 0;       // one zeroed ticket word per persistent GEMM launch of a step (SCHED_SLOTS, 64 B apart)
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
     void* lang_final = nullptr;
     std::vector<TransDesc> tdesc_host;
@@ -264,10 +268,7 @@ public:
         wdone_valid[par] = true;
         return RGQA_OK;
     }
-    static int wgrad_sets() {
-        static const int n = []() { const char* e = getenv("RGQA_WGRAD_SETS"); int v = e ? atoi(e) : NPAR; return v < 2 ? 2 : (v > NPAR ? NPAR : v); }();
-        return n;
-    }
+    static int wgrad_sets() { return NPAR; }
     // every launch on the side stream has joined `s` (the side stream is in order: the newest event covers the older ones); `next` = the set the
     // next period would use
     int join_wgrad(int next, hipStream_t s) {
@@ -307,18 +308,13 @@ public:
 
     void build_transpose_table() {
         // every [out,in] linear weight gets a transposed low-precision copy at the same arena offset
-        nn_only = LP && dgrad_nn_env();
-        auto add = [&](const Lin& l, int row_block = 0) {
-            // row_block: the smallest block of weight rows a dgrad of this module contracts (0: always the whole module; the fused q|k|v
-            // projection: its q block).  With nn_only only modules with a contraction that is not a multiple of 64 keep a transposed copy
-            // (the answer head's last layer, 1842 rows).
-            if (nn_only && dgrad_nn_shape(l, l.out) && (row_block == 0 || row_block % 64 == 0)) return;
+        auto add = [&](const Lin& l) {
             TransDesc d; d.src_off = (long)l.w; d.dst_off = (long)l.w; d.N = l.out; d.K = l.in; d.ld_dst = l.ldt; d.tile_start = tdesc_tiles;
             tdesc_tiles += cdiv(l.ldt, TRANSPOSE_TILE) * cdiv(l.in, TRANSPOSE_TILE);
             tdesc_host.push_back(d);
         };
         add(mp.visn_fc);
-        auto addatt = [&](const AttP& a) { add(a.qkv, a.qkv.out / 3); add(a.o); };
+        auto addatt = [&](const AttP& a) { add(a.qkv); add(a.o); };
         auto addffn = [&](const FfnP& f) { add(f.up); add(f.down); };
         for (auto& a : mp.l_att) addatt(a);
         for (auto& f : mp.l_ffn) addffn(f);
@@ -439,7 +435,6 @@ public:
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
         for (int par = 0; par < NPAR; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
-        sched_pool = take<int>((size_t)SCHED_SLOTS * 16);
         sumsq_ws_segs = (int)grad_segs.size(); sumsq_ws = take<float>((size_t)sumsq_ws_segs * 1024);
         if (joint) {
             const size_t ni = (size_t)B * Oi, nt = (size_t)B * Tt;
@@ -449,10 +444,6 @@ public:
             u_st = take<float>(6 * ni);
             feats_lp = LP ? take<T>(ni * cfg.feat_dim) : nullptr;
         }
-        // split-contraction partials of one grouped weight-gradient launch (gemm_mfma256.hip plan_tn): up to 3 extra chunks of
-        // the largest layer's weights (cross + two self-attention blocks + two FFNs), f32
-        wpart_elems = LP ? (size_t)3 * ((size_t)12 * H * H + (size_t)4 * H * I + 65536) : 0;
-        wpart = LP ? take<float>(wpart_elems) : nullptr;
         tdesc = take<TransDesc>(n_tdesc + 1);
     }
     int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr; T* tail_x = nullptr; T* tail_dx = nullptr; T* pool_in = nullptr;
@@ -478,7 +469,8 @@ public:
         RGQA_REQUIRE(p != nullptr && w != nullptr, "bind: null parameter arena or workspace");
         RGQA_REQUIRE(B_ > 0 && T_ > 0 && O_ > 0 && T_ <= 64 && O_ <= 64, "bind: B=%d T=%d O=%d unsupported (T, O <= 64)", B_, T_, O_);
         RGQA_REQUIRE(T_ <= cfg.max_pos, "bind: T=%d exceeds max_position_embeddings=%d", T_, cfg.max_pos);
-        if (LP) RGQA_REQUIRE(plp != nullptr && plpt != nullptr, "bind: bf16 precision needs the low-precision arenas");
+        if (LP) RGQA_REQUIRE(plp != nullptr && plpt != nullptr, "bind: bf16 / bf16x3 precision needs the operand-copy arenas");
+        if (X3) RGQA_REQUIRE(((uintptr_t)plp % 128) == 0 && ((uintptr_t)plpt % 128) == 0, "bind: the split-f32 arenas must be 128-byte aligned");
         RGQA_REQUIRE(((uintptr_t)p % 256) == 0 && ((uintptr_t)w % 256) == 0, "bind: arenas must be 256-byte aligned");
         size_t need = workspace_bytes(B_, T_, O_);
         if (wb < need) { rgqa_set_error("bind: workspace too small (%zu < %zu bytes)", wb, need); return RGQA_ERR_WORKSPACE; }
@@ -527,7 +519,7 @@ public:
     int sync_weights(hipStream_t s) override {
         RGQA_REQUIRE(P != nullptr, "sync_weights: engine not bound");
         if (!LP) return RGQA_OK;
-        int r = k_cast_bf16(P, Pb, arena_elems, s);
+        int r = cast_lp(P, Pb, arena_elems, s);
         if (r) return r;
         return sync_transposed(s);
     }
@@ -539,7 +531,8 @@ public:
             RGQA_HIP(hipMemcpyAsync(tdesc, tdesc_host.data(), sizeof(TransDesc) * n_tdesc, hipMemcpyHostToDevice, s));
             tdesc_uploaded = true;
         }
-        return k_cast_transpose(Pb, 1, PbT, tdesc, n_tdesc, tdesc_tiles, s);     // from the bf16 copy (the optimizer kernel / sync_weights wrote it): half the read bytes
+        if constexpr (X3) return k_cast_transpose(P, 0, PbT, 1, tdesc, n_tdesc, tdesc_tiles, s);
+        return k_cast_transpose(Pb, 1, PbT, 0, tdesc, n_tdesc, tdesc_tiles, s);     // from the bf16 copy (the optimizer kernel / sync_weights wrote it): half the read bytes
     }
 
     // ------------------------------------------------------------------ GEMM helpers
@@ -559,28 +552,11 @@ public:
         p.aux = aux; p.ldaux = ldaux; p.epi = epi; p.drop_site = site;
     }
     // dx[rows, in] = dy[rows, cols] @ W[wrow0 : wrow0+cols, :]      ; DGRAD
-    // dgrad straight from the [out, in] weight (NN form): contraction a whole number of K-steps, rows 16-byte aligned
-    static bool dgrad_nn_env() {
-        static const bool env = getenv("RGQA_DGRAD_NN") != nullptr && getenv("RGQA_DGRAD_NN")[0] == '1';
-        return env;
-    }
-    // nn_only (RGQA_DGRAD_NN=1 when the engine was created): the transposed copy of a weight whose dgrads can all take the [K,N] form is
-    // never written (build_transpose_table), so those dgrads take it whatever rgqa_debug_set key 14 says later
-    bool nn_only = false;
-    bool dgrad_mixed = false;      // a group mixing [K,N] and [N,K] weight operands was built (never for the encoder's layer shapes): run_dgrad refuses it
-    static bool dgrad_nn_shape(const Lin& l, int wrows) { return wrows % 64 == 0 && wrows >= 64 && l.in % 8 == 0 && l.in >= 64; }
-    bool dgrad_nn(const Lin& l, int wrows) const {
-        const bool on = nn_only || (g_rgqa_dgrad_nn < 0 ? dgrad_nn_env() : g_rgqa_dgrad_nn != 0);
-        return on && dgrad_nn_shape(l, wrows);
-    }
     void add_dgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, void* dx, int lddx, int M, int epi, const void* aux, int ldaux) {
         GemmProblem& p = g.p[g.count++];
         memset(&p, 0, sizeof p);
         p.A = dy; p.lda = lddy; p.M = M; p.N = l.in; p.C = dx; p.ldc = lddx;
-        if (LP && dgrad_nn(l, wrows) && (g.count == 1 || g.b_kn)) {
-            // the weight as stored, [out, in]: rows wrow0 .. wrow0 + wrows are the contraction, no transposed copy involved (gemm.h b_kn)
-            g.b_kn = 1; p.B = Pb + l.w + (size_t)wrow0 * l.in; p.ldb = l.in; p.K = wrows;
-        } else if (LP) { if (g.b_kn) dgrad_mixed = true; p.B = PbT + l.w + wrow0; p.ldb = l.ldt; p.K = (wrow0 + wrows == l.out) ? (int)rup(wrows, 64) : wrows; if (p.K > l.ldt - wrow0) p.K = l.ldt - wrow0; }   // the transposed copy and dy are zero-padded up to ldt = round_up(out, 64): a whole number of K-steps for the LDS-DMA kernel
+        if (LP) { p.B = PbT + l.w + wrow0; p.ldb = l.ldt; p.K = (wrow0 + wrows == l.out) ? (int)rup(wrows, 64) : wrows; if (p.K > l.ldt - wrow0) p.K = l.ldt - wrow0; }   // the transposed copy and dy are zero-padded up to ldt = round_up(out, 64): a whole number of K-steps for the LDS-DMA kernel
         else { p.B = P + l.w + (size_t)wrow0 * l.in; p.ldb = l.in; p.K = wrows; }
         p.aux = aux; p.ldaux = ldaux; p.epi = epi;
     }
@@ -600,48 +576,29 @@ public:
             bytes += sizeof(T) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
         }
     }
-    static int nt_tickets() {
-        static const int env = []() { const char* e = getenv("RGQA_NT_TICKETS"); return e ? atoi(e) : 0; }();
-        return g_rgqa_nt_tickets < 0 ? env : g_rgqa_nt_tickets;
-    }
-    // forward() zeroes the pool once; every GEMM launch of the step (forward and backward) takes the next word
-    int sched_reset(hipStream_t s) {
-        sched_cursor = 0;
-        if (nt_tickets() > 0 && sched_pool != nullptr) RGQA_HIP(hipMemsetAsync(sched_pool, 0, (size_t)SCHED_SLOTS * 16 * sizeof(int), s));
-        return RGQA_OK;
-    }
-    void sched_assign(GemmGroup& g) {
-        const int n = nt_tickets();
-        g.sched = nullptr;
-        if (n > 0 && sched_pool != nullptr && sched_cursor < SCHED_SLOTS && !profiling) { g.sched = sched_pool + (size_t)(sched_cursor++) * 16; g_rgqa_nt_static_blocks = n; }
-    }
     int run_fwd(GemmGroup& g, hipStream_t s, int out_f32 = 0, int a_f32 = 0) {
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = a_f32;
-        sched_assign(g);
         double f, b; gemm_work(g, f, b);
         prof_begin(PC_GEMM_NT, f, b, s);
-        int r = LP ? launch_gemm_nt_bf16(g, out_f32, s) : launch_gemm_f32(g, 0, 0, s);
+        int r = nt_gemm(g, out_f32, 0, s);
         prof_end(s);
         return r;
     }
     int run_dgrad(GemmGroup& g, hipStream_t s) {
         if (g.count == 0) return RGQA_OK;
-        RGQA_REQUIRE(!dgrad_mixed, "dgrad: one grouped launch mixes stored and transposed weight operands");
-        sched_assign(g);
         double f, b; gemm_work(g, f, b);
         prof_begin(PC_GEMM_NT, f, b, s);
-        int r = LP ? launch_gemm_nt_bf16(g, 0, s) : launch_gemm_f32(g, 0, 1, s);
+        int r = nt_gemm(g, 0, 1, s);
         prof_end(s);
         return r;
     }
     int run_wgrad(GemmGroup& g, hipStream_t s, int b_f32 = 0) {
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = b_f32;
-        g.tn_scratch = wpart; g.tn_scratch_bytes = wpart_elems * sizeof(float);
         double f, b; gemm_work(g, f, b);
         prof_begin(PC_GEMM_TN, f, b, s);
-        int r = LP ? launch_gemm_tn_bf16(g, 1, s) : launch_gemm_f32(g, 1, 1, s);
+        int r = tn_gemm(g, s);
         prof_end(s);
         return r;
     }
@@ -656,10 +613,13 @@ public:
     // The pooler reads only token 0 of the final language output (modeling.py:575-581) and nothing else reads that output in mode
     // 'x': the FFN sub-block of the LAST cross-modality layer runs on the B [CLS] rows only (gathered in, kept compact: rows 0..B-1
     // of the stage buffers), forward and backward.  RGQA_CLS_TAIL=0 computes every row as the reference does.
-    bool cls_tail(const Stage& st) const {
+    bool fwd_cls_tail = true;          // latched by forward(): backward and get_activation follow the layout of the recorded pass
+    static bool cls_tail_wanted() {
         static const bool env_on = []() { const char* e = getenv("RGQA_CLS_TAIL"); return !(e && e[0] == '0'); }();
-        const bool on = g_rgqa_cls_tail < 0 ? env_on : g_rgqa_cls_tail != 0;       // rgqa_debug_set key 8 (tests: both paths in one process)
-        return on && cfg.arch == 0 && st.kind == ST_FFN && st.last_dead && st.active[0] && !st.active[1] && &st == &stages.back();
+        return g_rgqa_cls_tail < 0 ? env_on : g_rgqa_cls_tail != 0;       // rgqa_debug_set key 8 (tests: both paths in one process)
+    }
+    bool cls_tail(const Stage& st) const {
+        return fwd_cls_tail && cfg.arch == 0 && st.kind == ST_FFN && st.last_dead && st.active[0] && !st.active[1] && &st == &stages.back();
     }
     int seg_rows(int m) const { return m == 0 ? Rl : Rv; }
     int seg_len(int m) const { return m == 0 ? Tn : O; }
@@ -765,7 +725,7 @@ public:
                                      emb_mean, emb_rstd, B, Tt, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
         // image: LN(img_linear(feat)) + LN(pos_linear(pos)) + type_emb[1] -> LayerNorm -> dropout
         GemmGroup g; gg_init(g);
-        if (LP) CKP(PC_OTHER, k_cast_bf16(feats, feats_lp, (size_t)ni * cfg.feat_dim, s));
+        if (LP) CKP(PC_OTHER, cast_lp(feats, feats_lp, (size_t)ni * cfg.feat_dim, s));
         add_fwd(g, LP ? (const void*)feats_lp : (const void*)feats, cfg.feat_dim, mp.visn_fc, 0, H, u_zf, H, ni, EPI_BIAS, nullptr, 0, nullptr, 0);
         CK(run_fwd(g, s));
         CKP(PC_LN, k_ln_fwd<T>(u_zf, H, P + mp.visn_ln.w, P + mp.visn_ln.b, u_a1, H, u_st, u_st + ni, ni, H, cfg.ln_eps, s));
@@ -826,16 +786,9 @@ public:
             } else
             if (varlen && lens_dirty) { CK(k_set_lengths(lens_host.data(), B, Tn, lens_dev, cu_dev, row_src_dev, s)); lens_dirty = false; }
             fwd_varlen = varlen;
+            fwd_cls_tail = cls_tail_wanted();
         }
         const int* cu = fwd_varlen ? cu_dev : nullptr;
-        CK(sched_reset(s));
-        hipEvent_t seg_waited = nullptr;
-        auto wait_seg = [&](int id) -> int {      // weights of gradient segment `id` are updated (rgqa_engine_set_segment_weight_events)
-            if (id >= 0 && id < (int)wev_seg.size() && wev_seg[id] != nullptr && wev_seg[id] != seg_waited) { RGQA_HIP(hipStreamWaitEvent(s, wev_seg[id], 0)); seg_waited = wev_seg[id]; }
-            return RGQA_OK;
-        };
-        CK(wait_seg(n_seg_events - 1));           // embeddings, visual feature projection
-        if (wev_first) RGQA_HIP(hipStreamWaitEvent(s, wev_first, 0));      // embeddings + single-modality layers updated (rgqa_engine_set_weight_events)
         if (joint) CK(forward_joint_embeddings(feats, boxes, ids, seg, mask, s));
         else {
         if (!fwd_varlen) CKP(PC_OTHER, k_make_mask(mask, maskf, Rl, s));
@@ -844,7 +797,7 @@ public:
         {   // VisualFeatEncoder: GEMM on the RoI features (one f32->bf16 cast pass in bf16 precision, so that this GEMM and
             // its weight-gradient GEMM run on the LDS-DMA kernels), then the fused LN/LN/avg tail
             GemmGroup g; gg_init(g);
-            if (LP) CKP(PC_OTHER, k_cast_bf16(feats, feats_lp, (size_t)Rv * cfg.feat_dim, s));
+            if (LP) CKP(PC_OTHER, cast_lp(feats, feats_lp, (size_t)Rv * cfg.feat_dim, s));
             add_fwd(g, LP ? (const void*)feats_lp : (const void*)feats, cfg.feat_dim, mp.visn_fc, 0, H, zf, H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s));
             CKP(PC_OTHER, k_visn_combine_fwd<T>(zf, H, boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.visn_ln.b, P + mp.box_ln.w, P + mp.box_ln.b,
@@ -853,47 +806,18 @@ public:
         }
         bool gathered = false;
         const size_t n_lr_stages = 2 * (size_t)(cfg.l_layers > cfg.r_layers ? cfg.l_layers : cfg.r_layers);
-        static const bool two_env = getenv("RGQA_FWD_TWO_STREAM") != nullptr;
-        const bool two = two_env && !profiling && cfg.l_layers > 0 && cfg.r_layers > 0;
-        if (two) {
-            if (s_v == nullptr) {
-                RGQA_HIP(hipStreamCreateWithFlags(&s_v, hipStreamNonBlocking));
-                RGQA_HIP(hipEventCreateWithFlags(&ev_v[0], hipEventDisableTiming));
-                RGQA_HIP(hipEventCreateWithFlags(&ev_v[1], hipEventDisableTiming));
-            }
-            RGQA_HIP(hipEventRecord(ev_v[0], s));          // embeddings done
-            RGQA_HIP(hipStreamWaitEvent(s_v, ev_v[0], 0));
-        }
-        bool cross_waited = false;
         for (size_t si = 0; si < stages.size(); ++si) {
             Stage& st = stages[si];
             prof_block = si < n_lr_stages ? PB_LR : PB_X;
-            if (si >= n_lr_stages && !cross_waited) { if (wev_cross) RGQA_HIP(hipStreamWaitEvent(s, wev_cross, 0)); cross_waited = true; }
-            if (st.layer_first) CK(wait_seg(st.seg_event));
             if (st.kind == ST_ATT_CROSS && x0_needed && !gathered) {
                 if (x0_src[0] && Rl > 0) CK(rgqa_check_hip(hipMemcpyAsync(x0, x0_src[0], (size_t)Rl * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather lang"));
                 if (x0_src[1]) CK(rgqa_check_hip(hipMemcpyAsync(x0 + (size_t)Rl * H, x0_src[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather visn"));
                 gathered = true;
             }
-            if (two && si < n_lr_stages) {
-                // language and vision chains of the single-modality layers are independent: two streams, so the small language
-                // launches (and the four language-only layers) run beside vision work instead of alone on the chip
-                Stage sl = st, sv = st;
-                sl.active[1] = 0; sv.active[0] = 0;
-                if (sl.active[0]) CK(forward_stage(sl, cu, s));
-                if (sv.active[1]) CK(forward_stage(sv, cu, s_v));
-                if (si + 1 == n_lr_stages) {
-                    RGQA_HIP(hipEventRecord(ev_v[1], s_v));
-                    RGQA_HIP(hipStreamWaitEvent(s, ev_v[1], 0));
-                }
-                continue;
-            }
             CK(forward_stage(st, cu, s));
         }
         // ---- BertPooler (modeling.py:575-581) + answer head (gqa_model.py:22-27)
         prof_block = PB_HEAD;
-        if (!cross_waited && wev_cross) RGQA_HIP(hipStreamWaitEvent(s, wev_cross, 0));
-        CK(wait_seg(0));                          // pooler + head
         {
             GemmGroup g; gg_init(g);
             pool_in = cls_rows;
@@ -923,7 +847,6 @@ public:
         RGQA_REQUIRE(G != nullptr, "loss_backward: no gradient arena bound");
         // BCE on the f32 logits; dlogits written as f32 into `logits`' sibling then cast+padded to T
         prof_block = PB_HEAD;
-        if (wev_all) RGQA_HIP(hipStreamWaitEvent(s, wev_all, 0));          // every weight copy (the transposed dgrad operands included) is final
         float* dl32 = part;   // scratch [B, NAp] f32
         CKP(PC_OTHER, k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, cfg.num_answers, NAp, grad_scale, s));
         if (loss_out) CK(rgqa_check_hip(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s), "loss copy"));
@@ -933,7 +856,6 @@ public:
     int backward(const float* dl, int ldd, int accumulate, hipStream_t s) override {
         RGQA_REQUIRE(have_fwd, "backward: no forward pass recorded");
         RGQA_REQUIRE(G != nullptr && dl != nullptr, "backward: null gradient arena / dlogits");
-        if (wev_all) RGQA_HIP(hipStreamWaitEvent(s, wev_all, 0));
         CKP(PC_OTHER, k_cast_pad<T>(dl, ldd, dlogits, NAp, B, cfg.num_answers, 1.0f, s));
         return backward_impl(accumulate, s);
     }
@@ -1019,8 +941,10 @@ public:
         // ---- encoder stages in reverse; weight-gradient GEMMs are collected per layer and launched once
         GemmGroup wg; gg_init(wg);
         int par = 0; bool layer_open = false;
-        static const bool phase_env = !(getenv("RGQA_WGRAD_PHASE") != nullptr && getenv("RGQA_WGRAD_PHASE")[0] == 'l');     // default: ffn
-        const bool phase_ffn = g_rgqa_wgrad_phase < 0 ? phase_env : g_rgqa_wgrad_phase != 0;
+        // Where a layer's deferred wgrad GEMMs are launched: after every FFN stage - the launch then holds the attention wgrads of the layer
+        // above and this layer's FFN wgrads, and runs beside this layer's LayerNorm / attention kernels instead of beside the next layer's FFN
+        // GEMMs (-0.08 ms per step against one launch per layer, round 2)
+        constexpr bool phase_ffn = true;
         int flushes = 0;
         // phase_ffn: the first launch holds the last layer's FFN only (no layer is complete yet); every later one completes the layer above
         auto flush_after = [&](const Stage& st) { return phase_ffn ? st.kind == ST_FFN : st.layer_first != 0; };
@@ -1035,8 +959,7 @@ public:
             if (!layer_open) {     // first stage (in backward order) of a layer
                 CK(wait_wgrad(par, s)); layer_open = true;
                 fin_accumulate = accumulate;
-                static const bool defer_env = !(getenv("RGQA_LN_DEFER") && getenv("RGQA_LN_DEFER")[0] == '0');
-                if (g_rgqa_ln_defer < 0 ? defer_env : g_rgqa_ln_defer != 0) fin.begin(lnpart_s[par], LNPART_BLOCKS, H); else fin.begin(nullptr, 0, 0);
+                fin.begin(lnpart_s[par], LNPART_BLOCKS, H);     // LayerNorm-backward column sums: folded once per layer, with the layer's wgrad launch
             }
             T* gz = gz_s[par][st.slot]; T* gzd = gzd_s[par][st.slot]; T* gqkv = gqkv_s[par][st.slot]; T* gh = gh_s[par][st.slot];
             const bool cross = st.kind == ST_ATT_CROSS;
@@ -1185,9 +1108,7 @@ public:
         // `par` is now the OLDER gradient-buffer set (its weight-gradient launch precedes the first layer's on the side stream):
         // join it here - its qkv buffer becomes the split-K scratch below - and let the first layer's weight gradients, still
         // running on the side stream, overlap the embedding backward; they are joined at the end.
-        static const bool late_join = !(getenv("RGQA_WGRAD_LATE_JOIN") && getenv("RGQA_WGRAD_LATE_JOIN")[0] == '0');
         CK(wait_wgrad(par, s));
-        if (!late_join) CK(join_wgrad(par, s));
         prof_block = PB_EMBED;
         if (joint) {
             CK(backward_joint_embeddings(dyp[0], accumulate, s));
@@ -1217,8 +1138,7 @@ public:
             int S = Rv / 1024; if (S > 8) S = 8;
             const size_t scratch_bytes = (size_t)(Rl > 0 ? B * Tn + Rv : Rv) * 3 * H * sizeof(T);
             while (S > 1 && (size_t)S * wsz * sizeof(float) > scratch_bytes) --S;
-            static const bool no_split = getenv("RGQA_VISN_WGRAD_NOSPLIT") != nullptr;
-            if (LP && S >= 2 && !no_split && (wsz % 4) == 0) {
+            if (LP && S >= 2 && (wsz % 4) == 0) {
                 float* part_w = reinterpret_cast<float*>(gqkv_s[par][0]);
                 const int kc = (Rv / S) / 64 * 64;
                 gg_init(g);
@@ -1241,7 +1161,7 @@ public:
                 add_dgrad(g, dzf, H, mp.visn_fc, 0, H, dfeats_out, cfg.feat_dim, Rv, EPI_BIAS, nullptr, 0);
                 double f, b; gemm_work(g, f, b);
                 prof_begin(PC_GEMM_NT, f, b, s);
-                int r = LP ? launch_gemm_nt_bf16(g, 1, s) : launch_gemm_f32(g, 0, 1, s);
+                int r = nt_gemm(g, 1, 1, s);
                 prof_end(s);
                 CK(r);
             }
@@ -1304,13 +1224,21 @@ public:
             if (!visn && i == cfg.x_layers - 1 && cls_tail(stages.back())) n = (size_t)B * H;      // only the B [CLS] rows exist (compact)
         }
         RGQA_REQUIRE(src != nullptr, "get_activation: unknown activation '%s'", name);
-        RGQA_REQUIRE(cap >= n, "get_activation: buffer too small (%zu < %zu)", cap, n);
+        RGQA_REQUIRE(cap == n, "get_activation: '%s' holds %zu elements (%zu rows), the buffer %zu - size it from the layout of the recorded pass (packed rows; only the B [CLS] rows of the last language output)", name, n, n / H, cap);
         return k_to_f32<T>((const T*)src, H, out, H, (int)(n / H), H, s);
     }
 };
 
 template <> int Engine<float>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) { return k_attn_fwd_ref<float>(a, s); }
 template <> int Engine<float>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) { return k_attn_bwd_ref<float>(a, s); }
+template <> int Engine<sf32>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) {
+    if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_fwd_x3(a, s);
+    return k_attn_fwd_ref<sf32>(a, s);
+}
+template <> int Engine<sf32>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) {
+    if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_bwd_x3(a, s);
+    return k_attn_bwd_ref<sf32>(a, s);
+}
 template <> int Engine<bf16_t>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) {
     if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_fwd_mfma(a, s);
     return k_attn_fwd_ref<bf16_t>(a, s);
@@ -1322,5 +1250,6 @@ template <> int Engine<bf16_t>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t
 
 EngineBase* make_engine(const rgqa_config& cfg) {
     if (cfg.precision == RGQA_PRECISION_BF16) return new Engine<bf16_t>(cfg);
+    if (cfg.precision == RGQA_PRECISION_BF16X3) return new Engine<sf32>(cfg);
     return new Engine<float>(cfg);
 }

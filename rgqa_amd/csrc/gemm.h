@@ -40,13 +40,7 @@ struct GemmGroup {
     int count;
     int total_tiles;
     int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
-    int b_kn;           // NT LDS-DMA kernels only: every problem's B operand is stored [K, N] row-major (ldb = row pitch) instead of [N, K]: C = A B.  K % 64 == 0
-    int ablate;         // perf ablation (rgqa_debug_set key 3; results are garbage): 1 = no operand DMA in the K loop, 2 = no LDS reads / MFMAs
     const void* zeros;  // TN LDS-DMA kernel: >= 16 zero bytes on the device (source of the contraction tail's A rows)
-    void* tn_scratch;   // TN LDS-DMA kernel, host side only: f32 scratch for split-contraction partials (null: no splitting)
-    size_t tn_scratch_bytes;
-    int* sched;         // persistent NT kernel: a ZEROED device word of the caller = this launch's tile-ticket counter (null: every block walks tiles blockIdx, +grid, ...)
-    int sched_static;   // set by the launcher: blocks below it start on tile blockIdx, tickets hand out the tiles from it on
     DropCfg drop;
     GemmProblem p[GEMM_MAX_PROBLEMS];
 };
@@ -218,6 +212,9 @@ __device__ __forceinline__ void epi_finish(const GemmProblem& P, const int epi, 
 // host launchers (gemm_mfma.hip / gemm_f32.hip). out_f32: C is float (else bf16). All return RGQA_* codes.
 int launch_gemm_nt_bf16(GemmGroup& g, int out_f32, hipStream_t s);
 int launch_gemm_tn_bf16(GemmGroup& g, int out_f32, hipStream_t s);
+// bf16x3 precision (gemm_x3.hip): A / B (and C, aux unless out_f32) in the split-f32 layout
+int launch_gemm_nt_x3(GemmGroup& g, int out_f32, hipStream_t s);
+int launch_gemm_tn_x3(GemmGroup& g, hipStream_t s);
 // f32 generic: A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; everything f32.
 int launch_gemm_f32(GemmGroup& g, int trans_a, int trans_b, hipStream_t s);
 void gemm_group_finalize(GemmGroup& g, int bm, int bn);

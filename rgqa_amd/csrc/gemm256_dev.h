@@ -1,6 +1,7 @@
-// Device helpers shared by the LDS-DMA NT GEMM kernels (gemm_mfma256.hip, gemm_nt8p.hip): LDS-DMA issue, the swizzled operand
-// image, the XCD-aware tile map and the common epilogue.
+// Device helpers shared by the LDS-DMA GEMM kernels (gemm_nt256.h, gemm_mfma256.hip, gemm_x3.hip): LDS-DMA issue, the swizzled
+// operand image, the XCD-aware tile map and the common epilogue.
 #pragma once
+#include <type_traits>
 #include "gemm.h"
 
 #define TN 256
@@ -51,6 +52,10 @@ __device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch
 // (the operand stages are dead after the last barrier) so that every global access is a full 128-B line: 8 lanes x
 // 16 B per output row, instead of 16 rows x 32 B per store straight out of the MFMA layout (which ran HBM writes
 // at ~1.5-2.4 TB/s).
+// OutT = bf16_t / float / sf32 (split f32: the aux operand is then sf32 as well).  With an sf32 aux operand the tile's aux rows are
+// NOT all requested up front (twice the registers): they are loaded pass by pass, and `after_loads` - the persistent kernel's DMA of
+// the next tile's first K-steps - runs after the last of them (compiler-tracked loads issued behind the untracked LDS-DMA would make
+// every aux wait drain the DMA as well).
 template <typename OutT, int EPI, int MT, typename F>
 __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmProblem& P, unsigned char* lds, int wave, int lane,
                                                int m0, int n0, int wm, int wn, f32x4 (&acc)[MT][4], F&& after_loads) {
@@ -58,6 +63,8 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
     const int fr = lane & 15, fq = lane >> 4;
     constexpr int TP = NT256_TP(MT);                    // m-tiles (16 rows) per pass; TP*4 KiB of f32 per wave
     constexpr bool AUX = (EPI == EPI_RESID_DROP || EPI == EPI_DGELU || EPI == EPI_ADD || EPI == EPI_DTANH || EPI == EPI_DRELU_DROP);
+    constexpr bool SF = std::is_same<OutT, sf32>::value;       // split-f32 result and aux operand
+    constexpr bool AUX_UP = AUX && !SF;                        // bf16 aux: the whole tile's rows in flight before anything else
     unsigned char* wl = lds + wave * (TP * 4096);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
     const int nb = n0 + wn * 64 + ecol;                 // first of this lane's 8 output columns
@@ -70,15 +77,15 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
     if (P.bias != nullptr) { load4(P.bias + nbc, bias8); load4(P.bias + nbc + 4, bias8 + 4); }
     DropCfg dcf = g.drop; dcf.seed_hi ^= P.drop_site;
     // the whole tile's aux rows (residual / gelu'), coalesced 16 B per lane, in flight before anything else happens
-    uint4 auxv[AUX ? 2 * MT : 1];
-    if (AUX) {
+    uint4 auxv[AUX_UP ? 2 * MT : 1];
+    if (AUX_UP) {
 #pragma unroll
         for (int it = 0; it < 2 * MT; ++it) {
             int m = m0 + wm * (16 * MT) + it * 8 + erow; if (m > M - 1) m = M - 1;
             auxv[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(P.aux) + (size_t)m * P.ldaux + nbc);
         }
     }
-    after_loads();      // persistent kernel: the next tile's first K-steps are DMA'd from here on
+    if (!(AUX && SF)) after_loads();      // persistent kernel: the next tile's first K-steps are DMA'd from here on
 #pragma unroll
     for (int pass = 0; pass < MT / TP; ++pass) {
 #pragma unroll
@@ -94,9 +101,19 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
         if (pass == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(bias8[j]));
-            if (AUX) {
+            if (AUX_UP) {
 #pragma unroll
                 for (int it = 0; it < 2 * MT; ++it) asm volatile("" :: "v"(auxv[it].x), "v"(auxv[it].y), "v"(auxv[it].z), "v"(auxv[it].w));
+            }
+        }
+        // split-f32 aux rows of this pass: 2 x 16 B (hi, lo) per lane and row
+        uint4 auxh[AUX && SF ? 2 * TP : 1], auxl[AUX && SF ? 2 * TP : 1];
+        if (AUX && SF) {
+#pragma unroll
+            for (int it = 0; it < 2 * TP; ++it) {
+                int m = m0 + wm * (16 * MT) + pass * TP * 16 + it * 8 + erow; if (m > M - 1) m = M - 1;
+                const unsigned char* h = sf_hi(reinterpret_cast<const sf32*>(P.aux) + (size_t)m * P.ldaux + nbc);
+                auxh[it] = *reinterpret_cast<const uint4*>(h); auxl[it] = *reinterpret_cast<const uint4*>(h + 64);
             }
         }
 #pragma unroll
@@ -109,7 +126,16 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
             if (m >= M || nb >= N) continue;
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             float pre[8];
-            const bf16x8 ax = *reinterpret_cast<const bf16x8*>(&auxv[AUX ? pass * 2 * TP + it : 0]);
+            float ax[8];
+            if (AUX && SF) {
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&auxh[AUX && SF ? it : 0]), xl = *reinterpret_cast<const bf16x8*>(&auxl[AUX && SF ? it : 0]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ax[j] = (float)xh[j] + (float)xl[j];
+            } else {
+                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(&auxv[AUX_UP ? pass * 2 * TP + it : 0]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ax[j] = (float)xb[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += bias8[j];
             if (EPI == EPI_RELU || EPI == EPI_RELU_DROP) {
@@ -123,16 +149,21 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
                 pre[j] = x;
                 if (EPI == EPI_GELU) gelu_and_grad_fast(pre[j], x, pre[j]);      // C = gelu, C2 = gelu' (consumed by EPI_DGELU)
                 else if (EPI == EPI_TANH) x = tanhf(x);
-                else if (EPI == EPI_RESID_DROP) x = x + (float)ax[j];
-                else if (EPI == EPI_DGELU) x = x * (float)ax[j];
-                else if (EPI == EPI_ADD) x = x + (float)ax[j];
-                else if (EPI == EPI_DTANH) x = x * (1.0f - (float)ax[j] * (float)ax[j]);
-                else if (EPI == EPI_DRELU_DROP) x = (float)ax[j] > 0.f ? x * g.drop.scale : 0.f;
+                else if (EPI == EPI_RESID_DROP) x = x + ax[j];
+                else if (EPI == EPI_DGELU) x = x * ax[j];
+                else if (EPI == EPI_ADD) x = x + ax[j];
+                else if (EPI == EPI_DTANH) x = x * (1.0f - ax[j] * ax[j]);
+                else if (EPI == EPI_DRELU_DROP) x = ax[j] > 0.f ? x * g.drop.scale : 0.f;
                 v[j] = x;
             }
-            if (sizeof(OutT) == 4) {        // f32 result (the logits GEMM): two 16-B stores per lane, a full 256-B run per 8 lanes
+            if (std::is_same<OutT, float>::value) {        // f32 result (the logits GEMM): two 16-B stores per lane, a full 256-B run per 8 lanes
                 float* cf = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + nb;
                 store4(cf, v); store4(cf + 4, v + 4);
+                continue;
+            }
+            if (SF) {       // split f32: 16 B of hi parts + 16 B of lo parts per lane; 4 lanes write one whole 128-B line
+                sf_store8(reinterpret_cast<sf32*>(P.C) + (size_t)m * P.ldc + nb, v);
+                if (EPI == EPI_GELU && P.C2 != nullptr) sf_store8(reinterpret_cast<sf32*>(P.C2) + (size_t)m * P.ldc + nb, pre);
                 continue;
             }
             bf16x8 o, op;
@@ -143,6 +174,7 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
             if (EPI == EPI_GELU && P.C2 != nullptr) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(P.C2) + (size_t)m * P.ldc + nb) = op;
         }
     }
+    if (AUX && SF) after_loads();
 }
 
 // ---- row-major-over-the-contraction LDS images (wgrad operands; the weight operand of the NN dgrad): 32-byte granule swizzle + transposed fragment reads

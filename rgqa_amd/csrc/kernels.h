@@ -1,5 +1,5 @@
 // Internal kernel launchers (host side). Every function enqueues work on `s` and returns an RGQA_* code;
-// none allocates, frees or synchronises.  T = float (parity mode) or bf16_t (throughput mode).
+// none allocates, frees or synchronises.  T = float (exact-f32 mode), bf16_t (throughput mode) or sf32 (split f32: bf16x3 precision).
 #pragma once
 #include "common.h"
 #include "gemm.h"
@@ -70,6 +70,8 @@ template <typename T> int k_attn_bwd_ref(const AttnArgs& a, hipStream_t s);
 template <typename T> int k_attn_probs(const AttnArgs& a, float* out /* [B, nh, Lq, Lk] */, hipStream_t s);
 int k_attn_fwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
 int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
+int k_attn_fwd_x3(const AttnArgs& a, hipStream_t s);     // split f32 (attn_x3.hip): every product as hi*hi + hi*lo + lo*hi on the bf16 matrix pipe
+int k_attn_bwd_x3(const AttnArgs& a, hipStream_t s);
 
 // ---- embed.hip
 // lang[b*T+t] = dropout(LN(word[ids] + pos[t] + type[seg]))      (reference BertEmbeddings, modeling.py:278-292)
@@ -111,7 +113,8 @@ int k_bce_fwd_bwd(const float* logits, int ldl, const float* target, int ldt, fl
 int k_sumsq(const float* g, size_t n, float* partial /*>=1024 floats*/, float* out_sumsq, int accumulate_into_out, hipStream_t s);
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
-    void* p_lp;            // optional bf16 copy at the same element offsets (null in f32 mode)
+    void* p_lp;            // optional low-precision operand copy at the same element offsets (null in f32 mode)
+    int lp_split;          // p_lp holds split-f32 pairs (bf16x3 precision) instead of bf16
     size_t n;
     float lr_t, b1, b2, eps, wd;
     const float* sumsq;    // device scalar: sum of squared grads (for clip); null = no clipping
@@ -122,8 +125,9 @@ int k_bertadam(const AdamArgs& a, hipStream_t s);
 // dst_t[k][n] = (bf16) src[n][k] for each listed [N,K] matrix; desc on device: {src_off, dst_off, N, K, tile_start}
 #define TRANSPOSE_TILE 64   // tile_start counts cdiv(ld_dst, TRANSPOSE_TILE) * cdiv(K, TRANSPOSE_TILE) tiles per matrix
 struct TransDesc { long src_off, dst_off; int N, K, ld_dst, tile_start; };
-int k_cast_transpose(const void* src, int src_is_bf16, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s);
+int k_cast_transpose(const void* src, int src_is_bf16, void* dst, int dst_split, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s);
 int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+int k_cast_split(const float* src, void* dst_split, size_t n, hipStream_t s);
 int k_sum_bf16_parts(const void* parts, size_t stride, int nparts, float* dst, size_t n, hipStream_t s);
 
 // ---- misc.hip

@@ -100,7 +100,7 @@ template int k_fill_rows<bf16_t>(bf16_t*, int, const bf16_t*, int, int, int, hip
 template <typename T>
 __global__ void cast_pad_kernel(const float* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int cols, float scale) {
     const int r = blockIdx.x;
-    for (int c = threadIdx.x; c < ldd; c += blockDim.x) dst[(size_t)r * ldd + c] = from_f32<T>(c < cols ? src[(size_t)r * lds + c] * scale : 0.f);
+    for (int c = threadIdx.x; c < ldd; c += blockDim.x) st_elem(dst + (size_t)r * ldd + c, c < cols ? src[(size_t)r * lds + c] * scale : 0.f);
 }
 template <typename T>
 int k_cast_pad(const float* src, int lds, T* dst, int ldd, int rows, int cols, float scale, hipStream_t s) {
@@ -111,12 +111,13 @@ int k_cast_pad(const float* src, int lds, T* dst, int ldd, int rows, int cols, f
 }
 template int k_cast_pad<float>(const float*, int, float*, int, int, int, float, hipStream_t);
 template int k_cast_pad<bf16_t>(const float*, int, bf16_t*, int, int, int, float, hipStream_t);
+template int k_cast_pad<sf32>(const float*, int, sf32*, int, int, int, float, hipStream_t);
 
 // dst f32 [rows, cols] = src T
 template <typename T>
 __global__ void to_f32_kernel(const T* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int cols) {
     const int r = blockIdx.x;
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(size_t)r * ldd + c] = to_f32(src[(size_t)r * lds + c]);
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(size_t)r * ldd + c] = ld_elem(src + (size_t)r * lds + c);
 }
 template <typename T>
 int k_to_f32(const T* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s) {
@@ -127,12 +128,13 @@ int k_to_f32(const T* src, int lds, float* dst, int ldd, int rows, int cols, hip
 }
 template int k_to_f32<float>(const float*, int, float*, int, int, int, hipStream_t);
 template int k_to_f32<bf16_t>(const bf16_t*, int, float*, int, int, int, hipStream_t);
+template int k_to_f32<sf32>(const sf32*, int, float*, int, int, int, hipStream_t);
 
 // y = dy * dg, dg = the gelu'(pre) saved by the forward EPI_GELU epilogue (head backward: no GEMM between LN-bwd and GeLU)
 template <typename T>
 __global__ void dgelu_mul_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = from_f32<T>(to_f32(dy[i]) * to_f32(pre[i]));
+        st_elem(out + i, ld_elem(dy + i) * ld_elem(pre + i));
 }
 template <typename T>
 int k_dgelu_mul(const T* dy, const T* pre, T* out, size_t n, hipStream_t s) {
@@ -144,13 +146,14 @@ int k_dgelu_mul(const T* dy, const T* pre, T* out, size_t n, hipStream_t s) {
 }
 template int k_dgelu_mul<float>(const float*, const float*, float*, size_t, hipStream_t);
 template int k_dgelu_mul<bf16_t>(const bf16_t*, const bf16_t*, bf16_t*, size_t, hipStream_t);
+template int k_dgelu_mul<sf32>(const sf32*, const sf32*, sf32*, size_t, hipStream_t);
 
 // out = dy * (1 - y^2)   (backward through tanh given its output)
 template <typename T>
 __global__ void dtanh_mul_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float t = to_f32(y[i]);
-        out[i] = from_f32<T>(to_f32(dy[i]) * (1.0f - t * t));
+        const float t = ld_elem(y + i);
+        st_elem(out + i, ld_elem(dy + i) * (1.0f - t * t));
     }
 }
 template <typename T>
@@ -163,6 +166,7 @@ int k_dtanh_mul(const T* dy, const T* y, T* out, size_t n, hipStream_t s) {
 }
 template int k_dtanh_mul<float>(const float*, const float*, float*, size_t, hipStream_t);
 template int k_dtanh_mul<bf16_t>(const bf16_t*, const bf16_t*, bf16_t*, size_t, hipStream_t);
+template int k_dtanh_mul<sf32>(const sf32*, const sf32*, sf32*, size_t, hipStream_t);
 
 // ---- unpadded ("varlen") language rows: per-sample lengths -> cu (exclusive prefix sums) and the packed-row -> token map.
 // The lengths travel as kernel ARGUMENTS (copied at launch time): no host buffer has to outlive the call and nothing
@@ -227,6 +231,9 @@ template int k_gather_rows<float>(const float*, int, const int*, int, float*, in
 template int k_gather_rows<bf16_t>(const bf16_t*, int, const int*, int, bf16_t*, int, int, int, hipStream_t);
 template int k_scatter_rows<float>(const float*, int, float*, int, const int*, int, int, int, hipStream_t);
 template int k_scatter_rows<bf16_t>(const bf16_t*, int, bf16_t*, int, const int*, int, int, int, hipStream_t);
+// split-f32 rows are copied slot by slot (whole 128-byte lines: cols % 32 == 0), which moves the hi and lo parts unchanged
+template int k_gather_rows<sf32>(const sf32*, int, const int*, int, sf32*, int, int, int, hipStream_t);
+template int k_scatter_rows<sf32>(const sf32*, int, sf32*, int, const int*, int, int, int, hipStream_t);
 
 // out[i] (+)= sum_s part[s][i]  (fixed order: deterministic split-K reduction of a weight gradient)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int S, size_t n, float* __restrict__ out, int accumulate) {

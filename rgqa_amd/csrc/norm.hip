@@ -57,7 +57,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 
 // bf16 rows with N = 256 * NC columns (768, 1536): HALF a wave per row, every access a full 16 bytes per lane (the 8-byte bf16x4 accesses
 // of the generic kernel run at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).  Lane l of a half owns the 8-column chunks l, l + 32, ...
-int g_rgqa_ln16 = -1;      // rgqa_debug_set key 9: 0 = generic kernels only, 1 / -1 = 16-byte kernels where they apply
 __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -315,7 +314,7 @@ int k_ln_fwd2(const T* x, int ldx, const float* gamma, const float* beta, const 
               int M, int N, float eps, hipStream_t s) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: N=%d must be a multiple of 4 and <= %d", N, LN_MAXV * 256);
     if (M <= 0) return RGQA_OK;
-    if (std::is_same<T, bf16_t>::value && g_rgqa_ln16 != 0 && (N == 768 || N == 1536) && ldx % 8 == 0 && ldy % 8 == 0 &&
+    if (std::is_same<T, bf16_t>::value && (N == 768 || N == 1536) && ldx % 8 == 0 && ldy % 8 == 0 &&
         ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0) {
         const bf16_t* xb = reinterpret_cast<const bf16_t*>(x); bf16_t* yb = reinterpret_cast<bf16_t*>(y);
         if (N == 768) hipLaunchKernelGGL(ln_fwd16_kernel<3>, dim3(cdiv(M, 8)), dim3(256), 0, s, xb, ldx, gamma, beta, yb, ldy, mean, rstd, M, eps, split, gamma2, beta2);
@@ -336,12 +335,15 @@ int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, i
     return k_ln_fwd2<T>(x, ldx, gamma, beta, gamma, beta, M, y, ldy, mean, rstd, M, N, eps, s);
 }
 
-static int ln_bwd_waves(int N) { return cdiv(N / 4, 64) <= 3 ? 16 : 4; }
-int ln_bwd_blocks(int M, int N) { const int nw = ln_bwd_waves(N); const int b = cdiv(M, nw), cap = nw == 16 ? 256 : 512; return b > cap ? cap : b; }
+// waves per block: narrow rows live on occupancy (16 waves = 4 per SIMD at <= 128 VGPRs with 2-byte elements); the 4-byte element types (f32,
+// split f32) carry twice the staged registers per row and spill at that budget (528 us instead of ~30 per launch, rocprofv3): 8 waves for them
+template <typename T> static int ln_bwd_waves(int N) { return cdiv(N / 4, 64) <= 3 ? (sizeof(T) == 2 ? 16 : 8) : 4; }
+template <typename T> static int ln_bwd_blocks_t(int M, int N) { const int nw = ln_bwd_waves<T>(N); const int b = cdiv(M, nw), cap = nw == 4 ? 512 : 256; return b > cap ? cap : b; }
+int ln_bwd_blocks(int M, int N) { return ln_bwd_blocks_t<bf16_t>(M, N); }
 
 template <typename T>
 static int ln_bwd_launch(const LnBwdSeg<T>& a, const LnBwdSeg<T>& b, int nblk0, int nblk, int lddy, int ldz, int lddz, float* part, int N, float dy_scale, hipStream_t s) {
-#define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, (NVV <= 3 ? 1024 : 256)>), dim3(nblk), dim3(NVV <= 3 ? 1024 : 256), 0, s, a, b, nblk0, lddy, ldz, lddz, part, N, dy_scale)
+#define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, (NVV <= 3 ? (sizeof(T) == 2 ? 1024 : 512) : 256)>), dim3(nblk), dim3(NVV <= 3 ? (sizeof(T) == 2 ? 1024 : 512) : 256), 0, s, a, b, nblk0, lddy, ldz, lddz, part, N, dy_scale)
     const int nvl = cdiv(N / 4, 64);
     if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4);
     else if (nvl <= 6) LN_BWD(6); else LN_BWD(8);
@@ -356,7 +358,7 @@ int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, con
              FinDefer* defer) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256, "layernorm bwd: N=%d unsupported", N);
     if (M <= 0) return RGQA_OK;
-    const int nblk = ln_bwd_blocks(M, N);
+    const int nblk = ln_bwd_blocks_t<T>(M, N);
     if (part && defer && !defer->room(nblk, 3, N)) defer = nullptr;
     const int blk0 = defer ? defer->blk : 0;
     if (part && defer) part = defer->take(nblk);
@@ -389,7 +391,7 @@ int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, con
               int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s, FinDefer* defer) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256 && part != nullptr && M0 > 0 && M1 > 0, "layernorm bwd2: bad arguments (N=%d)", N);
     const DropCfg nodrop = make_drop(0.f, 0, 0);
-    int nb0 = ln_bwd_blocks(M0, N), nb1 = ln_bwd_blocks(M1, N);
+    int nb0 = ln_bwd_blocks_t<T>(M0, N), nb1 = ln_bwd_blocks_t<T>(M1, N);
     if (nb0 > 256) nb0 = 256;                       // the partial-sum scratch holds 512 blocks
     if (nb1 > 256) nb1 = 256;
     LnBwdSeg<T> a, b;
@@ -425,11 +427,16 @@ int k_colsum(const T* x, int ldx, float* part, float* out, int accumulate, int M
 
 template int k_ln_fwd2<float>(const float*, int, const float*, const float*, const float*, const float*, int, float*, int, float*, float*, int, int, float, hipStream_t);
 template int k_ln_fwd2<bf16_t>(const bf16_t*, int, const float*, const float*, const float*, const float*, int, bf16_t*, int, float*, float*, int, int, float, hipStream_t);
+template int k_ln_fwd2<sf32>(const sf32*, int, const float*, const float*, const float*, const float*, int, sf32*, int, float*, float*, int, int, float, hipStream_t);
 template int k_ln_fwd<float>(const float*, int, const float*, const float*, float*, int, float*, float*, int, int, float, hipStream_t);
 template int k_ln_fwd<bf16_t>(const bf16_t*, int, const float*, const float*, bf16_t*, int, float*, float*, int, int, float, hipStream_t);
+template int k_ln_fwd<sf32>(const sf32*, int, const float*, const float*, sf32*, int, float*, float*, int, int, float, hipStream_t);
 template int k_ln_bwd2<float>(const float*, int, const float*, int, const float*, const float*, float*, float*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
 template int k_ln_bwd2<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, bf16_t*, bf16_t*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
+template int k_ln_bwd2<sf32>(const sf32*, int, const sf32*, int, const float*, const float*, sf32*, sf32*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
 template int k_ln_bwd<float>(const float*, int, const float*, int, const float*, const float*, const float*, float*, float*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*);
 template int k_ln_bwd<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, bf16_t*, bf16_t*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*);
+template int k_ln_bwd<sf32>(const sf32*, int, const sf32*, int, const float*, const float*, const float*, sf32*, sf32*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*);
 template int k_colsum<float>(const float*, int, float*, float*, int, int, int, hipStream_t);
 template int k_colsum<bf16_t>(const bf16_t*, int, float*, float*, int, int, int, hipStream_t);
+template int k_colsum<sf32>(const sf32*, int, float*, float*, int, int, int, hipStream_t);

@@ -59,8 +59,15 @@ __device__ __forceinline__ void adam_tail(const AdamArgs& a, float coef, size_t 
         float m = a.m[i] * a.b1 + (1.f - a.b1) * gg, v = a.v[i] * a.b2 + (1.f - a.b2) * gg * gg;
         float u = m / (sqrtf(v) + a.eps) + a.wd * a.p[i];
         a.p[i] -= a.lr_t * u; a.m[i] = m; a.v[i] = v;
-        if (a.p_lp) reinterpret_cast<bf16_t*>(a.p_lp)[i] = (bf16_t)a.p[i];
+        if (a.p_lp && a.lp_split) sf_store1(reinterpret_cast<sf32*>(a.p_lp) + i, a.p[i]);
+        else if (a.p_lp) reinterpret_cast<bf16_t*>(a.p_lp)[i] = (bf16_t)a.p[i];
     }
+}
+// the low-precision operand copy of 4 updated parameters: bf16, or the split-f32 pair (bf16x3 precision) at the same element offsets
+__device__ __forceinline__ void adam_store_lp(const AdamArgs& a, size_t i4, const float p[4]) {
+    if (a.p_lp == nullptr) return;
+    if (a.lp_split) store4(reinterpret_cast<sf32*>(a.p_lp) + i4, p);
+    else store4(reinterpret_cast<bf16_t*>(a.p_lp) + i4, p);
 }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -75,8 +82,8 @@ template <bool NT> __device__ __forceinline__ void st4(float* p, const float v[4
     if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(p)); else *reinterpret_cast<f32x4v*>(p) = t;
 }
 // NT: non-temporal 16-byte accesses for the streamed-once f32 state (p, g, m, v in; p, m, v out): 6 GB per step that would otherwise wash
-// through the 256 MB Infinity Cache and displace what the next forward pass re-reads; the bf16 weight copy, which that pass reads, stays a
-// normal store.  In situ (tools/ab_bench.sh, three interleaved rounds): 11.64 vs 11.84 ms per step.
+// through the 256 MB Infinity Cache and displace what the next forward pass re-reads; the low-precision weight copy, which that pass
+// reads, stays a normal store.  In situ (three interleaved A/B rounds, round 2): 11.64 vs 11.84 ms per step.
 template <bool NT>
 __global__ __launch_bounds__(256) void bertadam_kernel(const AdamArgs a) {
     // clip coefficient exactly as torch's clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied when < 1
@@ -92,85 +99,17 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const AdamArgs a) {
         ld4<NT>(a.p + i * 4, p); ld4<NT>(a.g + i * 4, g); ld4<NT>(a.m + i * 4, m); ld4<NT>(a.v + i * 4, v);
         adam_update4(a, coef, p, g, m, v);
         st4<NT>(a.p + i * 4, p); st4<NT>(a.m + i * 4, m); st4<NT>(a.v + i * 4, v);
-        if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + i * 4, p);
+        adam_store_lp(a, i * 4, p);
     }
     adam_tail(a, coef, nv);
-}
-
-// The same update confined to gridDim.x CUs: 1024-thread blocks that each claim more than half of a CU's LDS (so two never share a
-// CU), two groups of four 16-byte loads in flight per lane.  Used when the update runs on a side stream BESIDE the next forward
-// pass (Engine.adam_step(pipeline="background")): the persistent GEMM blocks of that pass need whole CUs (all registers, 128 KiB of
-// LDS) - an update spread over every CU starves them until it has drained, one that owns a quarter of the chip leaves them the rest.
-#define NARROW_THREADS 1024
-#define NARROW_LDS (84 * 1024)
-template <bool NT, int UNROLL>
-__global__ __launch_bounds__(NARROW_THREADS) void bertadam_narrow_kernel(const AdamArgs a) {
-    extern __shared__ unsigned char narrow_pad[];
-    float coef = a.grad_prescale;
-    if (a.sumsq) {
-        const float norm = sqrtf(*a.sumsq) * a.grad_prescale;
-        const float c = a.max_norm / (norm + 1e-6f);
-        if (c < 1.f) coef *= c;
-    }
-    const size_t nv = a.n >> 2, stride = (size_t)gridDim.x * NARROW_THREADS;
-    size_t i = (size_t)blockIdx.x * NARROW_THREADS + threadIdx.x;
-    auto one = [&](size_t k) {
-        float p[4], g[4], m[4], v[4];
-        ld4<NT>(a.p + k * 4, p); ld4<NT>(a.g + k * 4, g); ld4<NT>(a.m + k * 4, m); ld4<NT>(a.v + k * 4, v);
-        adam_update4(a, coef, p, g, m, v);
-        st4<NT>(a.p + k * 4, p); st4<NT>(a.m + k * 4, m); st4<NT>(a.v + k * 4, v);
-        if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + k * 4, p);      // the forward pass reads this copy next: cached
-    };
-    if (UNROLL == 2) {
-        for (; i + stride < nv; i += 2 * stride) {
-            const size_t i2 = i + stride;
-            float p[4], g[4], m[4], v[4], p2[4], g2[4], m2[4], v2[4];
-            ld4<NT>(a.p + i * 4, p); ld4<NT>(a.g + i * 4, g); ld4<NT>(a.m + i * 4, m); ld4<NT>(a.v + i * 4, v);
-            ld4<NT>(a.p + i2 * 4, p2); ld4<NT>(a.g + i2 * 4, g2); ld4<NT>(a.m + i2 * 4, m2); ld4<NT>(a.v + i2 * 4, v2);
-            adam_update4(a, coef, p, g, m, v);
-            st4<NT>(a.p + i * 4, p); st4<NT>(a.m + i * 4, m); st4<NT>(a.v + i * 4, v);
-            if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + i * 4, p);
-            adam_update4(a, coef, p2, g2, m2, v2);
-            st4<NT>(a.p + i2 * 4, p2); st4<NT>(a.m + i2 * 4, m2); st4<NT>(a.v + i2 * 4, v2);
-            if (a.p_lp) store4(reinterpret_cast<bf16_t*>(a.p_lp) + i2 * 4, p2);
-        }
-    }
-    for (; i < nv; i += stride) one(i);
-    adam_tail(a, coef, nv);
-}
-
-int g_rgqa_narrow_cus = 0;     // rgqa_debug_set key 13: > 0 = the optimizer / weight-copy kernels launched next stay on that many CUs (one 1024-thread block each)
-static int narrow_blocks() {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bertadam_narrow_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bertadam_narrow_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bertadam_narrow_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bertadam_narrow_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
-        attr = true;
-    }
-    return g_rgqa_narrow_cus;
 }
 
 int k_bertadam(const AdamArgs& a, hipStream_t s) {
     if (a.n == 0) return RGQA_OK;
     RGQA_REQUIRE(((uintptr_t)a.p % 16) == 0 && ((uintptr_t)a.g % 16) == 0 && ((uintptr_t)a.m % 16) == 0 && ((uintptr_t)a.v % 16) == 0, "bertadam: 16-byte alignment required");
     size_t nb = (a.n / 4 + 255) / 256;
-    if (const int ncu = narrow_blocks(); ncu > 0 && nb > (size_t)ncu * 4) {
-        static const int variant = []() { const char* e = getenv("RGQA_ADAM_NARROW_VARIANT"); return e ? atoi(e) : 3; }();     // bit 0: non-temporal, bit 1: two groups of loads in flight
-        switch (variant & 3) {
-            case 0: hipLaunchKernelGGL((bertadam_narrow_kernel<false, 1>), dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, a); break;
-            case 1: hipLaunchKernelGGL((bertadam_narrow_kernel<true, 1>), dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, a); break;
-            case 2: hipLaunchKernelGGL((bertadam_narrow_kernel<false, 2>), dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, a); break;
-            default: hipLaunchKernelGGL((bertadam_narrow_kernel<true, 2>), dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, a); break;
-        }
-        RGQA_LAUNCH_CHECK("bertadam_narrow_kernel");
-        return RGQA_OK;
-    }
-    static const bool nt = []() { const char* e = getenv("RGQA_ADAM_NT"); return !(e != nullptr && e[0] == '0'); }();     // default on
     int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
-    if (nt) hipLaunchKernelGGL(bertadam_kernel<true>, dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(bertadam_kernel<false>, dim3(nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bertadam_kernel<true>, dim3(nblk), dim3(256), 0, s, a);
     RGQA_LAUNCH_CHECK("bertadam_kernel");
     return RGQA_OK;
 }
@@ -190,6 +129,26 @@ int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
     int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblk), dim3(256), 0, s, src, reinterpret_cast<bf16_t*>(dst), n);
     RGQA_LAUNCH_CHECK("cast_bf16_kernel");
+    return RGQA_OK;
+}
+
+// f32 -> split f32 (bf16x3 precision), element i of src -> slot i of dst: the weight arena's operand copy, the RoI features
+__global__ __launch_bounds__(256) void cast_split_kernel(const float* __restrict__ src, sf32* __restrict__ dst, size_t n) {
+    const size_t nv = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        float v[4];
+        load4(src + i * 4, v);
+        store4(dst + i * 4, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) sf_store1(dst + (nv << 2) + threadIdx.x, src[(nv << 2) + threadIdx.x]);
+}
+int k_cast_split(const float* src, void* dst, size_t n, hipStream_t s) {
+    if (n == 0) return RGQA_OK;
+    RGQA_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "cast_split: 16-byte alignment required");
+    size_t nb = (n / 4 + 255) / 256;
+    int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
+    hipLaunchKernelGGL(cast_split_kernel, dim3(nblk), dim3(256), 0, s, src, reinterpret_cast<sf32*>(dst), n);
+    RGQA_LAUNCH_CHECK("cast_split_kernel");
     return RGQA_OK;
 }
 
@@ -250,7 +209,8 @@ __device__ __forceinline__ void transpose_tile_load(const S* __restrict__ src, c
         for (int j = 0; j < 4; ++j) tile[ty + r * 16][tx * 4 + j] = v[j];
     }
 }
-__device__ __forceinline__ void transpose_tile_store(bf16_t* __restrict__ dst, const TransDesc& d, int n0, int k0, float (*tile)[TRANSPOSE_TILE + 1], int ltid, bool nt) {
+template <typename D>
+__device__ __forceinline__ void transpose_tile_store(D* __restrict__ dst, const TransDesc& d, int n0, int k0, float (*tile)[TRANSPOSE_TILE + 1], int ltid) {
     constexpr int TT = TRANSPOSE_TILE;
     const int tx = ltid & 15, ty = ltid >> 4;
     const bool n4 = (d.ld_dst & 3) == 0;
@@ -261,58 +221,27 @@ __device__ __forceinline__ void transpose_tile_store(bf16_t* __restrict__ dst, c
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = tile[tx * 4 + j][ty + r * 16];
-        bf16_t* dp = dst + d.dst_off + (size_t)k * d.ld_dst + n;
-        if (n4 && n + 4 <= d.ld_dst) {
-            if (nt) {       // the transposed copy is read by a backward pass milliseconds later: do not let it displace cached data now
-                bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-                __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(dp));
-            } else store4(dp, v);
-        }
-        else { for (int j = 0; j < 4; ++j) if (n + j < d.ld_dst) dp[j] = (bf16_t)v[j]; }
+        D* dp = dst + d.dst_off + (size_t)k * d.ld_dst + n;
+        if (n4 && n + 4 <= d.ld_dst) store4(dp, v);
+        else { for (int j = 0; j < 4; ++j) if (n + j < d.ld_dst) st_elem(dp + j, v[j]); }
     }
 }
-template <typename S>
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc, int nt) {
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict__ src, D* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc) {
     __shared__ float tile[TRANSPOSE_TILE][TRANSPOSE_TILE + 1];
     TransDesc d; int n0, k0;
     transpose_tile_load<S>(src, desc, ndesc, blockIdx.x, tile, threadIdx.x, d, n0, k0);
     __syncthreads();
-    transpose_tile_store(dst, d, n0, k0, tile, threadIdx.x, nt != 0);
+    transpose_tile_store<D>(dst, d, n0, k0, tile, threadIdx.x);
 }
-// confined to gridDim.x CUs (see bertadam_narrow_kernel): four 256-thread groups per block, each walking its own tiles
-template <typename S>
-__global__ __launch_bounds__(NARROW_THREADS) void cast_transpose_narrow_kernel(const S* __restrict__ src, bf16_t* __restrict__ dst, const TransDesc* __restrict__ desc, int ndesc, int total_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char narrow_lds[];
-    const int sub = threadIdx.x >> 8, ltid = threadIdx.x & 255;
-    float (*tile)[TRANSPOSE_TILE + 1] = reinterpret_cast<float (*)[TRANSPOSE_TILE + 1]>(narrow_lds) + sub * TRANSPOSE_TILE;
-    const int step = (int)gridDim.x * 4;
-    for (int base = 0; base < total_tiles; base += step) {        // block-uniform trip count: every thread reaches both barriers
-        const int t = base + (int)blockIdx.x * 4 + sub;
-        TransDesc d; int n0 = 0, k0 = 0;
-        if (t < total_tiles) transpose_tile_load<S>(src, desc, ndesc, t, tile, ltid, d, n0, k0);
-        __syncthreads();
-        if (t < total_tiles) transpose_tile_store(dst, d, n0, k0, tile, ltid, true);
-        __syncthreads();
-    }
-}
-// src: the f32 master weights, or (src_is_bf16) their bf16 copy at the same element offsets - half the bytes to read, same result
-int k_cast_transpose(const void* src, int src_is_bf16, void* dst_bf16, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s) {
+// src: the f32 master weights, or (src_is_bf16) their bf16 copy at the same element offsets - half the bytes to read, same result;
+// dst_split: the transposed copy is written in the split-f32 layout (bf16x3 precision; the source must then be the f32 master)
+int k_cast_transpose(const void* src, int src_is_bf16, void* dst, int dst_split, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s) {
     if (ndesc <= 0 || total_tiles <= 0) return RGQA_OK;
-    if (const int ncu = narrow_blocks(); ncu > 0 && total_tiles > ncu * 16) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cast_transpose_narrow_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cast_transpose_narrow_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
-            attr = true;
-        }
-        if (src_is_bf16) hipLaunchKernelGGL(cast_transpose_narrow_kernel<bf16_t>, dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc, total_tiles);
-        else hipLaunchKernelGGL(cast_transpose_narrow_kernel<float>, dim3(ncu), dim3(NARROW_THREADS), NARROW_LDS, s, reinterpret_cast<const float*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc, total_tiles);
-        RGQA_LAUNCH_CHECK("cast_transpose_narrow_kernel");
-        return RGQA_OK;
-    }
-    const int ntf = 0;       // (non-temporal stores of the transposed copy, of the wgrad output, of gelu' and non-temporal loads in the gradient norm: +-0 in situ, 11.73 vs 11.69 ms; only the optimizer's state streams pay, RGQA_ADAM_NT)
-    if (src_is_bf16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc, ntf);
-    else hipLaunchKernelGGL(cast_transpose_kernel<float>, dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const float*>(src), reinterpret_cast<bf16_t*>(dst_bf16), desc_dev, ndesc, ntf);
+    RGQA_REQUIRE(!(dst_split && src_is_bf16), "cast_transpose: the split-f32 copy is made from the f32 master weights");
+    if (dst_split) hipLaunchKernelGGL((cast_transpose_kernel<float, sf32>), dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const float*>(src), reinterpret_cast<sf32*>(dst), desc_dev, ndesc);
+    else if (src_is_bf16) hipLaunchKernelGGL((cast_transpose_kernel<bf16_t, bf16_t>), dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(dst), desc_dev, ndesc);
+    else hipLaunchKernelGGL((cast_transpose_kernel<float, bf16_t>), dim3(total_tiles), dim3(256), 0, s, reinterpret_cast<const float*>(src), reinterpret_cast<bf16_t*>(dst), desc_dev, ndesc);
     RGQA_LAUNCH_CHECK("cast_transpose_kernel");
     return RGQA_OK;
 }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void pos_proj_kernel(const float* __restrict__
     for (int n = threadIdx.x; n < H; n += blockDim.x) {
         float a = bp[n];
         for (int k = 0; k < pd; ++k) a = fmaf(px[k], Wp[(size_t)n * pd + k], a);
-        out[(size_t)row * ldo + n] = from_f32<T>(a);
+        st_elem(out + (size_t)row * ldo + n, a);
     }
 }
 template <typename T>
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void pos_wgrad_kernel(const T* __restrict__ dz
 #pragma unroll
         for (int k = 0; k < UNITER_MAXPOS; ++k) acc[k] = 0.f;
         for (int row = blockIdx.x; row < M; row += gridDim.x) {
-            const float g = to_f32(dzp[(size_t)row * ld + n]);
+            const float g = ld_elem(dzp + (size_t)row * ld + n);
 #pragma unroll
             for (int k = 0; k < UNITER_MAXPOS; ++k) if (k < pd) acc[k] = fmaf(g, pos[(size_t)row * pd + k], acc[k]);
         }
@@ -154,7 +154,10 @@ int k_sum3_ln_fwd(const T* a, const T* b, int ld, const float* trow, const float
 
 template int k_pos_proj<float>(const float*, int, const float*, const float*, float*, int, int, int, hipStream_t);
 template int k_pos_proj<bf16_t>(const float*, int, const float*, const float*, bf16_t*, int, int, int, hipStream_t);
+template int k_pos_proj<sf32>(const float*, int, const float*, const float*, sf32*, int, int, int, hipStream_t);
 template int k_pos_wgrad<float>(const float*, int, const float*, int, float*, float*, int, int, int, hipStream_t);
 template int k_pos_wgrad<bf16_t>(const bf16_t*, int, const float*, int, float*, float*, int, int, int, hipStream_t);
+template int k_pos_wgrad<sf32>(const sf32*, int, const float*, int, float*, float*, int, int, int, hipStream_t);
 template int k_sum3_ln_fwd<float>(const float*, const float*, int, const float*, const float*, const float*, const int*, float*, int, float*, float*, float*, int, int, float, DropCfg, hipStream_t);
 template int k_sum3_ln_fwd<bf16_t>(const bf16_t*, const bf16_t*, int, const float*, const float*, const float*, const int*, bf16_t*, int, bf16_t*, float*, float*, int, int, float, DropCfg, hipStream_t);
+template int k_sum3_ln_fwd<sf32>(const sf32*, const sf32*, int, const float*, const float*, const float*, const int*, sf32*, int, sf32*, float*, float*, int, int, float, DropCfg, hipStream_t);

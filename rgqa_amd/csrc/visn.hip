@@ -258,5 +258,7 @@ int k_visn_combine_bwd(const T* dout, int lddo, const T* zf, int ldz, const floa
 
 template int k_visn_combine_fwd<float>(const float*, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, int, float*, int, int, int, float, DropCfg, hipStream_t);
 template int k_visn_combine_fwd<bf16_t>(const bf16_t*, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, float*, int, int, int, float, DropCfg, hipStream_t);
+template int k_visn_combine_fwd<sf32>(const sf32*, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, sf32*, int, float*, int, int, int, float, DropCfg, hipStream_t);
 template int k_visn_combine_bwd<float>(const float*, int, const float*, int, const float*, const float*, const float*, const float*, const float*, const float*, float*, int, float*, float*, float*, float*, float*, float*, float*, float*, int, int, int, int, DropCfg, float*, hipStream_t);
 template int k_visn_combine_bwd<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, float*, float*, float*, float*, float*, float*, float*, float*, int, int, int, int, DropCfg, float*, hipStream_t);
+template int k_visn_combine_bwd<sf32>(const sf32*, int, const sf32*, int, const float*, const float*, const float*, const float*, const float*, const float*, sf32*, int, float*, float*, float*, float*, float*, float*, float*, float*, int, int, int, int, DropCfg, float*, hipStream_t);

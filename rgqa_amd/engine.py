@@ -4,12 +4,11 @@ torch is plumbing only here: it owns device memory (arenas, workspace, I/O tenso
 Every tensor operation of the hot path happens inside librgqa_hip.so.
 """
 import ctypes as C
-import os
 
 import torch
 
 from . import _lib
-from ._lib import Config, check, ptr, PREC_BF16, PREC_F32
+from ._lib import Config, check, ptr, PREC_BF16, PREC_BF16X3, PREC_F32
 
 
 def _stream():
@@ -39,7 +38,11 @@ class Engine:
                  ln_eps=1e-12, hidden_dropout=0.1, attn_dropout=0.1, arch=0, emb_dim=300):
         self.lib = _lib.load()
         self.precision = precision
-        prec = {"bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
+        # "bf16x3": split-f32 operands, three bf16 MFMA products per f32 product - the fast mode inside the reference's 1e-3 logits bound;
+        # "bf16": BASELINE config 3's mode (outside that bound); "f32": exact f32 FMA arithmetic on the vector ALU (slow; the on-device reference)
+        precision = {"fp32": "f32", "x3": "bf16x3"}.get(precision, precision)
+        self.precision = precision
+        prec = {"bf16": PREC_BF16, "f32": PREC_F32, "bf16x3": PREC_BF16X3}[precision]
         self.cfg = Config(vocab_size, hidden, heads, inter, max_pos, type_vocab, l_layers, x_layers, r_layers, feat_dim,
                           pos_dim, num_answers, prec, ln_eps, hidden_dropout, attn_dropout, arch, emb_dim)
         h = C.c_void_p()
@@ -64,6 +67,7 @@ class Engine:
         self.adam_m = self.adam_v = None
         self._seg_sumsq = None
         self._seg_sumsq_valid = False
+        self._sharded_owner = None       # set by parallel.ShardedExchange while the f32 masters / Adam moments are valid on their owner rank only
         self.shape = None
         self._io = {}
 
@@ -90,6 +94,9 @@ class Engine:
         if self.precision == "bf16":
             self.params_lp = torch.zeros(n, dtype=torch.bfloat16, device=device)
             self.params_lp_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        elif self.precision == "bf16x3":     # split-f32 operand copies: 4 bytes per element slot (csrc/common.h sf32), opaque to torch
+            self.params_lp = torch.zeros(n, dtype=torch.int32, device=device)
+            self.params_lp_t = torch.zeros(n, dtype=torch.int32, device=device)
         self.shape = None
         return self
 
@@ -113,7 +120,7 @@ class Engine:
                         loss=torch.zeros(1, dtype=torch.float32, device=self.device))
 
     def sync_weights(self):
-        """Refreshes the bf16 weight copies (direct + transposed) from the f32 master arena."""
+        """Refreshes the operand copies of the weights (direct + transposed; bf16 or split f32) from the f32 master arena."""
         if self.shape is None:
             raise RuntimeError("sync_weights before the first ensure_shape/bind")
         check(self.lib.rgqa_engine_sync_weights(self.h, _stream()))
@@ -178,6 +185,8 @@ class Engine:
         check(self.lib.rgqa_engine_set_input_grads(self.h, ptr(dfeats), ptr(dboxes)))
 
     def activation(self, name, rows, cols=None):
+        """f32 copy of a saved activation of the last forward pass; `rows` must be the row count of the recorded layout (packed
+        language rows; B rows for the last language output, of which only the [CLS] rows are computed)."""
         out = torch.empty(rows, cols or self.cfg.hidden, dtype=torch.float32, device=self.device)
         check(self.lib.rgqa_engine_get_activation(self.h, name.encode(), ptr(out), out.numel(), _stream()))
         return out
@@ -253,21 +262,17 @@ class Engine:
         n = self.arena_elems
         return [(0, b), (e, n)] if e > b else [(0, n)]
 
-    def cross_offset(self):
-        """arena offset of the first cross-modality parameter: [0, offset) = embeddings + language / vision layers"""
-        offs = [sp.offset for sp in self.specs if ".x_layers." in sp.name]
-        return min(offs) if offs else None
-
-    def adam_step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, grad_prescale=1.0, clip=True, pipeline=False):
+    def adam_step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, grad_prescale=1.0, clip=True):
         """clip_grad_norm_(params, max_norm) + BertAdam.step over every parameter that receives a gradient
-        (gqa_conf.py:201-202); then refreshes the bf16 weight copies.
-        pipeline=True (LXMERT engine): the update runs on a side stream in forward order - first the ranges the next forward pass
-        reads first - and the next forward / backward wait for exactly the ranges they need (rgqa_engine_set_weight_events), so most
-        of the optimizer's 6 GB of HBM traffic runs beside the next step's embedding and single-modality layers.  Same results."""
+        (gqa_conf.py:201-202), on the caller's stream; the same kernel re-writes the operand copy of the weights (bf16 / split f32)
+        and the transposed copies follow."""
+        if self._sharded_owner is not None:
+            raise RuntimeError("adam_step: the optimizer state of this engine is sharded over the data-parallel ranks "
+                               "(ShardedExchange); step through the exchange, or call its gather_master() / release() first")
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
-        if getattr(self, "_sumsq", None) is None:        # (the sharded data-parallel optimizer may have created the moments already)
+        if getattr(self, "_sumsq", None) is None:
             self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._sq_ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
         s = _stream()
@@ -278,92 +283,14 @@ class Engine:
             for i, (a, b) in enumerate(rngs):
                 check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
         self._seg_sumsq_valid = False
-
-        def update(a, b, st):
-            lp = ptr(self.params_lp[a:b]) if self.precision == "bf16" else None     # the kernel re-casts the bf16 copy in the same pass
+        lp_split = 1 if self.precision == "bf16x3" else 0
+        for a, b in rngs:
+            lp = ptr(self.params_lp[a:b]) if self.params_lp is not None else None
             check(self.lib.rgqa_bertadam_step(ptr(self.params[a:b]), ptr(self.grads[a:b]), ptr(self.adam_m[a:b]), ptr(self.adam_v[a:b]),
-                                              lp, b - a, lr_t, b1, b2, eps, weight_decay, ptr(self._sumsq) if clip else None,
-                                              max_norm, grad_prescale, st))
-
-        if pipeline == "background" and self.cfg.arch == 0:
-            return self._adam_background(update, rngs, s)
-        x0 = self.cross_offset() if (pipeline and self.cfg.arch == 0) else None
-        if x0 is None:
-            for a, b in rngs:
-                update(a, b, s)
-            if self.precision == "bf16":
-                check(self.lib.rgqa_engine_sync_transposed(self.h, s))
-            return
-        if getattr(self, "_opt_stream", None) is None:
-            self._opt_stream = torch.cuda.Stream(device=self.device)
-            self._opt_events = [torch.cuda.Event() for _ in range(3)]
-        cur = torch.cuda.current_stream()
-        self._opt_stream.wait_stream(cur)                  # gradients + clip norm are final
-        ev_first, ev_cross, ev_all = self._opt_events
-        with torch.cuda.stream(self._opt_stream):
-            so = C.c_void_p(self._opt_stream.cuda_stream)
-            first = [(max(a, 0), min(b, x0)) for a, b in rngs if a < x0]
-            rest = [(max(a, x0), b) for a, b in rngs if b > x0]
-            for a, b in first:
-                update(a, b, so)
-            ev_first.record(self._opt_stream)
-            for a, b in rest:
-                update(a, b, so)
-            ev_cross.record(self._opt_stream)
-            if self.precision == "bf16":
-                check(self.lib.rgqa_engine_sync_transposed(self.h, so))
-            ev_all.record(self._opt_stream)
-        check(self.lib.rgqa_engine_set_weight_events(self.h, C.c_void_p(ev_first.cuda_event), C.c_void_p(ev_cross.cuda_event), C.c_void_p(ev_all.cuda_event)))
-
-    def _adam_background(self, update, rngs, s):
-        """pipeline="background": the update of everything but the first layers runs on a side stream on RGQA_OPT_CUS CUs (default 64;
-        kernels of 1024-thread blocks that own a CU each, rgqa_debug_set key 13) BESIDE the next forward pass, gradient segment by
-        gradient segment in forward order, and that pass waits for each layer's event right before it reads the layer
-        (rgqa_engine_set_segment_weight_events).  The embeddings + the first RGQA_OPT_HEAD_LAYERS layers (default 1) are updated on the
-        caller's stream, whole chip, first: the forward pass needs them at once.  Same arithmetic per element, same results."""
-        ncu = int(os.environ.get("RGQA_OPT_CUS", "64"))
-        head_layers = int(os.environ.get("RGQA_OPT_HEAD_LAYERS", "1"))
-        group = max(1, int(os.environ.get("RGQA_OPT_GROUP", "1")))        # layers per event
-        segs = self.grad_segments()
-        n_ev = max(ev for _, _, ev in segs) + 1
-        by_ev = {}
-        for a, b, ev in segs:
-            by_ev.setdefault(ev, []).append((a, b))
-        order = sorted(by_ev, reverse=True)                   # forward order: embeddings, l/r layers, x layers, pooler + head
-        if getattr(self, "_opt_stream", None) is None:
-            self._opt_stream = torch.cuda.Stream(device=self.device)
-            self._opt_events = [torch.cuda.Event() for _ in range(3)]
-        if getattr(self, "_seg_wevents", None) is None or len(self._seg_wevents) != n_ev:
-            self._seg_wevents = [torch.cuda.Event() for _ in range(n_ev)]
-        cur = torch.cuda.current_stream()
-        self._opt_stream.wait_stream(cur)                     # gradients + clip norm are final
-        head, rest = order[:1 + head_layers], order[1 + head_layers:]
-        for ev in head:                                       # exposed part, whole chip
-            for a, b in by_ev[ev]:
-                update(a, b, s)
-        table = (C.c_void_p * n_ev)()
-        ev_all = self._opt_events[2]
-        with torch.cuda.stream(self._opt_stream):
-            so = C.c_void_p(self._opt_stream.cuda_stream)
-            check(self.lib.rgqa_debug_set(13, ncu))
-            try:
-                for k in range(0, len(rest), group):
-                    chunk = rest[k:k + group]
-                    for ev in chunk:
-                        for a, b in by_ev[ev]:
-                            update(a, b, so)
-                    e = self._seg_wevents[chunk[-1]]
-                    e.record(self._opt_stream)
-                    for ev in chunk:
-                        table[ev] = e.cuda_event
-                if self.precision == "bf16":
-                    self._opt_stream.wait_stream(cur)         # the transposed copies also cover the ranges updated on the caller's stream
-                    check(self.lib.rgqa_engine_sync_transposed(self.h, so))
-            finally:
-                check(self.lib.rgqa_debug_set(13, 0))
-            ev_all.record(self._opt_stream)
-        check(self.lib.rgqa_engine_set_segment_weight_events(self.h, table, n_ev))
-        check(self.lib.rgqa_engine_set_weight_events(self.h, None, None, C.c_void_p(ev_all.cuda_event)))
+                                              lp, lp_split, b - a, lr_t, b1, b2, eps, weight_decay, ptr(self._sumsq) if clip else None,
+                                              max_norm, grad_prescale, s))
+        if self.params_lp is not None:
+            check(self.lib.rgqa_engine_sync_transposed(self.h, s))
 
     def grad_norm(self):
         """Global L2 norm of the live gradient ranges (what clip_grad_norm_ measures, gqa_conf.py:201) as a device scalar."""

@@ -270,7 +270,19 @@ class _EngineFunction(torch.autograd.Function):
         # torch.distributed initialised (torchrun, one process per GPU) every backward averages the gradient arena over the ranks
         # before clip_grad_norm_ / BertAdam.step see it - the incoming gradient is scaled by 1/world, the arena SUM-all-reduced.
         rank, world = _dp_rank_world()
+        # The exchange belongs to TRAINING steps only: a backward in eval() mode (the test-time scorers that differentiate w.r.t. the
+        # inputs, tasks/gqa_odin.py:97-121, run under model.eval()) exchanges nothing - ranks may then run different numbers of passes
+        # without deadlocking, and no 819-MB collective rides on a scoring pass.
+        if world > 1 and not owner.training:
+            world = 1
         if world > 1:
+            if not ctx.want_logits and not owner.__dict__.get("_dp_warned"):
+                import warnings
+                warnings.warn("rgqa: data parallelism exchanges the engine's gradient arena only. This backward came through the pooled "
+                              "output (LXRTEncoder under a head that attach_head() did not fuse): the parameters of that head are NOT "
+                              "averaged over the ranks - all-reduce their .grad yourself, or use a Linear-GeLU-LayerNorm-Linear head "
+                              "(tasks/gqa_model.py:22-27), which is fused and exchanged.  See INTEGRATION.md §3.", RuntimeWarning)
+                owner.__dict__["_dp_warned"] = True
             if acc:
                 raise RuntimeError("rgqa: gradient accumulation over several backward() calls is not supported under data parallelism "
                                    "(the exchange would count the earlier contributions again): call zero_grad() before every backward")

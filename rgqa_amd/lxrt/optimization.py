@@ -144,14 +144,14 @@ class BertAdam(Optimizer):
                 else:
                     lr_scheduled = group['lr']
                 if r["m"] is not None:
-                    _lib.check(lib.rgqa_bertadam_step(C.c_void_p(r["p0"]), C.c_void_p(r["g0"]), _lib.ptr(r["m"]), _lib.ptr(r["v"]), None,
+                    _lib.check(lib.rgqa_bertadam_step(C.c_void_p(r["p0"]), C.c_void_p(r["g0"]), _lib.ptr(r["m"]), _lib.ptr(r["v"]), None, 0,
                                                       r["n"], lr_scheduled, group['b1'], group['b2'], group['e'], group['weight_decay'],
                                                       None, 0.0, 1.0, stream))
                 else:
                     for p in r["params"]:
                         st = self.state[p]
                         _lib.check(lib.rgqa_bertadam_step(_lib.ptr(p.data), _lib.ptr(p.grad), _lib.ptr(st["next_m"]), _lib.ptr(st["next_v"]),
-                                                          None, p.numel(), lr_scheduled, group['b1'], group['b2'], group['e'],
+                                                          None, 0, p.numel(), lr_scheduled, group['b1'], group['b2'], group['e'],
                                                           group['weight_decay'], None, 0.0, 1.0, stream))
                 for p in r["params"]:
                     self.state[p]["step"] += 1

@@ -3,7 +3,7 @@ on ROCm; "gloo" in the CPU / single-GPU tests).
 
 Replaces the reference's single-process nn.DataParallel (lxrt/entry.py:102-103): samples are independent through the whole
 forward, so each rank runs its own shard of the batch and the only exchange per step is the gradient arena.
-Three modes (`make_exchange`, env RGQA_DP_MODE):
+Three modes (`make_exchange`, env RGQA_DP_MODE; RGQA_DP_OVERLAP=0 issues any of them after backward instead of beside it):
 
   allreduce        f32 SUM all-reduce of the live arena ranges (819 MB), buckets of >= 64 MB issued from a side stream as backward
                    finalises them; every rank then clips and runs BertAdam over the whole arena (round 1).
@@ -11,10 +11,14 @@ Three modes (`make_exchange`, env RGQA_DP_MODE):
   sharded          (default) reduce-scatter as ONE all-to-all per chunk with a bf16 payload: rank r receives every rank's bf16 copy
                    of the 1/N range it owns and accumulates them in f32 in rank order (rgqa_sum_bf16_parts: deterministic, no
                    bf16 running sum); clip + BertAdam then touch only that 1/N (sum(g^2) of the shards is one scalar
-                   all-reduce), and the updated bf16 weights are all-gathered into every rank's forward copy.  On the 8-GPU xGMI
-                   mesh an all-to-all uses all 7 links of a GPU at once, the wire carries 2 x 7/8 x 410 MB per GPU per step
-                   instead of 2 x 7/8 x 819 MB, and the optimizer's 6 GB of HBM traffic shrinks 8x.  The f32 master copy of a
-                   range is current only on its owner: `gather_master()` refreshes all of them (checkpoints, state_dict).
+                   all-reduce), and the updated weights are all-gathered into every rank's forward copy (bf16 engines: the bf16
+                   copy; f32 / bf16x3 engines: the f32 masters).  The chunks are the gradient segments backward finalises (merged
+                   to >= 64 MB), each exchanged on a side stream as soon as its event fires, so only the last one is exposed.  On
+                   the 8-GPU xGMI mesh an all-to-all uses all 7 links of a GPU at once, the wire carries 2 x 7/8 x 410 MB per GPU
+                   per step instead of 2 x 7/8 x 819 MB, and the optimizer's 6 GB of HBM traffic shrinks 8x.  While this mode is
+                   active the f32 master copy and the Adam moments of a range are current only on its owner: the engine refuses
+                   `adam_step` (Engine._sharded_owner), `gather_master()` refreshes the masters (checkpoints, state_dict) and
+                   `release()` gathers masters + moments and hands the optimizer back to the engine.
 
 The dead range (x_layers.<last>.visn_*: never receives gradients in mode 'x') is in no bucket.  The exchange entry points
 return immediately; ordering is by streams and events, never by host synchronisation."""
@@ -94,6 +98,9 @@ class _HipOps:
 class GradAllReduce:
     """modes 'allreduce' / 'allreduce_bf16'"""
 
+    def release(self):
+        pass
+
     def __init__(self, engine, dist, bucket_mb=64, overlap=None, bf16=False, ops=None):
         self.e, self.dist, self.bf16 = engine, dist, bf16
         self.ops = ops if ops is not None else (_HipOps(engine.lib) if bf16 else None)
@@ -154,20 +161,38 @@ class ShardedExchange:
     """mode 'sharded' (module docstring).  exchange(): bf16 all-to-all reduce-scatter with f32 accumulation at the owner;
     step(): sharded clip + BertAdam, bf16 weight all-gather, transposed-copy refresh."""
 
-    def __init__(self, engine, dist, chunk_mb=256, ops=None):
+    def __init__(self, engine, dist, chunk_mb=256, bucket_mb=64, overlap=None, ops=None):
         self.e, self.dist = engine, dist
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.ops = ops if ops is not None else _HipOps(engine.lib)
-        self.chunks = shard_layout(engine.live_ranges(), self.world, chunk_mb * (1 << 20) // 2)
+        if overlap is None:
+            overlap = os.environ.get("RGQA_DP_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and hasattr(engine, "grad_segments") and hasattr(engine, "wait_grad_event")
+        if self.overlap:       # chunks = the gradient segments in the order backward finalises them, each with the event to wait for
+            self.chunks, self.events = [], []
+            for a, b, ev in merge_segments(engine.grad_segments(), bucket_mb * (1 << 20) // 4):
+                for c in shard_layout([(a, b)], self.world, chunk_mb * (1 << 20) // 2):
+                    self.chunks.append(c)
+                    self.events.append(ev)
+        else:
+            self.chunks = shard_layout(engine.live_ranges(), self.world, chunk_mb * (1 << 20) // 2)
+            self.events = [-1] * len(self.chunks)
         self.smax = max(s for _, _, s in self.chunks)
-        self._send = self._recv = self._sumsq = self._sqws = None
+        dev = engine.grads.device
+        self._send = torch.zeros(self.world * self.smax, dtype=torch.bfloat16, device=dev)
+        self._recv = torch.zeros(self.world * self.smax, dtype=torch.bfloat16, device=dev)
+        self._sumsq = self._sqws = None
+        self.side = None
         backend = dist.get_backend()
         self._host_staged = backend != "nccl"      # rehearsal on one device over gloo: collectives run on host copies
+        # what is all-gathered after the update: the bf16 operand copy (bf16 engines), else the f32 masters (a split-f32 copy cannot be
+        # cut at arbitrary element offsets: a 128-byte line holds the hi and the lo parts of 32 elements; it is re-made from the masters)
         self.lp = engine.precision == "bf16"
 
     def describe(self):
-        return "sharded: bf16 all-to-all reduce-scatter + sharded BertAdam + %s weight all-gather, %d chunk(s) of <= %d MB" % (
-            "bf16" if self.lp else "f32", len(self.chunks), self.smax * self.world * 2 >> 20)
+        return "sharded: bf16 all-to-all reduce-scatter + sharded BertAdam + %s weight all-gather, %d chunk(s) of <= %d MB, %s" % (
+            "bf16" if self.lp else "f32", len(self.chunks), self.smax * self.world * 2 >> 20,
+            "overlapped with backward" if self.overlap else "after backward")
 
     # -- collectives (RCCL on device tensors; host-staged under gloo, where device tensors are not supported by every op)
     def _a2a(self, recv, send):
@@ -190,13 +215,11 @@ class ShardedExchange:
         """After backward: leaves, in the gradient arena, the SUM over ranks of the ranges this rank owns (other ranges keep the
         local gradients and are not read again)."""
         g = self.e.grads if grads is None else grads
-        W, S = self.world, self.smax
+        W = self.world
         if hasattr(self.e, "invalidate_segment_sumsq"):
             self.e.invalidate_segment_sumsq()
-        if self._send is None:
-            self._send = torch.zeros(W * S, dtype=torch.bfloat16, device=g.device)
-            self._recv = torch.zeros(W * S, dtype=torch.bfloat16, device=g.device)
-        for a, b, s in self.chunks:
+
+        def one(a, b, s):
             n = b - a
             send, recv = self._send[:W * s], self._recv[:W * s]
             self.ops.cast_bf16(send[:n], g[a:b])            # part r of the chunk at send[r*s : (r+1)*s]; the ragged tail is never read
@@ -205,11 +228,30 @@ class ShardedExchange:
             if hi > lo:
                 self.ops.sum_parts(g[lo:hi], recv, s, W)    # f32 accumulation in rank order
 
+        if not (self.overlap and g.is_cuda):
+            for c in self.chunks:
+                one(*c)
+            return
+        # every chunk on ONE side stream (they share the staging buffers), each behind the event of the gradient segment it holds:
+        # the exchange of the layers backward has finished runs beside the layers it is still computing
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=g.device)
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(self.side):
+            for c, ev in zip(self.chunks, self.events):
+                self.e.wait_grad_event(ev, self.side)
+                one(*c)
+        cur.wait_stream(self.side)
+
     all_reduce = exchange
 
     def step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, clip=True):
         e, W = self.e, self.world
         dev = e.grads.device
+        if hasattr(e, "_sharded_owner"):
+            if e._sharded_owner is not None and e._sharded_owner is not self:
+                raise RuntimeError("ShardedExchange.step: another sharded exchange owns this engine's optimizer state; release() it first")
+            e._sharded_owner = self
         if e.adam_m is None:
             e.adam_m = torch.zeros_like(e.params)        # only the owned ranges are ever touched (288 GB HBM: no need to compact)
             e.adam_v = torch.zeros_like(e.params)
@@ -251,6 +293,8 @@ class ShardedExchange:
     def _after_weights(self, s):
         if self.lp:
             check(self.e.lib.rgqa_engine_sync_transposed(self.e.h, s))     # dgrad operand: transposed bf16 copies, from the gathered bf16 arena
+        elif getattr(self.e, "params_lp", None) is not None:
+            check(self.e.lib.rgqa_engine_sync_weights(self.e.h, s))        # bf16x3: both split-f32 copies re-made from the gathered f32 masters
 
     def _local_sumsq(self, lo, hi, s):
         e = self.e
@@ -259,12 +303,22 @@ class ShardedExchange:
     def _local_adam(self, lo, hi, lr_t, b1, b2, eps, wd, clip, max_norm, prescale, s):
         e = self.e
         lp = ptr(e.params_lp[lo:hi]) if self.lp else None
-        check(e.lib.rgqa_bertadam_step(ptr(e.params[lo:hi]), ptr(e.grads[lo:hi]), ptr(e.adam_m[lo:hi]), ptr(e.adam_v[lo:hi]), lp, hi - lo,
+        check(e.lib.rgqa_bertadam_step(ptr(e.params[lo:hi]), ptr(e.grads[lo:hi]), ptr(e.adam_m[lo:hi]), ptr(e.adam_v[lo:hi]), lp, 0, hi - lo,
                                        lr_t, b1, b2, eps, wd, ptr(self._sumsq) if clip else None, max_norm, prescale, s))
 
-    def gather_master(self):
+    def release(self):
+        """Gathers the f32 masters AND the Adam moments to every rank and hands the optimizer back to the engine (Engine.adam_step works
+        again; a later step() of this exchange re-shards without loss: every rank then holds the full state)."""
+        self.gather_master()
+        if self.e.adam_m is not None:
+            self.gather_master(self.e.adam_m)
+            self.gather_master(self.e.adam_v)
+        if hasattr(self.e, "_sharded_owner"):
+            self.e._sharded_owner = None
+
+    def gather_master(self, arena=None):
         """All-gathers the f32 master weights (each range is current only on its owner): before state_dict() / checkpoints."""
-        p = self.e.params
+        p = self.e.params if arena is None else arena
         for a, b, sz in self.chunks:
             n = b - a
             lo, hi = owned((a, b, sz), self.rank)

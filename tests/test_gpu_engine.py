@@ -1,6 +1,13 @@
 """End-to-end parity of the HIP engine against the golden fixtures (produced by the reference itself) and the
-oracle, through the C ABI.  f32 precision: logits within 1e-3 (BASELINE.json north_star; observed ~1e-5).
-bf16 precision: tolerance stated per test."""
+oracle, through the C ABI.
+
+Three precisions, one bound that matters: BASELINE.json's north star asks for logits within 1e-3 of the reference's f32 CPU path.
+  f32      exact f32 FMA arithmetic on the vector ALU: inside the bound (observed ~1e-5); slow, kept as the on-device reference
+  bf16x3   split-f32 operands, three bf16 MFMA products per f32 product: the FAST mode inside the bound (observed ~1e-4, printed)
+  bf16     BASELINE config 3's mode ("fwd+bwd B=256 bf16"): bf16 operands through 19 blocks leave the logits ~5e-2 from the
+           reference's - OUTSIDE the 1e-3 bound by construction.  Its tests therefore gate on what bf16 can promise: the mean
+           logit error and the loss / gradient-norm scalars (sums whose rounding errors cancel) first, the element-wise maxima
+           at <= 2x the observed values second."""
 import os
 
 import numpy as np
@@ -87,6 +94,32 @@ def test_f32_full_config_vs_golden(golden_dir, T):
         np.testing.assert_allclose(gr.reshape(-1)[sample_idx(k, gr.size)], ref, rtol=5e-3, atol=1e-6 + 5e-4 * np.abs(gr).max(), err_msg=k)
 
 
+@pytest.mark.parametrize("T", [20, 30])
+def test_x3_full_config_vs_golden(golden_dir, T):
+    """bf16x3 precision on the real 9/5/5 architecture against the reference's own outputs (G2): the north-star bound on the logits,
+    and gradients at f32-class accuracy (the bf16 mode's figures on the same fixture: logits 4e-2, sampled gradients 9e-3)."""
+    g = np.load(os.path.join(golden_dir, "g2_full_T%d.npz" % T))
+    e = make_engine(FULL, "bf16x3")
+    b = dev(full_batch(T))
+    e.ensure_shape(4, T, 36)
+    e.sync_weights()
+    lg, pl = run(e, b)
+    err = np.abs(lg.cpu().numpy() - g["logits"])
+    perr = np.abs(pl.cpu().numpy() - g["pooled"])
+    loss = e.loss_backward(b["target"]).item()
+    gn = e.grad_norm().item()
+    worst, wname, overall = _grad_sample_errors(e, g["grad_names"].tolist(), g["grad_counts"].tolist(), g["grad_samples"])
+    _report("bf16x3 full B=4 T=%d vs G2" % T, logits_max=err.max(), logits_mean=err.mean(), pooled_max=perr.max(), loss_rel=abs(loss - g["loss"]) / abs(g["loss"]),
+            grad_norm_rel=abs(gn - g["grad_norm"]) / g["grad_norm"], grad_samples_rel=overall, worst_tensor_rel=worst)
+    print("   worst tensor:", wname)
+    assert err.max() <= 1e-3, err.max()            # the north-star bound
+    assert perr.max() <= 1e-3, perr.max()
+    assert abs(loss - g["loss"]) < 1e-4 * abs(g["loss"])
+    assert abs(gn - g["grad_norm"]) < 1e-3 * g["grad_norm"]
+    assert overall < 2e-3, overall
+    assert worst < 1e-2, (wname, worst)
+
+
 MED = dict(vocab_size=512, hidden=128, heads=2, inter=256, max_pos=64, type_vocab=2, l_layers=3, x_layers=2, r_layers=2,
            feat_dim=64, pos_dim=4, num_answers=70)
 
@@ -103,7 +136,7 @@ def oracle_run(cfgd, b, want_grads=True):
     return lg.detach(), pl.detach(), loss.item(), P
 
 
-@pytest.mark.parametrize("precision,tol,gtol", [("f32", 1e-4, 2e-3), ("bf16", 1.5e-2, 3.5e-2)])    # bf16 observed: logits 7.6e-3, worst tensor 1.7e-2
+@pytest.mark.parametrize("precision,tol,gtol", [("f32", 1e-4, 2e-3), ("bf16x3", 2e-4, 2e-3), ("bf16", 1.5e-2, 3.5e-2)])    # bf16 observed: logits 7.6e-3, worst tensor 1.7e-2
 def test_medium_config_vs_oracle(precision, tol, gtol):
     """head size 64 / dims multiple of 64, so the bf16 MFMA kernels are the ones exercised.
     bf16 tolerance (2x observed): bf16 has 8 significant bits; through 7 blocks logits (|z|~1) land within 1.5e-2 abs, gradients within
@@ -186,11 +219,14 @@ def test_bf16_full_config_vs_golden(golden_dir, T):
     # logits max 3.8e-2 / 5.1e-2, mean 8.2e-3, pooled max 2.4e-2 / 2.7e-2, all sampled gradient entries 9.1e-3 / 9.0e-3 rel, worst
     # tensor 5.8e-2 / 4.1e-2.  The two scalars are sums whose rounding errors largely cancel, so they wander between kernel variants
     # (loss 1.3e-5 .. 1.4e-4 rel, gradient norm 8.7e-5 .. 5.0e-4 rel): bounded at 5e-4 / 1.5e-3.
-    assert err.max() < 1.0e-1 and err.mean() < 1.6e-2, (err.max(), err.mean())
-    assert perr.max() < 5.4e-2, perr.max()
+    # primary gates (what bf16 operands CAN promise; this mode is outside the north star's 1e-3 logits bound - see the module docstring)
+    assert err.mean() < 1.6e-2, err.mean()
     assert abs(loss - g["loss"]) < 5e-4 * abs(g["loss"])
     assert abs(gn - g["grad_norm"]) < 1.5e-3 * g["grad_norm"]
     assert overall < 1.8e-2, overall
+    # secondary: element-wise maxima at <= 2x the observed values
+    assert err.max() < 1.0e-1, err.max()
+    assert perr.max() < 5.4e-2, perr.max()
     assert worst < 0.115, (wname, worst)
 
 
@@ -247,11 +283,50 @@ def test_bf16_cfg3_b256_fwd_bwd_vs_oracle(layout):
     # tolerances: 2x the largest observed (both layouts agree to the digits shown): logits max 4.5e-2 .. 5.1e-2, mean 7.75e-3, sampled
     # gradient entries 6.3e-3 rel, worst tensor (word embeddings) 2.4e-2; the scalars (cancelling sums) observed at loss 1.8e-6 .. 7.7e-6 rel,
     # gradient norm 6.2e-5 .. 7.7e-5 rel: bounded at 1e-4 / 4e-4
-    assert err.max() < 1.0e-1 and err.mean() < 1.55e-2, (err.max(), err.mean())
+    # primary gates: mean logit error, loss, gradient norm, the sampled gradient entries; secondary: the element-wise maxima.  (bf16 is
+    # BASELINE config 3's mode and is OUTSIDE the north star's 1e-3 logits bound; the bound is met by bf16x3: the next test)
+    assert err.mean() < 1.55e-2, err.mean()
     assert abs(loss - o["loss"]) < 1e-4 * abs(o["loss"])
     assert abs(gn - o["grad_norm"]) < 4e-4 * o["grad_norm"]
     assert overall < 1.25e-2, overall
+    assert err.max() < 1.0e-1, err.max()
     assert worst < 4.8e-2, (wname, worst)
+
+
+def test_x3_cfg3_b256_fwd_bwd_vs_oracle():
+    """The tolerance-compliant train step at BASELINE's size (B=256, T=20, packed rows, dropout off for parity): bf16x3 forward +
+    backward against the CPU oracle: logits inside the north star's 1e-3, every sampled gradient entry at f32-class accuracy."""
+    o = _b256_oracle()
+    b = o["b"]
+    e = make_engine(FULL, "bf16x3")
+    d = dev(b)
+    e.ensure_shape(256, 20, 36)
+    e.sync_weights()
+    lengths = np.ascontiguousarray(b["lengths"], dtype=np.int32)
+    lg, pl = e.forward(d["feats"], d["boxes"], d["input_ids"], d["input_mask"], d["segment_ids"], train=False, seed=0, lengths=lengths)
+    err = np.abs(lg.cpu().numpy() - o["logits"])
+    loss = e.loss_backward(d["target"]).item()
+    gn = e.grad_norm().item()
+    byname = {sp.name: sp for sp in e.specs}
+    num = den = 0.0
+    worst, wname = 0.0, ""
+    for k, ref in o["grads"].items():
+        gr = e.view(e.grads, byname[k]).float().cpu().numpy().reshape(-1)
+        got = gr[sample_idx(k, gr.size)]
+        dd, rr = float(np.linalg.norm(got - ref)), float(np.linalg.norm(ref))
+        num += dd * dd
+        den += rr * rr
+        if rr > 1e-6 * max(1.0, float(np.abs(gr).max())) and dd / rr > worst:
+            worst, wname = dd / rr, k
+    overall = (num / den) ** 0.5
+    _report("bf16x3 full B=256 T=20 packed vs oracle", logits_max=err.max(), logits_mean=err.mean(), loss_rel=abs(loss - o["loss"]) / abs(o["loss"]),
+            grad_norm_rel=abs(gn - o["grad_norm"]) / o["grad_norm"], grad_samples_rel=overall, worst_tensor_rel=worst)
+    print("   worst tensor:", wname)
+    assert err.max() <= 1e-3, err.max()            # the north-star bound, at the benchmarked size
+    assert abs(loss - o["loss"]) < 2e-5 * abs(o["loss"])
+    assert abs(gn - o["grad_norm"]) < 2e-4 * o["grad_norm"]
+    assert overall < 2e-3, overall
+    assert worst < 1e-2, (wname, worst)
 
 
 def test_dropout_train_mode_is_deterministic_and_consistent():
@@ -321,173 +396,6 @@ def test_side_stream_wgrad_matches_serial():
         assert torch.equal(grads(0), ref)
 
 
-def test_wgrad_launch_phase_is_bit_identical():
-    """Where the deferred weight-gradient launches are cut (rgqa_debug_set key 11: 0 = after a layer's attention block, 1 = after every FFN
-    stage, so that a launch runs beside LayerNorm / attention kernels) changes only the grouping: every gradient is bit-identical, on the
-    side stream and on the main stream, full architecture (two-modality, language-only and cross-modality layers), packed rows."""
-    from rgqa_amd import _lib
-    L = _lib.load()
-    B, T, O = 32, 20, 36
-    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=15, min_len=3)
-    b = dev(raw)
-    lens = raw["lengths"].astype(np.int32)
-    e = make_engine(FULL, "bf16", dropout=0.1)
-    e.ensure_shape(B, T, O)
-    e.sync_weights()
-    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
-
-    def grads(phase, serial, packed):
-        assert L.rgqa_debug_set(11, phase) == 0 and L.rgqa_debug_set(2, serial) == 0
-        try:
-            e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=41, lengths=lens if packed else None)
-            e.loss_backward(b["target"])
-            gn = e.grad_norm().item()
-            torch.cuda.synchronize()
-            return e.grads[first:].clone(), gn
-        finally:
-            L.rgqa_debug_set(11, -1)
-            L.rgqa_debug_set(2, 0)
-
-    for packed in (True, False):
-        ref, gn_ref = grads(0, 1, packed)
-        assert float(ref.abs().max()) > 0
-        for phase, serial in ((1, 1), (1, 0), (0, 0), (1, 0)):
-            g, gn = grads(phase, serial, packed)
-            assert torch.equal(g, ref), (packed, phase, serial)
-            assert gn == gn_ref          # the per-segment sum of squares is taken when a segment's last gradient is final
-
-
-def test_ticket_scheduled_gemm_tiles_are_bit_identical():
-    """Persistent forward / dgrad GEMMs can hand out their tiles by ticket (rgqa_debug_set key 12: N = the first N blocks of a launch start on a
-    fixed tile, the rest are spares that only draw tickets) instead of the fixed walk b, b + grid, ...: which block computes a tile
-    changes nothing in the tile, so logits and every gradient are bit-identical - B = 128 so that the FFN / QKV launches have more tiles than
-    the chip has CUs."""
-    from rgqa_amd import _lib
-    L = _lib.load()
-    B, T, O = 128, 20, 36
-    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=17, min_len=3)
-    b = dev(raw)
-    lens = raw["lengths"].astype(np.int32)
-    e = make_engine(FULL, "bf16", dropout=0.1)
-    e.ensure_shape(B, T, O)
-    e.sync_weights()
-    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
-
-    def run_mode(n):
-        assert L.rgqa_debug_set(12, n) == 0
-        try:
-            lg, _ = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=43, lengths=lens)
-            lg = lg.clone()
-            e.loss_backward(b["target"])
-            torch.cuda.synchronize()
-            return lg, e.grads[first:].clone()
-        finally:
-            L.rgqa_debug_set(12, -1)
-
-    lg0, g0 = run_mode(0)
-    assert float(g0.abs().max()) > 0
-    for n in (256, 200, 64, 256):
-        lg, g = run_mode(n)
-        assert torch.equal(lg, lg0), n
-        assert torch.equal(g, g0), n
-
-
-@pytest.mark.parametrize("cfgname,B", [("MED", 6), ("FULL", 128)])
-def test_dgrad_from_stored_weight_is_bit_identical(cfgname, B):
-    """rgqa_debug_set key 14 = 1: the input-gradient GEMMs read the weight as stored, [out, in] (contraction rows staged as a row-major
-    LDS image, fragments by transposed LDS reads) instead of the transposed bf16 copy: the same operand values in the same MFMA order, so
-    every gradient is bit-identical - hidden size 128 (small tiles, deep-ring kernel) and the full architecture at B = 128 (persistent
-    kernel, more tiles than CUs), packed and padded rows."""
-    from rgqa_amd import _lib
-    L = _lib.load()
-    cfgd = MED if cfgname == "MED" else FULL
-    T, O = (12, 7) if cfgname == "MED" else (20, 36)
-    raw = synth.synth_batch(B, T, O=O, F=cfgd["feat_dim"], NA=cfgd["num_answers"], vocab=cfgd["vocab_size"], seed=19, min_len=2)
-    b = dev(raw)
-    lens = raw["lengths"].astype(np.int32)
-    e = make_engine(cfgd, "bf16", dropout=0.1)
-    e.ensure_shape(B, T, O)
-    e.sync_weights()
-    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
-
-    def grads(nn, packed):
-        assert L.rgqa_debug_set(14, nn) == 0
-        try:
-            e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=47, lengths=lens if packed else None)
-            e.loss_backward(b["target"])
-            torch.cuda.synchronize()
-            return e.grads[first:].clone()
-        finally:
-            L.rgqa_debug_set(14, -1)
-
-    for packed in (True, False):
-        ref = grads(0, packed)
-        assert float(ref.abs().max()) > 0
-        assert torch.equal(grads(1, packed), ref), packed
-
-
-def test_merged_layernorm_matches_per_modality(monkeypatch):
-    """Stages where both modalities run their own module share one LayerNorm launch (forward and backward) over the
-    adjacent [language | vision] rows; RGQA_LN_MERGE=0 keeps one launch per modality. Same arithmetic per row and the same
-    fixed-order fold of the per-block column sums, so logits and every gradient must be bit-identical (packed rows too)."""
-    B, T, O = 48, 20, 36
-    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=9, min_len=3)
-    lens = [int(v) for v in raw["input_mask"].sum(1)]
-    b = dev(raw)
-    out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("RGQA_LN_MERGE", flag)
-        e = make_engine(FULL, "bf16", dropout=0.1)
-        e.ensure_shape(B, T, O)
-        e.sync_weights()
-        logits = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=31, lengths=lens)[0].clone()
-        e.loss_backward(b["target"])
-        torch.cuda.synchronize()
-        out[flag] = (logits, e.grads.clone())
-        specs = e.specs
-        del e
-    assert float(out["1"][1].abs().max()) > 0
-    assert torch.equal(out["0"][0], out["1"][0])
-    # the embedding tables accumulate with float atomics (order varies run to run): everything downstream must be exact
-    specs = [sp for sp in specs if "_embeddings.weight" not in sp.name]
-    bad = [sp.name for sp in specs if not torch.equal(out["0"][1][sp.offset:sp.offset + sp.numel], out["1"][1][sp.offset:sp.offset + sp.numel])]
-    assert not bad, bad
-
-
-def test_wgrad_split_contraction_plan():
-    """Opt-in wgrad plan (rgqa_debug_set key 6 = 2): XCD-local placement + the long (vision) contractions cut into chunks whose
-    f32 partials are folded in a fixed order. Against the default launch: same gradients up to f32 re-association, bit-identical
-    from run to run, and nothing left unwritten (the gradient arena is poisoned before each pass)."""
-    from rgqa_amd import _lib
-    L = _lib.load()
-    B, T, O = 96, 20, 36
-    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=12, min_len=3)
-    lens = [int(v) for v in raw["input_mask"].sum(1)]
-    b = dev(raw)
-    e = make_engine(FULL, "bf16", dropout=0.1)
-    e.ensure_shape(B, T, O)
-    e.sync_weights()
-    specs = [sp for sp in e.specs if "_embeddings.weight" not in sp.name and not sp.dead]
-
-    def grads(plan):
-        assert L.rgqa_debug_set(6, plan) == 0
-        try:
-            e.grads.fill_(1.0e6)
-            e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=5, lengths=lens)
-            e.loss_backward(b["target"])
-            torch.cuda.synchronize()
-            return e.grads.clone()
-        finally:
-            L.rgqa_debug_set(6, -1)
-
-    ref, got, again = grads(0), grads(2), grads(2)
-    for sp in specs:
-        r, g = ref[sp.offset:sp.offset + sp.numel], got[sp.offset:sp.offset + sp.numel]
-        assert float(g.abs().max()) < 1.0e5, sp.name                      # no poison left
-        assert float((g - r).norm()) <= 1e-5 * float(r.norm()) + 1e-12, sp.name
-        assert torch.equal(g, again[sp.offset:sp.offset + sp.numel]), sp.name
-
-
 @pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("tag,T,prec,tol", [("small", 5, "f32", 2e-5), ("small", 8, "f32", 2e-5), ("full", 20, "f32", 1e-4), ("full", 20, "bf16", 3e-2)])
 def test_cross_attention_probabilities_vs_golden(golden_dir, tag, T, prec, tol, packed):
@@ -528,13 +436,15 @@ def test_cross_attention_probabilities_vs_golden(golden_dir, tag, T, prec, tol, 
         e.cross_attention(cfgd["x_layers"], "l2v")
 
 
-def test_config2_forward_b256_f32_logits_vs_cpu():
-    """BASELINE config 2: forward-only inference at B=256 (full 9/5/5 architecture, f32 operands); samples are independent,
-    so the CPU oracle is evaluated on a spread of 6 of the 256 rows and must agree within 1e-3 (observed ~1e-5)."""
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_config2_forward_b256_logits_vs_cpu(precision):
+    """BASELINE config 2: forward-only inference at B=256 (full 9/5/5 architecture) in the two precisions inside the north star's bound
+    (f32: exact FMA arithmetic, observed ~1e-5; bf16x3: the fast path, observed ~1e-4); samples are independent, so the CPU oracle is
+    evaluated on a spread of 6 of the 256 rows and must agree within 1e-3."""
     from oracle import lxmert_ref as R
     B, T = 256, 20
     b = synth.synth_batch(B, T, seed=2024)
-    e = make_engine(FULL, "f32")
+    e = make_engine(FULL, precision)
     d = dev(b)
     e.ensure_shape(B, T, 36)
     e.sync_weights()
@@ -546,6 +456,7 @@ def test_config2_forward_b256_f32_logits_vs_cpu():
         lr, pr = R.gqa_forward(P, cfg, torch.from_numpy(b["feats"][pick]), torch.from_numpy(b["boxes"][pick]),
                                torch.from_numpy(b["input_ids"][pick]), torch.from_numpy(b["input_mask"][pick]))
     err = float((lg[pick].cpu() - lr).abs().max())
+    _report("config 2 forward B=256 %s vs CPU oracle" % precision, logits_max=err, pooled_max=float((pl[pick].cpu() - pr).abs().max()))
     assert err <= 1e-3, err
     assert float((pl[pick].cpu() - pr).abs().max()) <= 1e-3
     assert torch.isfinite(lg).all()
@@ -556,7 +467,7 @@ def _grads_by_name(e):
     return {sp.name: e.view(e.grads, sp).clone() for sp in e.specs}
 
 
-@pytest.mark.parametrize("precision,ltol,gtol", [("f32", 2e-5, 2e-4), ("bf16", 6e-2, 8e-2)])
+@pytest.mark.parametrize("precision,ltol,gtol", [("f32", 2e-5, 2e-4), ("bf16x3", 2e-4, 1e-3), ("bf16", 6e-2, 8e-2)])
 def test_varlen_matches_padded(precision, ltol, gtol):
     """rgqa_engine_set_lengths packs the language rows to the real tokens.  Padded positions are masked keys with probability
     exactly 0 and the pooler reads token 0, so logits, loss and every gradient must agree with the padded pass (f32: to
@@ -602,7 +513,7 @@ def test_varlen_matches_padded(precision, ltol, gtol):
             assert torch.equal(g2[sp.name], g0[sp.name]), sp.name
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("train", [False, True])
 def test_cls_only_tail_matches_full_rows(precision, train):
     """Only token 0 of the last language FFN is consumed (modeling.py:575-581): running that sub-block on the B [CLS] rows
@@ -645,50 +556,6 @@ def test_cls_only_tail_matches_full_rows(precision, train):
                 worst = max(worst, float((g1[name] - ref).abs().max()) / den)
         _report("cls tail vs all rows %s train=%s packed=%s" % (precision, train, packed), logits_max=float((lg1 - lg0).abs().max()), grad_rel_max=worst)
         assert worst <= 1e-6
-
-
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_deferred_layernorm_column_sums_match_inline(precision):
-    """LayerNorm-backward column sums (dgamma, dbeta and the bias gradient of the GEMM before the LayerNorm) are folded once per layer beside
-    the layer's weight-gradient launch (default) or by every LayerNorm backward itself on the main stream (rgqa_debug_set key 10 = 0): the same
-    partials folded in the same order, so every LayerNorm / bias gradient is bit-identical; with dropout on, packed and padded rows, and
-    also when the weight-gradient launches run on the main stream (key 2)."""
-    from rgqa_amd import _lib
-    L = _lib.load()
-    B, T, O = 6, 12, 7
-    raw = synth.synth_batch(B, T, O=O, F=MED["feat_dim"], NA=MED["num_answers"], vocab=MED["vocab_size"], seed=35, min_len=2)
-    b = dev(raw)
-    lens = raw["lengths"].astype(np.int32)
-    from rgqa_amd.engine import Engine
-    e = Engine(precision=precision, hidden_dropout=0.1, attn_dropout=0.1, **MED).allocate("cuda")
-    for sp in e.specs:
-        e.view(e.params, sp).copy_(torch.from_numpy(synth.fill_value(sp.name, sp.shape)))
-    e.ensure_shape(B, T, O)
-    e.sync_weights()
-    res = {}
-    try:
-        for serial in (0, 1):
-            assert L.rgqa_debug_set(2, serial) == 0
-            for mode in (0, 1):
-                assert L.rgqa_debug_set(10, mode) == 0
-                for packed in (False, True):
-                    e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=9, lengths=lens if packed else None)
-                    e.loss_backward(b["target"])
-                    torch.cuda.synchronize()
-                    res[(serial, mode, packed)] = _grads_by_name(e)
-    finally:
-        L.rgqa_debug_set(10, -1)
-        L.rgqa_debug_set(2, 0)
-    n = 0
-    for serial in (0, 1):
-        for packed in (False, True):
-            g0, g1 = res[(serial, 0, packed)], res[(serial, 1, packed)]
-            for name, ref in g0.items():
-                if "embeddings" in name and "LayerNorm" not in name:
-                    continue       # scatter-added with atomics: not bit-reproducible between two runs of the same code either
-                assert torch.equal(g1[name], ref), (serial, packed, name)
-                n += 1
-    assert n > 400
 
 
 @pytest.mark.parametrize("T", [5, 8])
@@ -768,15 +635,16 @@ SWEEP = [   # (B, T, O, l, x, r, heads, hidden, answers, packed)
 ]
 
 
-@pytest.mark.parametrize("precision,tol,gtol", [("f32", 2e-4, 3e-3), ("bf16", 2e-2, 4.5e-2)])     # bf16 observed: logits <= 1.0e-2, worst tensor <= 2.2e-2
+@pytest.mark.parametrize("precision,tol,gtol", [("f32", 2e-4, 3e-3), ("bf16x3", 3e-4, 3e-3), ("bf16", 2e-2, 4.5e-2)])     # bf16 observed: logits <= 1.0e-2, worst tensor <= 2.2e-2
 @pytest.mark.parametrize("shape", SWEEP, ids=lambda s: "B%dT%dO%d_l%dx%dr%d_h%d" % (s[0], s[1], s[2], s[3], s[4], s[5], s[6]))
 def test_shape_sweep_vs_oracle(shape, precision, tol, gtol):
     """Edge shapes of the engine (single sample, no l- or r-layers, T beyond two query tiles, 2-token questions, 64 RoIs, answer
     counts that are not multiples of 8) against the oracle: logits, loss and every gradient, padded or packed language rows."""
     B, T, O, l, x, r, heads, hidden, na, packed = shape
+    F = 64 if precision == "bf16x3" else 48          # split-f32 rows are whole 128-byte lines: feature size a multiple of 32
     cfgd = dict(vocab_size=300, hidden=hidden, heads=heads, inter=2 * hidden, max_pos=64, type_vocab=2, l_layers=l, x_layers=x, r_layers=r,
-                feat_dim=48, pos_dim=4, num_answers=na)
-    b = synth.synth_batch(B, T, O=O, F=48, NA=na, vocab=300, seed=100 + B, min_len=2)
+                feat_dim=F, pos_dim=4, num_answers=na)
+    b = synth.synth_batch(B, T, O=O, F=F, NA=na, vocab=300, seed=100 + B, min_len=2)
     lg_r, pl_r, loss_r, Pr = oracle_run(cfgd, b)
     e = make_engine(cfgd, precision)
     d = dev(b)
@@ -813,7 +681,7 @@ def test_training_converges_bf16_like_f32():
     lens = raw["lengths"].astype(np.int32)
     b = dev(raw)
     curves = {}
-    for precision in ("f32", "bf16"):
+    for precision in ("f32", "bf16", "bf16x3"):
         e = make_engine(MED, precision, dropout=0.1)
         e.ensure_shape(B, T, O)
         e.sync_weights()
@@ -830,8 +698,10 @@ def test_training_converges_bf16_like_f32():
         # f32 engine from the same weights and seed in both layouts and absent in eval mode (measured in round 2); which step it
         # hits depends on the last bits of the trajectory, so a mean over the final steps is not a stable statistic
         assert np.median(losses[-9:]) < np.median(losses[:3]) / 3.0, (precision, losses[:3], losses[-9:])
-    f, h = np.median(curves["f32"][-11:]), np.median(curves["bf16"][-11:])
-    assert abs(f - h) < 0.35 * max(f, h), (f, h)
+    f = np.median(curves["f32"][-11:])
+    for other in ("bf16", "bf16x3"):
+        h = np.median(curves[other][-11:])
+        assert abs(f - h) < 0.35 * max(f, h), (other, f, h)
 
 
 def test_split_k_visual_projection_wgrad():
@@ -920,50 +790,3 @@ def test_full_size_batch_independence_and_roi_permutation():
     assert float((permuted - full).abs().mean()) <= 3e-3 * scale
 
 
-@pytest.mark.parametrize("mode", [True, "background"])
-def test_pipelined_optimizer_matches_inline(mode, monkeypatch):
-    """Engine.adam_step(pipeline=True): BertAdam on a side stream in forward order, the next forward / backward waiting on per-range
-    events (rgqa_engine_set_weight_events); pipeline="background": the update confined to a few CUs (here 48, with the ticket-scheduled
-    GEMMs that tolerate the missing CUs), per-layer events (rgqa_engine_set_segment_weight_events).  One step from identical state: every parameter outside the three embedding tables (whose
-    gradients are f32 atomic scatter-adds: order-dependent last bits in ANY two runs) and both bf16 copies come out bit-identical to
-    the in-line optimizer; over four train-mode steps the two runs stay as close as two in-line runs do."""
-    from rgqa_amd import _lib
-    L = _lib.load()
-    B, T, O = 64, 20, 36
-    b = dev(synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=15, min_len=3))
-    monkeypatch.setenv("RGQA_OPT_CUS", "48")
-
-    def train(pipe, steps):
-        L.rgqa_debug_set(12, 200 if pipe == "background" else -1)
-        try:
-            return train_(pipe, steps)
-        finally:
-            L.rgqa_debug_set(12, -1)
-
-    def train_(pipe, steps):
-        e = make_engine(FULL, "bf16", dropout=0.1)
-        e.ensure_shape(B, T, O)
-        e.sync_weights()
-        for step in range(steps):
-            run(e, b, True, 100 + step)
-            e.loss_backward(b["target"])
-            e.adam_step(1e-4, max_norm=5.0, pipeline=pipe)
-        lg, _ = run(e, b, False, 0)          # waits for the pipelined update of the ranges it reads
-        torch.cuda.synchronize()
-        first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
-        return e.params.clone(), e.params_lp.clone(), e.params_lp_t.clone(), lg.clone(), first
-
-    p0, lp0, lpt0, lg0, first = train(False, 1)
-    p1, lp1, lpt1, lg1, _ = train(mode, 1)
-    assert torch.equal(p0[first:], p1[first:]) and torch.equal(lp0[first:], lp1[first:]) and torch.equal(lpt0[first:], lpt1[first:])
-    assert torch.allclose(p0[:first], p1[:first], rtol=0, atol=2.1e-4)          # one BertAdam step of lr 1e-4 moves an element by <= 3.2e-4
-    assert float((lg0 - lg1).abs().max()) < 5e-2
-    a = train(False, 4)
-    bb = train(False, 4)
-    c = train(mode, 4)
-    # run-to-run spread of the in-line optimizer: the embedding tables' atomic scatter-adds, which BertAdam's m / sqrt(v) amplifies for elements
-    # with tiny gradients.  Two in-line runs under identical timing often reproduce the same order (spread 0 .. 3e-5 observed); a run whose
-    # kernels are scheduled differently need not, so the floor is the observed 2.7e-5 with margin - still 5x below what ONE step moves an
-    # element (3.2e-4), i.e. far below what a forward pass reading a layer's weights before their update would cause.
-    spread = float((a[0] - bb[0]).abs().max())
-    assert float((a[0] - c[0]).abs().max()) <= max(2.0 * spread, 6e-5)

@@ -237,7 +237,7 @@ class _TorchOps:
 def _fake_engine(n, rank, precision):
     base = (torch.arange(n) % 64).float()
     return types.SimpleNamespace(grads=base * (rank + 1), params=torch.ones(n), params_lp=torch.ones(n, dtype=torch.bfloat16), adam_m=None, adam_v=None,
-                                 precision=precision, live_ranges=lambda: [(0, 296), (360, n)], lib=None, h=None)
+                                 precision=precision, live_ranges=lambda: [(0, 296), (360, n)], lib=None, h=None, _sharded_owner=None)
 
 
 def _dp_worker(rank, world, port, q):
@@ -269,9 +269,11 @@ def _dp_worker(rank, world, port, q):
         ex = CpuSharded(eng, dist, ops=_TorchOps())
         ex.chunks = __import__("rgqa_amd.parallel", fromlist=["shard_layout"]).shard_layout(eng.live_ranges(), world, 256)    # several chunks, two of them ragged
         ex.smax = max(c[2] for c in ex.chunks)
+        ex.events = [-1] * len(ex.chunks)
         ex.exchange()
         mine = [__import__("rgqa_amd.parallel", fromlist=["owned"]).owned(c, rank) for c in ex.chunks]
         ex.step(0.5)
+        assert eng._sharded_owner is ex          # Engine.adam_step refuses to run on a sharded optimizer state
         ex.gather_master()
         out["sharded_" + prec] = dict(grads=eng.grads.numpy().copy(), local=local.numpy().copy(), mine=mine, params=eng.params.numpy().copy(),
                                       params_lp=eng.params_lp.float().numpy().copy(), sumsq=float(ex._sumsq), chunks=ex.chunks)
@@ -348,16 +350,6 @@ def test_bench_launches_its_own_ranks_when_no_launcher_is_present():
                        capture_output=True, text=True, timeout=240)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
-
-
-def test_ticket_atomic_result_is_not_touched_before_the_wait():
-    """The persistent NT GEMM requests its next tile ticket with an inline-asm atomic whose result hipcc believes valid at once; the kernel
-    reads it only after the K loop's first `s_waitcnt vmcnt(0)`.  tools/check_ticket_isa.py compiles the file to gfx950 assembly and checks
-    every instantiation: no instruction may read or write the result register between the atomic and that wait."""
-    import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_ticket_isa.py")], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "0 violations" in r.stdout and not r.stdout.startswith("0 ticket")
 
 
 def test_synth_batch_contract():
