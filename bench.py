@@ -1,18 +1,28 @@
 """Headline benchmark: QA-pairs/sec of one LXMERT-GQA train step (BASELINE.json), B=256 per GPU, T=20, O=36,
-bf16 MFMA operands / f32 accumulate, synthetic inputs already resident in HBM.
+synthetic inputs already resident in HBM.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                          (1 GPU, 100 timed steps)
     python bench.py --gpus N --steps K --warmup W            (N > 1 without WORLD_SIZE: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = forward (train mode, dropout 0.1) + BCE x NA loss + backward + [RCCL gradient all-reduce] +
-clip_grad_norm_(5.) + BertAdam + bf16 weight re-cast: everything tasks/gqa_conf.py:174-202 does per batch.
-Rank 0 prints ONE JSON line.
+A "step" = forward (train mode, dropout 0.1) + BCE x NA loss + backward + [RCCL gradient exchange] +
+clip_grad_norm_(5.) + BertAdam + re-cast of the weight operand copies: everything tasks/gqa_conf.py:174-202 does per batch.
+Rank 0 prints ONE JSON line.  The headline (`value`, `dtype` "bf16") is BASELINE config 3's mode; its logits are outside the north
+star's 1e-3 bound, so the same line carries `tolerance_compliant` - the bf16x3 mode (split-f32 operands, three bf16 MFMA products
+per f32 product) timed on the same workload, with its measured logits error against the CPU oracle - plus `forward_only_b256`
+(BASELINE config 2), `dropin_step` (the reference trainer's own statements through GQAModel / BertAdam on fresh batches from the
+device batcher) and the roofline of the dominant kernel against the datasheet peak and against the peak at the clock the chip
+actually holds under that kernel.
+
+Multi-GPU runs are supervised: the process that the launcher (or the user) started never touches the GPU; it runs the ranks as
+child processes and, when the default gradient exchange ("sharded": all-to-all + all-gather) fails or hangs, starts a FRESH set
+once with RGQA_DP_MODE=allreduce and reports `dp_fallback` in the JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,8 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FWD_BWD_GFLOP = {20: 30.3388, 30: 37.0403}   # per QA pair, SURVEY.md §8 D3
-PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16, MI355X_MICROARCH.md
-PMC_PROFILE = "r02_pmc_gemm_nt.json"
+FWD_GFLOP = {20: 10.5827, 30: 12.8330}
+PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16, MI355X_MICROARCH.md (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
+PMC_PROFILE = "r03_pmc_gemm_nt.json"
 FULL = dict(vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9, x_layers=5,
             r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842)
 
@@ -53,10 +64,12 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(T, sample_b, iters, warm=2, extra=True):
+def cpu_baseline(T, sample_b, iters, warm=2, extra=True, check=None):
     """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this box's host cores: `warm` untimed +
-    `iters` timed full train steps at B=sample_b (the headline entry), plus SURVEY §8 D4's other cases in `cases`:
-    BASELINE config 1 (B=4 train step) and the B=256 eval forward."""
+    `iters` timed full train steps at B=sample_b (the headline entry), plus SURVEY §8 D4's other cases in `cases`: BASELINE config 1
+    (B=4 train step), the B=64 and B=256 train steps and the B=256 eval forward.
+    check(P, batch, logits): called with the oracle's weights, the B=256 eval batch and the oracle's logits on it - the one place
+    where the oracle is the CHECKER of the GPU engines' logits (the `tolerance_compliant` figures); it is never what is measured there."""
     from oracle import lxmert_ref as R
     from rgqa_amd import synth
     cfg = R.RefConfig(**FULL)
@@ -65,11 +78,8 @@ def cpu_baseline(T, sample_b, iters, warm=2, extra=True):
     except Exception:
         ncpu = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(ncpu, 16)))     # the box's CPU share for one GPU
-    torch.manual_seed(0)
-    P = {}
-    for k, shp in R.param_shapes(cfg).items():
-        t = torch.randn(shp) * 0.02 if len(shp) > 1 else (torch.ones(shp) if "LayerNorm.weight" in k or "layer_norm.weight" in k else torch.zeros(shp))
-        P[k] = t.requires_grad_(True)
+    # the deterministic filler of the golden fixtures (biases / LayerNorm parameters non-trivial, |logit| ~ 1)
+    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(R.param_shapes(cfg)).items()}
     opt = R.BertAdamRef(list(P.values()), lr=1e-5, warmup=0.1, t_total=1000)
 
     def timed(fn, n_warm, n):
@@ -87,21 +97,30 @@ def cpu_baseline(T, sample_b, iters, warm=2, extra=True):
         batch = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
         return timed(lambda: R.train_step(P, cfg, batch, opt), n_warm, n)
 
-    t = train_case(sample_b, warm, iters)
-    out = dict(value=sample_b / t, unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port", cpu_model=_cpu_model(),
-               sample="full train step (fwd+BCE+bwd+clip+BertAdam), B=%d T=%d, fp32, %d warm-up + %d timed iters, median %.2fs" % (sample_b, T, warm, iters, t))
+    out_cases, checked = {}, None
     if extra:
-        cases = {}
-        t4 = train_case(4, 1, 3)
-        cases["train_step_B4"] = dict(value=round(4 / t4, 2), unit="QA-pairs/s", sample="BASELINE config 1: full train step B=4 T=%d, 1 warm-up + 3 timed, median %.2fs" % (T, t4))
+        # the eval forward first, on the untouched weights: its logits are what the GPU engines are checked against
         b = synth.synth_batch(256, T, seed=98)
         batch = {k: torch.from_numpy(v) for k, v in b.items() if k != "lengths"}
         with torch.no_grad():
             Pd = {k: v.detach() for k, v in P.items()}
-            te = timed(lambda: R.gqa_forward(Pd, cfg, batch["feats"], batch["boxes"], batch["input_ids"], batch["input_mask"], batch["segment_ids"]), 0, 2)
-        cases["eval_forward_B256"] = dict(value=round(256 / te, 2), unit="QA-pairs/s", sample="eval forward B=256 T=%d, 2 timed, median %.2fs" % (T, te))
-        out["cases"] = cases
-    return out
+            lg = []
+            te = timed(lambda: lg.append(R.gqa_forward(Pd, cfg, batch["feats"], batch["boxes"], batch["input_ids"], batch["input_mask"], batch["segment_ids"])[0]), 0, 2)
+        out_cases["eval_forward_B256"] = dict(value=round(256 / te, 2), unit="QA-pairs/s", sample="BASELINE config 2: eval forward B=256 T=%d, 2 timed, median %.2fs" % (T, te))
+        if check is not None:
+            checked = check({k: v.detach().clone() for k, v in P.items()}, b, lg[-1].detach())
+    t = train_case(sample_b, warm, iters)
+    out = dict(value=sample_b / t, unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port", cpu_model=_cpu_model(),
+               sample="full train step (fwd+BCE+bwd+clip+BertAdam), B=%d T=%d, fp32, %d warm-up + %d timed iters, median %.2fs" % (sample_b, T, warm, iters, t))
+    if extra:
+        t4 = train_case(4, 1, 3)
+        out_cases["train_step_B4"] = dict(value=round(4 / t4, 2), unit="QA-pairs/s", sample="BASELINE config 1: full train step B=4 T=%d, 1 warm-up + 3 timed, median %.2fs" % (T, t4))
+        t64 = train_case(64, 1, 3)
+        out_cases["train_step_B64"] = dict(value=round(64 / t64, 2), unit="QA-pairs/s", sample="full train step B=64 T=%d, 1 warm-up + 3 timed, median %.2fs" % (T, t64))
+        t256 = train_case(256, 0, 2)
+        out_cases["train_step_B256"] = dict(value=round(256 / t256, 2), unit="QA-pairs/s", sample="full train step B=256 T=%d (the headline's batch), 2 timed, median %.2fs" % (T, t256))
+        out["cases"] = out_cases
+    return out, checked
 
 
 _JSON_FD = None
@@ -117,25 +136,23 @@ def emit_json(obj):
         os.write(_JSON_FD, line)
 
 
-def self_launch(n):
-    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this parent - which never touches the GPU, so nothing
-    that has initialised HIP is ever exec'd or forked - starts N fresh rank processes of this same command line with
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what lxrt/entry.py:102-103's nn.DataParallel switch is to the reference),
-    relays rank 0's JSON line and returns non-zero when any rank fails (the survivors are then ended by PID)."""
+# ------------------------------------------------------------------------------------------------ supervision of the rank processes
+def _free_port():
     import socket
-    import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+        return sk.getsockname()[1]
+
+
+def _run_children(envs, deadline_s):
+    """Starts one child of this same command line per environment (child 0 inherits stdout: rank 0's JSON line), waits for all of them;
+    -> (rc, reason).  A failing or overdue child ends the attempt: the others are terminated by PID."""
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), RGQA_BENCH_CHILD="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for i, env in enumerate(envs):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))     # only rank 0 writes to stdout
-    deadline = time.time() + float(os.environ.get("RGQA_BENCH_LAUNCH_TIMEOUT", "1500"))
-    rc = 0
+                                      stdout=None if i == 0 else sys.stderr))
+    deadline = time.time() + deadline_s
+    rc, reason = 0, ""
     live = list(procs)
     while live and rc == 0:
         for pr in list(live):
@@ -144,49 +161,233 @@ def self_launch(n):
                 live.remove(pr)
                 if c != 0:
                     rc = c if c > 0 else 1
-        if time.time() > deadline:
-            rc = 124
+                    reason = "a rank process exited with code %d" % c
+        if time.time() > deadline and rc == 0 and live:
+            rc, reason = 124, "the rank processes did not finish within %d s" % int(deadline_s)
         if live and rc == 0:
             time.sleep(0.05)
-    for pr in live:             # a rank failed (or the launch timed out): end exactly the processes started here
+    for pr in live:             # end exactly the processes started here
         pr.terminate()
     for pr in live:
         try:
             pr.wait(timeout=20)
         except subprocess.TimeoutExpired:
             pr.kill()
+    return rc, reason
+
+
+def supervise(n_self_launch):
+    """The process the launcher started never touches the GPU (nothing that has initialised HIP is ever forked or exec'd): it runs the
+    rank(s) as children and exits with their code.
+      n_self_launch = N: `python bench.py --gpus N` without a launcher - N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+                         (what lxrt/entry.py:102-103's nn.DataParallel switch is to the reference);
+      n_self_launch = 0: this process IS one rank of a torch.distributed.run launch - one child with this rank's environment and a
+                         rendezvous of its own (MASTER_PORT + 1 + attempt; the launcher's agent store is not reused, so a second
+                         attempt starts from an empty store).
+    If the attempt fails or hangs under the default exchange (RGQA_DP_MODE unset or 'sharded'), ONE fresh attempt runs with
+    RGQA_DP_MODE=allreduce and RGQA_BENCH_DP_FALLBACK=<reason>: the JSON line then carries `dp_fallback`."""
+    mode = os.environ.get("RGQA_DP_MODE", "sharded")
+    total = float(os.environ.get("RGQA_BENCH_LAUNCH_TIMEOUT", "1500"))
+    base_port = int(os.environ.get("MASTER_PORT", "0"))
+
+    def envs_for(attempt, dp_mode, reason):
+        common = dict(os.environ, RGQA_BENCH_CHILD="1", RGQA_DP_MODE=dp_mode, MASTER_ADDR="127.0.0.1")
+        common.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        common.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        if reason:
+            common["RGQA_BENCH_DP_FALLBACK"] = reason
+        if n_self_launch:
+            port = _free_port()
+            return [dict(common, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_self_launch), LOCAL_WORLD_SIZE=str(n_self_launch),
+                         MASTER_PORT=str(port)) for r in range(n_self_launch)]
+        return [dict(common, MASTER_PORT=str(base_port + 1 + attempt))]
+
+    first_deadline = total if mode != "sharded" else min(total, max(120.0, 0.6 * total))
+    t0 = time.time()
+    rc, reason = _run_children(envs_for(0, mode, ""), first_deadline)
+    if rc != 0 and mode == "sharded":
+        sys.stderr.write("bench.py: %s under RGQA_DP_MODE=sharded; starting a fresh set of rank processes with RGQA_DP_MODE=allreduce\n" % reason)
+        rc, reason = _run_children(envs_for(1, "allreduce", "sharded exchange failed (%s); re-run with allreduce" % reason),
+                                   max(120.0, total - (time.time() - t0)))
     if rc != 0:
-        sys.stderr.write("bench.py: a rank process failed (exit code %d); %d rank(s) were ended\n" % (rc, len(live)))
+        sys.stderr.write("bench.py: %s\n" % reason)
     return rc
 
 
-def launch_check(world, rank, fail_rank):
-    """rehearsal of the launch path without a GPU (tests/test_host.py): rendezvous over gloo, one all-reduce, one JSON line"""
+def dp_selfcheck(dist, mode, device):
+    """Every collective the chosen exchange needs, once, on 1 MB, checked numerically - so that a broken or hanging collective is a fast
+    non-zero exit (the process group carries a short timeout) before any warm-up step, not a silent hang of the timed region."""
+    W, r = dist.get_world_size(), dist.get_rank()
+    n = 262144
+    want = float(sum(range(1, W + 1)))
+    t = torch.full((n,), float(r + 1), device=device)
+    dist.all_reduce(t)
+    ok = bool((t == want).all())
+    if mode == "allreduce_bf16":
+        tb = torch.full((n,), float(r + 1), device=device, dtype=torch.bfloat16)
+        dist.all_reduce(tb)
+        ok = ok and bool((tb.float() == want).all())
+    if mode == "sharded":
+        s = n // W
+        send = torch.full((W * s,), float(r + 1), device=device, dtype=torch.bfloat16)
+        recv = torch.zeros(W * s, device=device, dtype=torch.bfloat16)
+        dist.all_to_all_single(recv, send)
+        ok = ok and bool((recv.view(W, s).float() == torch.arange(1, W + 1, device=device, dtype=torch.float32)[:, None]).all())
+        full = torch.zeros(W * s, device=device, dtype=torch.bfloat16)
+        full[r * s:(r + 1) * s] = float(r + 1)
+        dist.all_gather_into_tensor(full, full[r * s:(r + 1) * s])          # in place, as ShardedExchange.step issues it
+        ok = ok and bool((full.view(W, s).float() == torch.arange(1, W + 1, device=device, dtype=torch.float32)[:, None]).all())
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    if not ok:
+        raise SystemExit("bench.py: collective self-check failed under RGQA_DP_MODE=%s" % mode)
+
+
+def launch_check(world, rank, fail_rank, fail_mode):
+    """rehearsal of the launch path without a GPU (tests/test_host.py): rendezvous over gloo, the exchange's self-check, one JSON line"""
     import torch.distributed as dist
-    if rank == fail_rank:
+    mode = os.environ.get("RGQA_DP_MODE", "sharded")
+    if rank == fail_rank and (fail_mode == "" or fail_mode == mode):
         raise SystemExit(3)
     if world > 1:
-        dist.init_process_group("gloo")
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
     t = torch.ones(1)
     if world > 1:
+        dp_selfcheck(dist, "allreduce" if mode == "sharded" else mode, torch.device("cpu"))      # (gloo has no all_to_all on CPU tensors in every build)
         dist.all_reduce(t)
         seen = dist.get_world_size()
     else:
         seen = 1
     if rank == 0:
-        emit_json({"launch_check": True, "n_gpus": world, "n_ranks_seen": seen, "sum": float(t.item())})
+        emit_json({"launch_check": True, "n_gpus": world, "n_ranks_seen": seen, "sum": float(t.item()), "dp_mode": mode,
+                   "dp_fallback": os.environ.get("RGQA_BENCH_DP_FALLBACK")})
     if world > 1:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ measurement helpers (rank 0, one GPU)
+def time_steps(fn, n, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def probe_sustained_clock(e):
+    """In-kernel shader clock under the dense bf16 GEMM loop: >= 1 s of back-to-back launches of the stamped instantiation of the
+    persistent NT kernel on random operands (the paired QKV projection's shape), median over the blocks of the last launch."""
+    import ctypes as C
+    from rgqa_amd._lib import check, ptr
+    M, N, K = 12356, 2304, 768
+    A = torch.randn(M, K, device=e.device).bfloat16()
+    W = (torch.randn(N, K, device=e.device) * 0.05).bfloat16()
+    Cc = torch.empty(M, N, device=e.device, dtype=torch.bfloat16)
+    st = torch.zeros(256 * 4, dtype=torch.int64, device=e.device)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t0 = time.perf_counter()
+    launches = 0
+    while time.perf_counter() - t0 < 1.2:
+        check(e.lib.rgqa_probe_gemm_clock(ptr(A), ptr(W), ptr(Cc), M, N, K, 200, ptr(st), s))
+        torch.cuda.synchronize()
+        launches += 200
+    v = st.view(-1, 4).cpu().numpy().astype(np.float64)
+    v = v[(v[:, 3] > v[:, 1])]
+    mhz = (v[:, 2] - v[:, 0]) / (v[:, 3] - v[:, 1]) * 100.0
+    return float(np.median(mhz)), launches
+
+
+def engine_step_fn(e, dev, lengths, rank=0, t_total=10000):
+    state = dict(i=0)
+
+    def step():
+        i = state["i"]
+        e.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=True, seed=4321 + rank + 1000003 * i, lengths=lengths)
+        e.loss_backward(dev["target"])
+        e.adam_step(1e-5 * warmup_linear(i / t_total, 0.1), max_norm=5.0)
+        state["i"] = i + 1
+    return step
+
+
+def dropin_step_leg(B, T, n_steps, precision):
+    """The reference trainer's own statements (tasks/gqa_conf.py:148-202) through the drop-in surface at B=256: a fresh batch from the
+    device batcher (feature store on disk -> pinned gather -> H2D -> device preparation), `model(feats, boxes, list_of_str)` (native
+    tokenizer), BCE x NA, `loss.backward()`, `nn.utils.clip_grad_norm_`, `BertAdam.step()` - everything the headline leaves out."""
+    import tempfile
+    import types
+    from rgqa_amd.data import FeatureStore, DeviceBatcher
+    tmp = tempfile.mkdtemp(prefix="rgqa_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        # vocabulary file in bert-base-uncased's layout (specials at their ids), synthetic words; questions built from it
+        words = ["what", "is", "the", "color", "of", "dog", "man", "woman", "left", "right", "to", "on", "in", "front", "behind", "table", "holding", "bottle",
+                 "red", "blue", "green", "who", "wearing", "shirt", "are", "there", "any", "cars", "photo", "side", "which", "kind", "animal", "standing", "near", "tree"]
+        vocab = ["[unused%d]" % i for i in range(30522)]
+        vocab[0], vocab[100], vocab[101], vocab[102], vocab[103] = "[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"
+        vocab[1029] = "?"
+        for i, w in enumerate(words):
+            vocab[2000 + i] = w
+        vpath = os.path.join(tmp, "vocab.txt")
+        with open(vpath, "w") as f:
+            f.write("\n".join(vocab) + "\n")
+        os.environ["RGQA_BERT_VOCAB"] = vpath
+        os.environ["RGQA_PRECISION"] = precision
+        N, O, F, NA = 2 * B, 36, 2048, 1842
+        rng = np.random.RandomState(5)
+        prefix = os.path.join(tmp, "store")
+        np.maximum(rng.standard_normal((N, O, F)), 0).astype(np.float16).tofile(prefix + ".feats.bin")
+        xy = np.sort(rng.uniform(0, 400, (N, O, 2, 2)), axis=3)                 # [.., axis (x|y), (lo, hi)]
+        np.stack([xy[:, :, 0, 0], xy[:, :, 1, 0], xy[:, :, 0, 1], xy[:, :, 1, 1]], -1).astype(np.float32).tofile(prefix + ".boxes.bin")
+        json.dump({"img_ids": ["i%d" % i for i in range(N)], "img_h": [480] * N, "img_w": [640] * N, "O": O, "F": F, "dtype": "f16"}, open(prefix + ".meta.json", "w"))
+        answers = ["a%d" % i for i in range(NA)]
+        ans2label = {a: i for i, a in enumerate(answers)}
+        data = []
+        for i in range(4 * B):
+            L = 3 + int(rng.randint(0, 16))
+            sent = " ".join(words[int(rng.randint(0, len(words)))] for _ in range(L)) + " ?"
+            label = {} if rng.uniform() < 0.25 else {answers[int(rng.randint(0, NA))]: 1.0}
+            data.append({"img_id": "i%d" % int(rng.randint(0, N)), "question_id": i, "sent": sent, "label": label})
+        from rgqa_amd.tasks.gqa_model import GQAModel
+        from rgqa_amd.lxrt.optimization import BertAdam
+        model = GQAModel(NA, max_seq_length=T, model_args=types.SimpleNamespace(llayers=9, xlayers=5, rlayers=5, from_scratch=True)).cuda()
+        model.train()
+        optim = BertAdam(list(model.parameters()), lr=1e-5, warmup=0.1, t_total=10000)
+        bce = torch.nn.BCEWithLogitsLoss()
+        batcher = DeviceBatcher(FeatureStore(prefix), ans2label, NA, B)
+        state = dict(i=0)
+
+        def step():
+            i = state["i"]
+            batch = [data[(i * B + k) % len(data)] for k in range(B)]
+            ques_id, feats, boxes, sent, target = batcher.batch(batch)
+            optim.zero_grad()
+            logit = model(feats, boxes, sent)
+            loss = bce(logit, target) * logit.size(1)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.)
+            optim.step()
+            state["i"] = i + 1
+
+        ms = time_steps(step, n_steps, 3)
+        del model, optim, batcher
+        torch.cuda.empty_cache()
+        return ms
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default long enough for the clock to be in its loaded steady state)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="QA pairs per GPU per step")
     ap.add_argument("--seq", type=int, default=20)
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="bf16", help="bf16 (BASELINE config 3, the headline) | bf16x3 (inside the 1e-3 logits bound) | f32 (exact, vector ALU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -196,15 +397,19 @@ def main():
     ap.add_argument("--mixup", action="store_true",
                     help="BASELINE config 4: RoI-mixup finetune (gqa_mixup_vis.py:134-181): every loader batch is doubled on the device "
                          "(mixup_v1, Beta(1,5)); the model sees 2x rows per QA pair; value still counts loader QA pairs")
-    ap.add_argument("--lean", action="store_true", help="only the warm-up and timed steps (no padded-layout / exchange-free legs, no live kernel timing, no CPU baseline): what runs under rocprofv3")
+    ap.add_argument("--lean", action="store_true", help="only the warm-up and timed steps (no extra legs, no live kernel timing, no CPU baseline): what runs under rocprofv3")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)          # CPU rehearsal of the N-rank launch path
     ap.add_argument("--launch-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check-fail-mode", default="", help=argparse.SUPPRESS)        # fail only under this RGQA_DP_MODE
     args = ap.parse_args()
     if args.lean:
         args.no_cpu_baseline, args.profile_steps = True, 0
 
+    child = os.environ.get("RGQA_BENCH_CHILD") == "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(args.gpus))     # before any torch.cuda / HIP call
+        raise SystemExit(supervise(args.gpus))       # before any torch.cuda / HIP call
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not child:
+        raise SystemExit(supervise(0))               # a launcher's rank: the work runs in a child, so a second attempt stays possible
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -217,18 +422,23 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.launch_check:
-        return launch_check(world, rank, args.launch_check_fail_rank)
+        return launch_check(world, rank, args.launch_check_fail_rank, args.launch_check_fail_mode)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda unavailable); there is no CPU path")
     local %= max(1, torch.cuda.device_count())      # rehearsal of N ranks on a box with fewer GPUs (the driver's node has one per rank)
     torch.cuda.set_device(local)
     dist = None
+    dp_mode = os.environ.get("RGQA_DP_MODE", "sharded")
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        tmo = datetime.timedelta(seconds=int(os.environ.get("RGQA_DP_TIMEOUT", "240")))      # a hung collective is a non-zero exit within minutes
         if torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", world)):
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:       # rehearsal only: RCCL refuses two ranks on one device; gloo stages the same all-reduce calls through the host
-            dist.init_process_group("gloo")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
+        else:       # rehearsal only: RCCL refuses two ranks on one device; gloo stages the same collectives through the host
+            dist.init_process_group("gloo", timeout=tmo)
+        if dist.get_backend() == "nccl":
+            dp_selfcheck(dist, dp_mode, torch.device("cuda", local))
 
     from rgqa_amd.engine import Engine
     from rgqa_amd import synth
@@ -280,11 +490,11 @@ def main():
             dev.update(feats=f2, boxes=b2, target=t2, input_ids=ids2, input_mask=mask2, segment_ids=seg2)
     e.ensure_shape(MB, T, O)
     e.sync_weights()
-    comm = make_exchange(e, dist) if world > 1 else None      # RGQA_DP_MODE: sharded (default) | allreduce | allreduce_bf16
-    if world == 1 and not args.butd and os.environ.get("RGQA_SEG_SUMSQ", "1") != "0":
+    comm = make_exchange(e, dist, mode=dp_mode) if world > 1 else None      # RGQA_DP_MODE: sharded (default) | allreduce | allreduce_bf16
+    if world == 1 and not args.butd:
         e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
     t_total = 10000
-    state = dict(step=0, lengths=lengths)
+    state = dict(step=0, lengths=lengths, comm=comm)
 
     def step(exchange=True):
         i = state["step"]
@@ -293,9 +503,10 @@ def main():
         e.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=True, seed=4321 + rank + 1000003 * i, lengths=state["lengths"])
         e.loss_backward(dev["target"])
         lr_t = 1e-5 * warmup_linear(i / t_total, 0.1)
-        if comm is not None and exchange:
-            comm.exchange()
-            comm.step(lr_t, max_norm=5.0)
+        c = state["comm"]
+        if c is not None and exchange:
+            c.exchange()
+            c.step(lr_t, max_norm=5.0)
         else:       # single GPU, or the collective-free legs after the timed region (local gradients, whole arena)
             e.adam_step(lr_t, max_norm=5.0, grad_prescale=1.0 / world)
         state["step"] = i + 1
@@ -336,25 +547,44 @@ def main():
             d = float(t2.item())
         return d / n * 1e3
 
-    # diagnostics outside the timed region (every rank takes part): the step without the gradient exchange -> what the exchange
-    # costs beyond what backward hides; the reference's padded layout (all B*T token positions computed)
-    exposed_comm_ms = None
+    # diagnostics outside the timed region (every rank takes part): the same exchange issued after backward instead of beside it, and
+    # the step without any exchange -> what the exchange costs beyond what backward hides; the reference's padded layout
+    dp_legs = None
     if dist is not None and not args.lean:
         n2 = max(3, min(args.steps, 10))
-        exposed_comm_ms = round(ms - timed_leg(n2, exchange=False), 3)
+        dp_legs = {"mode": comm.describe(), "ms_per_step": round(ms, 3)}
+        comm.release()                               # every rank holds the full optimizer state again
+        if hasattr(comm, "overlap"):
+            alt = make_exchange(e, dist, mode=dp_mode, overlap=not comm.overlap)
+            state["comm"] = alt
+            for _ in range(2):
+                step()
+            dp_legs["alt_mode"] = alt.describe()
+            dp_legs["alt_ms_per_step"] = round(timed_leg(n2), 3)
+            alt.release()
+        state["comm"] = None
+        for _ in range(2):
+            step(exchange=False)
+        local_ms = timed_leg(n2, exchange=False)
+        dp_legs["no_exchange_ms_per_step"] = round(local_ms, 3)
+        dp_legs["exposed_comm_ms"] = round(ms - local_ms, 3)
+        if "alt_ms_per_step" in dp_legs:
+            dp_legs["alt_exposed_comm_ms"] = round(dp_legs["alt_ms_per_step"] - local_ms, 3)
+    state["comm"] = None          # everything below runs on rank-local state (replicas may diverge from here on: nothing is exchanged again)
     padded_leg = None
     if lengths is not None and not (args.butd or args.uniter or args.mixup or args.lean):
         n2 = max(3, min(args.steps, 10))
         state["lengths"] = None
         for _ in range(2):
-            step()
-        pms = timed_leg(n2)
+            step(exchange=False)
+        pms = timed_leg(n2, exchange=False)
         state["lengths"] = lengths
-        step()
+        step(exchange=False)
         padded_leg = {"ms_per_step": round(pms, 3), "value": round(B * world / pms * 1e3, 1), "unit": "QA-pairs/s",
-                      "note": "same build, all %d token positions computed as the reference does (bench.py --padded); %d steps outside the timed region" % (MB * T, n2)}
+                      "note": "same build, all %d token positions computed as the reference does (bench.py --padded); %d steps outside the timed region%s" % (
+                          MB * T, n2, "" if world == 1 else ", no gradient exchange")}
 
-    # live roofline of the dominant kernel (the bf16 MFMA NT GEMM): HIP events around every launch, on the launch stream
+    # live roofline of the dominant kernel (the NT GEMM family): HIP events around every launch, on the launch stream
     roof = None
     prof = None
     blocks = None
@@ -372,7 +602,7 @@ def main():
             ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
             traffic, traffic_note = None, "no PMC profile for this workload"
             pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)    # separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), tools/pmc_summary.py
-            if os.path.exists(pmc) and B == 256 and T == 20 and not (args.mixup or args.uniter or args.butd or args.padded):
+            if os.path.exists(pmc) and B == 256 and T == 20 and args.precision == "bf16" and not (args.mixup or args.uniter or args.butd or args.padded):
                 from rgqa_amd.build import source_digest
                 pj = json.load(open(pmc))
                 if pj.get("kernel_source_digest") == source_digest():
@@ -380,14 +610,82 @@ def main():
                 else:       # the kernels changed since the counters were collected: a stale figure is worse than none
                     traffic_note = "profiles/%s was collected on other kernel sources (digest mismatch): not reported" % PMC_PROFILE
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_note, algorithmic_bytes_per_launch=round(nt["bytes"] / nt["launches"]), kernel="gemm_nt (gemm_nt8p_kernel / gemm_nt256_kernel / gemm_nt256d_kernel<EPI,MT> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
+                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_note, algorithmic_bytes_per_launch=round(nt["bytes"] / nt["launches"]),
+                        kernel="gemm_nt (gemm_nt256_kernel / gemm_nt256d_kernel<OutT,EPI,MT,X3> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
                         avg_launch_us=round(avg_ms * 1e3, 2), gflop_per_launch=round(per_launch_flops / 1e9, 3))
+            if args.precision == "bf16x3":
+                roof["note"] = "bf16x3: 3 MFMA products per counted FLOP - the matrix pipe does 3x the work `achieved` credits"
+            if not (args.butd or args.lean):
+                try:
+                    mhz, nl = probe_sustained_clock(e)
+                    sus = 256 * 4 * 1024 * mhz * 1e6 / 1e12
+                    roof["peak_sustained"] = dict(value=round(sus, 1), unit="TFLOP/s", shader_clock_mhz=round(mhz, 1), frac=round(ach / sus, 4),
+                                                  how="256 CUs x 4 SIMDs x 1024 FLOP/clk x the in-kernel clock (s_memtime / s_memrealtime over every block's life) of the stamped "
+                                                      "persistent NT kernel, %d back-to-back launches of 12356x2304x768 on random operands" % nl)
+                except Exception as ex:          # the probe is a diagnostic: never lose the line over it
+                    roof["peak_sustained"] = dict(error=str(ex))
     if dist is not None:
         dist.barrier()
 
+    extra_legs = rank == 0 and world == 1 and not (args.lean or args.butd or args.uniter or args.mixup or args.padded) and args.precision == "bf16"
+    tol = fwd_only = dropin = None
+    engines = {"bf16": e}
+    if extra_legs:
+        # ---- the tolerance-compliant mode on the same workload: second engine, same weights, same batch
+        n2 = max(5, min(args.steps, 20))
+        ex = Engine(precision="bf16x3", **FULL).allocate("cuda")
+        ex.params.copy_(e.params)
+        ex.ensure_shape(B, T, O)
+        ex.sync_weights()
+        ex.enable_segment_sumsq(True)
+        engines["bf16x3"] = ex
+        xms = time_steps(engine_step_fn(ex, dev, lengths), n2, 3)
+        tol = dict(precision="bf16x3", ms_per_step=round(xms, 3), value=round(B / xms * 1e3, 1), unit="QA-pairs/s", steps=n2,
+                   note="same workload, weights and batch as the headline; split-f32 operands, 3 bf16 MFMA products per f32 product (rgqa.h RGQA_PRECISION_BF16X3)")
+        # ---- BASELINE config 2: forward-only inference at B=256
+        fwd_only = {}
+        for name, en in engines.items():
+            fms = time_steps(lambda en=en: en.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=False, lengths=lengths), n2, 3)
+            fwd_only[name] = dict(ms=round(fms, 3), value=round(B / fms * 1e3, 1), unit="QA-pairs/s",
+                                  reference_equivalent_tflops=round(B / fms * 1e3 * FWD_GFLOP.get(T, FWD_GFLOP[20]) / 1e3, 1))
+        # ---- the reference trainer's statements through the drop-in modules
+        try:
+            dms = dropin_step_leg(B, T, n2, "bf16")
+            dropin = dict(ms_per_step=round(dms, 3), value=round(B / dms * 1e3, 1), unit="QA-pairs/s", steps=n2, vs_headline=round(dms / ms, 3),
+                          what="GQAModel(feats, boxes, list_of_str) + BCE x NA + backward + nn.utils.clip_grad_norm_ + BertAdam.step (tasks/gqa_conf.py:174-202) on a fresh "
+                               "batch per step from the f16 feature store (pinned gather + H2D + device preparation); bf16")
+        except Exception as exn:
+            dropin = dict(error=repr(exn))
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.uniter:
-        cpu = cpu_baseline(T, args.cpu_sample, 5)
+        def check(P, cb, ref_logits):
+            """the GPU engines on the oracle's weights and eval batch: max / mean |logit - oracle logit| over all 256 x 1842 entries"""
+            if not extra_legs:
+                return None
+            d2 = {k: torch.from_numpy(v).cuda() for k, v in cb.items() if k != "lengths"}
+            res = {}
+            for name, en in engines.items():
+                keep = en.params.clone()
+                for sp in en.specs:
+                    en.view(en.params, sp).copy_(P[sp.name])
+                en.sync_weights()
+                lg = en.forward(d2["feats"], d2["boxes"], d2["input_ids"], d2["input_mask"], d2["segment_ids"], train=False,
+                                lengths=np.ascontiguousarray(cb["lengths"], dtype=np.int32))[0]
+                err = (lg.cpu() - ref_logits).abs()
+                res[name] = dict(logits_max_err=float(err.max()), logits_mean_err=float(err.mean()))
+                en.params.copy_(keep)
+                en.sync_weights()
+            return res
+        cpu, checked = cpu_baseline(T, args.cpu_sample, 5, extra=not args.butd, check=check)
+        if checked and tol is not None:
+            tol.update(logits_max_err=checked["bf16x3"]["logits_max_err"], logits_mean_err=checked["bf16x3"]["logits_mean_err"], bound=1e-3,
+                       within_bound=bool(checked["bf16x3"]["logits_max_err"] <= 1e-3),
+                       checked_on="B=256 eval forward, golden-fixture filler weights, all 256 x 1842 logits against the CPU oracle (f32)",
+                       headline_mode_logits_max_err=checked["bf16"]["logits_max_err"], headline_mode_logits_mean_err=checked["bf16"]["logits_mean_err"])
+            if fwd_only is not None:
+                for name in fwd_only:
+                    fwd_only[name]["logits_max_err"] = checked[name]["logits_max_err"]
 
     if rank == 0:
         # UNITER, padded: 12 layers x (56 x 7,077,888 + 2 x 56^2 x 768) MAC + 36 x 2048 x 768 + head = 4.880 GMAC fwd per QA pair; x2 FLOP, x3 fwd+bwd
@@ -401,6 +699,8 @@ def main():
                                     "LXMERT-GQA RP finetune train step (fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768"), "model_rows_per_gpu": MB,
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "rois": O, "feat_dim": 2048,
                        "num_answers": 1842, "parallelism": "dp%d" % world, "dropout": 0.1,
+                       "precision_note": {"bf16": "BASELINE config 3's mode; logits outside the north star's 1e-3 bound (see tolerance_compliant)",
+                                          "bf16x3": "split-f32 operands: inside the 1e-3 logits bound", "f32": "exact f32 on the vector ALU"}.get(args.precision, ""),
                        "language_rows": ("padded: all %d token positions computed" % (MB * T)) if lengths is None else
                                         ("packed: %d real tokens of %d positions (question length ~ U{5..%d}); padding rows are not computed, results identical" % (int(lengths.sum()), MB * T, T))},
             "n_ranks_seen": n_ranks_seen,
@@ -409,18 +709,27 @@ def main():
             # (30.339 GFLOP per QA pair); with packed language rows part of them is never executed here
             "reference_equivalent_tflops_per_gpu": round(step_tflops / world, 1),
         }
-        if exposed_comm_ms is not None:
-            out["exposed_comm_ms"] = exposed_comm_ms      # step time minus the time of the same step with no exchange and a local whole-arena optimizer
-            out["dp_exchange"] = comm.describe() if hasattr(comm, "describe") else "all_reduce"
+        if tol is not None:
+            out["tolerance_compliant"] = tol
+        if fwd_only is not None:
+            out["forward_only_b256"] = fwd_only
+        if dropin is not None:
+            out["dropin_step"] = dropin
+        if world > 1:
+            out["dp_mode"] = dp_mode
+            out["dp_fallback"] = os.environ.get("RGQA_BENCH_DP_FALLBACK")
+        if dp_legs is not None:
+            out["exposed_comm_ms"] = dp_legs["exposed_comm_ms"]      # step time minus the time of the same step with no exchange and a local whole-arena optimizer
+            out["dp_exchange"] = dp_legs
         if padded_leg is not None:
             out["padded_layout"] = padded_leg
-        if prof is not None:
+        if prof is not None and args.profile_steps > 0:
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.profile_steps, 3) for k, v in prof.items() if v["launches"]}
             # the utilisation figure: FLOPs the engine actually executed (GEMMs + attention, packed rows) over the measured step time
-            ex = sum(v["flops"] for v in prof.values()) / max(1, args.profile_steps)
-            out["step_executed_tflops_per_gpu"] = round(ex / (ms * 1e-3) / 1e12, 1)
-            out["step_executed_frac_of_bf16_peak"] = round(ex / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
-            if blocks is not None and args.profile_steps > 0:
+            ex_fl = sum(v["flops"] for v in prof.values()) / max(1, args.profile_steps)
+            out["step_executed_tflops_per_gpu"] = round(ex_fl / (ms * 1e-3) / 1e12, 1)
+            out["step_executed_frac_of_bf16_peak"] = round(ex_fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+            if blocks is not None:
                 # the block the north-star target names: the five LXRTXLayers (cross-attention + self-attention + FFN of both
                 # modalities, forward + backward incl. their weight gradients): executed GEMM + attention FLOPs over the sum of
                 # ALL kernel durations of those layers (LayerNorm, attention and epilogue time included)

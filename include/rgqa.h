@@ -150,6 +150,14 @@ int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* 
  * names), 3 pooler + answer head + loss; ms = sum of kernel durations, flops = GEMM + attention FLOPs */
 int rgqa_engine_profile_blocks(rgqa_engine* e, double* ms, double* flops, int nblock);
 
+/* Clock probe for the roofline's sustained peak: `launches` back-to-back launches of the bf16 NT GEMM C[M,N] = A[M,K] W[N,K]^T (K % 64 == 0,
+ * N % 8 == 0; dense row-major bf16) on a separately instantiated copy of the product's persistent 256-row-tile kernel that stamps
+ * s_memtime / s_memrealtime at the entry and exit of every block; stamps (device, >= 4 * 256 uint64) receives, from the LAST launch,
+ * 4 words per block: cycles_in, ticks_in, cycles_out, ticks_out (100-MHz ticks): (cycles_out - cycles_in) / (ticks_out - ticks_in) x 100 MHz
+ * = the shader clock held under the dense MFMA loop.  No product kernel executes a stamp. */
+int rgqa_probe_gemm_clock(const void* A, const void* W, void* C, int M, int N, int K, int launches, unsigned long long* stamps,
+                          void* stream);
+
 /* ---- optimizer: replaces nn.utils.clip_grad_norm_(params, max_norm) (tasks/gqa_conf.py:201) followed by
  * BertAdam.step (lxrt/optimization.py:101-180) over arena ranges. */
 int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws /* >= 1024 f32 */, float* sumsq_out,

@@ -30,6 +30,23 @@ bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
     return true;
 }
 
+// Clock probe (bench.py roofline.peak_sustained): ONE launch of the persistent bf16 NT kernel at 256-row tiles with entry / exit stamps.
+int launch_gemm_nt256_probe(GemmGroup& g, hipStream_t s) {
+    constexpr int MT = 8, LDS_BYTES = NT256_LDS(MT);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<bf16_t, EPI_BIAS, MT, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    RGQA_REQUIRE(g.stamps != nullptr && gemm_nt256_eligible(g, 0), "clock probe: bad problem");
+    gemm_group_finalize(g, 32 * MT, TN);
+    int grid = g.total_tiles;
+    if (grid > rgqa_num_cus()) grid = rgqa_num_cus();
+    hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI_BIAS, MT, false, true>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
+    RGQA_LAUNCH_CHECK("gemm_nt256_kernel<probe>");
+    return RGQA_OK;
+}
+
 int launch_gemm_nt256_f32out(GemmGroup& g, hipStream_t s) { return launch256<float, EPI_BIAS, 2, false>(g, s); }
 
 int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {

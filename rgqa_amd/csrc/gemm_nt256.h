@@ -79,9 +79,13 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
 // unrolling the accumulator loops and pushes the 128 accumulators into scratch.
 // Persistent for MT >= 4: one block per CU walks tiles blockIdx, + grid, ... (XCD-aware order); the next tile's first two K-steps are
 // DMA'd behind the epilogue.
-template <typename OutT, int EPI, int MT, bool X3>
+// STAMP (the clock probe's own instantiation, never a product launch): thread 0 of every block records s_memtime / s_memrealtime at entry
+// and exit into g.stamps - shader cycles per 100-MHz tick over the block's life = the clock the chip holds under this loop.
+template <typename OutT, int EPI, int MT, bool X3, bool STAMP = false>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if (STAMP && threadIdx.x == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr bool PERSIST = NT256_PERSIST(MT);
     constexpr int TM = 32 * MT, A_BYTES = TM * TK * 2, STAGE_BYTES = A_BYTES + TN * TK * 2, AG = (MT + 1) / 2, NAG = 4 * MT;
     constexpr int EPI_OFF = PERSIST ? 2 * STAGE_BYTES : 0;
@@ -172,6 +176,10 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
         });
         if (!more) break;
         vt = nvt;
+    }
+    if (STAMP && threadIdx.x == 0) {
+        unsigned long long* o = g.stamps + (size_t)blockIdx.x * 4;
+        o[0] = st_c0; o[1] = st_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

@@ -346,10 +346,38 @@ def test_bench_launches_its_own_ranks_when_no_launcher_is_present():
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout      # nothing but the JSON line on stdout (gloo's rendezvous banner goes to stderr)
     out = json.loads(lines[0])
     assert out["n_ranks_seen"] == 2 and out["n_gpus"] == 2 and out["sum"] == 2.0
+    assert out["dp_mode"] == "sharded" and out["dp_fallback"] is None
+    # a rank that fails under EVERY exchange mode: the parent exits non-zero (after its one fallback attempt) and prints no JSON line
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--launch-check-fail-rank", "1"], env=env,
                        capture_output=True, text=True, timeout=240)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_falls_back_to_allreduce_when_the_sharded_exchange_fails():
+    """the first multi-GPU run must not come back empty.  A rank that fails only under RGQA_DP_MODE=sharded (the default)
+    makes the supervising parent start a FRESH set of rank processes with RGQA_DP_MODE=allreduce: exit code 0, one JSON line, with
+    `dp_mode` = allreduce and the reason in `dp_fallback`.  An explicitly requested mode is not second-guessed."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RGQA_DP_MODE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--launch-check-fail-rank", "1", "--launch-check-fail-mode", "sharded"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_ranks_seen"] == 2 and out["dp_mode"] == "allreduce" and "sharded exchange failed" in out["dp_fallback"]
+    assert "fresh set of rank processes" in r.stderr
+    # the same launch as ONE rank of a launcher (WORLD_SIZE set by torch.distributed.run): each rank supervises its own child
+    port = 29900 + (os.getpid() % 500) * 4
+    procs = [subprocess.Popen(cmd, env=dict(env, WORLD_SIZE="2", RANK=str(k), LOCAL_RANK=str(k), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(2)]
+    outs = [pr.communicate(timeout=240) for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), [o[1][-1500:] for o in outs]
+    got = [json.loads(l) for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(got) == 1 and got[0]["dp_mode"] == "allreduce" and got[0]["dp_fallback"] and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    r = subprocess.run(cmd, env=dict(env, RGQA_DP_MODE="allreduce"), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and json.loads(r.stdout.strip())["dp_fallback"] is None
 
 
 def test_synth_batch_contract():
@@ -399,4 +427,4 @@ def test_bench_profiling_section_has_no_collective():
     src = inspect.getsource(bench.main)
     prof = src[src.index("e.profile(True)"):src.index("e.profile(False)")]
     assert "step(exchange=False)" in prof and "step()" not in prof
-    assert "if comm is not None and exchange:" in src
+    assert "if c is not None and exchange:" in src
