@@ -162,6 +162,9 @@ int rgqa_probe_gemm_clock(const void* A, const void* W, void* C, int M, int N, i
  * BertAdam.step (lxrt/optimization.py:101-180) over arena ranges. */
 int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws /* >= 1024 f32 */, float* sumsq_out,
                     int accumulate, void* stream);
+/* the in-place half of clip_grad_norm_ for callers that clip and step in two calls (the drop-in BertAdam): grads *= max_norm /
+ * (sqrt(*sumsq) + 1e-6) if that is < 1; no memory traffic otherwise */
+int rgqa_clip_scale(float* grads, size_t n, const float* sumsq /* device scalar */, float max_norm, void* stream);
 int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp /* operand copy or null */,
                        int lp_split /* 0: p_lp is bf16, 1: split f32 (bf16x3 precision) */, size_t n,
                        float lr_t, float b1, float b2, float eps, float weight_decay,

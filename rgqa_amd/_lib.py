@@ -51,6 +51,7 @@ SIGNATURES = {
     "rgqa_engine_profile_blocks": [_vp, _vp, _vp, _i],
     "rgqa_probe_gemm_clock": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "rgqa_grad_sumsq": [_vp, _sz, _vp, _vp, _i, _vp],
+    "rgqa_clip_scale": [_vp, _sz, _vp, _f, _vp],
     "rgqa_bertadam_step": [_vp, _vp, _vp, _vp, _vp, _i, _sz, _f, _f, _f, _f, _f, _vp, _f, _f, _vp],
     "rgqa_cast_bf16": [_vp, _vp, _sz, _vp],
     "rgqa_split_f32": [_vp, _vp, _sz, _vp],

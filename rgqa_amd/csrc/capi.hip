@@ -169,6 +169,10 @@ int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws, float* sums
     RGQA_REQUIRE(grads && partial_ws && sumsq_out, "grad_sumsq: null argument");
     return k_sumsq(grads, n, partial_ws, sumsq_out, accumulate, S(stream));
 }
+int rgqa_clip_scale(float* grads, size_t n, const float* sumsq, float max_norm, void* stream) {
+    RGQA_REQUIRE(grads && sumsq, "clip_scale: null argument");
+    return k_clip_scale(grads, n, sumsq, max_norm, S(stream));
+}
 int rgqa_bertadam_step(float* p, const float* g, float* m, float* v, void* p_lp, int lp_split, size_t n, float lr_t, float b1, float b2, float eps, float wd,
                        const float* sumsq, float max_norm, float grad_prescale, void* stream) {
     RGQA_REQUIRE(p && g && m && v, "bertadam_step: null argument");

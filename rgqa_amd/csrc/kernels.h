@@ -122,6 +122,7 @@ struct AdamArgs {
     float grad_prescale;   // multiplies g before everything (1/world_size for DP sum-reduce), 1 otherwise
 };
 int k_bertadam(const AdamArgs& a, hipStream_t s);
+int k_clip_scale(float* g, size_t n, const float* sumsq, float max_norm, hipStream_t s);
 // dst_t[k][n] = (bf16) src[n][k] for each listed [N,K] matrix; desc on device: {src_off, dst_off, N, K, tile_start}
 #define TRANSPOSE_TILE 64   // tile_start counts cdiv(ld_dst, TRANSPOSE_TILE) * cdiv(K, TRANSPOSE_TILE) tiles per matrix
 struct TransDesc { long src_off, dst_off; int N, K, ld_dst, tile_start; };

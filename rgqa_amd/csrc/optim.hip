@@ -40,6 +40,29 @@ int k_sumsq(const float* g, size_t n, float* partial, float* out_sumsq, int accu
     return RGQA_OK;
 }
 
+// In-place part of nn.utils.clip_grad_norm_ (tasks/gqa_conf.py:201) for callers that clip and step separately (the drop-in BertAdam):
+// g *= max_norm / (sqrt(sumsq) + 1e-6) when that coefficient is below 1 - and nothing at all, not a byte of traffic, when it is not.
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, size_t n, const float* __restrict__ sumsq, float max_norm) {
+    const float c = max_norm / (sqrtf(*sumsq) + 1e-6f);
+    if (!(c < 1.f)) return;                 // block-uniform
+    const size_t nv = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        float4 v = reinterpret_cast<float4*>(g)[i];
+        v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+        reinterpret_cast<float4*>(g)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) g[(nv << 2) + threadIdx.x] *= c;
+}
+int k_clip_scale(float* g, size_t n, const float* sumsq, float max_norm, hipStream_t s) {
+    if (n == 0) return RGQA_OK;
+    RGQA_REQUIRE(((uintptr_t)g % 16) == 0, "clip_scale: 16-byte alignment required");
+    size_t nb = (n / 4 + 255) / 256;
+    int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(nblk), dim3(256), 0, s, g, n, sumsq, max_norm);
+    RGQA_LAUNCH_CHECK("clip_scale_kernel");
+    return RGQA_OK;
+}
+
 __device__ __forceinline__ void adam_update4(const AdamArgs& a, float coef, float p[4], const float g[4], float m[4], float v[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

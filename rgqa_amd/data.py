@@ -98,7 +98,11 @@ class FeatureStore(object):
 
 class DeviceBatcher(object):
     """Builds engine-ready batches from GQADataset-style datum dicts ({'img_id', 'question_id', 'sent', 'label': {answer: score}},
-    tasks/gqa_data.py:45-62) and a FeatureStore. Two staging sets alternate, so batch i+1 can be staged while batch i trains."""
+    tasks/gqa_data.py:45-62) and a FeatureStore.  Everything that crosses PCIe goes from pinned staging buffers on a COPY stream of its
+    own: the trainer's host thread runs ahead of the GPU, so the copies of batch i+1 proceed (on the DMA engines) while the compute
+    stream still executes step i, and the compute stream only waits for the copy's event.  Two staging sets alternate."""
+
+    LABEL_CAP = 16          # staged labels per sample (GQA: one answer per question; more grows the buffers)
 
     def __init__(self, store, ans2label, num_answers, max_batch, device="cuda:0"):
         self.store, self.ans2label, self.NA, self.maxB = store, ans2label, int(num_answers), int(max_batch)
@@ -108,14 +112,25 @@ class DeviceBatcher(object):
         self.lib = _lib.load()
         O, F = store.O, store.F
         tdt = torch.float16 if store.dtype == "f16" else torch.float32
+        self.copy_stream = torch.cuda.Stream(device=self.device)
         self.sets = []
         for _ in range(2):
             s = {"feats_h": torch.empty(self.maxB, O, F, dtype=tdt).pin_memory(), "boxes_h": torch.empty(self.maxB, O, 4).pin_memory(),
                  "hw_h": torch.empty(self.maxB, 2, dtype=torch.int32).pin_memory(),
                  "feats_raw": torch.empty(self.maxB, O, F, dtype=tdt, device=self.device), "boxes_raw": torch.empty(self.maxB, O, 4, device=self.device),
-                 "hw": torch.empty(self.maxB, 2, dtype=torch.int32, device=self.device), "event": None}
+                 "hw": torch.empty(self.maxB, 2, dtype=torch.int32, device=self.device), "event": None, "copied": None}
+            self._label_buffers(s, self.maxB * self.LABEL_CAP)
             self.sets.append(s)
         self.turn = 0
+
+    def _label_buffers(self, s, cap):
+        s["lab_cap"] = cap
+        s["offs_h"] = torch.empty(self.maxB + 1, dtype=torch.int32).pin_memory()
+        s["labs_h"] = torch.empty(cap, dtype=torch.int32).pin_memory()
+        s["scs_h"] = torch.empty(cap, dtype=torch.float32).pin_memory()
+        s["offs"] = torch.empty(self.maxB + 1, dtype=torch.int32, device=self.device)
+        s["labs"] = torch.empty(cap, dtype=torch.int32, device=self.device)
+        s["scs"] = torch.empty(cap, dtype=torch.float32, device=self.device)
 
     def batch(self, data, with_target=True):
         """-> (ques_ids, feats [B,O,F] f32, boxes [B,O,4] f32, sents, target [B,NA] f32 or None), device tensors, like one
@@ -130,29 +145,48 @@ class DeviceBatcher(object):
             raise KeyError("image %s is not in the feature store" % e)
         s = self.sets[self.turn]
         self.turn ^= 1
-        if s["event"] is not None:
-            s["event"].synchronize()                     # the previous batch staged through this set has left the pinned buffers
+        if s["copied"] is not None:
+            s["copied"].synchronize()                    # the batch staged through this set two calls ago has left the pinned buffers
         st.gather(rows, s["feats_h"][:B].numpy(), s["boxes_h"][:B].numpy(), s["hw_h"][:B].numpy())
-        stream = torch.cuda.current_stream(self.device)
-        s["feats_raw"][:B].copy_(s["feats_h"][:B], non_blocking=True)
-        s["boxes_raw"][:B].copy_(s["boxes_h"][:B], non_blocking=True)
-        s["hw"][:B].copy_(s["hw_h"][:B], non_blocking=True)
-        feats = torch.empty(B, st.O, st.F, dtype=torch.float32, device=self.device)
-        boxes = torch.empty(B, st.O, 4, dtype=torch.float32, device=self.device)
-        target = offs = labs = scs = None
+        nlab = 0
         if with_target:
             off, lab, sc = [0], [], []
             for d in data:
                 for ans, score in d.get("label", {}).items():
                     lab.append(self.ans2label.get(ans, -1)); sc.append(score)
                 off.append(len(lab))
-            offs = torch.tensor(off, dtype=torch.int32).to(self.device, non_blocking=True)
-            labs = torch.tensor(lab if lab else [0], dtype=torch.int32).to(self.device, non_blocking=True)
-            scs = torch.tensor(sc if sc else [0.0], dtype=torch.float32).to(self.device, non_blocking=True)
-            target = torch.empty(B, self.NA, dtype=torch.float32, device=self.device)
+            nlab = len(lab)
+            if nlab > s["lab_cap"]:
+                if s["event"] is not None:
+                    s["event"].synchronize()
+                self._label_buffers(s, 2 * nlab)
+            s["offs_h"][:B + 1] = torch.tensor(off, dtype=torch.int32)
+            if nlab:
+                s["labs_h"][:nlab] = torch.tensor(lab, dtype=torch.int32)
+                s["scs_h"][:nlab] = torch.tensor(sc, dtype=torch.float32)
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.copy_stream):
+            if s["event"] is not None:
+                self.copy_stream.wait_event(s["event"])  # the device-side staging buffers of this set are no longer being read
+            s["feats_raw"][:B].copy_(s["feats_h"][:B], non_blocking=True)
+            s["boxes_raw"][:B].copy_(s["boxes_h"][:B], non_blocking=True)
+            s["hw"][:B].copy_(s["hw_h"][:B], non_blocking=True)
+            if with_target:
+                s["offs"][:B + 1].copy_(s["offs_h"][:B + 1], non_blocking=True)
+                if nlab:
+                    s["labs"][:nlab].copy_(s["labs_h"][:nlab], non_blocking=True)
+                    s["scs"][:nlab].copy_(s["scs_h"][:nlab], non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self.copy_stream)
+        s["copied"] = copied
+        stream.wait_event(copied)
+        feats = torch.empty(B, st.O, st.F, dtype=torch.float32, device=self.device)
+        boxes = torch.empty(B, st.O, 4, dtype=torch.float32, device=self.device)
+        target = torch.empty(B, self.NA, dtype=torch.float32, device=self.device) if with_target else None
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         _lib.check(self.lib.rgqa_batch_prepare(p(s["feats_raw"]), 1 if st.dtype == "f16" else 0, p(feats), p(s["boxes_raw"]), p(s["hw"]), p(boxes),
-                                               p(offs), p(labs), p(scs), p(target), self.NA, B, st.O, st.F, self.NA, C.c_void_p(stream.cuda_stream)))
+                                               p(s["offs"]) if with_target else None, p(s["labs"]) if with_target else None, p(s["scs"]) if with_target else None,
+                                               p(target), self.NA, B, st.O, st.F, self.NA, C.c_void_p(stream.cuda_stream)))
         ev = torch.cuda.Event()
         ev.record(stream)
         s["event"] = ev

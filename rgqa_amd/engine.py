@@ -4,6 +4,7 @@ torch is plumbing only here: it owns device memory (arenas, workspace, I/O tenso
 Every tensor operation of the hot path happens inside librgqa_hip.so.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -13,6 +14,19 @@ from ._lib import Config, check, ptr, PREC_BF16, PREC_BF16X3, PREC_F32
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# engines by the address of their f32 parameter arena: lets the drop-in optimizer / clip helpers (rgqa_amd.lxrt.optimization) recognise
+# parameters that are views of an engine's arena and use its fused kernels and operand copies
+ARENAS = weakref.WeakValueDictionary()
+
+
+def engine_of(ptr_bytes):
+    """the engine whose parameter arena contains the device address, or None"""
+    for base, e in list(ARENAS.items()):
+        if e.params is not None and base <= ptr_bytes < base + 4 * e.arena_elems:
+            return e
+    return None
 
 
 class ParamSpec:
@@ -89,8 +103,11 @@ class Engine:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         n = self.arena_elems
+        for k in [k for k, v in list(ARENAS.items()) if v is self]:
+            del ARENAS[k]
         self.params = torch.zeros(n, dtype=torch.float32, device=device)
         self.grads = torch.zeros(n, dtype=torch.float32, device=device)
+        ARENAS[self.params.data_ptr()] = self
         if self.precision == "bf16":
             self.params_lp = torch.zeros(n, dtype=torch.bfloat16, device=device)
             self.params_lp_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
@@ -124,6 +141,10 @@ class Engine:
         if self.shape is None:
             raise RuntimeError("sync_weights before the first ensure_shape/bind")
         check(self.lib.rgqa_engine_sync_weights(self.h, _stream()))
+
+    def sync_transposed(self):
+        """only the transposed operand copies (after rgqa_bertadam_step wrote the direct copy itself)"""
+        check(self.lib.rgqa_engine_sync_transposed(self.h, _stream()))
 
     # ------------------------------------------------------------------ compute
     def forward(self, feats, boxes, input_ids, input_mask, segment_ids=None, train=False, seed=0, lengths=None):
@@ -291,6 +312,25 @@ class Engine:
                                               max_norm, grad_prescale, s))
         if self.params_lp is not None:
             check(self.lib.rgqa_engine_sync_transposed(self.h, s))
+
+    def clip_grads_(self, max_norm):
+        """nn.utils.clip_grad_norm_(params, max_norm) (tasks/gqa_conf.py:201) on the gradient arena, in place: the norm from the per-segment
+        sums backward left behind when they are valid (enable_segment_sumsq), else from one pass over the live ranges; the gradients are
+        rescaled by one kernel only when the norm exceeds max_norm.  Returns the total norm (device scalar), as torch does."""
+        if getattr(self, "_sumsq", None) is None:
+            self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._sq_ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
+        s = _stream()
+        rngs = self.live_ranges()
+        if self._seg_sumsq is not None and self._seg_sumsq_valid:
+            torch.sum(self._seg_sumsq, dim=0, keepdim=True, out=self._sumsq)
+        else:
+            for i, (a, b) in enumerate(rngs):
+                check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
+        self._seg_sumsq_valid = False            # the gradients change below (or may have: the caller owns them from here on)
+        for a, b in rngs:
+            check(self.lib.rgqa_clip_scale(ptr(self.grads[a:b]), b - a, ptr(self._sumsq), float(max_norm), s))
+        return self._sumsq.sqrt().reshape(())
 
     def grad_norm(self):
         """Global L2 norm of the live gradient ranges (what clip_grad_norm_ measures, gqa_conf.py:201) as a device scalar."""

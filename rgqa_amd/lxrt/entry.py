@@ -8,6 +8,13 @@ import torch.nn as nn
 
 from .tokenization import BertTokenizer
 from .modeling import LXRTFeatureExtraction as VisualBertForLXRFeature, VISUAL_CONFIG
+from . import optimization as _optimization
+
+# The unchanged trainers call `nn.utils.clip_grad_norm_(self.model.parameters(), 5.)` (tasks/gqa_conf.py:201, gqa_mixup_vis.py:258).  Importing the
+# drop-in entry module routes that name through rgqa_amd.lxrt.optimization.clip_grad_norm_: identical results, a fused fast path when the
+# parameters are the views of one engine's arena, torch's own implementation for everything else.  RGQA_PATCH_CLIP=0 leaves torch untouched.
+if os.environ.get("RGQA_PATCH_CLIP", "1") != "0" and torch.nn.utils.clip_grad_norm_ is not _optimization.clip_grad_norm_:
+    torch.nn.utils.clip_grad_norm_ = _optimization.clip_grad_norm_
 
 
 class InputFeatures(object):

@@ -14,8 +14,76 @@ from torch.optim import Optimizer
 from torch.optim.optimizer import required
 
 from .. import _lib
+from .. import engine as _engine
 
 logger = logging.getLogger(__name__)
+
+_torch_clip_grad_norm_ = torch.nn.utils.clip_grad_norm_
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False, foreach=None):
+    """`torch.nn.utils.clip_grad_norm_` with a fast path for the trainer's call (tasks/gqa_conf.py:201, unchanged): when every parameter
+    that has a gradient is a view of ONE engine's arena with its gradient the matching view of the gradient arena (what rgqa_amd
+    models hand out), the 2-norm comes from the sums backward already took segment by segment and the rescale is one kernel over
+    the arena that moves no data unless the norm exceeds max_norm - instead of ~440 tensors' norms, a stack, and ~440 multiplies.
+    Same result (in-place scaled .grad, the total norm returned as a tensor); anything else goes to torch's implementation."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    params = list(parameters)
+    eng = None
+    if float(norm_type) == 2.0 and not error_if_nonfinite and params:
+        sig = tuple(id(p) for p in params)
+        cached = _CLIP_CACHE.get(sig[0])
+        if cached is not None and cached[0] == sig and cached[1]() is not None:
+            eng = cached[1]()
+            # cheap revalidation: the views still point into the arenas (a re-materialised module re-packs), gradients are present
+            p0 = params[0]
+            if eng.params is None or p0.grad is None or engine_view_offset(eng, p0) is None:
+                eng = None
+        if eng is None:
+            eng = _arena_engine_of(params)
+            if eng is not None:
+                import weakref
+                _CLIP_CACHE.clear()
+                _CLIP_CACHE[sig[0]] = (sig, weakref.ref(eng))
+    if eng is None:
+        return _torch_clip_grad_norm_(params, max_norm, norm_type=norm_type, error_if_nonfinite=error_if_nonfinite, foreach=foreach)
+    binding = getattr(eng, "_binding_ref", None)
+    binding = binding() if binding is not None else None
+    if binding is None or not binding.grads_untouched():
+        eng.invalidate_segment_sumsq()           # someone wrote to a .grad since backward: take the norm from the arena itself
+    return eng.clip_grads_(max_norm)
+
+
+_CLIP_CACHE = {}
+
+
+def engine_view_offset(eng, p):
+    """element offset of parameter p in the engine's arena if p AND p.grad are the arena views, else None"""
+    off = p.data_ptr() - eng.params.data_ptr()
+    if off < 0 or off % 4 or off // 4 + p.numel() > eng.arena_elems or p.dtype != torch.float32:
+        return None
+    if p.grad is not None and p.grad.data_ptr() != eng.grads.data_ptr() + off:
+        return None
+    return off // 4
+
+
+def _arena_engine_of(params):
+    """the engine all of `params` belong to (every gradient-carrying one a full arena view, all live ranges covered), or None"""
+    live = [p for p in params if p.grad is not None]
+    if not live or not live[0].is_cuda:
+        return None
+    eng = _engine.engine_of(live[0].data_ptr())
+    if eng is None or eng.grads is None:
+        return None
+    covered = 0
+    for p in live:
+        if engine_view_offset(eng, p) is None or not p.grad.is_contiguous():
+            return None
+        covered += p.numel()
+    # every tensor that backward writes must be among them: otherwise the arena norm would count gradients the caller did not pass
+    want = sum(sp.numel for sp in eng.specs if not sp.dead)
+    return eng if covered == want else None
 
 
 def warmup_cosine(x, warmup=0.002):
@@ -132,6 +200,7 @@ class BertAdam(Optimizer):
                 self._runs[gi] = cached
             if stream is None:
                 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            touched = {}
             for r in cached[1]:
                 step = self.state[r["params"][0]]["step"]
                 if group['t_total'] != -1:
@@ -144,7 +213,21 @@ class BertAdam(Optimizer):
                 else:
                     lr_scheduled = group['lr']
                 if r["m"] is not None:
-                    _lib.check(lib.rgqa_bertadam_step(C.c_void_p(r["p0"]), C.c_void_p(r["g0"]), _lib.ptr(r["m"]), _lib.ptr(r["v"]), None, 0,
+                    # a run inside an engine's arena: the same kernel also re-writes the engine's operand copy of these weights (bf16 / split
+                    # f32), so the next forward need not re-cast the whole arena
+                    lp, lp_split = None, 0
+                    eng = _engine.engine_of(r["p0"])
+                    if eng is not None and eng.params_lp is not None and r["g0"] - eng.grads.data_ptr() == r["p0"] - eng.params.data_ptr():
+                        off = (r["p0"] - eng.params.data_ptr()) // 4
+                        lp_split = 1 if eng.precision == "bf16x3" else 0
+                        lp = C.c_void_p(eng.params_lp.data_ptr() + off * eng.params_lp.element_size())
+                        ent = touched.setdefault(id(eng), [eng, 0, None])
+                        ent[1] += sum(p.numel() for p in r["params"])
+                        if ent[2] is None:
+                            b = getattr(eng, "_binding_ref", None)
+                            b = b() if b is not None else None
+                            ent[2] = b if (b is not None and b.in_sync()) else False
+                    _lib.check(lib.rgqa_bertadam_step(C.c_void_p(r["p0"]), C.c_void_p(r["g0"]), _lib.ptr(r["m"]), _lib.ptr(r["v"]), lp, lp_split,
                                                       r["n"], lr_scheduled, group['b1'], group['b2'], group['e'], group['weight_decay'],
                                                       None, 0.0, 1.0, stream))
                 else:
@@ -159,4 +242,10 @@ class BertAdam(Optimizer):
                 # (the engine's bf16 weight copies) notice the change, as they would after any in-place torch op
                 p0 = r["params"][0]
                 torch._C._autograd._unsafe_set_version_counter((p0,), (p0._version + 1,))
+            for eng, n_upd, binding in touched.values():
+                # every live parameter of the engine went through the fused path and its copies were current before: finish them (the
+                # transposed copies) and tell the binding, instead of a full re-cast at the next forward
+                if binding and n_upd == sum(sp.numel for sp in eng.specs if not sp.dead):
+                    eng.sync_transposed()
+                    binding.mark_synced()
         return loss

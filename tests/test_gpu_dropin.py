@@ -177,6 +177,51 @@ def test_encoder_alone_under_a_foreign_head(env):
     os.remove(path + "_LXRT.pth")
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_trainer_step_fused_clip_and_operand_copies(env, precision):
+    """The unchanged trainer's `nn.utils.clip_grad_norm_` + `BertAdam.step` (tasks/gqa_conf.py:201-202) through the drop-in's fast paths:
+    importing lxrt.entry routes torch.nn.utils.clip_grad_norm_ through lxrt.optimization.clip_grad_norm_ (norm from the sums backward
+    left per gradient segment, one rescale kernel), and BertAdam.step lets the update kernel re-write the engine's operand copies.
+    Against the same steps with torch's own clip: same norm, same parameters; and the operand copies the fused path maintains equal a
+    full re-cast of the updated weights bit for bit (same logits before and after Engine.sync_weights)."""
+    import lxrt.entry  # noqa: F401  (installs the patch)
+    from lxrt.optimization import BertAdam, clip_grad_norm_ as fast_clip, _torch_clip_grad_norm_ as torch_clip
+    assert torch.nn.utils.clip_grad_norm_ is fast_clip
+    feats, boxes, target = batch(20)
+    res = {}
+    for which in ("fast", "torch"):
+        m, _ = build(precision, 20)
+        m.train()
+        # (dropout is off in the config these models are built with: the two runs can be compared exactly)
+        eng = m.lxrt_encoder.model._binding.engine
+        optim = BertAdam(list(m.parameters()), lr=1e-3, warmup=0.1, t_total=20)
+        norms = []
+        for step in range(3):
+            optim.zero_grad()
+            logit = m(feats.cuda(), boxes.cuda(), SENTS)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, target.cuda()) * logit.size(1)
+            loss.backward()
+            clip = torch.nn.utils.clip_grad_norm_ if which == "fast" else torch_clip
+            norms.append(float(clip(m.parameters(), 0.5)))          # small max_norm: the rescale kernel really runs
+            optim.step()
+        m.eval()
+        with torch.no_grad():
+            lg_a = m(feats.cuda(), boxes.cuda(), SENTS).clone()
+            in_sync = m.lxrt_encoder.model._binding.in_sync()
+            m.lxrt_encoder.model._binding.engine.sync_weights()
+            lg_b = m(feats.cuda(), boxes.cuda(), SENTS).clone()
+        res[which] = (norms, {k: v.detach().clone() for k, v in m.named_parameters()}, lg_a, lg_b, in_sync)
+    nf, pf, la, lb, sync_f = res["fast"]
+    nt, pt, _, _, _ = res["torch"]
+    assert sync_f                                   # the fused optimizer path left the copies current: no re-cast happened at the forward
+    assert torch.equal(la, lb)                      # ... and they are exactly what a full re-cast produces
+    np.testing.assert_allclose(nf, nt, rtol=2e-5)
+    assert min(nf) > 0.5                            # every step was clipped
+    worst = max(float((pf[k] - pt[k]).abs().max()) / max(1e-12, float(pt[k].abs().max())) for k in pt)
+    print("fused clip vs torch clip (%s): norms %s vs %s, worst relative parameter difference %.2e" % (precision, nf, nt, worst))
+    assert worst < 1e-4
+
+
 def test_train_mode_runs_and_is_seeded(env):
     """model.train(): dropout 0.1 active (reference BertConfig defaults); different forward calls draw different masks."""
     import rgqa_amd.lxrt.modeling as M
@@ -298,7 +343,7 @@ def _trainer_loop(m, feats, boxes, sents, target, steps):
     from lxrt.optimization import BertAdam
     optim = BertAdam(list(m.parameters()), lr=1e-3, warmup=0.1, t_total=20)
     bce = torch.nn.BCEWithLogitsLoss()
-    m.eval()
+    m.train()       # (dropout is 0 in the config these tests build: train mode is deterministic; under torch.distributed the exchange runs in train mode only)
     for _ in range(steps):
         optim.zero_grad()
         logit = m(feats.cuda(), boxes.cuda(), sents)
