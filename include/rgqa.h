@@ -160,7 +160,7 @@ int rgqa_probe_gemm_clock(const void* A, const void* W, void* C, int M, int N, i
 
 /* ---- optimizer: replaces nn.utils.clip_grad_norm_(params, max_norm) (tasks/gqa_conf.py:201) followed by
  * BertAdam.step (lxrt/optimization.py:101-180) over arena ranges. */
-int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws /* >= 1024 f32 */, float* sumsq_out,
+int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws /* >= 1025 f32, zeroed once: [1024] is a ticket word the kernel rewinds */, float* sumsq_out,
                     int accumulate, void* stream);
 /* the in-place half of clip_grad_norm_ for callers that clip and step in two calls (the drop-in BertAdam): grads *= max_norm /
  * (sqrt(*sumsq) + 1e-6) if that is < 1; no memory traffic otherwise */

@@ -48,7 +48,7 @@ struct Stage {
 // Optional per-launch timing with HIP events on the launch stream (bench.py's live roofline figures).
 enum ProfCat { PC_GEMM_NT = 0, PC_GEMM_TN = 1, PC_ATTN_FWD = 2, PC_ATTN_BWD = 3, PC_LN = 4, PC_OTHER = 5, PC_COUNT = 6 };
 enum ProfBlock { PB_EMBED = 0, PB_LR = 1, PB_X = 2, PB_HEAD = 3, PB_COUNT = 4 };   // input embeddings | l/r layers | cross-modality layers | pooler + head + loss
-struct ProfRec { hipEvent_t a, b; int cat; int block; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int cat; int block; double flops, bytes; char tag[48]; };
 struct ProfSummary { double ms[PC_COUNT]; double flops[PC_COUNT]; double bytes[PC_COUNT]; long launches[PC_COUNT]; };
 
 class EngineBase {
@@ -64,9 +64,10 @@ public:
         if (prof_used == prof_pool.size()) { hipEvent_t e; hipEventCreate(&e); prof_pool.push_back(e); }
         return prof_pool[prof_used++];
     }
-    void prof_begin(int cat, double flops, double bytes, hipStream_t s) {
+    void prof_begin(int cat, double flops, double bytes, hipStream_t s, const char* tag = "") {
         if (!profiling) return;
         ProfRec r; r.a = prof_event(); r.b = prof_event(); r.cat = cat; r.block = prof_block; r.flops = flops; r.bytes = bytes;
+        snprintf(r.tag, sizeof r.tag, "%s", tag);
         hipEventRecord(r.a, s);
         prof_recs.push_back(r);
     }
@@ -82,7 +83,7 @@ public:
             if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
                 out.ms[r.cat] += ms; out.flops[r.cat] += r.flops; out.bytes[r.cat] += r.bytes; out.launches[r.cat]++;
                 if (r.block >= 0 && r.block < PB_COUNT) { last_blk_ms[r.block] += ms; last_blk_flops[r.block] += r.flops; }
-                if (df) fprintf(df, "%d %d %.6e %.6e %.6f\n", r.cat, r.block, r.flops, r.bytes, ms);
+                if (df) fprintf(df, "%d %d %.6e %.6e %.6f %s\n", r.cat, r.block, r.flops, r.bytes, ms, r.tag[0] ? r.tag : "-");
             }
         }
         if (df) fclose(df);

@@ -148,6 +148,7 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 // sat 0.17 ms per step waiting for the set of two periods ago (profiles/r02_timeline_b256.txt); with four it runs on and the side stream
 // catches up beside the longer chains of the paired layers that follow.
 #define NPAR 4
+#define SUMSQ_WS_STRIDE 1088     // k_sumsq: 1024 block partials + the ticket word, per gradient segment
 #define LNPART_BLOCKS 1536     // per layer: <= 3 LayerNorm-backward launches of <= 512 blocks
 int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
 
@@ -299,7 +300,7 @@ public:
             if (sumsq_slots != nullptr && sumsq_ws != nullptr)
                 for (int k = 0; k < (int)grad_segs.size() && k < sumsq_ws_segs; ++k)
                     if (grad_segs[k].event == ev) {
-                        int r = k_sumsq(G + grad_segs[k].begin, grad_segs[k].end - grad_segs[k].begin, sumsq_ws + (size_t)k * 1024, sumsq_slots + k, 0, s);
+                        int r = k_sumsq(G + grad_segs[k].begin, grad_segs[k].end - grad_segs[k].begin, sumsq_ws + (size_t)k * SUMSQ_WS_STRIDE, sumsq_slots + k, 0, s);
                         if (r) return r;
                     }
         }
@@ -435,7 +436,7 @@ public:
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
         for (int par = 0; par < NPAR; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
-        sumsq_ws_segs = (int)grad_segs.size(); sumsq_ws = take<float>((size_t)sumsq_ws_segs * 1024);
+        sumsq_ws_segs = (int)grad_segs.size(); sumsq_ws = take<float>((size_t)sumsq_ws_segs * SUMSQ_WS_STRIDE);
         if (joint) {
             const size_t ni = (size_t)B * Oi, nt = (size_t)B * Tt;
             tlens_dev = take<int>(B); tcu_dev = take<int>(B + 1); trow_src_dev = take<int>(nt); text_dst_dev = take<int>(nt); img_dst_dev = take<int>(ni);
@@ -476,6 +477,7 @@ public:
         if (wb < need) { rgqa_set_error("bind: workspace too small (%zu < %zu bytes)", wb, need); return RGQA_ERR_WORKSPACE; }
         P = p; G = g; Pb = (T*)plp; PbT = (T*)plpt; ws = (char*)w; ws_bytes_ = wb;
         plan(B_, T_, O_);
+        RGQA_HIP(hipMemset(sumsq_ws, 0, sizeof(float) * (size_t)sumsq_ws_segs * SUMSQ_WS_STRIDE));       // the ticket words of k_sumsq start at zero
         varlen = false; lens_dirty = false;
         have_fwd = false;
         tdesc_uploaded = false;
@@ -568,6 +570,12 @@ public:
         p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.K = M; p.M = wrows; p.N = l.in;
         p.C = G + l.w + (size_t)wrow0 * l.in; p.ldc = l.in; p.epi = accumulate ? EPI_ACCUM : EPI_BIAS;
     }
+    // per-launch dump tag (RGQA_PROF_DUMP): problem count, epilogue, M0 x N0 x K0 [+ M1]
+    static const char* gemm_tag(const GemmGroup& g, char (&buf)[48]) {
+        if (g.count > 1) snprintf(buf, sizeof buf, "n%d_e%d_%dx%dx%d+%d", g.count, g.p[0].epi, g.p[0].M, g.p[0].N, g.p[0].K, g.p[1].M);
+        else snprintf(buf, sizeof buf, "n1_e%d_%dx%dx%d", g.p[0].epi, g.p[0].M, g.p[0].N, g.p[0].K);
+        return buf;
+    }
     void gemm_work(const GemmGroup& g, double& flops, double& bytes) const {
         flops = 0; bytes = 0;
         for (int i = 0; i < g.count; ++i) {
@@ -580,7 +588,8 @@ public:
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = a_f32;
         double f, b; gemm_work(g, f, b);
-        prof_begin(PC_GEMM_NT, f, b, s);
+        char tg[48];
+        prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "");
         int r = nt_gemm(g, out_f32, 0, s);
         prof_end(s);
         return r;
@@ -588,7 +597,8 @@ public:
     int run_dgrad(GemmGroup& g, hipStream_t s) {
         if (g.count == 0) return RGQA_OK;
         double f, b; gemm_work(g, f, b);
-        prof_begin(PC_GEMM_NT, f, b, s);
+        char tg[48];
+        prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "");
         int r = nt_gemm(g, 0, 1, s);
         prof_end(s);
         return r;
@@ -597,7 +607,8 @@ public:
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = b_f32;
         double f, b; gemm_work(g, f, b);
-        prof_begin(PC_GEMM_TN, f, b, s);
+        char tg[48];
+        prof_begin(PC_GEMM_TN, f, b, s, profiling ? gemm_tag(g, tg) : "");
         int r = tn_gemm(g, s);
         prof_end(s);
         return r;

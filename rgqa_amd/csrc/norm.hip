@@ -242,8 +242,128 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const LnBwdSeg<T
     }
 }
 
-// (A 16-byte-access variant of the backward kernel - lane l owning the 8-column chunks l and 64 + l - needs 48 column accumulators per lane
-// and spills at the 128-VGPR budget of a 16-wave block: 52 us against 24 us per launch, tools/lab/ln_lab.  Not kept.)
+// bf16 rows with N = 256 * NC columns (768, 1536): HALF a wave per row, every access 16 bytes per lane, as in ln_fwd16_kernel.  Lane l of a
+// half owns the 8-column chunks l, l + 32, ...: 3 x 8 x NC column accumulators per lane, which is why the block is 8 waves (256-VGPR budget;
+// a 16-wave block at 128 VGPRs spilled: 52 us against 24 us per launch, round 1).  Two rows per wave per trip, the next pair's loads issued
+// before the current pair's reductions; the two halves of a wave own the same columns, so their column sums meet in registers (one
+// shuffle) before the 8 waves fold through LDS in a fixed order.  Same partials layout as ln_bwd_kernel.
+template <int NC>
+__global__ __launch_bounds__(512) void ln_bwd16_kernel(const LnBwdSeg<bf16_t> sg0, const LnBwdSeg<bf16_t> sg1, int nblk0, int lddy, int ldz, int lddz,
+                                                       float* __restrict__ part, float dy_scale) {
+    constexpr int N = 256 * NC, NHW = 16, NW = 8;
+    const bool second = (int)blockIdx.x >= nblk0;            // block-uniform
+    const LnBwdSeg<bf16_t>& sg = second ? sg1 : sg0;
+    const bf16_t* __restrict__ dy = sg.dy; const bf16_t* __restrict__ z = sg.z;
+    const float* __restrict__ mean = sg.mean; const float* __restrict__ rstd = sg.rstd;
+    bf16_t* __restrict__ dz = sg.dz; bf16_t* __restrict__ dzd = sg.dzd;
+    const int M = sg.M;
+    const DropCfg drop = sg.drop, drop_in = sg.drop_in;
+    const int lblk = second ? (int)blockIdx.x - nblk0 : (int)blockIdx.x, lgrid = second ? (int)gridDim.x - nblk0 : nblk0;
+    __shared__ float red[NW / 2][N];
+    const int hl = threadIdx.x & 31, hw = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+    float ag[NC][8], ab[NC][8], ad[NC][8], gm[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        load4(sg.gamma + (hl + 32 * i) * 8, gm[i]); load4(sg.gamma + (hl + 32 * i) * 8 + 4, gm[i] + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ad[i][j] = 0.f; }
+    }
+    const int stride = lgrid * NHW;
+    int row = lblk * NHW + hw;
+    bf16x8 rd[NC], rz[NC];
+    float mu = 0.f, rs = 0.f;
+    if (row < M) {
+        mu = mean[row]; rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            rd[i] = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * lddy + (hl + 32 * i) * 8);
+            rz[i] = *reinterpret_cast<const bf16x8*>(z + (size_t)row * ldz + (hl + 32 * i) * 8);
+        }
+    }
+    // (a half-wave whose rows have run out keeps taking part in the shuffles below with zeros: the loop is uniform over the WAVE)
+    for (int base = lblk * NHW + (wave << 1); base < M; base += stride) {
+        const bool live = row < M;
+        float g[NC][8], xh[NC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            float d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = live ? (float)rd[i][j] : 0.f;
+            if (live) drop_apply_vec<8>(drop_in, (uint32_t)row * (uint32_t)N + (uint32_t)((hl + 32 * i) * 8), d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                d[j] *= dy_scale;
+                xh[i][j] = live ? ((float)rz[i][j] - mu) * rs : 0.f;
+                g[i][j] = d[j] * gm[i][j];
+                s1 += g[i][j];
+                s2 += g[i][j] * xh[i][j];
+                ag[i][j] += d[j] * xh[i][j];
+                ab[i][j] += d[j];
+            }
+        }
+        const float rs_cur = rs;
+        const int crow = row;
+        row += stride;
+        if (row < M) {
+            mu = mean[row]; rs = rstd[row];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                rd[i] = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * lddy + (hl + 32 * i) * 8);
+                rz[i] = *reinterpret_cast<const bf16x8*>(z + (size_t)row * ldz + (hl + 32 * i) * 8);
+            }
+        }
+        s1 = half_sum(s1) * (1.0f / (float)N);
+        s2 = half_sum(s2) * (1.0f / (float)N);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                float o[8], od[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o[j] = rs_cur * (g[i][j] - s1 - xh[i][j] * s2); od[j] = o[j]; }
+                drop_apply_vec<8>(drop, (uint32_t)crow * (uint32_t)N + (uint32_t)((hl + 32 * i) * 8), od);
+                bf16x8 ob, odb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ad[i][j] += od[j]; ob[j] = (bf16_t)o[j]; odb[j] = (bf16_t)od[j]; }
+                *reinterpret_cast<bf16x8*>(dz + (size_t)crow * lddz + (hl + 32 * i) * 8) = ob;
+                if (dzd) *reinterpret_cast<bf16x8*>(dzd + (size_t)crow * lddz + (hl + 32 * i) * 8) = odb;
+            }
+        }
+    }
+    if (part == nullptr) return;
+    // the two halves of a wave own the same columns: lower half + upper half (fixed order), then the 8 waves through LDS as in ln_bwd_kernel
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        float v[NC][8];
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float mine = which == 0 ? ag[i][j] : (which == 1 ? ab[i][j] : ad[i][j]);
+                const float other = __shfl_xor(mine, 32, 64);
+                v[i][j] = (threadIdx.x & 32) ? other + mine : mine + other;       // lower-half value first in both halves
+            }
+        __syncthreads();
+        if (wave >= NW / 2 && (threadIdx.x & 32) == 0) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) { store4(&red[wave - NW / 2][(hl + 32 * i) * 8], v[i]); store4(&red[wave - NW / 2][(hl + 32 * i) * 8 + 4], v[i] + 4); }
+        }
+        __syncthreads();
+        if (wave < NW / 2 && (threadIdx.x & 32) == 0) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[wave][(hl + 32 * i) * 8 + j] += v[i][j];
+        }
+        __syncthreads();
+        for (int n = threadIdx.x; n < N; n += 512) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW / 2; ++w) t += red[w][n];
+            part[((size_t)blockIdx.x * 3 + which) * N + n] = t;
+        }
+    }
+}
 
 // out[q][n*stride] (+)= sum_blk part[blk][q][n] for q < nq (null output pointers are skipped).
 // Block = 16 columns (4 lanes x float4) x 64 partial groups: every thread sums nblk/64 float4 partials (fixed order ->
@@ -343,6 +463,16 @@ int ln_bwd_blocks(int M, int N) { return ln_bwd_blocks_t<bf16_t>(M, N); }
 
 template <typename T>
 static int ln_bwd_launch(const LnBwdSeg<T>& a, const LnBwdSeg<T>& b, int nblk0, int nblk, int lddy, int ldz, int lddz, float* part, int N, float dy_scale, hipStream_t s) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        const bool al = lddy % 8 == 0 && ldz % 8 == 0 && lddz % 8 == 0 && ((uintptr_t)a.dy % 16) == 0 && ((uintptr_t)a.z % 16) == 0 && ((uintptr_t)a.dz % 16) == 0 &&
+                        (a.dzd == nullptr || ((uintptr_t)a.dzd % 16) == 0) && ((uintptr_t)b.dy % 16) == 0 && ((uintptr_t)b.z % 16) == 0 && ((uintptr_t)b.dz % 16) == 0 &&
+                        (b.dzd == nullptr || ((uintptr_t)b.dzd % 16) == 0) && ((uintptr_t)a.gamma % 16) == 0 && ((uintptr_t)b.gamma % 16) == 0;
+        if (al && N == 768) {            // (N = 1536, the answer head's LayerNorm over 256 rows, stays on the generic kernel: 144 column accumulators per lane would spill)
+            hipLaunchKernelGGL(ln_bwd16_kernel<3>, dim3(nblk), dim3(512), 0, s, a, b, nblk0, lddy, ldz, lddz, part, dy_scale);
+            RGQA_LAUNCH_CHECK("ln_bwd16_kernel");
+            return RGQA_OK;
+        }
+    }
 #define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, (NVV <= 3 ? (sizeof(T) == 2 ? 1024 : 512) : 256)>), dim3(nblk), dim3(NVV <= 3 ? (sizeof(T) == 2 ? 1024 : 512) : 256), 0, s, a, b, nblk0, lddy, ldz, lddz, part, N, dy_scale)
     const int nvl = cdiv(N / 4, 64);
     if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4);
@@ -394,6 +524,15 @@ int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, con
     int nb0 = ln_bwd_blocks_t<T>(M0, N), nb1 = ln_bwd_blocks_t<T>(M1, N);
     if (nb0 > 256) nb0 = 256;                       // the partial-sum scratch holds 512 blocks
     if (nb1 > 256) nb1 = 256;
+    if (nb0 + nb1 > 256) {
+        // ONE block per CU over both segments, split in proportion to their rows: every block then walks the same number of rows and pays
+        // its set-up and its column-sum fold once (two full-size grids back to back ran 453 blocks of 1-2 rows per half-wave)
+        int a0 = (int)((256.0 * M0) / ((double)M0 + M1) + 0.5);
+        if (a0 < 1) a0 = 1;
+        if (a0 > 255) a0 = 255;
+        if (a0 < nb0) nb0 = a0;
+        if (256 - nb0 < nb1) nb1 = 256 - nb0;
+    }
     LnBwdSeg<T> a, b;
     a.dy = dy; a.z = z; a.gamma = gamma0; a.mean = mean; a.rstd = rstd; a.dz = dz; a.dzd = drop0.thresh ? dzd : nullptr; a.M = M0; a.drop = drop0; a.drop_in = nodrop;
     b.dy = dy + (size_t)M0 * lddy; b.z = z + (size_t)M0 * ldz; b.gamma = gamma1; b.mean = mean + M0; b.rstd = rstd + M0;

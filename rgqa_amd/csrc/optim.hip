@@ -3,8 +3,13 @@
 // the updated weights.  HBM-bound: 4 f32 reads + 3 f32 writes (+1 bf16 write) per parameter.
 #include "kernels.h"
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+// sum(g^2) in ONE launch: every block parks its partial, the block whose ticket is last folds all partials in index order (fixed order:
+// bit-reproducible) and rewinds the ticket for the next launch.  partial: >= 1024 floats + 1 ticket word (partial[1024], as an int), zeroed
+// once by the owner (k_sumsq zeroes it on first use of a buffer through the `fresh` flag).  (Round 2 ran this as two launches per gradient
+// segment: 42 launches per step, the second one 5 us of pure launch latency.)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial, float* __restrict__ out, int accumulate) {
     __shared__ float red[4];
+    __shared__ int last;
     float acc = 0.f;
     const size_t nv = n >> 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
@@ -15,17 +20,29 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out, int accumulate) {
-    __shared__ double red[4];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) acc += (double)partial[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    int* ticket = reinterpret_cast<int*>(partial + 1024);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + blockIdx.x, red[0] + red[1] + red[2] + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1 store: visible beyond this CU's L2 slice
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) { float v = (float)(red[0] + red[1] + red[2] + red[3]); *out = accumulate ? *out + v : v; }
+    if (!last) return;                                          // block-uniform
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    double t = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    __shared__ double redd[4];
+    if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)(redd[0] + redd[1] + redd[2] + redd[3]);
+        *out = accumulate ? *out + v : v;
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 int k_sumsq(const float* g, size_t n, float* partial, float* out_sumsq, int accumulate_into_out, hipStream_t s) {
@@ -33,10 +50,8 @@ int k_sumsq(const float* g, size_t n, float* partial, float* out_sumsq, int accu
     int nblk = (int)((n / 4 + 255) / 256);
     if (nblk > 1024) nblk = 1024;
     if (nblk < 1) nblk = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, s, g, n, partial);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, s, g, n, partial, out_sumsq, accumulate_into_out);
     RGQA_LAUNCH_CHECK("sumsq_kernel");
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, out_sumsq, accumulate_into_out);
-    RGQA_LAUNCH_CHECK("sumsq_final_kernel");
     return RGQA_OK;
 }
 
