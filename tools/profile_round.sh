@@ -1,31 +1,41 @@
 #!/bin/bash
-# Reproduces the committed profiles of a round on a GPU box: tools/profile_round.sh r02   (writes gpurun_out/<tag>_*, copy what is to be
+# Reproduces the committed profiles of a round on a GPU box: tools/profile_round.sh r03   (writes gpurun_out/<tag>_*, copy what is to be
 # judged into profiles/).  Counter passes are separate runs, each with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section).
 set -u
-TAG="${1:-r02}"; OUT=gpurun_out; mkdir -p $OUT
+TAG="${1:-r03}"; OUT=gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 5 --warmup 2 --lean"
 STEPS=7
 run() { name=$1; shift; ( "$@" ) > $OUT/${TAG}_$name.log 2>&1; echo "$name rc=$?"; }
-# 1. the headline line (live HIP-event roofline + CPU baseline)
+# 1. the headline line (live HIP-event roofline, tolerance_compliant / forward-only / drop-in legs, CPU baseline)
 python3 bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err; echo "bench rc=$?"
-# 2. kernel trace + stats: shipped two-stream configuration, and wgrad serialised (what bench.py's live timing sees)
+# 2. kernel trace + stats: shipped two-stream configuration, and wgrad serialised (what bench.py's live timing sees); the bf16x3 mode
 run stats rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_p_stats -- $BENCH
 RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_p_stats_serial -- $BENCH > $OUT/${TAG}_stats_serial.log 2>&1; echo "stats_serial rc=$?"
+RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_p_stats_x3 -- $BENCH --precision bf16x3 > $OUT/${TAG}_stats_x3.log 2>&1; echo "stats_x3 rc=$?"
 python3 tools/prof_summary.py $(ls $OUT/${TAG}_p_stats/*/*kernel_stats.csv | head -1) $STEPS $OUT/${TAG}_kernel_stats_b256.md > /dev/null
 python3 tools/prof_summary.py $(ls $OUT/${TAG}_p_stats_serial/*/*kernel_stats.csv | head -1) $STEPS $OUT/${TAG}_kernel_stats_b256_serial.md > /dev/null
+python3 tools/prof_summary.py $(ls $OUT/${TAG}_p_stats_x3/*/*kernel_stats.csv | head -1) $STEPS $OUT/${TAG}_kernel_stats_b256_bf16x3_serial.md > /dev/null
 cp $(ls $OUT/${TAG}_p_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats_b256.csv
 cp $(ls $OUT/${TAG}_p_stats_serial/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats_b256_serial.csv
+cp $(ls $OUT/${TAG}_p_stats_x3/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats_b256_bf16x3_serial.csv
 python3 tools/timeline.py $(ls $OUT/${TAG}_p_stats/*/*kernel_trace.csv | head -1) 12 > $OUT/${TAG}_timeline_b256.txt 2>&1
-# 3. counters, one pass each
+# 3. per-launch tables (HIP events around every launch; GEMM launches grouped by shape)
+rm -f $OUT/${TAG}_pd.txt $OUT/${TAG}_pdx.txt
+RGQA_PROF_DUMP=$PWD/$OUT/${TAG}_pd.txt python3 tools/prof_dump.py bf16 3 > /dev/null 2>&1 && python3 tools/launch_table.py $OUT/${TAG}_pd.txt 3 > $OUT/${TAG}_launch_table_bf16.txt
+RGQA_PROF_DUMP=$PWD/$OUT/${TAG}_pdx.txt python3 tools/prof_dump.py bf16x3 3 > /dev/null 2>&1 && python3 tools/launch_table.py $OUT/${TAG}_pdx.txt 3 x3 > $OUT/${TAG}_launch_table_bf16x3.txt
+rm -f $OUT/${TAG}_pd.txt $OUT/${TAG}_pdx.txt
+# 4. counters, one pass each
 for c in FETCH_SIZE WRITE_SIZE; do
   RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_p_$c -- $BENCH > $OUT/${TAG}_pmc_$c.log 2>&1; echo "pmc $c rc=$?"
 done
 python3 tools/pmc_summary.py $(ls $OUT/${TAG}_p_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls $OUT/${TAG}_p_WRITE_SIZE/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_gemm_nt.json
 RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_p_mfma -- $BENCH > $OUT/${TAG}_pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
 python3 tools/mfma_util.py $(ls $OUT/${TAG}_p_mfma/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_mfma_util.json
+RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_p_mfma_x3 -- $BENCH --precision bf16x3 > $OUT/${TAG}_pmc_mfma_x3.log 2>&1; echo "pmc mfma x3 rc=$?"
+python3 tools/mfma_util.py $(ls $OUT/${TAG}_p_mfma_x3/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_mfma_util_bf16x3.json
 RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/${TAG}_p_sq -- $BENCH > $OUT/${TAG}_pmc_sq.log 2>&1; echo "pmc sq rc=$?"
 python3 tools/sq_breakdown.py $(ls $OUT/${TAG}_p_sq/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_sq_wave_breakdown.json "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU, RGQA_WGRAD_SERIAL=1 $BENCH; fractions of wave cycles"
 # keep the merge small: the raw traces stay on the box
-rm -rf $OUT/${TAG}_p_stats $OUT/${TAG}_p_stats_serial $OUT/${TAG}_p_FETCH_SIZE $OUT/${TAG}_p_WRITE_SIZE $OUT/${TAG}_p_mfma $OUT/${TAG}_p_sq
+rm -rf $OUT/${TAG}_p_stats $OUT/${TAG}_p_stats_serial $OUT/${TAG}_p_stats_x3 $OUT/${TAG}_p_FETCH_SIZE $OUT/${TAG}_p_WRITE_SIZE $OUT/${TAG}_p_mfma $OUT/${TAG}_p_mfma_x3 $OUT/${TAG}_p_sq
 ls $OUT | grep "^${TAG}_"
