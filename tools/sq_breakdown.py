@@ -7,7 +7,7 @@ import collections, csv, json, sys
 
 def family(k):
     for pat, name in (("gemm_nt8p", "gemm_nt8p (phase-interleaved, persistent)"), ("gemm_nt256d", "gemm_nt256d (deep ring, one tile per block)"),
-                      ("gemm_nt256", "gemm_nt256 (two-slot, persistent)"), ("gemm_tn_dma", "gemm_tn_dma (wgrad)"), ("attn_fwd", "attn_fwd_mfma"),
+                      ("gemm_nt256", "gemm_nt256 (two-slot, persistent)"), ("gemm_tn_dma", "gemm_tn_dma (wgrad)"), ("gemm_tn_x3", "gemm_tn_x3 (split-f32 wgrad)"), ("attn_fwd", "attn_fwd_mfma"),
                       ("attn_bwd", "attn_bwd_mfma"), ("ln_bwd", "ln_bwd"), ("ln_fwd", "ln_fwd"), ("bertadam", "bertadam")):
         if pat in k:
             return name
