@@ -1093,6 +1093,10 @@ public:
                     add_wgrad(wg, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, st.sb[m].x_in, H, seg_rows(m), accumulate, true);
                 }
             }
+            // the first layer's attention wgrads are the launch nothing of the encoder runs beside: start them here, beside this stage's
+            // own QKV dgrad and the embedding backward (they read dqkv / dz, which are final), not after the dgrad
+            // (-0.02 ms bf16, -0.12 ms bf16x3 per step, round 3)
+            if (si == 0 && phase_ffn && layer_open) CK(flush_layer(s));
             // input gradient: dx = dqkv @ Wqkv + dz (residual path)
             gg_init(g);
             if (shared_all) {
