@@ -287,15 +287,15 @@ def probe_sustained_clock(e):
     A = torch.randn(M, K, device=e.device).bfloat16()
     W = (torch.randn(N, K, device=e.device) * 0.05).bfloat16()
     Cc = torch.empty(M, N, device=e.device, dtype=torch.bfloat16)
-    st = torch.zeros(256 * 4, dtype=torch.int64, device=e.device)
+    st = torch.zeros(256 * 8, dtype=torch.int64, device=e.device)
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     t0 = time.perf_counter()
     launches = 0
     while time.perf_counter() - t0 < 1.2:
-        check(e.lib.rgqa_probe_gemm_clock(ptr(A), ptr(W), ptr(Cc), M, N, K, 200, ptr(st), s))
+        check(e.lib.rgqa_probe_gemm(ptr(A), ptr(W), ptr(Cc), None, M, N, K, 8, 0, 200, ptr(st), s))
         torch.cuda.synchronize()
         launches += 200
-    v = st.view(-1, 4).cpu().numpy().astype(np.float64)
+    v = st.view(-1, 8).cpu().numpy().astype(np.float64)
     v = v[(v[:, 3] > v[:, 1])]
     mhz = (v[:, 2] - v[:, 0]) / (v[:, 3] - v[:, 1]) * 100.0
     return float(np.median(mhz)), launches

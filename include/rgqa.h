@@ -150,13 +150,15 @@ int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* 
  * names), 3 pooler + answer head + loss; ms = sum of kernel durations, flops = GEMM + attention FLOPs */
 int rgqa_engine_profile_blocks(rgqa_engine* e, double* ms, double* flops, int nblock);
 
-/* Clock probe for the roofline's sustained peak: `launches` back-to-back launches of the bf16 NT GEMM C[M,N] = A[M,K] W[N,K]^T (K % 64 == 0,
- * N % 8 == 0; dense row-major bf16) on a separately instantiated copy of the product's persistent 256-row-tile kernel that stamps
- * s_memtime / s_memrealtime at the entry and exit of every block; stamps (device, >= 4 * 256 uint64) receives, from the LAST launch,
- * 4 words per block: cycles_in, ticks_in, cycles_out, ticks_out (100-MHz ticks): (cycles_out - cycles_in) / (ticks_out - ticks_in) x 100 MHz
- * = the shader clock held under the dense MFMA loop.  No product kernel executes a stamp. */
-int rgqa_probe_gemm_clock(const void* A, const void* W, void* C, int M, int N, int K, int launches, unsigned long long* stamps,
-                          void* stream);
+/* GEMM probe (roofline.peak_sustained in bench.py; tools/nt_stamps.py): `launches` back-to-back launches of the bf16 NT GEMM
+ * C[M,N] = A[M,K] W[N,K]^T (K % 64 == 0, N % 8 == 0; dense row-major bf16; gelu != 0: GELU epilogue, C2 = its second output) on separately
+ * instantiated, stamped copies of the product kernels at tile height 32 * mt (8, 7: the persistent loop; 5, 2: the deep ring; 0 = 8).
+ * stamps (device, >= 8 * blocks uint64; blocks = min(tiles, CUs) for mt 8 / 7, tiles otherwise) receives, from the LAST launch, 8 words per
+ * block: [0] shader cycles and [1] 100-MHz ticks at entry, [2] / [3] at exit ((c_out - c_in) / (t_out - t_in) x 100 MHz = the shader clock
+ * held under the dense MFMA loop), [4] ticks when the block's first operands have landed, [5] at the end of its first tile's K loop,
+ * [6] after that tile's epilogue (stores issued), [7] tiles walked.  No product kernel executes a stamp. */
+int rgqa_probe_gemm(const void* A, const void* W, void* C, void* C2, int M, int N, int K, int mt, int gelu, int launches,
+                    unsigned long long* stamps, void* stream);
 
 /* ---- optimizer: replaces nn.utils.clip_grad_norm_(params, max_norm) (tasks/gqa_conf.py:201) followed by
  * BertAdam.step (lxrt/optimization.py:101-180) over arena ranges. */

@@ -5,7 +5,7 @@
 
 struct rgqa_engine { EngineBase* impl; };
 EngineBase* make_butd_engine(const rgqa_config& cfg);
-int launch_gemm_nt256_probe(GemmGroup& g, hipStream_t s);      // gemm_mfma256.hip
+int launch_gemm_nt256_probe(GemmGroup& g, int mt, hipStream_t s);      // gemm_mfma256.hip
 
 #define S(x) reinterpret_cast<hipStream_t>(x)
 #define NEED(e) do { if ((e) == nullptr || (e)->impl == nullptr) { rgqa_set_error("null engine handle"); return RGQA_ERR_ARG; } } while (0)
@@ -230,16 +230,18 @@ int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int
     if (dtype == 2) return launch_gemm_nt_x3(g, 0, S(stream));
     return dtype == 1 ? launch_gemm_nt_bf16(g, 0, S(stream)) : launch_gemm_f32(g, 0, 0, S(stream));
 }
-// Clock probe: `launches` back-to-back launches of the bf16 NT GEMM C = A W^T (the persistent 256-row-tile kernel, stamped instantiation);
-// stamps[4 * b + 0..3] of the LAST launch = (s_memtime, s_memrealtime) at entry and exit of block b.
-int rgqa_probe_gemm_clock(const void* A, const void* W, void* C, int M, int N, int K, int launches, unsigned long long* stamps, void* stream) {
-    RGQA_REQUIRE(A && W && C && stamps && launches >= 1, "probe_gemm_clock: null argument");
+// GEMM probe: `launches` back-to-back launches of the bf16 NT GEMM C = A W^T on a stamped instantiation of the product kernels (tile height
+// 32 * mt: 8 / 7 = the persistent loop, 5 / 2 = the deep ring; gelu != 0: the GELU epilogue with C2 as its second output).
+// stamps[8 * b + 0..7] of the LAST launch: (s_memtime, s_memrealtime) at entry and at exit of block b, s_memrealtime at first operands
+// landed / end of the first tile's K loop / after its epilogue, tiles walked.
+int rgqa_probe_gemm(const void* A, const void* W, void* C, void* C2, int M, int N, int K, int mt, int gelu, int launches, unsigned long long* stamps, void* stream) {
+    RGQA_REQUIRE(A && W && C && stamps && launches >= 1, "probe_gemm: null argument");
     for (int i = 0; i < launches; ++i) {
         GemmGroup g; memset(&g, 0, sizeof g);
         g.count = 1; g.drop = make_drop(0.f, 0, 0); g.stamps = stamps;
         GemmProblem& p = g.p[0];
-        p.A = A; p.B = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.epi = EPI_BIAS;
-        if (int r = launch_gemm_nt256_probe(g, S(stream))) return r;
+        p.A = A; p.B = W; p.C = C; p.C2 = gelu ? C2 : nullptr; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.epi = gelu ? EPI_GELU : EPI_BIAS;
+        if (int r = launch_gemm_nt256_probe(g, mt, S(stream))) return r;
     }
     return RGQA_OK;
 }

@@ -41,7 +41,7 @@ struct GemmGroup {
     int total_tiles;
     int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
     const void* zeros;  // TN LDS-DMA kernel: >= 16 zero bytes on the device (source of the contraction tail's A rows)
-    unsigned long long* stamps;   // clock probe only (rgqa_probe_gemm_clock, a separately instantiated kernel): 4 words per block
+    unsigned long long* stamps;   // clock probe only (rgqa_probe_gemm: separately instantiated, stamped kernels): 8 words per block
     DropCfg drop;
     GemmProblem p[GEMM_MAX_PROBLEMS];
 };

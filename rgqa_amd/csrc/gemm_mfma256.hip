@@ -30,21 +30,47 @@ bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
     return true;
 }
 
-// Clock probe (bench.py roofline.peak_sustained): ONE launch of the persistent bf16 NT kernel at 256-row tiles with entry / exit stamps.
-int launch_gemm_nt256_probe(GemmGroup& g, hipStream_t s) {
-    constexpr int MT = 8, LDS_BYTES = NT256_LDS(MT);
-    static bool attr_set = false;
-    if (!attr_set) {
-        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<bf16_t, EPI_BIAS, MT, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
-    RGQA_REQUIRE(g.stamps != nullptr && gemm_nt256_eligible(g, 0), "clock probe: bad problem");
+// Probe launches (bench.py roofline.peak_sustained, tools/nt_stamps.py): ONE launch of a stamped instantiation of the bf16 NT kernels - the
+// persistent loop at 256- / 224-row tiles, the deep ring at 160- / 64-row tiles, plain-bias or GELU epilogue.  8 words per block.
+template <int EPI, int MT>
+static int launch_probe(GemmGroup& g, hipStream_t s) {
     gemm_group_finalize(g, 32 * MT, TN);
-    int grid = g.total_tiles;
-    if (grid > rgqa_num_cus()) grid = rgqa_num_cus();
-    hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI_BIAS, MT, false, true>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
-    RGQA_LAUNCH_CHECK("gemm_nt256_kernel<probe>");
+    static bool attr_set = false;
+    if constexpr (MT == 2 || MT == 5) {
+        constexpr int NSD = MT == 2 ? 4 : 3;
+        constexpr int LDS_D = NSD * (32 * MT * TK * 2 + TN * TK * 2);
+        if (!attr_set) {
+            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<bf16_t, EPI, MT, NSD, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_nt256d_kernel<bf16_t, EPI, MT, NSD, false, true>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, g);
+    } else {
+        constexpr int LDS_BYTES = NT256_LDS(MT);
+        if (!attr_set) {
+            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<bf16_t, EPI, MT, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+            attr_set = true;
+        }
+        int grid = g.total_tiles;
+        if (grid > rgqa_num_cus()) grid = rgqa_num_cus();
+        hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI, MT, false, true>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
+    }
+    RGQA_LAUNCH_CHECK("gemm_nt256 probe");
     return RGQA_OK;
+}
+int launch_gemm_nt256_probe(GemmGroup& g, int mt, hipStream_t s) {
+    RGQA_REQUIRE(g.stamps != nullptr && gemm_nt256_eligible(g, 0), "gemm probe: bad problem");
+    const int epi = g.p[0].epi;
+    RGQA_REQUIRE(epi == EPI_BIAS || epi == EPI_GELU, "gemm probe: bias or GELU epilogue");
+    if (mt == 0) mt = 8;
+    if (epi == EPI_GELU) {
+        switch (mt) { case 8: return launch_probe<EPI_GELU, 8>(g, s); case 7: return launch_probe<EPI_GELU, 7>(g, s);
+                      case 5: return launch_probe<EPI_GELU, 5>(g, s); case 2: return launch_probe<EPI_GELU, 2>(g, s); }
+    } else {
+        switch (mt) { case 8: return launch_probe<EPI_BIAS, 8>(g, s); case 7: return launch_probe<EPI_BIAS, 7>(g, s);
+                      case 5: return launch_probe<EPI_BIAS, 5>(g, s); case 2: return launch_probe<EPI_BIAS, 2>(g, s); }
+    }
+    rgqa_set_error("gemm probe: tile height 32 * %d has no stamped instantiation (8, 7, 5, 2)", mt);
+    return RGQA_ERR_ARG;
 }
 
 int launch_gemm_nt256_f32out(GemmGroup& g, hipStream_t s) { return launch256<float, EPI_BIAS, 2, false>(g, s); }

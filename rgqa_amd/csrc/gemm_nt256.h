@@ -79,12 +79,14 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
 // unrolling the accumulator loops and pushes the 128 accumulators into scratch.
 // Persistent for MT >= 4: one block per CU walks tiles blockIdx, + grid, ... (XCD-aware order); the next tile's first two K-steps are
 // DMA'd behind the epilogue.
-// STAMP (the clock probe's own instantiation, never a product launch): thread 0 of every block records s_memtime / s_memrealtime at entry
-// and exit into g.stamps - shader cycles per 100-MHz tick over the block's life = the clock the chip holds under this loop.
+// STAMP (the probe's own instantiations, never a product launch): thread 0 of every block records into g.stamps[8 * block + ..]
+// 0/1 s_memtime / s_memrealtime at entry, 2/3 at exit (shader cycles per 100-MHz tick over the block's life = the clock the chip holds
+// under this loop), 4 s_memrealtime when the first tile's first operands have landed, 5 at the end of its K loop, 6 after its epilogue
+// (stores issued, not drained), 7 the number of tiles the block walked.
 template <typename OutT, int EPI, int MT, bool X3, bool STAMP = false>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned long long st_c0 = 0, st_r0 = 0;
+    unsigned long long st_c0 = 0, st_r0 = 0, st_r1 = 0, st_r2 = 0, st_r3 = 0, st_nt = 0;
     if (STAMP && threadIdx.x == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr bool PERSIST = NT256_PERSIST(MT);
     constexpr int TM = 32 * MT, A_BYTES = TM * TK * 2, STAGE_BYTES = A_BYTES + TN * TK * 2, AG = (MT + 1) / 2, NAG = 4 * MT;
@@ -156,12 +158,14 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             const int st = kt & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if (STAMP && threadIdx.x == 0 && kt == 0 && st_nt == 0) st_r1 = __builtin_amdgcn_s_memrealtime();
             if (kt + 1 < nkt && !(pre1 && kt == 0)) issue(st ^ 1, kt + 1);
             const unsigned char* a = lds + st * STAGE_BYTES;
             const unsigned char* w = a + A_BYTES;
             nt256_kstep<MT, X3>(a, w, wm, wn, fr, fq, acc);
         }
         __syncthreads();   // every wave is done with the operand stages: they may be refilled (PERSIST) or reused as scratch
+        if (STAMP && threadIdx.x == 0 && st_nt == 0) st_r2 = __builtin_amdgcn_s_memrealtime();
         const int cpi = pi, cm0 = m0, cn0 = n0;
         const int nvt = vt + (int)gridDim.x;
         const bool more = PERSIST && nvt < g.total_tiles;
@@ -174,12 +178,14 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
                 if (pre1) issue(1, 1);
             }
         });
+        if (STAMP && threadIdx.x == 0) { if (st_nt == 0) st_r3 = __builtin_amdgcn_s_memrealtime(); ++st_nt; }
         if (!more) break;
         vt = nvt;
     }
     if (STAMP && threadIdx.x == 0) {
-        unsigned long long* o = g.stamps + (size_t)blockIdx.x * 4;
+        unsigned long long* o = g.stamps + (size_t)blockIdx.x * 8;
         o[0] = st_c0; o[1] = st_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = st_r1; o[5] = st_r2; o[6] = st_r3; o[7] = st_nt;
     }
 }
 
@@ -189,9 +195,11 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
 // costs a full L2/MALL round trip (~1 us) whatever the MFMA work.  One tile per block, so the whole 160 KiB of LDS can hold
 // the ring: NS = 4 slots for MT = 2 (40 KiB each) - three K-steps in flight under counted vmcnt waits; the epilogue scratch
 // aliases the ring once the last step has been consumed.
-template <typename OutT, int EPI, int MT, int NS, bool X3>
+template <typename OutT, int EPI, int MT, int NS, bool X3, bool STAMP = false>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned long long st_c0 = 0, st_r0 = 0, st_r1 = 0, st_r2 = 0;
+    if (STAMP && threadIdx.x == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int TM = 32 * MT, A_BYTES = TM * TK * 2, STAGE_BYTES = A_BYTES + TN * TK * 2, AG = (MT + 1) / 2, NAG = 4 * MT;
     constexpr int KV = X3 ? 2 : 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -259,13 +267,20 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
         const int ahead = nkt - 1 - kt;                 // slots after this one that have been issued at most NS - 2
         wait_keep(ahead < NS - 2 ? ahead : NS - 2);
         __builtin_amdgcn_s_barrier();                   // slot kt visible to all; everyone is done reading slot kt-1
+        if (STAMP && threadIdx.x == 0 && kt == 0) st_r1 = __builtin_amdgcn_s_memrealtime();
         if (kt + NS - 1 < nkt) issue(kt + NS - 1);      // refills slot (kt-1) % NS
         const unsigned char* a = lds + (kt % NS) * STAGE_BYTES;
         const unsigned char* w = a + A_BYTES;
         nt256_kstep<MT, X3>(a, w, wm, wn, fr, fq, acc);
     }
     __syncthreads();   // the ring is dead: reuse it as the epilogue's transpose scratch
+    if (STAMP && threadIdx.x == 0) st_r2 = __builtin_amdgcn_s_memrealtime();
     nt256_epilogue<OutT, EPI, MT>(g, P, lds, wave, lane, m0, n0, wm, wn, acc, []() {});
+    if (STAMP && threadIdx.x == 0) {
+        unsigned long long* o = g.stamps + (size_t)blockIdx.x * 8;
+        const unsigned long long r3 = __builtin_amdgcn_s_memrealtime();
+        o[0] = st_c0; o[1] = st_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = r3; o[4] = st_r1; o[5] = st_r2; o[6] = r3; o[7] = 1;
+    }
 }
 
 static inline int rgqa_num_cus() {
