@@ -7,6 +7,13 @@ export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 5 --warmup 2 --lean"
 STEPS=7
 run() { name=$1; shift; ( "$@" ) > $OUT/${TAG}_$name.log 2>&1; echo "$name rc=$?"; }
+# 0. fabric traffic of the NT launches (separate FETCH_SIZE / WRITE_SIZE passes) FIRST: bench.py reports `roofline.traffic` from profiles/<tag>_pmc_gemm_nt.json
+#    only while its kernel-source digest matches the build it runs on
+for c in FETCH_SIZE WRITE_SIZE; do
+  RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_p_$c -- $BENCH > $OUT/${TAG}_pmc_$c.log 2>&1; echo "pmc $c rc=$?"
+done
+python3 tools/pmc_summary.py $(ls $OUT/${TAG}_p_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls $OUT/${TAG}_p_WRITE_SIZE/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_gemm_nt.json
+cp $OUT/${TAG}_pmc_gemm_nt.json profiles/${TAG}_pmc_gemm_nt.json
 # 1. the headline line (live HIP-event roofline, tolerance_compliant / forward-only / drop-in legs, CPU baseline)
 python3 bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err; echo "bench rc=$?"
 # 2. kernel trace + stats: shipped two-stream configuration, and wgrad serialised (what bench.py's live timing sees); the bf16x3 mode
@@ -26,10 +33,6 @@ RGQA_PROF_DUMP=$PWD/$OUT/${TAG}_pd.txt python3 tools/prof_dump.py bf16 3 > /dev/
 RGQA_PROF_DUMP=$PWD/$OUT/${TAG}_pdx.txt python3 tools/prof_dump.py bf16x3 3 > /dev/null 2>&1 && python3 tools/launch_table.py $OUT/${TAG}_pdx.txt 3 x3 > $OUT/${TAG}_launch_table_bf16x3.txt
 rm -f $OUT/${TAG}_pd.txt $OUT/${TAG}_pdx.txt
 # 4. counters, one pass each
-for c in FETCH_SIZE WRITE_SIZE; do
-  RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_p_$c -- $BENCH > $OUT/${TAG}_pmc_$c.log 2>&1; echo "pmc $c rc=$?"
-done
-python3 tools/pmc_summary.py $(ls $OUT/${TAG}_p_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls $OUT/${TAG}_p_WRITE_SIZE/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_gemm_nt.json
 RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_p_mfma -- $BENCH > $OUT/${TAG}_pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
 python3 tools/mfma_util.py $(ls $OUT/${TAG}_p_mfma/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_mfma_util.json
 RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_p_mfma_x3 -- $BENCH --precision bf16x3 > $OUT/${TAG}_pmc_mfma_x3.log 2>&1; echo "pmc mfma x3 rc=$?"
@@ -38,4 +41,6 @@ RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ
 python3 tools/sq_breakdown.py $(ls $OUT/${TAG}_p_sq/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_sq_wave_breakdown.json "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU, RGQA_WGRAD_SERIAL=1 $BENCH; fractions of wave cycles"
 # keep the merge small: the raw traces stay on the box
 rm -rf $OUT/${TAG}_p_stats $OUT/${TAG}_p_stats_serial $OUT/${TAG}_p_stats_x3 $OUT/${TAG}_p_FETCH_SIZE $OUT/${TAG}_p_WRITE_SIZE $OUT/${TAG}_p_mfma $OUT/${TAG}_p_mfma_x3 $OUT/${TAG}_p_sq
+# 5. in-kernel phase stamps of the NT kernels; the bf16x3 counters
+timeout -k 10 200 python3 tools/nt_stamps.py > $OUT/${TAG}_nt_stamps.txt 2>/dev/null; echo "stamps rc=$?"
 ls $OUT | grep "^${TAG}_"
