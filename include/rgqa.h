@@ -74,7 +74,9 @@ void rgqa_engine_destroy(rgqa_engine* e);
 int rgqa_engine_arena_elems(const rgqa_engine* e, size_t* out);
 int rgqa_engine_num_params(const rgqa_engine* e, int* out);
 int rgqa_engine_param_info(const rgqa_engine* e, int index, char* name, size_t name_cap, size_t* offset,
-                           int64_t shape[2], int* ndim, int* flags /* bit0 linear weight, bit1 dead in mode 'x' */);
+                           int64_t shape[2], int* ndim, int* flags /* bit0 linear weight (has low-precision operand copies), bit1 dead in mode 'x',
+                                                                       bit2 the forward reads this tensor from the f32 master arena in every precision
+                                                                       (biases, LayerNorm, embedding tables, the K = 4 box projection) */);
 /* element range [begin,end) of the parameters that never receive gradients in mode 'x' */
 int rgqa_engine_dead_range(const rgqa_engine* e, size_t* begin, size_t* end);
 int rgqa_engine_workspace_bytes(rgqa_engine* e, int B, int T, int O, size_t* out);

@@ -77,7 +77,7 @@ int rgqa_engine_param_info(const rgqa_engine* e, int index, char* name, size_t n
     RGQA_REQUIRE(name_cap > p.name.size(), "param_info: name buffer too small");
     strcpy(name, p.name.c_str());
     *offset = p.offset; shape[0] = p.shape[0]; shape[1] = p.shape[1]; *ndim = p.ndim;
-    *flags = (p.is_linear_weight ? 1 : 0) | (p.dead_in_x_mode ? 2 : 0);
+    *flags = (p.is_linear_weight ? 1 : 0) | (p.dead_in_x_mode ? 2 : 0) | ((!p.is_linear_weight || p.f32_master_read) ? 4 : 0);
     return RGQA_OK;
 }
 int rgqa_engine_dead_range(const rgqa_engine* e, size_t* b, size_t* en) { NEED(e); *b = e->impl->dead_begin; *en = e->impl->dead_end; return RGQA_OK; }

@@ -17,6 +17,7 @@ struct ParamInfo {
     long shape[2];
     int is_linear_weight;  // has a transposed low-precision copy
     int dead_in_x_mode;    // never receives a gradient when mode == 'x' 
+    int f32_master_read = 0;   // a linear weight the forward nevertheless reads from the f32 master (the K = pos_dim box projection)
 };
 
 struct Lin { size_t w, b; int out, in, ldt; };     // ldt: leading dim of the transposed copy (round_up(out, 64))

@@ -33,6 +33,7 @@ struct TableBuilder {
         cur += n > reserve ? n : reserve;
         return off;
     }
+    void read_as_f32(size_t off) { for (auto& p : out) if (p.offset == off) p.f32_master_read = 1; }
     Lin lin(const std::string& name, int o, int i) {
         Lin l; l.out = o; l.in = i; l.ldt = (int)rup(o, 64);
         l.w = add(name + ".weight", o, i, 2, (size_t)i * l.ldt, 1);
@@ -82,7 +83,7 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
         mp.visn_fc = tb.lin(pre + "img_embeddings.img_linear", H, c.feat_dim);
         mp.visn_ln = tb.ln(pre + "img_embeddings.img_layer_norm", H);
         mp.box_ln = tb.ln(pre + "img_embeddings.pos_layer_norm", H);
-        mp.box_fc = tb.lin(pre + "img_embeddings.pos_linear", H, c.pos_dim);
+        mp.box_fc = tb.lin(pre + "img_embeddings.pos_linear", H, c.pos_dim); tb.read_as_f32(mp.box_fc.w);
         mp.img_ln = tb.ln(pre + "img_embeddings.LayerNorm", H);
         char b2[64];
         for (int i = 0; i < c.l_layers; ++i) {
@@ -107,7 +108,7 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
     const std::string enc = pre + "encoder.";
     mp.visn_fc = tb.lin(enc + "visn_fc.visn_fc", H, c.feat_dim);
     mp.visn_ln = tb.ln(enc + "visn_fc.visn_layer_norm", H);
-    mp.box_fc = tb.lin(enc + "visn_fc.box_fc", H, c.pos_dim);
+    mp.box_fc = tb.lin(enc + "visn_fc.box_fc", H, c.pos_dim); tb.read_as_f32(mp.box_fc.w);
     mp.box_ln = tb.ln(enc + "visn_fc.box_layer_norm", H);
     char buf[64];
     for (int i = 0; i < c.l_layers; ++i) {

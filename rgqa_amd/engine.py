@@ -30,11 +30,12 @@ def engine_of(ptr_bytes):
 
 
 class ParamSpec:
-    __slots__ = ("name", "offset", "shape", "linear", "dead")
+    __slots__ = ("name", "offset", "shape", "linear", "dead", "f32_read")
 
     def __init__(self, name, offset, shape, flags):
         self.name, self.offset, self.shape = name, offset, tuple(shape)
         self.linear, self.dead = bool(flags & 1), bool(flags & 2)
+        self.f32_read = bool(flags & 4)      # the forward reads the f32 master of this tensor whatever the precision
 
     @property
     def numel(self):

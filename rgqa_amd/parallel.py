@@ -12,7 +12,8 @@ Three modes (`make_exchange`, env RGQA_DP_MODE; RGQA_DP_OVERLAP=0 issues any of 
                    of the 1/N range it owns and accumulates them in f32 in rank order (rgqa_sum_bf16_parts: deterministic, no
                    bf16 running sum); clip + BertAdam then touch only that 1/N (sum(g^2) of the shards is one scalar
                    all-reduce), and the updated weights are all-gathered into every rank's forward copy (bf16 engines: the bf16
-                   copy; f32 / bf16x3 engines: the f32 masters).  The chunks are the gradient segments backward finalises (merged
+                   copy, plus - in f32 - what the forward reads from the masters: biases, LayerNorm parameters, embedding tables;
+                   f32 / bf16x3 engines: the f32 masters).  The chunks are the gradient segments backward finalises (merged
                    to >= 64 MB), each exchanged on a side stream as soon as its event fires, so only the last one is exposed.  On
                    the 8-GPU xGMI mesh an all-to-all uses all 7 links of a GPU at once, the wire carries 2 x 7/8 x 410 MB per GPU
                    per step instead of 2 x 7/8 x 819 MB, and the optimizer's 6 GB of HBM traffic shrinks 8x.  While this mode is
@@ -161,7 +162,7 @@ class ShardedExchange:
     """mode 'sharded' (module docstring).  exchange(): bf16 all-to-all reduce-scatter with f32 accumulation at the owner;
     step(): sharded clip + BertAdam, bf16 weight all-gather, transposed-copy refresh."""
 
-    def __init__(self, engine, dist, chunk_mb=256, bucket_mb=64, overlap=None, ops=None):
+    def __init__(self, engine, dist, chunk_mb=256, bucket_mb=64, overlap=None, ops=None, f32_chunk_elems=1 << 18):
         self.e, self.dist = engine, dist
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.ops = ops if ops is not None else _HipOps(engine.lib)
@@ -188,6 +189,36 @@ class ShardedExchange:
         # what is all-gathered after the update: the bf16 operand copy (bf16 engines), else the f32 masters (a split-f32 copy cannot be
         # cut at arbitrary element offsets: a 128-byte line holds the hi and the lo parts of 32 elements; it is re-made from the masters)
         self.lp = engine.precision == "bf16"
+        # bf16 engines: the forward reads biases, LayerNorm parameters, the embedding tables and the K = 4 box projection from the F32 masters
+        # (ParamSpec.f32_read), which the bf16 all-gather does not carry.  Chunks that hold a large such tensor (the embedding tables) are
+        # gathered in f32 and their bf16 copy re-made from the result; the small tensors elsewhere travel as one packed f32 all-reduce in which
+        # every rank contributes the elements it owns and zeros for the rest.
+        self.f32_chunks, self._small_idx, self._small_own = set(), None, None
+        if self.lp and hasattr(engine, "specs"):
+            live = [sp for sp in engine.specs if getattr(sp, "f32_read", False) and not sp.dead]
+            big = [sp for sp in live if sp.numel >= f32_chunk_elems]
+            for ci, (a, b, _) in enumerate(self.chunks):
+                if any(sp.offset < b and sp.offset + sp.numel > a for sp in big):
+                    self.f32_chunks.add(ci)
+            idx = []
+            for sp in live:
+                lo, hi = sp.offset, sp.offset + sp.numel
+                covered = any(self.chunks[ci][0] <= lo and hi <= self.chunks[ci][1] for ci in self.f32_chunks)
+                if not covered:
+                    idx.append(torch.arange(lo, hi, dtype=torch.int64))
+            if idx:
+                idx = torch.cat(idx)
+                own = torch.zeros(idx.numel(), dtype=torch.bool)
+                for c in self.chunks:
+                    lo, hi = owned(c, self.rank)
+                    if hi > lo:
+                        own |= (idx >= lo) & (idx < hi)
+                # an element outside every chunk (no gradient segment covers it) is never updated: nobody owns it, it keeps its value
+                in_chunk = torch.zeros(idx.numel(), dtype=torch.bool)
+                for a, b, _ in self.chunks:
+                    in_chunk |= (idx >= a) & (idx < b)
+                self._small_idx = idx[in_chunk].to(dev)
+                self._small_own = own[in_chunk].to(dev)
 
     def describe(self):
         return "sharded: bf16 all-to-all reduce-scatter + sharded BertAdam + %s weight all-gather, %d chunk(s) of <= %d MB, %s" % (
@@ -274,19 +305,32 @@ class ShardedExchange:
         for lo, hi in mine:
             self._local_adam(lo, hi, lr_t, b1, b2, eps, weight_decay, clip, max_norm, 1.0 / W, s)
         # updated weights -> every rank's forward copy
-        wts = e.params_lp if self.lp else e.params
-        for a, b, sz in self.chunks:
+        for ci, (a, b, sz) in enumerate(self.chunks):
+            f32c = ci in self.f32_chunks                  # bf16 engine, chunk with a large f32-read tensor: gather the masters, re-make the copy
+            wts = e.params_lp if (self.lp and not f32c) else e.params
+            staged = self.lp and not f32c                  # the bf16 staging buffers fit a bf16 chunk only
             n = b - a
             lo, hi = owned((a, b, sz), self.rank)
             if n == W * sz:
                 self._ag(wts[a:b], wts[lo:hi])            # in place: part r of the output is this rank's own input
             else:                                           # ragged chunk: through a padded buffer
-                buf = self._recv[:W * sz] if self.lp else torch.empty(W * sz, dtype=wts.dtype, device=dev)
-                mine_pad = self._send[:sz] if self.lp else torch.zeros(sz, dtype=wts.dtype, device=dev)
+                buf = self._recv[:W * sz] if staged else torch.empty(W * sz, dtype=wts.dtype, device=dev)
+                mine_pad = self._send[:sz] if staged else torch.zeros(sz, dtype=wts.dtype, device=dev)
                 if hi > lo:
                     mine_pad[:hi - lo].copy_(wts[lo:hi])
                 self._ag(buf, mine_pad)
                 wts[a:b].copy_(buf[:n])
+            if f32c:
+                self.ops.cast_bf16(e.params_lp[a:b], e.params[a:b])
+        if self._small_idx is not None and self._small_idx.numel():
+            pack = e.params[self._small_idx] * self._small_own
+            if self._host_staged and pack.is_cuda:
+                t = pack.cpu()
+                self.dist.all_reduce(t)
+                pack.copy_(t)
+            else:
+                self.dist.all_reduce(pack)                  # exactly one rank contributes a non-zero to each element: the sum IS the owner's value
+            e.params[self._small_idx] = pack
         self._after_weights(s)
 
     # -- local arithmetic (HIP, through the C ABI)

@@ -51,11 +51,17 @@ def _worker(rank, world, port, mode, overlap, precision, q):
     shard = {k: v[rank * B:(rank + 1) * B] for k, v in full.items()}
     e, d = _make(shard, precision)
     kw = dict(bucket_mb=1, overlap=overlap) if mode != "sharded" else dict(chunk_mb=1, bucket_mb=1, overlap=overlap)
+    if mode == "sharded" and precision == "bf16" and overlap:
+        kw["f32_chunk_elems"] = 1 << 14        # the word-embedding table (64 k elements here) then takes the f32-chunk path, the rest the packed one
     comm = make_exchange(e, dist, mode, **kw)
     for _ in range(2):
         _step(e, d, comm, world)
+    # what the NEXT forward would read from the f32 masters (biases, LayerNorm, embedding tables): current on every rank without any gather
+    f32_read = torch.cat([e.params[sp.offset:sp.offset + sp.numel] for sp in e.specs if sp.f32_read and not sp.dead]).cpu().numpy()
     comm.gather_master()
     torch.cuda.synchronize()
+    f32_after = torch.cat([e.params[sp.offset:sp.offset + sp.numel] for sp in e.specs if sp.f32_read and not sp.dead]).cpu().numpy()
+    assert np.array_equal(f32_read, f32_after), "rank %d: f32-read parameters were stale before gather_master()" % rank
     nb = len(comm.buckets) if hasattr(comm, "buckets") else len(comm.chunks)
     q.put((rank, e.params.cpu().numpy(), None if e.params_lp is None else (e.params_lp.float() if e.params_lp.dtype == torch.bfloat16 else e.params_lp).cpu().numpy(), nb))
     dist.destroy_process_group()
@@ -106,4 +112,5 @@ def test_two_rank_step_equals_single_rank_on_concatenated_batch(mode, overlap, p
         # lr * 0.1 / sqrt(0.001) = 3.2 lr per step whatever the gradient's size, so an element whose tiny gradient changes sign
         # between the two runs differs by up to 2 steps x 2 x 3.2e-3 = 1.3e-2; the bulk differs by ~1e-6 (f32 engine) / ~1e-5 (bf16
         # engine, whose activations are also rounded differently under the other batch split): the MEAN is the meaningful bound.
-        assert diff.max() < 1.3e-2 and diff.mean() < (1.5e-4 if precision == "bf16" else 4e-6)      # observed means: 1.6e-6 / 9.4e-7 (f32 engine), 6.3e-5 (bf16 engine)
+        assert diff.max() < 1.3e-2 and diff.mean() < (1e-5 if precision == "bf16" else 4e-6)      # observed means: 1.6e-6 / 9.4e-7 (f32 engine), 2.3e-6 (bf16 engine;
+        # 6.3e-5 while the non-owners' biases / LayerNorm parameters / embedding tables were stale - round 3 fix)
