@@ -452,6 +452,15 @@ def main():
             dist.init_process_group("gloo", timeout=tmo)
         if dist.get_backend() == "nccl":
             dp_selfcheck(dist, dp_mode, torch.device("cuda", local))
+    elif os.environ.get("RGQA_BENCH_RCCL_REHEARSAL") == "1":
+        # one-GPU rehearsal of the N > 1 path ON RCCL: a process group of ONE rank, so every collective of the chosen exchange runs through
+        # the library (group creation with device_id and timeout, the bf16 all-to-all, the in-place all-gather, the scalar all-reduce) and
+        # the exchange's local arithmetic (casts, f32 sums of the shards, sharded BertAdam, copy refresh) is timed at full size
+        import datetime
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                                device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=120))
+        dp_selfcheck(dist, dp_mode, torch.device("cuda", local))
 
     from rgqa_amd.engine import Engine
     from rgqa_amd import synth
@@ -503,8 +512,8 @@ def main():
             dev.update(feats=f2, boxes=b2, target=t2, input_ids=ids2, input_mask=mask2, segment_ids=seg2)
     e.ensure_shape(MB, T, O)
     e.sync_weights()
-    comm = make_exchange(e, dist, mode=dp_mode) if world > 1 else None      # RGQA_DP_MODE: sharded (default) | allreduce | allreduce_bf16
-    if world == 1 and not args.butd:
+    comm = make_exchange(e, dist, mode=dp_mode) if dist is not None else None      # RGQA_DP_MODE: sharded (default) | allreduce | allreduce_bf16
+    if dist is None and not args.butd:
         e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
     t_total = 10000
     state = dict(step=0, lengths=lengths, comm=comm)
@@ -728,9 +737,11 @@ def main():
             out["forward_only_b256"] = fwd_only
         if dropin is not None:
             out["dropin_step"] = dropin
-        if world > 1:
+        if dist is not None:
             out["dp_mode"] = dp_mode
             out["dp_fallback"] = os.environ.get("RGQA_BENCH_DP_FALLBACK")
+            if world == 1:
+                out["rccl_rehearsal"] = "one rank on RCCL: every collective of the exchange runs through the library; the exchange's local arithmetic is timed at full size"
         if dp_legs is not None:
             out["exposed_comm_ms"] = dp_legs["exposed_comm_ms"]      # step time minus the time of the same step with no exchange and a local whole-arena optimizer
             out["dp_exchange"] = dp_legs

@@ -114,3 +114,50 @@ def test_two_rank_step_equals_single_rank_on_concatenated_batch(mode, overlap, p
         # engine, whose activations are also rounded differently under the other batch split): the MEAN is the meaningful bound.
         assert diff.max() < 1.3e-2 and diff.mean() < (1e-5 if precision == "bf16" else 4e-6)      # observed means: 1.6e-6 / 9.4e-7 (f32 engine), 2.3e-6 (bf16 engine;
         # 6.3e-5 while the non-owners' biases / LayerNorm parameters / embedding tables were stale - round 3 fix)
+
+
+def _rccl_worker(port, mode, precision, q):
+    import torch.distributed as dist
+    from rgqa_amd.parallel import make_exchange
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    e, d = _make(_full_batch(), precision)
+    kw = dict(bucket_mb=1) if mode != "sharded" else dict(chunk_mb=1, bucket_mb=1, f32_chunk_elems=1 << 14)
+    comm = make_exchange(e, dist, mode, overlap=True, **kw)
+    assert not getattr(comm, "_host_staged", False)            # device tensors straight into the library
+    for _ in range(2):
+        _step(e, d, comm, 1)
+    comm.gather_master()
+    torch.cuda.synchronize()
+    q.put(e.params.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,precision", [("sharded", "bf16"), ("sharded", "bf16x3"), ("allreduce", "bf16"), ("allreduce_bf16", "f32")])
+def test_exchange_on_rccl_single_rank_group(mode, precision):
+    """RCCL itself (torch.distributed backend "nccl"), as far as a one-GPU box allows: a process group of ONE rank - group creation with
+    device_id, the bf16 all_to_all_single, the in-place all_gather_into_tensor, the packed f32 / scalar all_reduce, each on device tensors from
+    the exchange's side stream - and the result against the plain single-process step (a bf16 payload rounds the gradients once)."""
+    import torch.multiprocessing as mp
+    e, d = _make(_full_batch(), precision)
+    for _ in range(2):
+        _step(e, d, None, 1)
+    ref = e.params.cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 11 * ["sharded", "allreduce", "allreduce_bf16"].index(mode) + 3 * ["f32", "bf16", "bf16x3"].index(precision)
+    p = ctx.Process(target=_rccl_worker, args=(port, mode, precision, q), daemon=True)
+    p.start()
+    try:
+        got = q.get(timeout=240)
+        p.join(60)
+    finally:
+        if p.is_alive():
+            p.terminate()
+    assert p.exitcode == 0
+    diff = np.abs(got - ref)
+    print("rccl world-1 %s/%s: |params - plain step| max %.3e mean %.3e" % (mode, precision, diff.max(), diff.mean()))
+    if mode == "allreduce":
+        np.testing.assert_array_equal(got, ref)                  # f32 SUM over one rank: the identity
+    else:
+        assert diff.max() < 1.3e-2 and diff.mean() < 1e-5
