@@ -25,7 +25,8 @@ extern "C" {
                                    the 1e-3 bound (bf16 rounding through 19 blocks, ~5e-2) */
 #define RGQA_PRECISION_BF16X3 2 /* split-f32 ("bf16x3"): every activation / weight operand a bf16 pair hi + lo (16-17 significant bits),
                                    products on the bf16 matrix pipe as hi*hi + hi*lo + lo*hi with f32 accumulation: the fast path whose
-                                   logits stay within 1e-3 of the reference CPU path (lxrt/modeling.py:309-346 is f32 end to end) */
+                                   logits stay within 1e-3 of the reference CPU path (lxrt/modeling.py:309-346 is f32 end to end); arch 0 (LXMERT)
+                                   and 2 (UNITER), head size 64, hidden / inter / feat_dim multiples of 32 */
 
 typedef struct rgqa_config {
     int32_t vocab_size, hidden, heads, inter, max_pos, type_vocab; /* BertConfig, lxrt/modeling.py:172-258 */

@@ -57,8 +57,8 @@ int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out) {
     RGQA_REQUIRE(cfg->l_layers >= 0 && cfg->x_layers >= 0 && cfg->r_layers >= 0, "engine_create: negative layer count");
     RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16 || cfg->precision == RGQA_PRECISION_BF16X3, "engine_create: unknown precision %d", cfg->precision);
     if (cfg->precision == RGQA_PRECISION_BF16X3)
-        RGQA_REQUIRE(cfg->arch == 0 && cfg->hidden % 64 == 0 && cfg->hidden / cfg->heads == 64 && cfg->inter % 32 == 0 && cfg->feat_dim % 32 == 0,
-                     "engine_create: bf16x3 precision needs the LXMERT engine with head size 64 and hidden / intermediate / feature sizes that are multiples of 32");
+        RGQA_REQUIRE(cfg->hidden % 64 == 0 && cfg->hidden / cfg->heads == 64 && cfg->inter % 32 == 0 && cfg->feat_dim % 32 == 0,
+                     "engine_create: bf16x3 precision needs head size 64 and hidden / intermediate / feature sizes that are multiples of 32");
     RGQA_REQUIRE(cfg->hidden_dropout >= 0.f && cfg->hidden_dropout < 1.f && cfg->attn_dropout >= 0.f && cfg->attn_dropout < 1.f, "engine_create: dropout out of range");
     rgqa_engine* e = new (std::nothrow) rgqa_engine;
     if (!e) { rgqa_set_error("engine_create: out of host memory"); return RGQA_ERR_STATE; }

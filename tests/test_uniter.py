@@ -109,10 +109,10 @@ def test_engine_f32_small_vs_golden(golden_dir, tag, T, packed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec,packed", [("f32", False), ("f32", True), ("bf16", True)])
+@pytest.mark.parametrize("prec,packed", [("f32", False), ("f32", True), ("bf16", True), ("bf16x3", True), ("bf16x3", False)])
 def test_engine_full_config_vs_golden(golden_dir, prec, packed):
-    """bert-base UNITER: 12 layers over 56-token sequences. f32 operands: logits within the north-star 1e-3 of the reference's CPU
-    path; bf16: within the tolerance the LXMERT bf16 path is held to."""
+    """bert-base UNITER: 12 layers over 56-token sequences. f32 and split-f32 (bf16x3) operands: logits within the north-star 1e-3 of the
+    reference's CPU path; bf16: within the tolerance the LXMERT bf16 path is held to."""
     g = np.load(os.path.join(golden_dir, "g11_uniter_full_T20.npz"))
     cfgd, raw = case("full", 20)
     b = dev(raw)
@@ -122,7 +122,8 @@ def test_engine_full_config_vs_golden(golden_dir, prec, packed):
     e.sync_weights()
     lg, pl = e.forward(b["feats"], b["pos7"], b["input_ids"], b["input_mask"], b["segment_ids"], lengths=lens)
     err = np.abs(lg.cpu().numpy() - g["logits"]).max()
-    assert err <= (1e-3 if prec == "f32" else 6e-2), err
+    print("uniter full config %s packed=%s: max |logit - reference| %.3e" % (prec, packed, err))
+    assert err <= (6e-2 if prec == "bf16" else 1e-3), err
     perr = np.abs(pl.cpu().numpy() - g["pooled"]).max()
     np.testing.assert_allclose(pl.cpu().numpy(), g["pooled"], rtol=0, atol=2e-4 if prec == "f32" else 3e-2)
     loss = e.loss_backward(b["target"])
