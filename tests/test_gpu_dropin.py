@@ -402,3 +402,33 @@ def test_unchanged_trainer_is_data_parallel_under_torch_distributed(env, golden_
         # BCEWithLogitsLoss takes the mean over the LOCAL batch: the average of the two half-batch means == the full-batch mean
         np.testing.assert_allclose(res[0][k], ref[k], rtol=2e-4, atol=2e-5, err_msg=k)
     print("drop-in DP, 2 ranks vs 1: max |param diff| = %.3e" % worst)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "bf16x3"])
+def test_parameter_changes_after_a_forward_reach_the_operand_copies(env, precision, tmp_path):
+    """What a trainer does to a model that has already run (gqa_conf.py:96-110, entry.py:126-152; foreign optimizers): in-place updates of
+    the device parameters, `load_state_dict` on the device, `LXRTEncoder.save` / `.load`.  Every one must reach the engine's low-precision /
+    split-f32 / transposed operand copies before the next forward."""
+    m, _ = build(precision)
+    m.eval()
+    feats, boxes, _ = batch()
+    f, b = feats.cuda(), boxes.cuda()
+    with torch.no_grad():
+        lg1 = m(f, b, SENTS).float().cpu()
+        for p in m.parameters():
+            p.mul_(1.05)                       # in place, after the engine has made its copies
+        lg2 = m(f, b, SENTS).float().cpu()
+        assert float((lg2 - lg1).abs().max()) > 1e-3
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        m2, _ = build(precision)
+        m2.eval()
+        m2(f, b, SENTS)
+        m2.load_state_dict(sd)                 # checkpoint load on the device, after a forward
+        assert torch.equal(m2(f, b, SENTS).float().cpu(), lg2)
+        m.lxrt_encoder.save(str(tmp_path / "ck"))
+        m3, _ = build(precision)
+        m3.eval()
+        m3(f, b, SENTS)
+        m3.lxrt_encoder.load(str(tmp_path / "ck"))
+        m3.logit_fc.load_state_dict(m.logit_fc.state_dict())
+        assert torch.equal(m3(f, b, SENTS).float().cpu(), lg2)
