@@ -148,18 +148,6 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return cdf + x * pdf;
 }
 
-// Fast erf for the bf16 kernels: Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 absolute (two orders below bf16
-// resolution); the f32 parity kernels keep the library erff above. ~12 VALU instructions vs ~60 for erff.
-__device__ __forceinline__ float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float r = 1.0f - p * t * __expf(-ax * ax);
-    return copysignf(r, x);
-}
 // gelu(x) and gelu'(x) from one erf / one exp (the exp inside the erf approximation IS the Gaussian pdf term).
 // Phi(x) = 1 - h for x >= 0, h for x < 0, with h = 0.5 * erfc(|x|/sqrt 2) = (p(t) * t) * exp(-x^2/2), t = 1/(1 + 0.3275911 |x|/sqrt 2)
 // (Abramowitz-Stegun 7.1.26, coefficients pre-multiplied by 0.5; |error| of Phi <= 8e-8).  v_rcp_f32 (1 ulp) instead of an IEEE
@@ -176,12 +164,6 @@ __device__ __forceinline__ void gelu_and_grad_fast(float x, float& g, float& dg)
     const float cdf = x >= 0.f ? 1.0f - h : h;
     g = x * cdf;
     dg = fmaf(x, 0.39894228040143267794f * e, cdf);
-}
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float dgelu_fast(float x) {
-    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
 }
 
 // ---------------------------------------------------------------- counter-based dropout RNG

@@ -27,13 +27,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-// same with the source as wave-uniform base (SGPR pair) + per-lane 32-bit byte offset: one VGPR per source instead of two and no
-// 64-bit vector add per K-step (the base advances with a scalar add)
-__device__ __forceinline__ void dma16o(unsigned voff, const void* sbase, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(p);
 }
