@@ -50,11 +50,12 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // ============================================================================ forward
+// (body + two kernels: one problem per launch, or TWO problems - the language and the vision side of a paired stage, or the two directions of
+// a cross-attention stage - in one launch, the heavier one's blocks first: round 3)
 template <int NQT, int NKT>
-__global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char vs[NKT * 16 * ROWB];
+__device__ __forceinline__ void attn_fwd_mfma_body(const AttnArgs& a, const int blk, unsigned char* vs /* NKT * 16 * ROWB bytes */) {
     const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const int b = blk / a.nh, h = blk % a.nh;
     ATTN_SAMPLE_ROWS(a, b)      // q0, k0: first row of this sample; Lq, Lk: its valid row counts (<= a.Lq, a.Lk)
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + q0 * a.ldq + h * 64;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + k0 * a.ldk + h * 64;
@@ -164,15 +165,19 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
 // from ~2200 to ~800 instructions.  dS takes the K image's place once every dQ is done (held packed in registers until then); the Pd
 // image is the only new LDS (pitch NKT * 32 + 16 bytes).
 template <int NQT, int NKT>
-__global__ __launch_bounds__(64) void attn_bwd1_mfma_kernel(const AttnArgs a) {
+__host__ __device__ constexpr int attn_bwd1_smem() {
+    return (NKT * 16 * ROWB > NQT * 16 * (NKT * 32 + 16) ? NKT * 16 * ROWB : NQT * 16 * (NKT * 32 + 16)) + 2 * NQT * 16 * ROWB + NQT * 16 * (NKT * 32 + 16);
+}
+template <int NQT, int NKT>
+__device__ __forceinline__ void attn_bwd1_mfma_body(const AttnArgs& a, const int blk, unsigned char* smem /* attn_bwd1_smem<NQT, NKT>() bytes */) {
     constexpr int P2 = NKT * 32 + 16;                  // pitch of the [query][key] images
     constexpr int KS_BYTES = NKT * 16 * ROWB > NQT * 16 * P2 ? NKT * 16 * ROWB : NQT * 16 * P2;
-    __shared__ __attribute__((aligned(16))) unsigned char ks_[KS_BYTES];     // K image; after the query-major pass: dS[q][key]
-    __shared__ __attribute__((aligned(16))) unsigned char qs_[NQT * 16 * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char os_[NQT * 16 * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char pd_[NQT * 16 * P2];  // Pd[q][key] = dropout(P)
+    unsigned char* ks_ = smem;                                   // K image; after the query-major pass: dS[q][key]
+    unsigned char* qs_ = ks_ + KS_BYTES;
+    unsigned char* os_ = qs_ + NQT * 16 * ROWB;
+    unsigned char* pd_ = os_ + NQT * 16 * ROWB;                  // Pd[q][key] = dropout(P)
     const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const int b = blk / a.nh, h = blk % a.nh;
     ATTN_SAMPLE_ROWS(a, b)
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + q0 * a.ldq + h * 64;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + k0 * a.ldk + h * 64;
@@ -346,6 +351,31 @@ static int mfma_check(const AttnArgs& a, bool bwd) {
     return RGQA_OK;
 }
 
+template <int NQT, int NKT>
+__global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NKT * 16 * ROWB];
+    attn_fwd_mfma_body<NQT, NKT>(a, blockIdx.x, smem);
+}
+template <int NQT, int NKT>
+__global__ __launch_bounds__(64) void attn_bwd1_mfma_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[attn_bwd1_smem<NQT, NKT>()];
+    attn_bwd1_mfma_body<NQT, NKT>(a, blockIdx.x, smem);
+}
+// two problems in one launch: blocks [0, n0) work on a0 with <Q0, K0> tiles, the rest on a1 with <Q1, K1> (block-uniform branch)
+template <int Q0, int K0, int Q1, int K1>
+__global__ __launch_bounds__(64) void attn_fwd_mfma_pair_kernel(const AttnArgs a0, const AttnArgs a1, const int n0) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(K0 > K1 ? K0 : K1) * 16 * ROWB];
+    if ((int)blockIdx.x < n0) attn_fwd_mfma_body<Q0, K0>(a0, blockIdx.x, smem);
+    else attn_fwd_mfma_body<Q1, K1>(a1, blockIdx.x - n0, smem);
+}
+template <int Q0, int K0, int Q1, int K1>
+__global__ __launch_bounds__(64) void attn_bwd1_mfma_pair_kernel(const AttnArgs a0, const AttnArgs a1, const int n0) {
+    constexpr int S0 = attn_bwd1_smem<Q0, K0>(), S1 = attn_bwd1_smem<Q1, K1>();
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S0 > S1 ? S0 : S1];
+    if ((int)blockIdx.x < n0) attn_bwd1_mfma_body<Q0, K0>(a0, blockIdx.x, smem);
+    else attn_bwd1_mfma_body<Q1, K1>(a1, blockIdx.x - n0, smem);
+}
+
 #define DISPATCH_TILES(KERNEL, nqt, nkt)                                                                          \
     switch ((nqt) * 8 + (nkt)) {                                                                                  \
         case 1 * 8 + 1: hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(64), 0, s, a); break;                        \
@@ -384,4 +414,43 @@ int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s) {
     DISPATCH_TILES(attn_bwd1_mfma_kernel, nqt, nkt)
     RGQA_LAUNCH_CHECK("attn_bwd_mfma_kernel");
     return RGQA_OK;
+}
+
+// The two attention problems of a stage in ONE launch when their tile shapes are the GQA ones (questions of 17..32 tokens, 33..48 regions):
+// self-attention <2,2> + <3,3>, cross-attention <2,3> + <3,2>; the heavier problem's blocks first.  Returns 1 when it launched, 0 when the
+// caller should launch the two problems separately, < 0 on error.
+static int pair_shape(const AttnArgs& a0, const AttnArgs& a1) {
+    const int q0 = cdiv(a0.Lq, 16), k0 = cdiv(a0.Lk, 16), q1 = cdiv(a1.Lq, 16), k1 = cdiv(a1.Lk, 16);
+    if (a0.nh != a1.nh || a0.dh != a1.dh) return 0;
+    if (q0 == 3 && k0 == 3 && q1 == 2 && k1 == 2) return 1;
+    if (q0 == 3 && k0 == 2 && q1 == 2 && k1 == 3) return 2;
+    return 0;
+}
+int k_attn_fwd_mfma_pair(const AttnArgs& x, const AttnArgs& y, hipStream_t s) {
+    const bool swap = x.Lq * x.Lk < y.Lq * y.Lk || (x.Lq * x.Lk == y.Lq * y.Lk && x.Lq < y.Lq);
+    const AttnArgs& a0 = swap ? y : x; const AttnArgs& a1 = swap ? x : y;
+    const int shape = pair_shape(a0, a1);
+    if (shape == 0) return 0;
+    int r = mfma_check(a0, false); if (r) return r;
+    r = mfma_check(a1, false); if (r) return r;
+    const int n0 = a0.B * a0.nh;
+    dim3 grid(n0 + a1.B * a1.nh);
+    if (shape == 1) hipLaunchKernelGGL((attn_fwd_mfma_pair_kernel<3, 3, 2, 2>), grid, dim3(64), 0, s, a0, a1, n0);
+    else hipLaunchKernelGGL((attn_fwd_mfma_pair_kernel<3, 2, 2, 3>), grid, dim3(64), 0, s, a0, a1, n0);
+    RGQA_LAUNCH_CHECK("attn_fwd_mfma_pair_kernel");
+    return 1;
+}
+int k_attn_bwd_mfma_pair(const AttnArgs& x, const AttnArgs& y, hipStream_t s) {
+    const bool swap = x.Lq * x.Lk < y.Lq * y.Lk || (x.Lq * x.Lk == y.Lq * y.Lk && x.Lq < y.Lq);
+    const AttnArgs& a0 = swap ? y : x; const AttnArgs& a1 = swap ? x : y;
+    const int shape = pair_shape(a0, a1);
+    if (shape == 0) return 0;
+    int r = mfma_check(a0, true); if (r) return r;
+    r = mfma_check(a1, true); if (r) return r;
+    const int n0 = a0.B * a0.nh;
+    dim3 grid(n0 + a1.B * a1.nh);
+    if (shape == 1) hipLaunchKernelGGL((attn_bwd1_mfma_pair_kernel<3, 3, 2, 2>), grid, dim3(64), 0, s, a0, a1, n0);
+    else hipLaunchKernelGGL((attn_bwd1_mfma_pair_kernel<3, 2, 2, 3>), grid, dim3(64), 0, s, a0, a1, n0);
+    RGQA_LAUNCH_CHECK("attn_bwd1_mfma_pair_kernel");
+    return 1;
 }

@@ -69,12 +69,13 @@ __device__ __forceinline__ const bf16_t* head_base(const void* p, size_t row0, i
 }
 
 // ============================================================================ forward
+// (body + one-problem and two-problem kernels, as in attn_mfma.hip)
 template <int NQT, int NKT>
-__global__ __launch_bounds__(64) void attn_fwd_x3_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char vsh[NKT * 16 * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char vsl[NKT * 16 * ROWB];
+__device__ __forceinline__ void attn_fwd_x3_body(const AttnArgs& a, const int blk, unsigned char* smem /* 2 * NKT * 16 * ROWB bytes */) {
+    unsigned char* vsh = smem;
+    unsigned char* vsl = smem + NKT * 16 * ROWB;
     const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const int b = blk / a.nh, h = blk % a.nh;
     ATTN_SAMPLE_ROWS(a, b)
     const bf16_t* Q = head_base(a.q, q0, a.ldq, h);
     const bf16_t* K = head_base(a.k, k0, a.ldk, h);
@@ -181,15 +182,19 @@ __global__ __launch_bounds__(64) void attn_fwd_x3_kernel(const AttnArgs a) {
 // Query-major pass: P recomputed from the saved log-sum-exp, dP = dO V^T, dS = P (dP - delta) scale, dQ = dS K; dS and dropout(P) are
 // parked (hi and lo images) for the key-major pass, which fetches them transposed: dK = dS^T Q, dV = dropout(P)^T dO.
 template <int NQT, int NKT>
-__global__ __launch_bounds__(64) void attn_bwd_x3_kernel(const AttnArgs a) {
+__host__ __device__ constexpr int attn_bwd_x3_smem() {
+    return 2 * ((NKT * 16 * ROWB > NQT * 16 * (NKT * 32 + 16) ? NKT * 16 * ROWB : NQT * 16 * (NKT * 32 + 16)) + 2 * NQT * 16 * ROWB + NQT * 16 * (NKT * 32 + 16));
+}
+template <int NQT, int NKT>
+__device__ __forceinline__ void attn_bwd_x3_body(const AttnArgs& a, const int blk, unsigned char* smem /* attn_bwd_x3_smem<NQT, NKT>() bytes */) {
     constexpr int P2 = NKT * 32 + 16;                  // pitch of the [query][key] images
     constexpr int KS_BYTES = NKT * 16 * ROWB > NQT * 16 * P2 ? NKT * 16 * ROWB : NQT * 16 * P2;
-    __shared__ __attribute__((aligned(16))) unsigned char ksh[KS_BYTES], ksl[KS_BYTES];     // K images; after the query-major pass: dS[q][key]
-    __shared__ __attribute__((aligned(16))) unsigned char qsh[NQT * 16 * ROWB], qsl[NQT * 16 * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char osh[NQT * 16 * ROWB], osl[NQT * 16 * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char pdh[NQT * 16 * P2], pdl[NQT * 16 * P2];  // Pd[q][key] = dropout(P)
+    unsigned char* ksh = smem; unsigned char* ksl = ksh + KS_BYTES;               // K images; after the query-major pass: dS[q][key]
+    unsigned char* qsh = ksl + KS_BYTES; unsigned char* qsl = qsh + NQT * 16 * ROWB;
+    unsigned char* osh = qsl + NQT * 16 * ROWB; unsigned char* osl = osh + NQT * 16 * ROWB;
+    unsigned char* pdh = osl + NQT * 16 * ROWB; unsigned char* pdl = pdh + NQT * 16 * P2;     // Pd[q][key] = dropout(P)
     const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const int b = blk / a.nh, h = blk % a.nh;
     ATTN_SAMPLE_ROWS(a, b)
     const bf16_t* Q = head_base(a.q, q0, a.ldq, h);
     const bf16_t* K = head_base(a.k, k0, a.ldk, h);
@@ -354,6 +359,30 @@ __global__ __launch_bounds__(64) void attn_bwd_x3_kernel(const AttnArgs a) {
 }
 
 // ============================================================================ host side
+template <int NQT, int NKT>
+__global__ __launch_bounds__(64) void attn_fwd_x3_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NKT * 16 * ROWB];
+    attn_fwd_x3_body<NQT, NKT>(a, blockIdx.x, smem);
+}
+template <int NQT, int NKT>
+__global__ __launch_bounds__(64) void attn_bwd_x3_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[attn_bwd_x3_smem<NQT, NKT>()];
+    attn_bwd_x3_body<NQT, NKT>(a, blockIdx.x, smem);
+}
+template <int Q0, int K0, int Q1, int K1>
+__global__ __launch_bounds__(64) void attn_fwd_x3_pair_kernel(const AttnArgs a0, const AttnArgs a1, const int n0) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (K0 > K1 ? K0 : K1) * 16 * ROWB];
+    if ((int)blockIdx.x < n0) attn_fwd_x3_body<Q0, K0>(a0, blockIdx.x, smem);
+    else attn_fwd_x3_body<Q1, K1>(a1, blockIdx.x - n0, smem);
+}
+template <int Q0, int K0, int Q1, int K1>
+__global__ __launch_bounds__(64) void attn_bwd_x3_pair_kernel(const AttnArgs a0, const AttnArgs a1, const int n0) {
+    constexpr int S0 = attn_bwd_x3_smem<Q0, K0>(), S1 = attn_bwd_x3_smem<Q1, K1>();
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S0 > S1 ? S0 : S1];
+    if ((int)blockIdx.x < n0) attn_bwd_x3_body<Q0, K0>(a0, blockIdx.x, smem);
+    else attn_bwd_x3_body<Q1, K1>(a1, blockIdx.x - n0, smem);
+}
+
 static int x3_check(const AttnArgs& a, bool bwd) {
     RGQA_REQUIRE(a.dh == 64, "x3 attention: head size must be 64 (got %d)", a.dh);
     RGQA_REQUIRE(a.B > 0 && a.nh > 0 && a.Lq > 0 && a.Lk > 0 && a.Lq <= 64 && a.Lk <= 64, "x3 attention: Lq/Lk must be in 1..64 (got %d %d)", a.Lq, a.Lk);
@@ -407,4 +436,41 @@ int k_attn_bwd_x3(const AttnArgs& a, hipStream_t s) {
     DISPATCH_TILES(attn_bwd_x3_kernel, nqt, nkt)
     RGQA_LAUNCH_CHECK("attn_bwd_x3_kernel");
     return RGQA_OK;
+}
+
+// two problems of a stage in one launch (see attn_mfma.hip): 1 = launched, 0 = launch them separately, < 0 = error
+static int pair_shape(const AttnArgs& a0, const AttnArgs& a1) {
+    const int q0 = cdiv(a0.Lq, 16), k0 = cdiv(a0.Lk, 16), q1 = cdiv(a1.Lq, 16), k1 = cdiv(a1.Lk, 16);
+    if (a0.nh != a1.nh || a0.dh != a1.dh) return 0;
+    if (q0 == 3 && k0 == 3 && q1 == 2 && k1 == 2) return 1;
+    if (q0 == 3 && k0 == 2 && q1 == 2 && k1 == 3) return 2;
+    return 0;
+}
+int k_attn_fwd_x3_pair(const AttnArgs& x, const AttnArgs& y, hipStream_t s) {
+    const bool swap = x.Lq * x.Lk < y.Lq * y.Lk || (x.Lq * x.Lk == y.Lq * y.Lk && x.Lq < y.Lq);
+    const AttnArgs& a0 = swap ? y : x; const AttnArgs& a1 = swap ? x : y;
+    const int shape = pair_shape(a0, a1);
+    if (shape == 0) return 0;
+    int r = x3_check(a0, false); if (r) return r;
+    r = x3_check(a1, false); if (r) return r;
+    const int n0 = a0.B * a0.nh;
+    dim3 grid(n0 + a1.B * a1.nh);
+    if (shape == 1) hipLaunchKernelGGL((attn_fwd_x3_pair_kernel<3, 3, 2, 2>), grid, dim3(64), 0, s, a0, a1, n0);
+    else hipLaunchKernelGGL((attn_fwd_x3_pair_kernel<3, 2, 2, 3>), grid, dim3(64), 0, s, a0, a1, n0);
+    RGQA_LAUNCH_CHECK("attn_fwd_x3_pair_kernel");
+    return 1;
+}
+int k_attn_bwd_x3_pair(const AttnArgs& x, const AttnArgs& y, hipStream_t s) {
+    const bool swap = x.Lq * x.Lk < y.Lq * y.Lk || (x.Lq * x.Lk == y.Lq * y.Lk && x.Lq < y.Lq);
+    const AttnArgs& a0 = swap ? y : x; const AttnArgs& a1 = swap ? x : y;
+    const int shape = pair_shape(a0, a1);
+    if (shape == 0) return 0;
+    int r = x3_check(a0, true); if (r) return r;
+    r = x3_check(a1, true); if (r) return r;
+    const int n0 = a0.B * a0.nh;
+    dim3 grid(n0 + a1.B * a1.nh);
+    if (shape == 1) hipLaunchKernelGGL((attn_bwd_x3_pair_kernel<3, 3, 2, 2>), grid, dim3(64), 0, s, a0, a1, n0);
+    else hipLaunchKernelGGL((attn_bwd_x3_pair_kernel<3, 2, 2, 3>), grid, dim3(64), 0, s, a0, a1, n0);
+    RGQA_LAUNCH_CHECK("attn_bwd_x3_pair_kernel");
+    return 1;
 }

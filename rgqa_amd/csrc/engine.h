@@ -73,6 +73,7 @@ public:
         prof_recs.push_back(r);
     }
     void prof_end(hipStream_t s) { if (profiling) hipEventRecord(prof_recs.back().b, s); }
+    void prof_cancel() { if (profiling) prof_recs.pop_back(); }      // the bracketed launch did not happen
     // host-synchronising: call after the stream has been synchronised
     void prof_collect(ProfSummary& out) {
         memset(&out, 0, sizeof out);

@@ -617,6 +617,10 @@ public:
     int attn_fwd(const AttnArgs& a, hipStream_t s) { return attn_fwd_dispatch(a, s); }
     int attn_fwd_dispatch(const AttnArgs& a, hipStream_t s);
     int attn_bwd_dispatch(const AttnArgs& a, hipStream_t s);
+    // both attention problems of a stage in one launch: 1 = launched, 0 = not covered (launch them separately), < 0 = error
+    int attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
+    int attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
+    static bool attn_pair_wanted() { const char* e = getenv("RGQA_ATTN_PAIR"); return e == nullptr || atoi(e) != 0; }
 
 #define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
 // CK + HIP-event timing of the call under profiling (non-GEMM kernels: they count towards the per-block times)
@@ -688,22 +692,37 @@ public:
             }
             CK(run_fwd(g, s));
         }
-        for (int m = 0; m < 2; ++m) if (st.active[m]) {
-            const int km = cross ? 1 - m : m;    // modality that provides keys / values
-            AttnArgs a; memset(&a, 0, sizeof a);
-            a.q = st.sb[m].qkv; a.ldq = 3 * H;
-            a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
-            a.out = st.sb[m].ctx; a.ldo = H;
-            a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;      // only language keys carry a padding mask (entry.py:119)
-            a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;  // packed language rows: the window IS the mask
-            a.lse = st.sb[m].lse;
-            a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
-            a.scale = 1.0f / sqrtf((float)dh);
-            a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
-            prof_begin(PC_ATTN_FWD, 4.0 * B * nh * a.Lq * a.Lk * dh, sizeof(T) * (double)B * nh * dh * (2.0 * a.Lq + 2.0 * a.Lk), s);
-            int ra = attn_fwd_dispatch(a, s);
-            prof_end(s);
-            CK(ra);
+        {
+            AttnArgs aa[2];
+            for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                const int km = cross ? 1 - m : m;    // modality that provides keys / values
+                AttnArgs& a = aa[m]; memset(&a, 0, sizeof a);
+                a.q = st.sb[m].qkv; a.ldq = 3 * H;
+                a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
+                a.out = st.sb[m].ctx; a.ldo = H;
+                a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;      // only language keys carry a padding mask (entry.py:119)
+                a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;  // packed language rows: the window IS the mask
+                a.lse = st.sb[m].lse;
+                a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
+                a.scale = 1.0f / sqrtf((float)dh);
+                a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
+            }
+            auto fl = [&](const AttnArgs& a) { return 4.0 * B * nh * a.Lq * a.Lk * dh; };
+            auto by = [&](const AttnArgs& a) { return sizeof(T) * (double)B * nh * dh * (2.0 * a.Lq + 2.0 * a.Lk); };
+            int paired = 0;
+            if (st.active[0] && st.active[1] && attn_pair_wanted()) {      // language | vision (or the two cross directions) in ONE launch
+                prof_begin(PC_ATTN_FWD, fl(aa[0]) + fl(aa[1]), by(aa[0]) + by(aa[1]), s);
+                paired = attn_fwd_pair_dispatch(aa[0], aa[1], s);
+                if (paired != 0) prof_end(s); else prof_cancel();
+                if (paired < 0) return paired;
+            }
+            if (paired == 0)
+                for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                    prof_begin(PC_ATTN_FWD, fl(aa[m]), by(aa[m]), s);
+                    int ra = attn_fwd_dispatch(aa[m], s);
+                    prof_end(s);
+                    CK(ra);
+                }
         }
         {
             GemmGroup g; gg_init(g); g.drop = drop_base(pd);
@@ -1059,24 +1078,39 @@ public:
                 // dead visn-query direction: lang rows get no dk/dv, visn rows get no dq
                 CK(rgqa_check_hip(hipMemsetAsync(gqkv, 0, (size_t)R * 3 * H * sizeof(T), s), "zero dqkv"));
             }
-            for (int m = 0; m < 2; ++m) if (st.active[m]) {
-                const int km = cross ? 1 - m : m;
-                AttnArgs a; memset(&a, 0, sizeof a);
-                a.q = st.sb[m].qkv; a.ldq = 3 * H;
-                a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
-                a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;
-                a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;
-                a.lse = st.sb[m].lse;
-                a.dout = rowp(gctx, m, H); a.lddo = H;
-                a.dq = rowp(gqkv, m, 3 * H); a.dk = rowp(gqkv, km, 3 * H) + H; a.dv = rowp(gqkv, km, 3 * H) + 2 * H;
-                a.lddq = a.lddk = a.lddv = 3 * H;
-                a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
-                a.scale = 1.0f / sqrtf((float)dh);
-                a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
-                prof_begin(PC_ATTN_BWD, 10.0 * B * nh * a.Lq * a.Lk * dh, sizeof(T) * (double)B * nh * dh * (4.0 * a.Lq + 4.0 * a.Lk), s);
-                int ra = attn_bwd_dispatch(a, s);
-                prof_end(s);
-                CK(ra);
+            {
+                AttnArgs aa[2];
+                for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                    const int km = cross ? 1 - m : m;
+                    AttnArgs& a = aa[m]; memset(&a, 0, sizeof a);
+                    a.q = st.sb[m].qkv; a.ldq = 3 * H;
+                    a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
+                    a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;
+                    a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;
+                    a.lse = st.sb[m].lse;
+                    a.dout = rowp(gctx, m, H); a.lddo = H;
+                    a.dq = rowp(gqkv, m, 3 * H); a.dk = rowp(gqkv, km, 3 * H) + H; a.dv = rowp(gqkv, km, 3 * H) + 2 * H;
+                    a.lddq = a.lddk = a.lddv = 3 * H;
+                    a.B = B; a.nh = nh; a.Lq = seg_len(m); a.Lk = seg_len(km); a.dh = dh;
+                    a.scale = 1.0f / sqrtf((float)dh);
+                    a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
+                }
+                auto fl = [&](const AttnArgs& a) { return 10.0 * B * nh * a.Lq * a.Lk * dh; };
+                auto by = [&](const AttnArgs& a) { return sizeof(T) * (double)B * nh * dh * (4.0 * a.Lq + 4.0 * a.Lk); };
+                int paired = 0;
+                if (st.active[0] && st.active[1] && attn_pair_wanted()) {      // the two problems write disjoint rows / columns of dqkv: one launch
+                    prof_begin(PC_ATTN_BWD, fl(aa[0]) + fl(aa[1]), by(aa[0]) + by(aa[1]), s);
+                    paired = attn_bwd_pair_dispatch(aa[0], aa[1], s);
+                    if (paired != 0) prof_end(s); else prof_cancel();
+                    if (paired < 0) return paired;
+                }
+                if (paired == 0)
+                    for (int m = 0; m < 2; ++m) if (st.active[m]) {
+                        prof_begin(PC_ATTN_BWD, fl(aa[m]), by(aa[m]), s);
+                        int ra = attn_bwd_dispatch(aa[m], s);
+                        prof_end(s);
+                        CK(ra);
+                    }
             }
             // weight / bias gradients (GEMMs deferred to the end of the layer)
             if (shared_all) {
@@ -1262,6 +1296,21 @@ template <> int Engine<bf16_t>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t
 template <> int Engine<bf16_t>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) {
     if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_bwd_mfma(a, s);
     return k_attn_bwd_ref<bf16_t>(a, s);
+}
+
+template <> int Engine<float>::attn_fwd_pair_dispatch(const AttnArgs&, const AttnArgs&, hipStream_t) { return 0; }
+template <> int Engine<float>::attn_bwd_pair_dispatch(const AttnArgs&, const AttnArgs&, hipStream_t) { return 0; }
+template <> int Engine<sf32>::attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
+    return (a0.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) ? k_attn_fwd_x3_pair(a0, a1, s) : 0;
+}
+template <> int Engine<sf32>::attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
+    return (a0.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) ? k_attn_bwd_x3_pair(a0, a1, s) : 0;
+}
+template <> int Engine<bf16_t>::attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
+    return (a0.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) ? k_attn_fwd_mfma_pair(a0, a1, s) : 0;
+}
+template <> int Engine<bf16_t>::attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
+    return (a0.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) ? k_attn_bwd_mfma_pair(a0, a1, s) : 0;
 }
 
 EngineBase* make_engine(const rgqa_config& cfg) {

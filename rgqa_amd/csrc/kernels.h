@@ -72,6 +72,12 @@ int k_attn_fwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
 int k_attn_bwd_mfma(const AttnArgs& a, hipStream_t s);   // bf16 only
 int k_attn_fwd_x3(const AttnArgs& a, hipStream_t s);     // split f32 (attn_x3.hip): every product as hi*hi + hi*lo + lo*hi on the bf16 matrix pipe
 int k_attn_bwd_x3(const AttnArgs& a, hipStream_t s);
+// the two attention problems of a stage (language | vision, or the two cross directions) in ONE launch: 1 = launched, 0 = shapes not covered
+// (launch them separately), < 0 = error
+int k_attn_fwd_mfma_pair(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
+int k_attn_bwd_mfma_pair(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
+int k_attn_fwd_x3_pair(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
+int k_attn_bwd_x3_pair(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
 
 // ---- embed.hip
 // lang[b*T+t] = dropout(LN(word[ids] + pos[t] + type[seg]))      (reference BertEmbeddings, modeling.py:278-292)

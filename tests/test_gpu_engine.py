@@ -368,6 +368,34 @@ def test_dropout_train_mode_is_deterministic_and_consistent():
     assert abs(num - ana) / max(1e-6, abs(ana)) < 2e-2, (num, ana)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("packed", [False, True])
+def test_paired_attention_launch_is_bit_identical(precision, packed, monkeypatch):
+    """Round 3: the two attention problems of a stage (language | vision self-attention, the two cross-attention directions) go out as ONE
+    launch when their tile shapes are the GQA ones (T in 17..32, 33..48 regions).  Same per-block code on the same operands: logits and
+    every gradient (outside the atomically accumulated embedding tables) are bit-identical to the two-launch path (RGQA_ATTN_PAIR=0),
+    train mode, padded and packed rows."""
+    B, T, O = 5, 20, 36
+    cfgd = dict(MED, l_layers=2, x_layers=2, r_layers=1)
+    raw = synth.synth_batch(B, T, O=O, F=cfgd["feat_dim"], NA=cfgd["num_answers"], vocab=cfgd["vocab_size"], seed=77, min_len=3)
+    b = dev(raw)
+    lens = [int(v) for v in raw["input_mask"].sum(1)] if packed else None
+    outs = {}
+    for pair in ("0", "1"):
+        monkeypatch.setenv("RGQA_ATTN_PAIR", pair)
+        e = make_engine(cfgd, precision, dropout=0.1)
+        e.ensure_shape(B, T, O)
+        e.sync_weights()
+        lg, _ = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=99, lengths=lens)
+        lg = lg.clone()
+        e.loss_backward(b["target"])
+        first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
+        outs[pair] = (lg, e.grads[first:].clone())
+    assert torch.equal(outs["0"][0], outs["1"][0])
+    assert torch.equal(outs["0"][1], outs["1"][1])
+    assert float(outs["1"][1].abs().max()) > 0
+
+
 def test_side_stream_wgrad_matches_serial():
     """The deferred per-layer weight-gradient launches run on a side stream against double-buffered gradient sets;
     forcing them onto the main stream (rgqa_debug_set key 2) must give bit-identical gradients, repeatedly."""
