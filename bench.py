@@ -359,15 +359,10 @@ def dropin_step_leg(B, T, n_steps, precision):
         batcher = DeviceBatcher(FeatureStore(prefix), ans2label, NA, B)
         state = dict(i=0)
 
-        fixed = os.environ.get("RGQA_DROPIN_FIXED_BATCH") == "1"      # diagnostic: one batch built once (what the batcher + H2D cost per step)
-
         def step():
             i = state["i"]
-            if fixed and "b" in state:
-                ques_id, feats, boxes, sent, target = state["b"]
-            else:
-                batch = [data[(i * B + k) % len(data)] for k in range(B)]
-                ques_id, feats, boxes, sent, target = state["b"] = batcher.batch(batch)
+            batch = [data[(i * B + k) % len(data)] for k in range(B)]
+            ques_id, feats, boxes, sent, target = batcher.batch(batch)
             optim.zero_grad()
             logit = model(feats, boxes, sent)
             loss = bce(logit, target) * logit.size(1)
@@ -377,14 +372,6 @@ def dropin_step_leg(B, T, n_steps, precision):
             state["i"] = i + 1
 
         ms = time_steps(step, n_steps, 3)
-        if os.environ.get("RGQA_DROPIN_HOST_TIME"):       # diagnostic (tools/dropin_profile.py): host time to ISSUE a step, GPU idle at the start
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n_steps):
-                step()
-            host = (time.perf_counter() - t0) / n_steps * 1e3
-            torch.cuda.synchronize()
-            sys.stderr.write("dropin: host issue time %.3f ms/step (GPU-bound when this is below the step time %.3f)\n" % (host, ms))
         del model, optim, batcher
         torch.cuda.empty_cache()
         return ms
