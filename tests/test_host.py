@@ -428,3 +428,32 @@ def test_bench_profiling_section_has_no_collective():
     prof = src[src.index("e.profile(True)"):src.index("e.profile(False)")]
     assert "step(exchange=False)" in prof and "step()" not in prof
     assert "if c is not None and exchange:" in src
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The JSON line the driver parses (profiles/rNN_bench_n1.json = bench.py's stdout on an MI355X): every field of the contract, the
+    metric / workload BASELINE.json names, roofline consistency (achieved / peak = frac; flops per launch / mean launch duration = achieved)
+    and the cpu_baseline object.  A host test: it guards the line's SHAPE against edits of bench.py between GPU runs."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_n1.json")))
+    assert files
+    d = json.loads(open(files[-1]).readline())
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert base["metric"].startswith(d["metric"]) and d["unit"] == "QA-pairs/s"      # BASELINE's name without its ", 1/2/4/8 MI355X" tail (n_gpus says which)
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "bf16" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["gflop_per_launch"] / r["avg_launch_us"] * 1e3 * 1e-3) / r["achieved"] < 5e-3      # GFLOP / us = 1000 TFLOP/s
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.9
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    t = d["tolerance_compliant"]
+    assert t["precision"] == "bf16x3" and t["within_bound"] is True and t["logits_max_err"] <= t["bound"] == 1e-3
