@@ -51,7 +51,8 @@ int rgqa_version(void);
 /* test switches: key 0: 1 forces the 128x128 register-staged GEMM kernels everywhere; key 1: forces the NT tile height (16-row
  * m-tiles per wave: 2, 4..8; 0 = cost model); key 2: 1 runs the deferred weight-gradient launches on the caller's stream instead of
  * the side stream; key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots; key 8: 0 computes
- * the last language FFN on every row (as the reference does), 1 on the [CLS] rows only (default), -1 = environment RGQA_CLS_TAIL. */
+ * the last language FFN on every row (as the reference does), 1 on the [CLS] rows only (default), -1 = environment RGQA_CLS_TAIL;
+ * key 16: 0 launches the two attention problems of a stage separately, 1 as one launch (default). */
 int rgqa_debug_set(int key, int value);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over
@@ -165,7 +166,7 @@ int rgqa_probe_gemm(const void* A, const void* W, void* C, void* C2, int M, int 
 
 /* ---- optimizer: replaces nn.utils.clip_grad_norm_(params, max_norm) (tasks/gqa_conf.py:201) followed by
  * BertAdam.step (lxrt/optimization.py:101-180) over arena ranges. */
-int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws /* >= 1025 f32, zeroed once: [1024] is a ticket word the kernel rewinds */, float* sumsq_out,
+int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws /* >= 1025 f32 of scratch, any content ([1024] is a ticket word the call zeroes on the stream) */, float* sumsq_out,
                     int accumulate, void* stream);
 /* the in-place half of clip_grad_norm_ for callers that clip and step in two calls (the drop-in BertAdam): grads *= max_norm /
  * (sqrt(*sumsq) + 1e-6) if that is < 1; no memory traffic otherwise */

@@ -25,6 +25,8 @@ OUT = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
 from rgqa_amd import synth  # noqa: E402
+from rgqa_amd.synth import (SMALL, FULL, small_batch, full_batch, sample_idx, BUTD_WORDS, BUTD_SENTS,  # noqa: E402,F401
+                            U_SMALL, U_FULL, uniter_batch)
 
 
 def import_reference():
@@ -70,37 +72,6 @@ def build_reference(M, cfgd):
     filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()})
     m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
     return m
-
-
-def sample_idx(name, numel, k=64):
-    k = min(k, numel)
-    return (synth.hash_u32("gradsample." + name, k) % np.uint64(numel)).astype(np.int64)
-
-
-SMALL = dict(vocab_size=64, hidden=64, heads=4, inter=128, max_pos=32, type_vocab=2, l_layers=2, x_layers=2,
-             r_layers=2, feat_dim=32, pos_dim=4, num_answers=11)
-FULL = dict(vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9,
-            x_layers=5, r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842)
-
-
-def small_batch(T):
-    b = synth.synth_batch(3, T, O=6, F=32, NA=11, vocab=64, seed=77 + T, uq_frac=0.34, min_len=2)
-    b["input_ids"][1, 1:] = 0          # a 1-token question: only [CLS] survives as a real token
-    b["input_ids"][1, 0] = 2
-    b["input_mask"] = (b["input_ids"] != 0).astype(np.int64)
-    return b
-
-
-def full_batch(T):
-    b = synth.synth_batch(4, T, seed=4242 + T)
-    ids = b["input_ids"]
-    ids[0, :] = 0
-    ids[0, 0], ids[0, 1] = 101, 102   # shortest question: [CLS][SEP]
-    full = 1000 + (synth.hash_u32("fullrow%d" % T, T) % np.uint64(29000)).astype(np.int64)
-    ids[3, :] = full
-    ids[3, 0], ids[3, T - 1] = 101, 102  # max-length question, no padding
-    b["input_mask"] = (ids != 0).astype(np.int64)
-    return b
 
 
 def run_reference(m, b, train_grads=True, want_dfeats=False):
@@ -374,10 +345,6 @@ def gen_mixup():
     print("g5 ok")
 
 
-BUTD_WORDS = "what color is the dog 's a an on in to left right man woman cat table red blue who holding bottle".split()
-BUTD_SENTS = ["What color is the man's dog?", "Is the cat on the table, to the left?", "who is holding the red bottle", "zebra", ""]
-
-
 def gen_butd():
     """G7: the reference's GQABUTD (butd/butd.py) with a 22-word dictionary, hidden 1024 is fixed by the class, so the
     fixture keeps the real architecture and only shrinks the batch (B=5, 36 RoIs): logits, attention, loss, all gradients'
@@ -515,27 +482,6 @@ def gen_loader():
     z["boxes_norm"] = np.stack(nb); z["target"] = np.stack(tg)
     np.savez_compressed(os.path.join(OUT, "g10_loader.npz"), **z)
     print("g10_loader.npz written")
-
-
-U_SMALL = dict(vocab_size=64, hidden=64, heads=4, inter=128, max_pos=32, type_vocab=2, l_layers=3, x_layers=0, r_layers=0,
-               feat_dim=32, pos_dim=7, num_answers=11)
-U_FULL = dict(vocab_size=28996, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=12, x_layers=0, r_layers=0,
-              feat_dim=2048, pos_dim=7, num_answers=1842)
-
-
-def uniter_batch(cfgd, T, B, O, seed):
-    """Deterministic UNITER batch: a synth LXMERT batch + 7-d position features (normalised box, w, h, area: entry of
-    GQATorchDataset._uniterBoxes, tasks/gqa_data.py:240-250)."""
-    b = synth.synth_batch(B, T, O=O, F=cfgd["feat_dim"], NA=cfgd["num_answers"], vocab=cfgd["vocab_size"], seed=seed, min_len=2)
-    if B >= 3:
-        b["input_ids"][1, 1:] = 0          # a 1-token question
-        b["input_ids"][1, 0] = 2 if cfgd["vocab_size"] < 1000 else 101
-        b["input_ids"][2, :] = np.maximum(b["input_ids"][2, :], 3)        # a full-length question (no padding)
-        b["input_mask"] = (b["input_ids"] != 0).astype(np.int64)
-    bx = b["boxes"]
-    w, h = bx[:, :, 2] - bx[:, :, 0], bx[:, :, 3] - bx[:, :, 1]
-    b["pos7"] = np.stack([bx[:, :, 0], bx[:, :, 1], bx[:, :, 2], bx[:, :, 3], w, h, w * h], 2).astype(np.float32)
-    return b
 
 
 def gen_uniter():

@@ -42,7 +42,7 @@ public:
     const float* in_feats = nullptr; const float* in_boxes = nullptr; const int64_t* in_toks = nullptr;
     int last_train = 0; uint64_t last_seed = 0; bool have_fwd = false;
     // workspace
-    float *sumsq = nullptr, *partial = nullptr, *wlin_eff = nullptr, *att = nullptr, *logits = nullptr, *dwscr = nullptr, *dw_part = nullptr, *db_part = nullptr, *loss_dev = nullptr;
+    float *sumsq = nullptr, *sumsq_scr = nullptr, *partial = nullptr, *wlin_eff = nullptr, *att = nullptr, *logits = nullptr, *dwscr = nullptr, *dw_part = nullptr, *db_part = nullptr, *loss_dev = nullptr;
     T *X = nullptr, *GI = nullptr, *GH = nullptr, *Hall = nullptr, *Rg = nullptr, *Zg = nullptr, *Ng = nullptr, *GHN = nullptr;
     T *IF = nullptr, *IP = nullptr, *QP = nullptr, *IE = nullptr, *QR = nullptr, *IR = nullptr, *J = nullptr, *C1 = nullptr, *dlogits = nullptr;
     T *dC1 = nullptr, *dJ = nullptr, *dQR = nullptr, *dIR = nullptr, *dIE = nullptr, *dIP = nullptr, *dQP = nullptr, *dq = nullptr, *dHa = nullptr, *dHb = nullptr,
@@ -98,7 +98,7 @@ public:
     void plan(int B_, int L_, int O_) {
         B = B_; L = L_; O = O_;
         ws_used = 0;
-        sumsq = take<float>(64); loss_dev = take<float>(64);
+        sumsq = take<float>(64); loss_dev = take<float>(64); sumsq_scr = take<float>(1088);      // k_sumsq's partials + ticket: not shared with the column-sum scratch
         { size_t pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp; partial = take<float>(256 * pw); }
         for (BLin* l : lins) {
             l->eff = ws_used; take<T>((size_t)l->out * l->kp);
@@ -147,7 +147,7 @@ public:
         for (BLin* l : lins) {
             const float* g = nullptr; const float* ss = nullptr;
             if (l->wn) {
-                CKB(k_sumsq(P + l->v, (size_t)l->out * l->in, partial, sumsq + l->norm, 0, s));
+                CKB(k_sumsq(P + l->v, (size_t)l->out * l->in, sumsq_scr, sumsq + l->norm, 0, s));
                 g = P + l->g; ss = sumsq + l->norm;
             }
             CKB(kb_wn_eff<T>(P + l->v, g, ss, effp(*l), l->kp, LP ? efftp(*l) : nullptr, l->op, l->out, l->in, s));

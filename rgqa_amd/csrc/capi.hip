@@ -19,6 +19,7 @@ extern int g_rgqa_force_mt;
 extern int g_rgqa_wgrad_serial;
 extern int g_rgqa_tn_mtw;
 extern int g_rgqa_cls_tail;
+extern int g_rgqa_attn_pair;
 // debug / test switches (include/rgqa.h)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -26,6 +27,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 2) { g_rgqa_wgrad_serial = value; return RGQA_OK; }
     if (key == 4) { g_rgqa_tn_mtw = value; return RGQA_OK; }
     if (key == 8) { g_rgqa_cls_tail = value; return RGQA_OK; }
+    if (key == 16) { g_rgqa_attn_pair = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }

@@ -149,9 +149,10 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 // sat 0.17 ms per step waiting for the set of two periods ago (profiles/r02_timeline_b256.txt); with four it runs on and the side stream
 // catches up beside the longer chains of the paired layers that follow.
 #define NPAR 4
-#define SUMSQ_WS_STRIDE 1088     // k_sumsq: 1024 block partials + the ticket word, per gradient segment
+#define SUMSQ_WS_STRIDE 1088     // k_sumsq_owned: 1024 block partials + the ticket word, per gradient segment
 #define LNPART_BLOCKS 1536     // per layer: <= 3 LayerNorm-backward launches of <= 512 blocks
 int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
+int g_rgqa_attn_pair = 1;      // rgqa_debug_set(16, v): 0 = the two attention problems of a stage as two launches (the bit-identity test's other arm)
 
 template <typename T>
 class Engine : public EngineBase {
@@ -301,7 +302,7 @@ public:
             if (sumsq_slots != nullptr && sumsq_ws != nullptr)
                 for (int k = 0; k < (int)grad_segs.size() && k < sumsq_ws_segs; ++k)
                     if (grad_segs[k].event == ev) {
-                        int r = k_sumsq(G + grad_segs[k].begin, grad_segs[k].end - grad_segs[k].begin, sumsq_ws + (size_t)k * SUMSQ_WS_STRIDE, sumsq_slots + k, 0, s);
+                        int r = k_sumsq_owned(G + grad_segs[k].begin, grad_segs[k].end - grad_segs[k].begin, sumsq_ws + (size_t)k * SUMSQ_WS_STRIDE, sumsq_slots + k, 0, s);
                         if (r) return r;
                     }
         }
@@ -478,7 +479,7 @@ public:
         if (wb < need) { rgqa_set_error("bind: workspace too small (%zu < %zu bytes)", wb, need); return RGQA_ERR_WORKSPACE; }
         P = p; G = g; Pb = (T*)plp; PbT = (T*)plpt; ws = (char*)w; ws_bytes_ = wb;
         plan(B_, T_, O_);
-        RGQA_HIP(hipMemset(sumsq_ws, 0, sizeof(float) * (size_t)sumsq_ws_segs * SUMSQ_WS_STRIDE));       // the ticket words of k_sumsq start at zero
+        RGQA_HIP(hipMemset(sumsq_ws, 0, sizeof(float) * (size_t)sumsq_ws_segs * SUMSQ_WS_STRIDE));       // the ticket words of k_sumsq_owned start at zero
         varlen = false; lens_dirty = false;
         have_fwd = false;
         tdesc_uploaded = false;
@@ -620,7 +621,7 @@ public:
     // both attention problems of a stage in one launch: 1 = launched, 0 = not covered (launch them separately), < 0 = error
     int attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
     int attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
-    static bool attn_pair_wanted() { const char* e = getenv("RGQA_ATTN_PAIR"); return e == nullptr || atoi(e) != 0; }
+    static bool attn_pair_wanted() { return g_rgqa_attn_pair != 0; }
 
 #define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
 // CK + HIP-event timing of the call under profiling (non-GEMM kernels: they count towards the per-block times)
@@ -1279,38 +1280,40 @@ public:
     }
 };
 
+// RGQA_ATTN_REF (test switch: the plain attention kernels instead of the MFMA ones), read once
+static bool attn_ref_forced() { static const bool v = getenv("RGQA_ATTN_REF") != nullptr; return v; }
 template <> int Engine<float>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) { return k_attn_fwd_ref<float>(a, s); }
 template <> int Engine<float>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) { return k_attn_bwd_ref<float>(a, s); }
 template <> int Engine<sf32>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) {
-    if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_fwd_x3(a, s);
+    if (a.dh == 64 && !attn_ref_forced()) return k_attn_fwd_x3(a, s);
     return k_attn_fwd_ref<sf32>(a, s);
 }
 template <> int Engine<sf32>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) {
-    if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_bwd_x3(a, s);
+    if (a.dh == 64 && !attn_ref_forced()) return k_attn_bwd_x3(a, s);
     return k_attn_bwd_ref<sf32>(a, s);
 }
 template <> int Engine<bf16_t>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) {
-    if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_fwd_mfma(a, s);
+    if (a.dh == 64 && !attn_ref_forced()) return k_attn_fwd_mfma(a, s);
     return k_attn_fwd_ref<bf16_t>(a, s);
 }
 template <> int Engine<bf16_t>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) {
-    if (a.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) return k_attn_bwd_mfma(a, s);
+    if (a.dh == 64 && !attn_ref_forced()) return k_attn_bwd_mfma(a, s);
     return k_attn_bwd_ref<bf16_t>(a, s);
 }
 
 template <> int Engine<float>::attn_fwd_pair_dispatch(const AttnArgs&, const AttnArgs&, hipStream_t) { return 0; }
 template <> int Engine<float>::attn_bwd_pair_dispatch(const AttnArgs&, const AttnArgs&, hipStream_t) { return 0; }
 template <> int Engine<sf32>::attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
-    return (a0.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) ? k_attn_fwd_x3_pair(a0, a1, s) : 0;
+    return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_fwd_x3_pair(a0, a1, s) : 0;
 }
 template <> int Engine<sf32>::attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
-    return (a0.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) ? k_attn_bwd_x3_pair(a0, a1, s) : 0;
+    return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_bwd_x3_pair(a0, a1, s) : 0;
 }
 template <> int Engine<bf16_t>::attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
-    return (a0.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) ? k_attn_fwd_mfma_pair(a0, a1, s) : 0;
+    return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_fwd_mfma_pair(a0, a1, s) : 0;
 }
 template <> int Engine<bf16_t>::attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
-    return (a0.dh == 64 && getenv("RGQA_ATTN_REF") == nullptr) ? k_attn_bwd_mfma_pair(a0, a1, s) : 0;
+    return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_bwd_mfma_pair(a0, a1, s) : 0;
 }
 
 EngineBase* make_engine(const rgqa_config& cfg) {

@@ -23,7 +23,10 @@ struct GemmProblem {
     const void* A;
     const void* B;
     void* C;
-    void* C2;           // optional second output (pre-activation), same type / ld as C
+    void* C2;           // optional second output (pre-activation), same type / ld as C (bf16 when c2_lp is set)
+    void* Cb;           // split-f32 results only: optional bf16 image of C at the same element offsets (ldc), or null - what the bf16 backward of the
+                        // bf16x3_fwd precision reads (the image IS the hi part of every element: one more 16-byte store per lane, no arithmetic)
+    int c2_lp;          // split-f32 results only: C2 is a bf16 buffer (gelu' is read by the backward alone)
     const float* bias;  // [N] or null
     const void* aux;    // [M,N] residual or pre-activation, act type
     int M, N, K;

@@ -156,7 +156,20 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmPro
             }
             if (SF) {       // split f32: 16 B of hi parts + 16 B of lo parts per lane; 4 lanes write one whole 128-B line
                 sf_store8(reinterpret_cast<sf32*>(P.C) + (size_t)m * P.ldc + nb, v);
-                if (EPI == EPI_GELU && P.C2 != nullptr) sf_store8(reinterpret_cast<sf32*>(P.C2) + (size_t)m * P.ldc + nb, pre);
+                if (P.Cb != nullptr) {          // bf16x3_fwd precision: the bf16 image the backward pass reads
+                    bf16x8 ob;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)v[j];
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(P.Cb) + (size_t)m * P.ldc + nb) = ob;
+                }
+                if (EPI == EPI_GELU && P.C2 != nullptr) {
+                    if (P.c2_lp) {
+                        bf16x8 op;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) op[j] = (bf16_t)pre[j];
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(P.C2) + (size_t)m * P.ldc + nb) = op;
+                    } else sf_store8(reinterpret_cast<sf32*>(P.C2) + (size_t)m * P.ldc + nb, pre);
+                }
                 continue;
             }
             bf16x8 o, op;

@@ -24,7 +24,10 @@ int launch_gemm_nt_x3(GemmGroup& g, int out_f32, hipStream_t s) {
         // A / W rows may start at any 32-aligned column of a wider split-f32 matrix: the row pitch and the base keep whole lines
         RGQA_REQUIRE(x3_aligned(p.A, p.lda) && x3_aligned(p.B, p.ldb), "gemm_x3[%d]: operands must be 128-byte aligned with ld %% 32 == 0 (lda=%d ldb=%d)", i, p.lda, p.ldb);
         if (out_f32) RGQA_REQUIRE((p.ldc % 4) == 0 && (((uintptr_t)p.C) & 15) == 0, "gemm_x3[%d]: f32 result needs ldc %% 4 and 16-byte alignment", i);
-        else RGQA_REQUIRE(x3_aligned(p.C, p.ldc) && x3_aligned(p.C2, p.ldc), "gemm_x3[%d]: split-f32 result must be 128-byte aligned with ldc %% 32 == 0 (ldc=%d)", i, p.ldc);
+        else {
+            RGQA_REQUIRE(x3_aligned(p.C, p.ldc) && (p.c2_lp || x3_aligned(p.C2, p.ldc)), "gemm_x3[%d]: split-f32 result must be 128-byte aligned with ldc %% 32 == 0 (ldc=%d)", i, p.ldc);
+            RGQA_REQUIRE((((uintptr_t)p.Cb) & 15) == 0 && (!p.c2_lp || (((uintptr_t)p.C2) & 15) == 0), "gemm_x3[%d]: the bf16 images must be 16-byte aligned", i);
+        }
         if (epi_needs_aux(epi)) RGQA_REQUIRE(p.aux != nullptr && x3_aligned(p.aux, p.ldaux), "gemm_x3[%d]: epilogue %d needs a split-f32 aux operand (ldaux=%d)", i, epi, p.ldaux);
     }
     long tiles = 0;

@@ -116,7 +116,8 @@ int k_visn_combine_bwd(const T* dout, int lddo, const T* zf, int ldz, const floa
 int k_bce_fwd_bwd(const float* logits, int ldl, const float* target, int ldt, float* loss_out, float* dlogits, int lddl, int B, int NA, int NAp, float grad_scale, hipStream_t s);
 
 // ---- optim.hip
-int k_sumsq(const float* g, size_t n, float* partial /* >= 1025 floats, zeroed once ([1024] = ticket word) */, float* out_sumsq, int accumulate_into_out, hipStream_t s);
+int k_sumsq(const float* g, size_t n, float* partial /* >= 1025 floats, any content ([1024] = ticket word, zeroed on the stream by the call) */, float* out_sumsq, int accumulate_into_out, hipStream_t s);
+int k_sumsq_owned(const float* g, size_t n, float* partial /* >= 1025 floats touched by nothing else, [1024] zeroed once by the owner */, float* out_sumsq, int accumulate_into_out, hipStream_t s);
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
     void* p_lp;            // optional low-precision operand copy at the same element offsets (null in f32 mode)

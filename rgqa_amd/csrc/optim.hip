@@ -4,9 +4,11 @@
 #include "kernels.h"
 
 // sum(g^2) in ONE launch: every block parks its partial, the block whose ticket is last folds all partials in index order (fixed order:
-// bit-reproducible) and rewinds the ticket for the next launch.  partial: >= 1024 floats + 1 ticket word (partial[1024], as an int), zeroed
-// once by the owner (k_sumsq zeroes it on first use of a buffer through the `fresh` flag).  (Round 2 ran this as two launches per gradient
-// segment: 42 launches per step, the second one 5 us of pure launch latency.)
+// bit-reproducible) and rewinds the ticket for the next launch.  partial: >= 1024 floats + 1 ticket word (partial[1024], as an int).
+// Two entry points: k_sumsq zeroes the ticket word itself on the stream (any scratch will do, shared or recycled: the BUTD engine, the public
+// rgqa_grad_sumsq); k_sumsq_owned is for a scratch that only these launches ever touch and that its owner zeroed once (the engine's
+// per-segment slots: 21 launches per step without a memset node each).  (Round 2 ran this as two launches per gradient segment: 42 launches
+// per step, the second one 5 us of pure launch latency.)
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial, float* __restrict__ out, int accumulate) {
     __shared__ float red[4];
     __shared__ int last;
@@ -46,6 +48,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 }
 
 int k_sumsq(const float* g, size_t n, float* partial, float* out_sumsq, int accumulate_into_out, hipStream_t s) {
+    RGQA_HIP(hipMemsetAsync(partial + 1024, 0, sizeof(int), s));
+    return k_sumsq_owned(g, n, partial, out_sumsq, accumulate_into_out, s);
+}
+int k_sumsq_owned(const float* g, size_t n, float* partial, float* out_sumsq, int accumulate_into_out, hipStream_t s) {
     RGQA_REQUIRE(((uintptr_t)g % 16) == 0, "sumsq: 16-byte alignment required");
     int nblk = (int)((n / 4 + 255) / 256);
     if (nblk > 1024) nblk = 1024;

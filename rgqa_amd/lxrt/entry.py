@@ -15,6 +15,10 @@ from . import optimization as _optimization
 # parameters are the views of one engine's arena, torch's own implementation for everything else.  RGQA_PATCH_CLIP=0 leaves torch untouched.
 if os.environ.get("RGQA_PATCH_CLIP", "1") != "0" and torch.nn.utils.clip_grad_norm_ is not _optimization.clip_grad_norm_:
     torch.nn.utils.clip_grad_norm_ = _optimization.clip_grad_norm_
+    import logging as _logging
+    _logging.getLogger(__name__).info("rgqa_amd: torch.nn.utils.clip_grad_norm_ is routed through rgqa_amd.lxrt.optimization.clip_grad_norm_ for this process "
+                                      "(engine arenas take a fused path, everything else torch's own implementation; RGQA_PATCH_CLIP=0 disables; names bound "
+                                      "with `from torch.nn.utils import clip_grad_norm_` BEFORE this import keep torch's function)")
 
 
 class InputFeatures(object):

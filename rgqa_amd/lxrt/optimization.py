@@ -36,16 +36,25 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
         cached = _CLIP_CACHE.get(sig[0])
         if cached is not None and cached[0] == sig and cached[1]() is not None:
             eng = cached[1]()
-            # cheap revalidation: the views still point into the arenas (a re-materialised module re-packs), gradients are present
-            p0 = params[0]
-            if eng.params is None or p0.grad is None or engine_view_offset(eng, p0) is None:
+            # revalidation on EVERY call: each gradient is still the arena view it was when the engine was recognised (a foreign
+            # tensor bound to .grad - a clone, an unscaled copy, None for a frozen parameter - sends the call to torch's implementation),
+            # and the arenas themselves have not moved (a re-materialised module re-packs).  One data_ptr() per parameter.
+            if eng.params is None or eng.grads is None or eng.grads.data_ptr() != cached[3]:
                 eng = None
+            else:
+                for p, want in zip(params, cached[2]):
+                    g = p.grad
+                    if (g is None) != (want is None) or (g is not None and g.data_ptr() != want):
+                        eng = None
+                        break
+            if eng is None:
+                _CLIP_CACHE.clear()
         if eng is None:
             eng = _arena_engine_of(params)
             if eng is not None:
                 import weakref
                 _CLIP_CACHE.clear()
-                _CLIP_CACHE[sig[0]] = (sig, weakref.ref(eng))
+                _CLIP_CACHE[sig[0]] = (sig, weakref.ref(eng), [None if p.grad is None else p.grad.data_ptr() for p in params], eng.grads.data_ptr())
     if eng is None:
         return _torch_clip_grad_norm_(params, max_norm, norm_type=norm_type, error_if_nonfinite=error_if_nonfinite, foreach=foreach)
     binding = getattr(eng, "_binding_ref", None)

@@ -101,3 +101,63 @@ def synth_batch(B, T, O=36, F=2048, NA=1842, vocab=30522, seed=1234, uq_frac=0.2
             target[b, cls[b]] = 1.0
     return dict(feats=feats, boxes=boxes, input_ids=ids, input_mask=mask, segment_ids=seg,
                 target=target, lengths=lens)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Fixture configurations and batches shared by the golden generator (oracle/gen_golden.py), the tests and the tools: they
+# describe DATA (shapes, seeds, which rows are edge cases), so they live with the filler, not with the script that imports the
+# reference.
+def sample_idx(name, numel, k=64):
+    k = min(k, numel)
+    return (hash_u32("gradsample." + name, k) % np.uint64(numel)).astype(np.int64)
+
+
+SMALL = dict(vocab_size=64, hidden=64, heads=4, inter=128, max_pos=32, type_vocab=2, l_layers=2, x_layers=2,
+             r_layers=2, feat_dim=32, pos_dim=4, num_answers=11)
+FULL = dict(vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9,
+            x_layers=5, r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842)
+
+
+def small_batch(T):
+    b = synth_batch(3, T, O=6, F=32, NA=11, vocab=64, seed=77 + T, uq_frac=0.34, min_len=2)
+    b["input_ids"][1, 1:] = 0          # a 1-token question: only [CLS] survives as a real token
+    b["input_ids"][1, 0] = 2
+    b["input_mask"] = (b["input_ids"] != 0).astype(np.int64)
+    return b
+
+
+def full_batch(T):
+    b = synth_batch(4, T, seed=4242 + T)
+    ids = b["input_ids"]
+    ids[0, :] = 0
+    ids[0, 0], ids[0, 1] = 101, 102   # shortest question: [CLS][SEP]
+    full = 1000 + (hash_u32("fullrow%d" % T, T) % np.uint64(29000)).astype(np.int64)
+    ids[3, :] = full
+    ids[3, 0], ids[3, T - 1] = 101, 102  # max-length question, no padding
+    b["input_mask"] = (ids != 0).astype(np.int64)
+    return b
+
+
+BUTD_WORDS = "what color is the dog 's a an on in to left right man woman cat table red blue who holding bottle".split()
+BUTD_SENTS = ["What color is the man's dog?", "Is the cat on the table, to the left?", "who is holding the red bottle", "zebra", ""]
+
+
+U_SMALL = dict(vocab_size=64, hidden=64, heads=4, inter=128, max_pos=32, type_vocab=2, l_layers=3, x_layers=0, r_layers=0,
+               feat_dim=32, pos_dim=7, num_answers=11)
+U_FULL = dict(vocab_size=28996, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=12, x_layers=0, r_layers=0,
+              feat_dim=2048, pos_dim=7, num_answers=1842)
+
+
+def uniter_batch(cfgd, T, B, O, seed):
+    """Deterministic UNITER batch: a synth LXMERT batch + 7-d position features (normalised box, w, h, area: entry of
+    GQATorchDataset._uniterBoxes, tasks/gqa_data.py:240-250)."""
+    b = synth_batch(B, T, O=O, F=cfgd["feat_dim"], NA=cfgd["num_answers"], vocab=cfgd["vocab_size"], seed=seed, min_len=2)
+    if B >= 3:
+        b["input_ids"][1, 1:] = 0          # a 1-token question
+        b["input_ids"][1, 0] = 2 if cfgd["vocab_size"] < 1000 else 101
+        b["input_ids"][2, :] = np.maximum(b["input_ids"][2, :], 3)        # a full-length question (no padding)
+        b["input_mask"] = (b["input_ids"] != 0).astype(np.int64)
+    bx = b["boxes"]
+    w, h = bx[:, :, 2] - bx[:, :, 0], bx[:, :, 3] - bx[:, :, 1]
+    b["pos7"] = np.stack([bx[:, :, 0], bx[:, :, 1], bx[:, :, 2], bx[:, :, 3], w, h, w * h], 2).astype(np.float32)
+    return b

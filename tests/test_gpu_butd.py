@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-from oracle.gen_golden import BUTD_WORDS, BUTD_SENTS, sample_idx     # noqa: E402
+from rgqa_amd.synth import BUTD_WORDS, BUTD_SENTS, sample_idx     # noqa: E402
 from rgqa_amd import synth                                           # noqa: E402
 
 

@@ -16,7 +16,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle.gen_golden import SMALL, FULL, small_batch, full_batch, sample_idx   # noqa: E402
+from rgqa_amd.synth import SMALL, FULL, small_batch, full_batch, sample_idx   # noqa: E402
 from rgqa_amd import synth                                                      # noqa: E402
 
 
@@ -373,7 +373,7 @@ def test_dropout_train_mode_is_deterministic_and_consistent():
 def test_paired_attention_launch_is_bit_identical(precision, packed, monkeypatch):
     """Round 3: the two attention problems of a stage (language | vision self-attention, the two cross-attention directions) go out as ONE
     launch when their tile shapes are the GQA ones (T in 17..32, 33..48 regions).  Same per-block code on the same operands: logits and
-    every gradient (outside the atomically accumulated embedding tables) are bit-identical to the two-launch path (RGQA_ATTN_PAIR=0),
+    every gradient (outside the atomically accumulated embedding tables) are bit-identical to the two-launch path (rgqa_debug_set key 16 = 0),
     train mode, padded and packed rows."""
     B, T, O = 5, 20, 36
     cfgd = dict(MED, l_layers=2, x_layers=2, r_layers=1)
@@ -381,8 +381,10 @@ def test_paired_attention_launch_is_bit_identical(precision, packed, monkeypatch
     b = dev(raw)
     lens = [int(v) for v in raw["input_mask"].sum(1)] if packed else None
     outs = {}
+    from rgqa_amd import _lib
+    L = _lib.load()
     for pair in ("0", "1"):
-        monkeypatch.setenv("RGQA_ATTN_PAIR", pair)
+        assert L.rgqa_debug_set(16, int(pair)) == 0
         e = make_engine(cfgd, precision, dropout=0.1)
         e.ensure_shape(B, T, O)
         e.sync_weights()
@@ -391,6 +393,7 @@ def test_paired_attention_launch_is_bit_identical(precision, packed, monkeypatch
         e.loss_backward(b["target"])
         first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
         outs[pair] = (lg, e.grads[first:].clone())
+    L.rgqa_debug_set(16, 1)
     assert torch.equal(outs["0"][0], outs["1"][0])
     assert torch.equal(outs["0"][1], outs["1"][1])
     assert float(outs["1"][1].abs().max()) > 0

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import lxmert_ref as R
-from oracle.gen_golden import SMALL, FULL, small_batch, full_batch, sample_idx
+from rgqa_amd.synth import SMALL, FULL, small_batch, full_batch, sample_idx
 from rgqa_amd import synth
 
 
@@ -184,7 +184,7 @@ def butd_fill(cfgb):
 def test_g7_butd(golden_dir):
     """BUTD oracle (oracle/butd_ref.py) vs the reference's GQABUTD run in the build container."""
     from oracle import butd_ref as BR
-    from oracle.gen_golden import BUTD_WORDS, BUTD_SENTS
+    from rgqa_amd.synth import BUTD_WORDS, BUTD_SENTS
     g = np.load(os.path.join(golden_dir, "g7_butd.npz"))
     c = BR.ButdConfig(ntoken=len(BUTD_WORDS), num_answers=23)
     P = {k: torch.from_numpy(np.asarray(v)).requires_grad_(True) for k, v in butd_fill(c).items()}

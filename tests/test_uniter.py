@@ -10,7 +10,7 @@ import torch
 
 from oracle import lxmert_ref as R
 from oracle import uniter_ref as U
-from oracle.gen_golden import U_SMALL, U_FULL, uniter_batch, sample_idx
+from rgqa_amd.synth import U_SMALL, U_FULL, uniter_batch, sample_idx
 from rgqa_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -9,11 +9,20 @@ STEPS=7
 run() { name=$1; shift; ( "$@" ) > $OUT/${TAG}_$name.log 2>&1; echo "$name rc=$?"; }
 # 0. fabric traffic of the NT launches (separate FETCH_SIZE / WRITE_SIZE passes) FIRST: bench.py reports `roofline.traffic` from profiles/<tag>_pmc_gemm_nt.json
 #    only while its kernel-source digest matches the build it runs on
+rm -f $OUT/${TAG}_pmc_gemm_nt.json
+pmc_ok=1
 for c in FETCH_SIZE WRITE_SIZE; do
-  RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_p_$c -- $BENCH > $OUT/${TAG}_pmc_$c.log 2>&1; echo "pmc $c rc=$?"
+  rm -rf $OUT/${TAG}_p_$c
+  RGQA_WGRAD_SERIAL=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_p_$c -- $BENCH > $OUT/${TAG}_pmc_$c.log 2>&1; rc=$?; echo "pmc $c rc=$rc"
+  [ $rc -eq 0 ] || pmc_ok=0
 done
-python3 tools/pmc_summary.py $(ls $OUT/${TAG}_p_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls $OUT/${TAG}_p_WRITE_SIZE/*/*counter_collection.csv | head -1) $OUT/${TAG}_pmc_gemm_nt.json
-cp $OUT/${TAG}_pmc_gemm_nt.json profiles/${TAG}_pmc_gemm_nt.json
+# the committed profile is replaced only by a complete, fresh one: both passes and the summary must have succeeded
+if [ $pmc_ok -eq 1 ] && python3 tools/pmc_summary.py "$(ls $OUT/${TAG}_p_FETCH_SIZE/*/*counter_collection.csv | head -1)" "$(ls $OUT/${TAG}_p_WRITE_SIZE/*/*counter_collection.csv | head -1)" $OUT/${TAG}_pmc_gemm_nt.json \
+   && [ -s $OUT/${TAG}_pmc_gemm_nt.json ]; then
+  cp $OUT/${TAG}_pmc_gemm_nt.json profiles/${TAG}_pmc_gemm_nt.json
+else
+  echo "pmc traffic: a pass failed - profiles/${TAG}_pmc_gemm_nt.json left as it was"
+fi
 # 1. the headline line (live HIP-event roofline, tolerance_compliant / forward-only / drop-in legs, CPU baseline)
 python3 bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err; echo "bench rc=$?"
 # 2. kernel trace + stats: shipped two-stream configuration, and wgrad serialised (what bench.py's live timing sees); the bf16x3 mode

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import lxmert_ref as R            # noqa: E402
-from oracle.gen_golden import FULL, full_batch  # noqa: E402
+from rgqa_amd.synth import FULL, full_batch  # noqa: E402
 from rgqa_amd import synth                    # noqa: E402
 
 r = lambda t: t.bfloat16().float()
