@@ -398,6 +398,7 @@ def main():
                     help="BASELINE config 4: RoI-mixup finetune (gqa_mixup_vis.py:134-181): every loader batch is doubled on the device "
                          "(mixup_v1, Beta(1,5)); the model sees 2x rows per QA pair; value still counts loader QA pairs")
     ap.add_argument("--lean", action="store_true", help="only the warm-up and timed steps (no extra legs, no live kernel timing, no CPU baseline): what runs under rocprofv3")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline + live kernel timing only (no bf16x3 / forward-only / drop-in legs): quick A/B runs")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)          # CPU rehearsal of the N-rank launch path
     ap.add_argument("--launch-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--launch-check-fail-mode", default="", help=argparse.SUPPRESS)        # fail only under this RGQA_DP_MODE
@@ -636,7 +637,7 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    extra_legs = rank == 0 and world == 1 and not (args.lean or args.butd or args.uniter or args.mixup or args.padded) and args.precision == "bf16"
+    extra_legs = rank == 0 and world == 1 and not (args.no_extra_legs or args.lean or args.butd or args.uniter or args.mixup or args.padded) and args.precision == "bf16"
     tol = fwd_only = dropin = None
     engines = {"bf16": e}
     if extra_legs:

@@ -27,6 +27,11 @@ extern "C" {
                                    products on the bf16 matrix pipe as hi*hi + hi*lo + lo*hi with f32 accumulation: the fast path whose
                                    logits stay within 1e-3 of the reference CPU path (lxrt/modeling.py:309-346 is f32 end to end); arch 0 (LXMERT)
                                    and 2 (UNITER), head size 64, hidden / inter / feat_dim multiples of 32 */
+#define RGQA_PRECISION_BF16X3_FWD 3 /* the forward pass of RGQA_PRECISION_BF16X3 (the SAME kernels: logits within 1e-3 of the reference CPU path)
+                                   with the backward pass of RGQA_PRECISION_BF16 (BASELINE config 3 prescribes a bf16 backward): the forward
+                                   kernels leave a bf16 image of every tensor the backward reads beside the split-f32 one.  Gradients carry bf16
+                                   rounding (held to the bf16 mode's loss / gradient-norm / sampled-gradient gates), weights, moments and the
+                                   optimizer stay f32.  Operand copies: params_lp split f32 (4 B / element), params_lp_t bf16 (2 B / element). */
 
 typedef struct rgqa_config {
     int32_t vocab_size, hidden, heads, inter, max_pos, type_vocab; /* BertConfig, lxrt/modeling.py:172-258 */

@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RGQA_LIB") or os.path.join(_HERE, "lib", "librgqa_hip.so")      # RGQA_LIB: development A/B of two builds
 
-PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X3_FWD = 0, 1, 2, 3
 
 
 class Config(C.Structure):

@@ -151,6 +151,7 @@ __device__ __forceinline__ void attn_fwd_x3_body(const AttnArgs& a, const int bl
     }
     // ctx^T[d][q] = sum_key V^T[d][key] P^T[key][q]
     sf32* O = reinterpret_cast<sf32*>(a.out) + q0 * a.ldo + h * 64;
+    bf16_t* Ob = a.out_b ? reinterpret_cast<bf16_t*>(a.out_b) + q0 * a.ldo + h * 64 : nullptr;      // bf16x3_fwd precision: the image the bf16 backward reads
     constexpr int NKS = (NKT + 1) / 2;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     pair8 pb[NKS][NQT];
@@ -173,6 +174,7 @@ __device__ __forceinline__ void attn_fwd_x3_body(const AttnArgs& a, const int bl
             if (q < Lq) {
                 float v[4] = {o[0], o[1], o[2], o[3]};
                 store4(O + (size_t)q * a.ldo + dt * 16 + 4 * g, v);
+                if (Ob) store4(Ob + (size_t)q * a.ldo + dt * 16 + 4 * g, v);
             }
         }
     }

@@ -20,12 +20,14 @@ extern int g_rgqa_wgrad_serial;
 extern int g_rgqa_tn_mtw;
 extern int g_rgqa_cls_tail;
 extern int g_rgqa_attn_pair;
+extern int g_rgqa_skip_wgrad;
 // debug / test switches (include/rgqa.h)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
     if (key == 1) { g_rgqa_force_mt = value; return RGQA_OK; }
     if (key == 2) { g_rgqa_wgrad_serial = value; return RGQA_OK; }
     if (key == 4) { g_rgqa_tn_mtw = value; return RGQA_OK; }
+    if (key == 5) { g_rgqa_skip_wgrad = value; return RGQA_OK; }
     if (key == 8) { g_rgqa_cls_tail = value; return RGQA_OK; }
     if (key == 16) { g_rgqa_attn_pair = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
@@ -57,8 +59,9 @@ int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out) {
     RGQA_REQUIRE(cfg->pos_dim >= 1 && cfg->pos_dim <= (cfg->arch == 2 ? 8 : 4), "engine_create: pos_dim %d unsupported", cfg->pos_dim);
     RGQA_REQUIRE(cfg->vocab_size > 0 && cfg->max_pos > 0 && cfg->type_vocab > 0 && cfg->num_answers > 0, "engine_create: empty table");
     RGQA_REQUIRE(cfg->l_layers >= 0 && cfg->x_layers >= 0 && cfg->r_layers >= 0, "engine_create: negative layer count");
-    RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16 || cfg->precision == RGQA_PRECISION_BF16X3, "engine_create: unknown precision %d", cfg->precision);
-    if (cfg->precision == RGQA_PRECISION_BF16X3)
+    RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16 || cfg->precision == RGQA_PRECISION_BF16X3 || cfg->precision == RGQA_PRECISION_BF16X3_FWD,
+                 "engine_create: unknown precision %d", cfg->precision);
+    if (cfg->precision == RGQA_PRECISION_BF16X3 || cfg->precision == RGQA_PRECISION_BF16X3_FWD)
         RGQA_REQUIRE(cfg->hidden % 64 == 0 && cfg->hidden / cfg->heads == 64 && cfg->inter % 32 == 0 && cfg->feat_dim % 32 == 0,
                      "engine_create: bf16x3 precision needs head size 64 and hidden / intermediate / feature sizes that are multiples of 32");
     RGQA_REQUIRE(cfg->hidden_dropout >= 0.f && cfg->hidden_dropout < 1.f && cfg->attn_dropout >= 0.f && cfg->attn_dropout < 1.f, "engine_create: dropout out of range");

@@ -152,22 +152,72 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 #define SUMSQ_WS_STRIDE 1088     // k_sumsq_owned: 1024 block partials + the ticket word, per gradient segment
 #define LNPART_BLOCKS 1536     // per layer: <= 3 LayerNorm-backward launches of <= 512 blocks
 int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
+int g_rgqa_skip_wgrad = 0;     // rgqa_debug_set(5, v): MEASUREMENT ONLY - the deferred weight-gradient launches are not issued (gradients are then wrong)
 int g_rgqa_attn_pair = 1;      // rgqa_debug_set(16, v): 0 = the two attention problems of a stage as two launches (the bit-identity test's other arm)
 
-template <typename T>
+// RGQA_ATTN_REF (test switch: the plain attention kernels instead of the MFMA ones), read once
+static bool attn_ref_forced() { static const bool v = getenv("RGQA_ATTN_REF") != nullptr; return v; }
+// attention kernels by element type (forward: the engine's activation type; backward: its gradient type)
+template <typename U> static int attn_fwd_any(const AttnArgs& a, hipStream_t s) {
+    if constexpr (std::is_same<U, sf32>::value) { if (a.dh == 64 && !attn_ref_forced()) return k_attn_fwd_x3(a, s); }
+    else if constexpr (std::is_same<U, bf16_t>::value) { if (a.dh == 64 && !attn_ref_forced()) return k_attn_fwd_mfma(a, s); }
+    return k_attn_fwd_ref<U>(a, s);
+}
+template <typename U> static int attn_bwd_any(const AttnArgs& a, hipStream_t s) {
+    if constexpr (std::is_same<U, sf32>::value) { if (a.dh == 64 && !attn_ref_forced()) return k_attn_bwd_x3(a, s); }
+    else if constexpr (std::is_same<U, bf16_t>::value) { if (a.dh == 64 && !attn_ref_forced()) return k_attn_bwd_mfma(a, s); }
+    return k_attn_bwd_ref<U>(a, s);
+}
+template <typename U> static int attn_fwd_pair_any(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
+    if constexpr (std::is_same<U, sf32>::value) return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_fwd_x3_pair(a0, a1, s) : 0;
+    else if constexpr (std::is_same<U, bf16_t>::value) return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_fwd_mfma_pair(a0, a1, s) : 0;
+    else return 0;
+}
+template <typename U> static int attn_bwd_pair_any(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
+    if constexpr (std::is_same<U, sf32>::value) return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_bwd_x3_pair(a0, a1, s) : 0;
+    else if constexpr (std::is_same<U, bf16_t>::value) return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_bwd_mfma_pair(a0, a1, s) : 0;
+    else return 0;
+}
+
+// T = type of the activations the FORWARD pass computes in (and of the direct weight operand copy).  MIXED (T = sf32 only; rgqa.h
+// RGQA_PRECISION_BF16X3_FWD): the backward pass runs on the bf16 kernels - TB = bf16_t is then the type of every gradient buffer, of the
+// transposed weight copy, and of a bf16 IMAGE of every forward tensor the backward reads.  The image lives in a mirror of the workspace at
+// half its size: the element at byte offset o of the split-f32 workspace has its bf16 image at byte offset o / 2 of the mirror (img()), so
+// no second set of pointers is planned; the forward kernels write both (the image is the hi part of every element: one more store, no
+// arithmetic; GEMM epilogues, LayerNorm, attention context), small one-off tensors get theirs from k_sf_image.
+template <typename T, bool MIXED = false>
 class Engine : public EngineBase {
 public:
+    static_assert(!MIXED || std::is_same<T, sf32>::value, "the mixed precision is a split-f32 forward with a bf16 backward");
+    using TB = typename std::conditional<MIXED, bf16_t, T>::type;
     static constexpr bool LP = !std::is_same<T, float>::value;       // operand copies of the weights (direct + transposed) exist
     static constexpr bool X3 = std::is_same<T, sf32>::value;         // split-f32 activations and operand copies (bf16x3 precision)
-    static int nt_gemm(GemmGroup& g, int out_f32, int trans_b, hipStream_t s) {
-        if constexpr (X3) return launch_gemm_nt_x3(g, out_f32, s);
-        else if constexpr (LP) return launch_gemm_nt_bf16(g, out_f32, s);
+    template <typename U> static int nt_gemm_t(GemmGroup& g, int out_f32, int trans_b, hipStream_t s) {
+        if constexpr (std::is_same<U, sf32>::value) return launch_gemm_nt_x3(g, out_f32, s);
+        else if constexpr (std::is_same<U, bf16_t>::value) return launch_gemm_nt_bf16(g, out_f32, s);
         else return launch_gemm_f32(g, 0, trans_b, s);
     }
+    static int nt_gemm(GemmGroup& g, int out_f32, int trans_b, hipStream_t s) { return nt_gemm_t<T>(g, out_f32, trans_b, s); }
+    static int nt_gemm_b(GemmGroup& g, int out_f32, int trans_b, hipStream_t s) { return nt_gemm_t<TB>(g, out_f32, trans_b, s); }      // dgrad
     static int tn_gemm(GemmGroup& g, hipStream_t s) {
-        if constexpr (X3) return launch_gemm_tn_x3(g, s);
-        else if constexpr (LP) return launch_gemm_tn_bf16(g, 1, s);
+        if constexpr (std::is_same<TB, sf32>::value) return launch_gemm_tn_x3(g, s);
+        else if constexpr (std::is_same<TB, bf16_t>::value) return launch_gemm_tn_bf16(g, 1, s);
         else return launch_gemm_f32(g, 1, 1, s);
+    }
+    // bf16 image of a forward tensor (MIXED), for the kernels that write it (null otherwise) ...
+    bf16_t* img(const void* p) const {
+        if constexpr (MIXED) return (p == nullptr || ws == nullptr) ? nullptr : reinterpret_cast<bf16_t*>(ws + mirror_off + (((const char*)p - ws) >> 1));
+        else return nullptr;
+    }
+    // ... and what the backward pass reads in place of forward tensor p
+    const TB* sv(const void* p) const {
+        if constexpr (MIXED) return img(p);
+        else return reinterpret_cast<const TB*>(p);
+    }
+    size_t mirror_off = 0;
+    int image_of(const void* p, int ld, int rows, int cols, hipStream_t s) {        // one-off tensors: the image by a copy kernel
+        if constexpr (MIXED) return k_sf_image(reinterpret_cast<const sf32*>(p), ld, img(p), ld, rows, cols, s);
+        else return RGQA_OK;
     }
     // f32 -> the activation type of the LDS-DMA GEMM operands (the RoI features)
     static int cast_lp(const float* src, T* dst, size_t n, hipStream_t s) {
@@ -177,7 +227,7 @@ public:
     ModelParams mp;
     std::vector<Stage> stages;
     // bound memory
-    float* P = nullptr; float* G = nullptr; T* Pb = nullptr; T* PbT = nullptr;
+    float* P = nullptr; float* G = nullptr; T* Pb = nullptr; TB* PbT = nullptr;
     char* ws = nullptr; size_t ws_bytes_ = 0, ws_used = 0;
     int B = 0, Tn = 0, O = 0, Rl = 0, Rv = 0, R = 0, NAp = 0;
     bool dry = false;
@@ -189,14 +239,14 @@ public:
     T *emb_out = nullptr, *emb_z = nullptr; float *emb_mean = nullptr, *emb_rstd = nullptr;
     T *zf = nullptr, *visn_out = nullptr, *feats_lp = nullptr; float* visn_stats = nullptr;
     T *pooled = nullptr, *h1pre = nullptr, *h1 = nullptr, *h2 = nullptr; float *hd_mean = nullptr, *hd_rstd = nullptr;
-    float* logits = nullptr; T* dlogits = nullptr; float* loss_dev = nullptr;
-    T *gA = nullptr, *gB = nullptr, *gctx = nullptr;
-    T *gz_s[NPAR][3] = {}, *gzd_s[NPAR][3] = {}, *gqkv_s[NPAR][3] = {}, *gh_s[NPAR][3] = {};   // [ring position of the launch period][stage slot]
+    float* logits = nullptr; TB* dlogits = nullptr; float* loss_dev = nullptr;
+    TB *gA = nullptr, *gB = nullptr, *gctx = nullptr;
+    TB *gz_s[NPAR][3] = {}, *gzd_s[NPAR][3] = {}, *gqkv_s[NPAR][3] = {}, *gh_s[NPAR][3] = {};   // [ring position of the launch period][stage slot]
     hipStream_t s_w = nullptr;                 // side stream: the deferred weight-gradient GEMMs of a layer run beside the next layer's chain
     hipEvent_t ev_chain[NPAR] = {}, ev_wdone[NPAR] = {};
     bool wdone_valid[NPAR] = {};
-    T* gemb = nullptr;
-    T *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
+    TB* gemb = nullptr;
+    TB *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
     static constexpr bool ln_merge = true;   // one LayerNorm launch over [language | vision] rows
     float* lnpart_s[NPAR] = {}; FinDefer fin; int fin_accumulate = 0;   // LayerNorm-backward column sums of the open layer (finalised with its wgrad launch)
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
@@ -354,7 +404,7 @@ public:
         ws_used = 0;
         stages.clear();
         maskf = take<float>(RlC);
-        lens_dev = take<int>(B); cu_dev = take<int>(B + 1); row_src_dev = take<int>(RlC); cls_rows = take<T>((size_t)B * H); tail_x = take<T>((size_t)B * H); tail_dx = take<T>((size_t)B * H);
+        lens_dev = take<int>(B); cu_dev = take<int>(B + 1); row_src_dev = take<int>(RlC); cls_rows = take<T>((size_t)B * H); tail_x = take<T>((size_t)B * H); tail_dx = take<TB>((size_t)B * H);
         emb_out = take<T>((size_t)RC * H); emb_z = take<T>((size_t)RlC * H); emb_mean = take<float>(RlC); emb_rstd = take<float>(RlC);
         zf = take<T>((size_t)Rv * H); visn_stats = take<float>((size_t)Rv * 4);
         feats_lp = LP ? take<T>((size_t)Rv * cfg.feat_dim) : nullptr;   // bf16 copy of the RoI features: read by visn_fc forward AND its wgrad
@@ -423,18 +473,18 @@ public:
         visn_final = cur[1];
         pooled = take<T>((size_t)B * H); h1pre = take<T>((size_t)B * 2 * H); h1 = take<T>((size_t)B * 2 * H); h2 = take<T>((size_t)B * 2 * H);
         hd_mean = take<float>(B); hd_rstd = take<float>(B);
-        logits = take<float>((size_t)B * NAp); dlogits = take<T>((size_t)B * NAp); loss_dev = take<float>(64);
-        gA = take<T>((size_t)RC * H); gB = take<T>((size_t)RC * H); gctx = take<T>((size_t)RC * H); gemb = take<T>((size_t)RC * H);
+        logits = take<float>((size_t)B * NAp); dlogits = take<TB>((size_t)B * NAp); loss_dev = take<float>(64);
+        gA = take<TB>((size_t)RC * H); gB = take<TB>((size_t)RC * H); gctx = take<TB>((size_t)RC * H); gemb = take<TB>((size_t)RC * H);
         // one set of per-stage gradient buffers per stage slot of a layer: the weight-gradient GEMMs of a whole layer are
         // deferred into ONE grouped launch (432-504 tiles: fills the 256 CUs), so their operands must outlive the stage
         // ... and two such sets (layer parity): layer i's wgrad launch reads its set on the side stream while layer i-1
         // already overwrites the other one on the main stream
         for (int par = 0; par < NPAR; ++par)
             for (int k = 0; k < 3; ++k) {
-                gz_s[par][k] = take<T>((size_t)RC * H); gzd_s[par][k] = take<T>((size_t)RC * H);
-                gqkv_s[par][k] = take<T>((size_t)RC * 3 * H); gh_s[par][k] = take<T>((size_t)RC * I);
+                gz_s[par][k] = take<TB>((size_t)RC * H); gzd_s[par][k] = take<TB>((size_t)RC * H);
+                gqkv_s[par][k] = take<TB>((size_t)RC * 3 * H); gh_s[par][k] = take<TB>((size_t)RC * I);
             }
-        gp1 = take<T>((size_t)B * 2 * H); gp2 = take<T>((size_t)B * 2 * H); gp3 = take<T>((size_t)B * 2 * H);
+        gp1 = take<TB>((size_t)B * 2 * H); gp2 = take<TB>((size_t)B * 2 * H); gp3 = take<TB>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part = take<float>((size_t)512 * 10 * pw);
         for (int par = 0; par < NPAR; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
@@ -443,19 +493,23 @@ public:
             const size_t ni = (size_t)B * Oi, nt = (size_t)B * Tt;
             tlens_dev = take<int>(B); tcu_dev = take<int>(B + 1); trow_src_dev = take<int>(nt); text_dst_dev = take<int>(nt); img_dst_dev = take<int>(ni);
             u_zf = take<T>(ni * H); u_zp = take<T>(ni * H); u_a1 = take<T>(ni * H); u_a2 = take<T>(ni * H); u_x3 = take<T>(ni * H);
-            u_g = take<T>(ni * H); u_dx3 = take<T>(ni * H); u_dz = take<T>(ni * H); u_gt = take<T>(nt * H); u_de = take<T>(nt * H);
+            u_g = take<TB>(ni * H); u_dx3 = take<TB>(ni * H); u_dz = take<TB>(ni * H); u_gt = take<TB>(nt * H); u_de = take<TB>(nt * H);
             u_st = take<float>(6 * ni);
             feats_lp = LP ? take<T>(ni * cfg.feat_dim) : nullptr;
         }
         tdesc = take<TransDesc>(n_tdesc + 1);
+        if (MIXED) {          // the bf16 images: a half-size mirror of everything planned above (img())
+            mirror_off = rup(ws_used, 256);
+            ws_used = mirror_off + rup(mirror_off / 2, 256);
+        }
     }
-    int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr; T* tail_x = nullptr; T* tail_dx = nullptr; T* pool_in = nullptr;
+    int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr; T* tail_x = nullptr; TB* tail_dx = nullptr; T* pool_in = nullptr;
     // UNITER (arch 2): ONE sequence per sample, [text tokens ; image regions], laid out as the engine's language modality with
     // Tn = Tt + Oi rows per sample (packed: real text tokens + Oi) and no vision modality; only the embedding front-end differs.
     bool joint = false; int Tt = 0, Oi = 0, jstate = 0, n_text = 0;      // jstate: index arrays built for 1 = padded / 2 = packed rows
     std::vector<int> tlens_host;
     int *tlens_dev = nullptr, *tcu_dev = nullptr, *trow_src_dev = nullptr, *text_dst_dev = nullptr, *img_dst_dev = nullptr;
-    T *u_zf = nullptr, *u_zp = nullptr, *u_a1 = nullptr, *u_a2 = nullptr, *u_x3 = nullptr, *u_g = nullptr, *u_dx3 = nullptr, *u_dz = nullptr, *u_gt = nullptr, *u_de = nullptr;
+    T *u_zf = nullptr, *u_zp = nullptr, *u_a1 = nullptr, *u_a2 = nullptr, *u_x3 = nullptr; TB *u_g = nullptr, *u_dx3 = nullptr, *u_dz = nullptr, *u_gt = nullptr, *u_de = nullptr;
     float *u_st = nullptr;     // [6][B*Oi]: mean / rstd of img_layer_norm, pos_layer_norm, LayerNorm
     bool varlen = false, lens_dirty = false, fwd_varlen = false;   // fwd_varlen: layout of the recorded forward pass
     int n_lang = 0; std::vector<int> lens_host;
@@ -473,11 +527,11 @@ public:
         RGQA_REQUIRE(B_ > 0 && T_ > 0 && O_ > 0 && T_ <= 64 && O_ <= 64, "bind: B=%d T=%d O=%d unsupported (T, O <= 64)", B_, T_, O_);
         RGQA_REQUIRE(T_ <= cfg.max_pos, "bind: T=%d exceeds max_position_embeddings=%d", T_, cfg.max_pos);
         if (LP) RGQA_REQUIRE(plp != nullptr && plpt != nullptr, "bind: bf16 / bf16x3 precision needs the operand-copy arenas");
-        if (X3) RGQA_REQUIRE(((uintptr_t)plp % 128) == 0 && ((uintptr_t)plpt % 128) == 0, "bind: the split-f32 arenas must be 128-byte aligned");
+        if (X3) RGQA_REQUIRE(((uintptr_t)plp % 128) == 0 && ((uintptr_t)plpt % 128) == 0, "bind: the split-f32 arenas must be 128-byte aligned");      // (MIXED: the transposed copy is bf16; the same alignment costs nothing)
         RGQA_REQUIRE(((uintptr_t)p % 256) == 0 && ((uintptr_t)w % 256) == 0, "bind: arenas must be 256-byte aligned");
         size_t need = workspace_bytes(B_, T_, O_);
         if (wb < need) { rgqa_set_error("bind: workspace too small (%zu < %zu bytes)", wb, need); return RGQA_ERR_WORKSPACE; }
-        P = p; G = g; Pb = (T*)plp; PbT = (T*)plpt; ws = (char*)w; ws_bytes_ = wb;
+        P = p; G = g; Pb = (T*)plp; PbT = (TB*)plpt; ws = (char*)w; ws_bytes_ = wb;
         plan(B_, T_, O_);
         RGQA_HIP(hipMemset(sumsq_ws, 0, sizeof(float) * (size_t)sumsq_ws_segs * SUMSQ_WS_STRIDE));       // the ticket words of k_sumsq_owned start at zero
         varlen = false; lens_dirty = false;
@@ -535,8 +589,9 @@ public:
             RGQA_HIP(hipMemcpyAsync(tdesc, tdesc_host.data(), sizeof(TransDesc) * n_tdesc, hipMemcpyHostToDevice, s));
             tdesc_uploaded = true;
         }
-        if constexpr (X3) return k_cast_transpose(P, 0, PbT, 1, tdesc, n_tdesc, tdesc_tiles, s);
-        return k_cast_transpose(Pb, 1, PbT, 0, tdesc, n_tdesc, tdesc_tiles, s);     // from the bf16 copy (the optimizer kernel / sync_weights wrote it): half the read bytes
+        if constexpr (MIXED) return k_cast_transpose(P, 0, PbT, 0, tdesc, n_tdesc, tdesc_tiles, s);      // bf16 transposed copy (the dgrad operand) from the f32 masters
+        else if constexpr (X3) return k_cast_transpose(P, 0, PbT, 1, tdesc, n_tdesc, tdesc_tiles, s);
+        else return k_cast_transpose(Pb, 1, PbT, 0, tdesc, n_tdesc, tdesc_tiles, s);     // from the bf16 copy (the optimizer kernel / sync_weights wrote it): half the read bytes
     }
 
     // ------------------------------------------------------------------ GEMM helpers
@@ -554,6 +609,10 @@ public:
         p.ldb = l.in;
         p.bias = bias ? P + l.b + wrow0 : nullptr;
         p.aux = aux; p.ldaux = ldaux; p.epi = epi; p.drop_site = site;
+        if (MIXED) {      // the bf16 image of the result beside it; gelu' (read by the backward alone) only as its image
+            p.Cb = img(y);
+            if (c2 != nullptr) { p.C2 = img(c2); p.c2_lp = 1; }
+        }
     }
     // dx[rows, in] = dy[rows, cols] @ W[wrow0 : wrow0+cols, :]      ; DGRAD
     void add_dgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, void* dx, int lddx, int M, int epi, const void* aux, int ldaux) {
@@ -589,6 +648,7 @@ public:
     int run_fwd(GemmGroup& g, hipStream_t s, int out_f32 = 0, int a_f32 = 0) {
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = a_f32;
+        if (out_f32) for (int i = 0; i < g.count; ++i) g.p[i].Cb = nullptr;      // f32 results (the logits) have no image
         double f, b; gemm_work(g, f, b);
         char tg[48];
         prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "");
@@ -601,12 +661,12 @@ public:
         double f, b; gemm_work(g, f, b);
         char tg[48];
         prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "");
-        int r = nt_gemm(g, 0, 1, s);
+        int r = nt_gemm_b(g, 0, 1, s);
         prof_end(s);
         return r;
     }
     int run_wgrad(GemmGroup& g, hipStream_t s, int b_f32 = 0) {
-        if (g.count == 0) return RGQA_OK;
+        if (g.count == 0 || g_rgqa_skip_wgrad) return RGQA_OK;
         g.a_f32 = b_f32;
         double f, b; gemm_work(g, f, b);
         char tg[48];
@@ -615,12 +675,11 @@ public:
         prof_end(s);
         return r;
     }
-    int attn_fwd(const AttnArgs& a, hipStream_t s) { return attn_fwd_dispatch(a, s); }
-    int attn_fwd_dispatch(const AttnArgs& a, hipStream_t s);
-    int attn_bwd_dispatch(const AttnArgs& a, hipStream_t s);
+    int attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) { return attn_fwd_any<T>(a, s); }
+    int attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) { return attn_bwd_any<TB>(a, s); }
     // both attention problems of a stage in one launch: 1 = launched, 0 = not covered (launch them separately), < 0 = error
-    int attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
-    int attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s);
+    int attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) { return attn_fwd_pair_any<T>(a0, a1, s); }
+    int attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) { return attn_bwd_pair_any<TB>(a0, a1, s); }
     static bool attn_pair_wanted() { return g_rgqa_attn_pair != 0; }
 
 #define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
@@ -649,12 +708,13 @@ public:
         if (st.kind == ST_FFN && cls_tail(st)) {
             GemmGroup g; gg_init(g);
             CKP(PC_OTHER, k_gather_rows<T>((const T*)st.sb[0].x_in, H, cu, Tn, tail_x, H, B, H, s));      // the [CLS] row of every sample
+            CK(image_of(tail_x, H, B, H, s));
             add_fwd(g, tail_x, H, st.ffn[0]->up, 0, I, st.sb[0].h, I, B, EPI_GELU, nullptr, 0, st.sb[0].hpre, 0);
             CK(run_fwd(g, s));
             gg_init(g); g.drop = drop_base(pd);
             add_fwd(g, st.sb[0].h, I, st.ffn[0]->down, 0, H, st.sb[0].z, H, B, EPI_RESID_DROP, tail_x, H, nullptr, st.site + 1);
             CK(run_fwd(g, s));
-            CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.ffn[0]->ln.w, P + st.ffn[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, B, H, cfg.ln_eps, s));
+            CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.ffn[0]->ln.w, P + st.ffn[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, B, H, cfg.ln_eps, s, img(st.sb[0].y)));
             return RGQA_OK;
         }
         if (st.kind == ST_FFN) {
@@ -669,11 +729,11 @@ public:
             if (ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && (T*)st.sb[1].y == (T*)st.sb[0].y + (size_t)Rl * H) {
                 // language | vision rows are adjacent in the stage buffers: one launch, per-segment module parameters
                 CKP(PC_LN, k_ln_fwd2<T>((T*)st.sb[0].z, H, P + st.ffn[0]->ln.w, P + st.ffn[0]->ln.b, P + st.ffn[1]->ln.w, P + st.ffn[1]->ln.b, Rl,
-                                        (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
+                                        (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s, img(st.sb[0].y)));
                 return RGQA_OK;
             }
             for (int m = 0; m < 2; ++m) if (st.active[m])
-                CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.ffn[m]->ln.w, P + st.ffn[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
+                CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.ffn[m]->ln.w, P + st.ffn[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s, img(st.sb[m].y)));
             return RGQA_OK;
         }
         // ---- attention stages
@@ -700,7 +760,7 @@ public:
                 AttnArgs& a = aa[m]; memset(&a, 0, sizeof a);
                 a.q = st.sb[m].qkv; a.ldq = 3 * H;
                 a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
-                a.out = st.sb[m].ctx; a.ldo = H;
+                a.out = st.sb[m].ctx; a.ldo = H; a.out_b = img(st.sb[m].ctx);
                 a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;      // only language keys carry a padding mask (entry.py:119)
                 a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;  // packed language rows: the window IS the mask
                 a.lse = st.sb[m].lse;
@@ -736,13 +796,13 @@ public:
             CK(run_fwd(g, s));
         }
         if (cross && st.active[1]) {
-            CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
+            CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s, img(st.sb[0].y)));
         } else if (ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && (T*)st.sb[1].y == (T*)st.sb[0].y + (size_t)Rl * H) {
             CKP(PC_LN, k_ln_fwd2<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, P + st.att[1]->ln.w, P + st.att[1]->ln.b, Rl,
-                                    (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s));
+                                    (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s, img(st.sb[0].y)));
         } else {
             for (int m = 0; m < 2; ++m) if (st.active[m])
-                CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.att[m]->ln.w, P + st.att[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s));
+                CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[m].z, H, P + st.att[m]->ln.w, P + st.att[m]->ln.b, (T*)st.sb[m].y, H, st.sb[m].mean, st.sb[m].rstd, seg_rows(m), H, cfg.ln_eps, s, img(st.sb[m].y)));
         }
             return RGQA_OK;
     }
@@ -755,9 +815,11 @@ public:
         // text: word + position + token type -> LayerNorm -> dropout; pre-LN sums and statistics kept in text order for the backward
         CKP(PC_OTHER, k_embed_fwd<T>(ids, seg, trow_src_dev, text_dst_dev, n_text, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z,
                                      emb_mean, emb_rstd, B, Tt, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
+        CK(image_of(emb_z, H, n_text, H, s));
         // image: LN(img_linear(feat)) + LN(pos_linear(pos)) + type_emb[1] -> LayerNorm -> dropout
         GemmGroup g; gg_init(g);
         if (LP) CKP(PC_OTHER, cast_lp(feats, feats_lp, (size_t)ni * cfg.feat_dim, s));
+        if (MIXED) CKP(PC_OTHER, k_cast_bf16(feats, img(feats_lp), (size_t)ni * cfg.feat_dim, s));
         add_fwd(g, LP ? (const void*)feats_lp : (const void*)feats, cfg.feat_dim, mp.visn_fc, 0, H, u_zf, H, ni, EPI_BIAS, nullptr, 0, nullptr, 0);
         CK(run_fwd(g, s));
         CKP(PC_LN, k_ln_fwd<T>(u_zf, H, P + mp.visn_ln.w, P + mp.visn_ln.b, u_a1, H, u_st, u_st + ni, ni, H, cfg.ln_eps, s));
@@ -765,31 +827,33 @@ public:
         CKP(PC_LN, k_ln_fwd<T>(u_zp, H, P + mp.box_ln.w, P + mp.box_ln.b, u_a2, H, u_st + 2 * ni, u_st + 3 * ni, ni, H, cfg.ln_eps, s));
         CKP(PC_LN, k_sum3_ln_fwd<T>(u_a1, u_a2, H, P + mp.type + H, P + mp.img_ln.w, P + mp.img_ln.b, img_dst_dev, emb_out, H, u_x3, u_st + 4 * ni, u_st + 5 * ni,
                                     ni, H, cfg.ln_eps, drop_site(pd, 2), s));
+        // images of what the backward pass reads: the joint embedding rows (first layer's wgrad operand) and the pre-LayerNorm sums
+        CK(image_of(emb_out, H, R, H, s)); CK(image_of(u_zp, H, ni, H, s)); CK(image_of(u_x3, H, ni, H, s));
         return RGQA_OK;
     }
     // dy = gradient w.r.t. the joint embedding rows
-    int backward_joint_embeddings(const T* dy, int accumulate, hipStream_t s) {
+    int backward_joint_embeddings(const TB* dy, int accumulate, hipStream_t s) {
         const int H = cfg.hidden, ni = B * Oi;
         const float pd = cfg.hidden_dropout;
         const DropCfg nodrop = make_drop(0.f, 0, 0);
         RGQA_REQUIRE(dfeats_out == nullptr && dboxes_out == nullptr, "backward: input gradients are not available for the UNITER backbone");
         // text rows -> text order, LayerNorm backward, scatter into the tables (only the word table has padding_idx, :563-568)
-        CKP(PC_OTHER, k_gather_rows<T>(dy, H, text_dst_dev, 0, u_gt, H, n_text, H, s));
-        CKP(PC_LN, k_ln_bwd<T>(u_gt, H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, u_de, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, n_text, H,
+        CKP(PC_OTHER, k_gather_rows<TB>(dy, H, text_dst_dev, 0, u_gt, H, n_text, H, s));
+        CKP(PC_LN, k_ln_bwd<TB>(u_gt, H, sv(emb_z), H, P + mp.emb_ln.w, emb_mean, emb_rstd, u_de, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, n_text, H,
                                nodrop, drop_site(pd, 1), 1.0f, s));
-        CKP(PC_OTHER, k_embed_scatter<T>(u_de, in_ids, in_seg, trow_src_dev, n_text, G + mp.word, G + mp.pos, G + mp.type, B, Tt, H, 0, s));
+        CKP(PC_OTHER, k_embed_scatter<TB>(u_de, in_ids, in_seg, trow_src_dev, n_text, G + mp.word, G + mp.pos, G + mp.type, B, Tt, H, 0, s));
         // image rows: final LayerNorm, then the same gradient enters both branch LayerNorms and the type-1 embedding row
-        CKP(PC_OTHER, k_gather_rows<T>(dy, H, img_dst_dev, 0, u_g, H, ni, H, s));
-        CKP(PC_LN, k_ln_bwd<T>(u_g, H, u_x3, H, P + mp.img_ln.w, u_st + 4 * ni, u_st + 5 * ni, u_dx3, nullptr, H, part, G + mp.img_ln.w, G + mp.img_ln.b, nullptr, accumulate, ni, H,
+        CKP(PC_OTHER, k_gather_rows<TB>(dy, H, img_dst_dev, 0, u_g, H, ni, H, s));
+        CKP(PC_LN, k_ln_bwd<TB>(u_g, H, sv(u_x3), H, P + mp.img_ln.w, u_st + 4 * ni, u_st + 5 * ni, u_dx3, nullptr, H, part, G + mp.img_ln.w, G + mp.img_ln.b, nullptr, accumulate, ni, H,
                                nodrop, drop_site(pd, 2), 1.0f, s));
-        CKP(PC_OTHER, k_colsum<T>(u_dx3, H, part, G + mp.type + H, 1, ni, H, s));       // the tables were zeroed (or hold the accumulated sum)
-        CKP(PC_LN, k_ln_bwd<T>(u_dx3, H, u_zp, H, P + mp.box_ln.w, u_st + 2 * ni, u_st + 3 * ni, u_dz, nullptr, H, part, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.box_fc.b, accumulate, ni, H,
+        CKP(PC_OTHER, k_colsum<TB>(u_dx3, H, part, G + mp.type + H, 1, ni, H, s));       // the tables were zeroed (or hold the accumulated sum)
+        CKP(PC_LN, k_ln_bwd<TB>(u_dx3, H, sv(u_zp), H, P + mp.box_ln.w, u_st + 2 * ni, u_st + 3 * ni, u_dz, nullptr, H, part, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.box_fc.b, accumulate, ni, H,
                                nodrop, nodrop, 1.0f, s));
-        CKP(PC_OTHER, k_pos_wgrad<T>(u_dz, H, in_boxes, cfg.pos_dim, part, G + mp.box_fc.w, accumulate, ni, H, s));
-        CKP(PC_LN, k_ln_bwd<T>(u_dx3, H, u_zf, H, P + mp.visn_ln.w, u_st, u_st + ni, u_dz, nullptr, H, part, G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.visn_fc.b, accumulate, ni, H,
+        CKP(PC_OTHER, k_pos_wgrad<TB>(u_dz, H, in_boxes, cfg.pos_dim, part, G + mp.box_fc.w, accumulate, ni, H, s));
+        CKP(PC_LN, k_ln_bwd<TB>(u_dx3, H, sv(u_zf), H, P + mp.visn_ln.w, u_st, u_st + ni, u_dz, nullptr, H, part, G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.visn_fc.b, accumulate, ni, H,
                                nodrop, nodrop, 1.0f, s));
         GemmGroup g; gg_init(g);
-        add_wgrad(g, u_dz, H, mp.visn_fc, 0, H, LP ? (const void*)feats_lp : (const void*)in_feats, cfg.feat_dim, ni, accumulate);
+        add_wgrad(g, u_dz, H, mp.visn_fc, 0, H, LP ? (const void*)sv(feats_lp) : (const void*)in_feats, cfg.feat_dim, ni, accumulate);
         return run_wgrad(g, s);
     }
 
@@ -826,14 +890,17 @@ public:
         if (!fwd_varlen) CKP(PC_OTHER, k_make_mask(mask, maskf, Rl, s));
         CKP(PC_OTHER, k_embed_fwd<T>(ids, seg, fwd_varlen ? row_src_dev : nullptr, nullptr, Rl, P + mp.word, P + mp.pos, P + mp.type, P + mp.emb_ln.w, P + mp.emb_ln.b, emb_out, H, emb_z,
                           emb_mean, emb_rstd, B, Tn, H, cfg.vocab_size, cfg.type_vocab, cfg.ln_eps, drop_site(pd, 1), s));
+        CK(image_of(emb_out, H, Rl, H, s)); CK(image_of(emb_z, H, Rl, H, s));
         {   // VisualFeatEncoder: GEMM on the RoI features (one f32->bf16 cast pass in bf16 precision, so that this GEMM and
             // its weight-gradient GEMM run on the LDS-DMA kernels), then the fused LN/LN/avg tail
             GemmGroup g; gg_init(g);
             if (LP) CKP(PC_OTHER, cast_lp(feats, feats_lp, (size_t)Rv * cfg.feat_dim, s));
+            if (MIXED) CKP(PC_OTHER, k_cast_bf16(feats, img(feats_lp), (size_t)Rv * cfg.feat_dim, s));      // the bf16 wgrad's operand
             add_fwd(g, LP ? (const void*)feats_lp : (const void*)feats, cfg.feat_dim, mp.visn_fc, 0, H, zf, H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s));
             CKP(PC_OTHER, k_visn_combine_fwd<T>(zf, H, boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.visn_ln.b, P + mp.box_ln.w, P + mp.box_ln.b,
                                      visn_out, H, visn_stats, Rv, H, cfg.pos_dim, cfg.ln_eps, drop_site(pd, 2), s));
+            CK(image_of(visn_out, H, Rv, H, s));
         }
         }
         bool gathered = false;
@@ -844,6 +911,8 @@ public:
             if (st.kind == ST_ATT_CROSS && x0_needed && !gathered) {
                 if (x0_src[0] && Rl > 0) CK(rgqa_check_hip(hipMemcpyAsync(x0, x0_src[0], (size_t)Rl * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather lang"));
                 if (x0_src[1]) CK(rgqa_check_hip(hipMemcpyAsync(x0 + (size_t)Rl * H, x0_src[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "x0 gather visn"));
+                if (x0_src[0] && Rl > 0) CK(image_of(x0, H, Rl, H, s));
+                if (x0_src[1]) CK(image_of(x0 + (size_t)Rl * H, H, Rv, H, s));
                 gathered = true;
             }
             CK(forward_stage(st, cu, s));
@@ -854,13 +923,13 @@ public:
             GemmGroup g; gg_init(g);
             pool_in = cls_rows;
             if (!stages.empty() && cls_tail(stages.back())) pool_in = (T*)lang_final;      // already the B compact [CLS] rows
-            else CKP(PC_OTHER, k_gather_rows<T>((const T*)lang_final, H, cu, Tn, cls_rows, H, B, H, s));     // the [CLS] row of every sample
+            else { CKP(PC_OTHER, k_gather_rows<T>((const T*)lang_final, H, cu, Tn, cls_rows, H, B, H, s)); CK(image_of(cls_rows, H, B, H, s)); }     // the [CLS] row of every sample
             add_fwd(g, pool_in, H, mp.pooler, 0, H, pooled, H, B, EPI_TANH, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s));
             gg_init(g);
             add_fwd(g, pooled, H, mp.head0, 0, 2 * H, h1, 2 * H, B, EPI_GELU, nullptr, 0, h1pre, 0);
             CK(run_fwd(g, s));
-            CKP(PC_LN, k_ln_fwd<T>(h1, 2 * H, P + mp.head_ln.w, P + mp.head_ln.b, h2, 2 * H, hd_mean, hd_rstd, B, 2 * H, cfg.ln_eps, s));
+            CKP(PC_LN, k_ln_fwd<T>(h1, 2 * H, P + mp.head_ln.w, P + mp.head_ln.b, h2, 2 * H, hd_mean, hd_rstd, B, 2 * H, cfg.ln_eps, s, img(h2)));
             gg_init(g);
             // N = NAp (a multiple of 64): the arena slots of logit_fc.3.weight / .bias are zero-padded up to NAp rows, so the extra
             // logits columns come out as exact zeros and the GEMM runs on the LDS-DMA kernel
@@ -882,18 +951,18 @@ public:
         float* dl32 = part;   // scratch [B, NAp] f32
         CKP(PC_OTHER, k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, cfg.num_answers, NAp, grad_scale, s));
         if (loss_out) CK(rgqa_check_hip(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s), "loss copy"));
-        CKP(PC_OTHER, k_cast_pad<T>(dl32, NAp, dlogits, NAp, B, NAp, 1.0f, s));
+        CKP(PC_OTHER, k_cast_pad<TB>(dl32, NAp, dlogits, NAp, B, NAp, 1.0f, s));
         return backward_impl(accumulate, s);
     }
     int backward(const float* dl, int ldd, int accumulate, hipStream_t s) override {
         RGQA_REQUIRE(have_fwd, "backward: no forward pass recorded");
         RGQA_REQUIRE(G != nullptr && dl != nullptr, "backward: null gradient arena / dlogits");
-        CKP(PC_OTHER, k_cast_pad<T>(dl, ldd, dlogits, NAp, B, cfg.num_answers, 1.0f, s));
+        CKP(PC_OTHER, k_cast_pad<TB>(dl, ldd, dlogits, NAp, B, cfg.num_answers, 1.0f, s));
         return backward_impl(accumulate, s);
     }
 
     int colsum_bias(const void* dy, int ld, const Lin& l, int col0, int cols, int M, int accumulate, hipStream_t s) {
-        return k_colsum<T>((const T*)dy + col0, ld, part, G + l.b + col0, accumulate, M, cols, s);
+        return k_colsum<TB>((const TB*)dy + col0, ld, part, G + l.b + col0, accumulate, M, cols, s);
     }
 
     int backward_impl(int accumulate, hipStream_t s) {
@@ -910,14 +979,14 @@ public:
         // ---- head
         // padded columns of dlogits are exact zeros and the bias slot reserves round_up(NA, 64) elements
         CKP(PC_OTHER, colsum_bias(dlogits, NAp, mp.head3, 0, NAp, B, accumulate, s));
-        gg_init(g); add_wgrad(g, dlogits, NAp, mp.head3, 0, NA, h2, 2 * H, B, accumulate); CK(run_wgrad(g, s));
+        gg_init(g); add_wgrad(g, dlogits, NAp, mp.head3, 0, NA, sv(h2), 2 * H, B, accumulate); CK(run_wgrad(g, s));
         gg_init(g); add_dgrad(g, dlogits, NAp, mp.head3, 0, NA, gp1, 2 * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
-        CKP(PC_LN, k_ln_bwd<T>(gp1, 2 * H, h1, 2 * H, P + mp.head_ln.w, hd_mean, hd_rstd, gp2, nullptr, 2 * H, part, G + mp.head_ln.w, G + mp.head_ln.b, nullptr,
+        CKP(PC_LN, k_ln_bwd<TB>(gp1, 2 * H, sv(h1), 2 * H, P + mp.head_ln.w, hd_mean, hd_rstd, gp2, nullptr, 2 * H, part, G + mp.head_ln.w, G + mp.head_ln.b, nullptr,
                        accumulate, B, 2 * H, nodrop, nodrop, 1.0f, s));
-        CKP(PC_OTHER, k_dgelu_mul<T>(gp2, h1pre, gp3, (size_t)B * 2 * H, s));
+        CKP(PC_OTHER, k_dgelu_mul<TB>(gp2, sv(h1pre), gp3, (size_t)B * 2 * H, s));
         CKP(PC_OTHER, colsum_bias(gp3, 2 * H, mp.head0, 0, 2 * H, B, accumulate, s));
-        gg_init(g); add_wgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, pooled, H, B, accumulate); CK(run_wgrad(g, s));
-        gg_init(g); add_dgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, gp1, H, B, EPI_DTANH, pooled, H); CK(run_dgrad(g, s));   // gp1[B,H] = d(pooler pre-tanh)
+        gg_init(g); add_wgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, sv(pooled), H, B, accumulate); CK(run_wgrad(g, s));
+        gg_init(g); add_dgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, gp1, H, B, EPI_DTANH, sv(pooled), H); CK(run_dgrad(g, s));   // gp1[B,H] = d(pooler pre-tanh)
         return backward_encoder(accumulate, s);
     }
 
@@ -931,8 +1000,8 @@ public:
             if (dead_end > dead_begin) CK(rgqa_check_hip(hipMemsetAsync(G + dead_begin, 0, sizeof(float) * (dead_end - dead_begin), s), "zero dead grads"));
             CK(rgqa_check_hip(hipMemsetAsync(G + mp.head0.w, 0, sizeof(float) * (arena_elems - mp.head0.w), s), "zero head grads"));
         }
-        CKP(PC_OTHER, k_cast_pad<T>(dpooled, ld, gp2, H, B, H, 1.0f, s));
-        CKP(PC_OTHER, k_dtanh_mul<T>(gp2, pooled, gp1, (size_t)B * H, s));
+        CKP(PC_OTHER, k_cast_pad<TB>(dpooled, ld, gp2, H, B, H, 1.0f, s));
+        CKP(PC_OTHER, k_dtanh_mul<TB>(gp2, sv(pooled), gp1, (size_t)B * H, s));
         return backward_encoder(accumulate, s);
     }
 
@@ -945,28 +1014,28 @@ public:
         GemmGroup g;
         CKP(PC_OTHER, colsum_bias(gp1, H, mp.pooler, 0, H, B, accumulate, s));
         const int* cu = fwd_varlen ? cu_dev : nullptr;
-        gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, pool_in, H, B, accumulate); CK(run_wgrad(g, s));
+        gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, sv(pool_in), H, B, accumulate); CK(run_wgrad(g, s));
         // gradient w.r.t. the final hidden states: zero except the [CLS] rows of lang
         // Gradient w.r.t. the current stage's output, one pointer per modality: a stage moves only the modalities it computes to
         // the other buffer, so a modality that merely passes through (vision under the language-only layers) stays where it is
         // instead of being copied.  Stages that treat [language | vision] as one row range need the two adjacent; single-modality
         // stages come in pairs (attention + FFN), so adjacency is back whenever it is needed - adjacent() re-establishes it otherwise.
-        T* dyp[2] = {gA, gA + (size_t)Rl * H};
-        T* dxp[2] = {gB, gB + (size_t)Rl * H};
+        TB* dyp[2] = {gA, gA + (size_t)Rl * H};
+        TB* dxp[2] = {gB, gB + (size_t)Rl * H};
         auto adjacent = [&]() -> int {
             if (dyp[1] != dyp[0] + (size_t)Rl * H) {
-                T* want = dyp[0] + (size_t)Rl * H;
-                int r = rgqa_check_hip(hipMemcpyAsync(want, dyp[1], (size_t)Rv * H * sizeof(T), hipMemcpyDeviceToDevice, s), "grad rows adjacent");
+                TB* want = dyp[0] + (size_t)Rl * H;
+                int r = rgqa_check_hip(hipMemcpyAsync(want, dyp[1], (size_t)Rv * H * sizeof(TB), hipMemcpyDeviceToDevice, s), "grad rows adjacent");
                 if (r) return r;
                 dxp[1] = dyp[1]; dyp[1] = want;
             }
             if (dxp[1] != dxp[0] + (size_t)Rl * H) dxp[1] = dxp[0] + (size_t)Rl * H;      // the free halves always pair up again
             return RGQA_OK;
         };
-        CK(rgqa_check_hip(hipMemsetAsync(dyp[0], 0, (size_t)R * H * sizeof(T), s), "zero dy"));
+        CK(rgqa_check_hip(hipMemsetAsync(dyp[0], 0, (size_t)R * H * sizeof(TB), s), "zero dy"));
         gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, gp2, H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
         const bool tail = !stages.empty() && cls_tail(stages.back());
-        if (!tail) CKP(PC_OTHER, k_scatter_rows<T>(gp2, H, dyp[0], H, cu, Tn, B, H, s));     // tail: the last FFN stage takes gp2 [B,H] as it is
+        if (!tail) CKP(PC_OTHER, k_scatter_rows<TB>(gp2, H, dyp[0], H, cu, Tn, B, H, s));     // tail: the last FFN stage takes gp2 [B,H] as it is
         seg_cursor = 0;
         CK(mark_segment(s));     // head + pooler gradients are final
 
@@ -993,24 +1062,24 @@ public:
                 fin_accumulate = accumulate;
                 fin.begin(lnpart_s[par], LNPART_BLOCKS, H);     // LayerNorm-backward column sums: folded once per layer, with the layer's wgrad launch
             }
-            T* gz = gz_s[par][st.slot]; T* gzd = gzd_s[par][st.slot]; T* gqkv = gqkv_s[par][st.slot]; T* gh = gh_s[par][st.slot];
+            TB* gz = gz_s[par][st.slot]; TB* gzd = gzd_s[par][st.slot]; TB* gqkv = gqkv_s[par][st.slot]; TB* gh = gh_s[par][st.slot];
             const bool cross = st.kind == ST_ATT_CROSS;
             const bool shared_all = cross && st.active[1];
-            auto rowp = [&](T* base, int m, int width) { return base + (size_t)(m == 0 ? 0 : Rl) * width; };
+            auto rowp = [&](TB* base, int m, int width) { return base + (size_t)(m == 0 ? 0 : Rl) * width; };
             if (st.kind == ST_FFN && tail && si == (int)stages.size() - 1) {
                 // B compact [CLS] rows: LayerNorm / FFN backward on them, then the input gradient goes back to the [CLS] rows of a zeroed buffer
                 const FfnP& f = *st.ffn[0];
                 DropCfg d = drop_site(pd, st.site + 1);
-                CKP(PC_LN, k_ln_bwd<T>(gp2, H, (T*)st.sb[0].z, H, P + f.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b,
+                CKP(PC_LN, k_ln_bwd<TB>(gp2, H, sv(st.sb[0].z), H, P + f.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b,
                                accumulate, B, H, d, nodrop, 1.0f, s, &fin));
-                T* gzm = d.thresh ? gzd : gz;
-                gg_init(g); add_dgrad(g, gzm, H, f.down, 0, H, gh, I, B, EPI_DGELU, st.sb[0].hpre, I); CK(run_dgrad(g, s));
-                add_wgrad(wg, gzm, H, f.down, 0, H, st.sb[0].h, I, B, accumulate);
-                add_wgrad(wg, gh, I, f.up, 0, I, tail_x, H, B, accumulate, true);
+                TB* gzm = d.thresh ? gzd : gz;
+                gg_init(g); add_dgrad(g, gzm, H, f.down, 0, H, gh, I, B, EPI_DGELU, sv(st.sb[0].hpre), I); CK(run_dgrad(g, s));
+                add_wgrad(wg, gzm, H, f.down, 0, H, sv(st.sb[0].h), I, B, accumulate);
+                add_wgrad(wg, gh, I, f.up, 0, I, sv(tail_x), H, B, accumulate, true);
                 gg_init(g); add_dgrad(g, gh, I, f.up, 0, I, tail_dx, H, B, EPI_ADD, gz, H); CK(run_dgrad(g, s));
-                CK(rgqa_check_hip(hipMemsetAsync(dxp[0], 0, (size_t)Rl * H * sizeof(T), s), "zero tail dx"));
-                CKP(PC_OTHER, k_scatter_rows<T>(tail_dx, H, dxp[0], H, cu, Tn, B, H, s));
-                { T* t = dyp[0]; dyp[0] = dxp[0]; dxp[0] = t; }
+                CK(rgqa_check_hip(hipMemsetAsync(dxp[0], 0, (size_t)Rl * H * sizeof(TB), s), "zero tail dx"));
+                CKP(PC_OTHER, k_scatter_rows<TB>(tail_dx, H, dxp[0], H, cu, Tn, B, H, s));
+                { TB* t = dyp[0]; dyp[0] = dxp[0]; dxp[0] = t; }
                 if (flush_after(st)) CK(flush_layer(s));
                 continue;
             }
@@ -1018,55 +1087,55 @@ public:
                 const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && dyp[1] == dyp[0] + (size_t)Rl * H;
                 if (both) {
                     const FfnP &f0 = *st.ffn[0], &f1 = *st.ffn[1];
-                    CKP(PC_LN, k_ln_bwd2<T>(dyp[0], H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
+                    CKP(PC_LN, k_ln_bwd2<TB>(dyp[0], H, sv(st.sb[0].z), H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
                                             Rl, P + f0.ln.w, G + f0.ln.w, G + f0.ln.b, G + f0.down.b, drop_site(pd, st.site + 1),
                                             Rv, P + f1.ln.w, G + f1.ln.w, G + f1.ln.b, G + f1.down.b, drop_site(pd, st.site + 5), s, &fin));
                 }
                 for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const FfnP& f = *st.ffn[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
-                    CKP(PC_LN, k_ln_bwd<T>(dyp[m], H, (T*)st.sb[m].z, H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                    CKP(PC_LN, k_ln_bwd<TB>(dyp[m], H, sv(st.sb[m].z), H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
                                    d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s, &fin));
                 }
-                T* gzm = drop_base(pd).thresh ? gzd : gz;
+                TB* gzm = drop_base(pd).thresh ? gzd : gz;
                 gg_init(g);
                 for (int m = 0; m < 2; ++m) if (st.active[m])
-                    add_dgrad(g, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, rowp(gh, m, I), I, seg_rows(m), EPI_DGELU, st.sb[m].hpre, I);
+                    add_dgrad(g, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, rowp(gh, m, I), I, seg_rows(m), EPI_DGELU, sv(st.sb[m].hpre), I);
                 CK(run_dgrad(g, s));
                 for (int m = 0; m < 2; ++m) if (st.active[m]) {
-                    add_wgrad(wg, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, st.sb[m].h, I, seg_rows(m), accumulate);
-                    add_wgrad(wg, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, st.sb[m].x_in, H, seg_rows(m), accumulate, true);
+                    add_wgrad(wg, rowp(gzm, m, H), H, st.ffn[m]->down, 0, H, sv(st.sb[m].h), I, seg_rows(m), accumulate);
+                    add_wgrad(wg, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, sv(st.sb[m].x_in), H, seg_rows(m), accumulate, true);
                 }
                 gg_init(g);
                 for (int m = 0; m < 2; ++m) if (st.active[m])
                     add_dgrad(g, rowp(gh, m, I), I, st.ffn[m]->up, 0, I, dxp[m], H, seg_rows(m), EPI_ADD, rowp(gz, m, H), H);
                 CK(run_dgrad(g, s));
                 // an inactive modality's gradient passes through untouched: its pointers simply do not move
-                for (int m = 0; m < 2; ++m) if (st.active[m]) { T* t = dyp[m]; dyp[m] = dxp[m]; dxp[m] = t; }
+                for (int m = 0; m < 2; ++m) if (st.active[m]) { TB* t = dyp[m]; dyp[m] = dxp[m]; dxp[m] = t; }
                 if (flush_after(st)) CK(flush_layer(s));
                 continue;
             }
             // ---- attention stage backward
-            T* gzm = drop_base(pd).thresh ? gzd : gz;
+            TB* gzm = drop_base(pd).thresh ? gzd : gz;
             if (shared_all) {
                 const AttP& ap = *st.att[0];
                 DropCfg d = drop_site(pd, st.site + 1);
                 CK(adjacent());
-                CKP(PC_LN, k_ln_bwd<T>(dyp[0], H, (T*)st.sb[0].z, H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
+                CKP(PC_LN, k_ln_bwd<TB>(dyp[0], H, sv(st.sb[0].z), H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
                                G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, R, H, d, nodrop, 1.0f, s, &fin));
                 gg_init(g); add_dgrad(g, gzm, H, ap.o, 0, H, gctx, H, R, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
             } else {
                 const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && dyp[1] == dyp[0] + (size_t)Rl * H;
                 if (both) {
                     const AttP &a0 = *st.att[0], &a1 = *st.att[1];
-                    CKP(PC_LN, k_ln_bwd2<T>(dyp[0], H, (T*)st.sb[0].z, H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
+                    CKP(PC_LN, k_ln_bwd2<TB>(dyp[0], H, sv(st.sb[0].z), H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
                                             Rl, P + a0.ln.w, G + a0.ln.w, G + a0.ln.b, G + a0.o.b, drop_site(pd, st.site + 1),
                                             Rv, P + a1.ln.w, G + a1.ln.w, G + a1.ln.b, G + a1.o.b, drop_site(pd, st.site + 5), s, &fin));
                 }
                 for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const AttP& ap = *st.att[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
-                    CKP(PC_LN, k_ln_bwd<T>(dyp[m], H, (T*)st.sb[m].z, H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                    CKP(PC_LN, k_ln_bwd<TB>(dyp[m], H, sv(st.sb[m].z), H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
                                    d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s, &fin));
                 }
                 gg_init(g);
@@ -1077,15 +1146,15 @@ public:
             // attention core backward -> gqkv (packed like the forward qkv buffer)
             if (cross && !st.active[1]) {
                 // dead visn-query direction: lang rows get no dk/dv, visn rows get no dq
-                CK(rgqa_check_hip(hipMemsetAsync(gqkv, 0, (size_t)R * 3 * H * sizeof(T), s), "zero dqkv"));
+                CK(rgqa_check_hip(hipMemsetAsync(gqkv, 0, (size_t)R * 3 * H * sizeof(TB), s), "zero dqkv"));
             }
             {
                 AttnArgs aa[2];
                 for (int m = 0; m < 2; ++m) if (st.active[m]) {
                     const int km = cross ? 1 - m : m;
                     AttnArgs& a = aa[m]; memset(&a, 0, sizeof a);
-                    a.q = st.sb[m].qkv; a.ldq = 3 * H;
-                    a.k = (T*)st.sb[km].qkv + H; a.v = (T*)st.sb[km].qkv + 2 * H; a.ldk = a.ldv = 3 * H;
+                    a.q = sv(st.sb[m].qkv); a.ldq = 3 * H;
+                    a.k = sv(st.sb[km].qkv) + H; a.v = sv(st.sb[km].qkv) + 2 * H; a.ldk = a.ldv = 3 * H;
                     a.mask = (km == 0 && !fwd_varlen) ? maskf : nullptr;
                     a.cu_q = m == 0 ? cu : nullptr; a.cu_k = km == 0 ? cu : nullptr;
                     a.lse = st.sb[m].lse;
@@ -1097,7 +1166,7 @@ public:
                     a.drop = drop_base(pa); a.drop_site = st.site + m * 4;
                 }
                 auto fl = [&](const AttnArgs& a) { return 10.0 * B * nh * a.Lq * a.Lk * dh; };
-                auto by = [&](const AttnArgs& a) { return sizeof(T) * (double)B * nh * dh * (4.0 * a.Lq + 4.0 * a.Lk); };
+                auto by = [&](const AttnArgs& a) { return sizeof(TB) * (double)B * nh * dh * (4.0 * a.Lq + 4.0 * a.Lk); };
                 int paired = 0;
                 if (st.active[0] && st.active[1] && attn_pair_wanted()) {      // the two problems write disjoint rows / columns of dqkv: one launch
                     prof_begin(PC_ATTN_BWD, fl(aa[0]) + fl(aa[1]), by(aa[0]) + by(aa[1]), s);
@@ -1116,17 +1185,17 @@ public:
             // weight / bias gradients (GEMMs deferred to the end of the layer)
             if (shared_all) {
                 const AttP& ap = *st.att[0];
-                add_wgrad(wg, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, R, accumulate);
-                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, 3 * H, st.sb[0].x_in, H, R, accumulate, true);
+                add_wgrad(wg, gzm, H, ap.o, 0, H, sv(st.sb[0].ctx), H, R, accumulate);
+                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, 3 * H, sv(st.sb[0].x_in), H, R, accumulate, true);
             } else if (cross) {
                 const AttP& ap = *st.att[0];
-                add_wgrad(wg, gzm, H, ap.o, 0, H, st.sb[0].ctx, H, Rl, accumulate);
-                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, H, st.sb[0].x_in, H, Rl, accumulate, true);
-                add_wgrad(wg, rowp(gqkv, 1, 3 * H) + H, 3 * H, ap.qkv, H, 2 * H, st.sb[1].x_in, H, Rv, accumulate, true);
+                add_wgrad(wg, gzm, H, ap.o, 0, H, sv(st.sb[0].ctx), H, Rl, accumulate);
+                add_wgrad(wg, gqkv, 3 * H, ap.qkv, 0, H, sv(st.sb[0].x_in), H, Rl, accumulate, true);
+                add_wgrad(wg, rowp(gqkv, 1, 3 * H) + H, 3 * H, ap.qkv, H, 2 * H, sv(st.sb[1].x_in), H, Rv, accumulate, true);
             } else {
                 for (int m = 0; m < 2; ++m) if (st.active[m]) {
-                    add_wgrad(wg, rowp(gzm, m, H), H, st.att[m]->o, 0, H, st.sb[m].ctx, H, seg_rows(m), accumulate);
-                    add_wgrad(wg, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, st.sb[m].x_in, H, seg_rows(m), accumulate, true);
+                    add_wgrad(wg, rowp(gzm, m, H), H, st.att[m]->o, 0, H, sv(st.sb[m].ctx), H, seg_rows(m), accumulate);
+                    add_wgrad(wg, rowp(gqkv, m, 3 * H), 3 * H, st.att[m]->qkv, 0, 3 * H, sv(st.sb[m].x_in), H, seg_rows(m), accumulate, true);
                 }
             }
             // the first layer's attention wgrads are the launch nothing of the encoder runs beside: start them here, beside this stage's
@@ -1148,7 +1217,7 @@ public:
             }
             CK(run_dgrad(g, s));
             // a cross stage writes both modalities' input gradients (the dead last layer too: vision keys / values are live)
-            for (int m = 0; m < 2; ++m) if (st.active[m] || cross) { T* t = dyp[m]; dyp[m] = dxp[m]; dxp[m] = t; }
+            for (int m = 0; m < 2; ++m) if (st.active[m] || cross) { TB* t = dyp[m]; dyp[m] = dxp[m]; dxp[m] = t; }
             if (flush_after(st)) CK(flush_layer(s));
         }
         prof_block = PB_LR;
@@ -1167,19 +1236,19 @@ public:
             CK(mark_segment(s));
             return RGQA_OK;
         }
-        T* gz = gemb;
+        TB* gz = gemb;
         // ---- embeddings: dropout -> LN backward -> scatter-add into the three tables
         {
             DropCfg din = drop_site(pd, 1);
-            CKP(PC_LN, k_ln_bwd<T>(dyp[0], H, emb_z, H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
+            CKP(PC_LN, k_ln_bwd<TB>(dyp[0], H, sv(emb_z), H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
                            nodrop, din, 1.0f, s));
-            CKP(PC_OTHER, k_embed_scatter<T>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, 1, s));
+            CKP(PC_OTHER, k_embed_scatter<TB>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, 1, s));
         }
         // ---- visual embedding
         {
-            T* dyv = dyp[1];
-            T* dzf = gz + (size_t)Rl * H;
-            CKP(PC_OTHER, k_visn_combine_bwd<T>(dyv, H, zf, H, in_boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.box_ln.w, visn_stats, dzf, H, part,
+            TB* dyv = dyp[1];
+            TB* dzf = gz + (size_t)Rl * H;
+            CKP(PC_OTHER, k_visn_combine_bwd<TB>(dyv, H, sv(zf), H, in_boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.box_ln.w, visn_stats, dzf, H, part,
                                      G + mp.visn_ln.w, G + mp.visn_ln.b, G + mp.box_ln.w, G + mp.box_ln.b, G + mp.visn_fc.b, G + mp.box_fc.w, G + mp.box_fc.b,
                                      accumulate, Rv, H, cfg.pos_dim, drop_site(pd, 2), dboxes_out, s));
             // dW_visn_fc [H, feat_dim] contracts over all B*O rows but has only (H/256)*(feat_dim/256) = 24 output tiles, and nothing
@@ -1187,7 +1256,7 @@ public:
             // them in a fixed order.  The scratch is the qkv-gradient buffer of the older buffer set (joined above).
             const size_t wsz = (size_t)H * cfg.feat_dim;
             int S = Rv / 1024; if (S > 8) S = 8;
-            const size_t scratch_bytes = (size_t)(Rl > 0 ? B * Tn + Rv : Rv) * 3 * H * sizeof(T);
+            const size_t scratch_bytes = (size_t)(Rl > 0 ? B * Tn + Rv : Rv) * 3 * H * sizeof(TB);
             while (S > 1 && (size_t)S * wsz * sizeof(float) > scratch_bytes) --S;
             if (LP && S >= 2 && (wsz % 4) == 0) {
                 float* part_w = reinterpret_cast<float*>(gqkv_s[par][0]);
@@ -1197,14 +1266,14 @@ public:
                     GemmProblem& p = g.p[g.count++];
                     memset(&p, 0, sizeof p);
                     const int r0 = i * kc, rows = (i == S - 1) ? Rv - r0 : kc;
-                    p.A = dzf + (size_t)r0 * H; p.lda = H; p.B = feats_lp + (size_t)r0 * cfg.feat_dim; p.ldb = cfg.feat_dim;
+                    p.A = dzf + (size_t)r0 * H; p.lda = H; p.B = sv(feats_lp) + (size_t)r0 * cfg.feat_dim; p.ldb = cfg.feat_dim;
                     p.K = rows; p.M = H; p.N = cfg.feat_dim; p.C = part_w + (size_t)i * wsz; p.ldc = cfg.feat_dim; p.epi = EPI_BIAS;
                 }
                 CK(run_wgrad(g, s));
                 CKP(PC_OTHER, k_sum_partials(part_w, S, wsz, G + mp.visn_fc.w, accumulate, s));
             } else {
                 gg_init(g);
-                add_wgrad(g, dzf, H, mp.visn_fc, 0, H, LP ? (const void*)feats_lp : (const void*)in_feats, cfg.feat_dim, Rv, accumulate);
+                add_wgrad(g, dzf, H, mp.visn_fc, 0, H, LP ? (const void*)sv(feats_lp) : (const void*)in_feats, cfg.feat_dim, Rv, accumulate);
                 CK(run_wgrad(g, s));
             }
             if (dfeats_out) {       // input gradient dL/dfeats [B*O, feat_dim] f32 = dzf . W_visn_fc   (ODIN, tasks/gqa_odin.py:97-121)
@@ -1212,7 +1281,7 @@ public:
                 add_dgrad(g, dzf, H, mp.visn_fc, 0, H, dfeats_out, cfg.feat_dim, Rv, EPI_BIAS, nullptr, 0);
                 double f, b; gemm_work(g, f, b);
                 prof_begin(PC_GEMM_NT, f, b, s);
-                int r = nt_gemm(g, 1, 1, s);
+                int r = nt_gemm_b(g, 1, 1, s);
                 prof_end(s);
                 CK(r);
             }
@@ -1280,44 +1349,9 @@ public:
     }
 };
 
-// RGQA_ATTN_REF (test switch: the plain attention kernels instead of the MFMA ones), read once
-static bool attn_ref_forced() { static const bool v = getenv("RGQA_ATTN_REF") != nullptr; return v; }
-template <> int Engine<float>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) { return k_attn_fwd_ref<float>(a, s); }
-template <> int Engine<float>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) { return k_attn_bwd_ref<float>(a, s); }
-template <> int Engine<sf32>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) {
-    if (a.dh == 64 && !attn_ref_forced()) return k_attn_fwd_x3(a, s);
-    return k_attn_fwd_ref<sf32>(a, s);
-}
-template <> int Engine<sf32>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) {
-    if (a.dh == 64 && !attn_ref_forced()) return k_attn_bwd_x3(a, s);
-    return k_attn_bwd_ref<sf32>(a, s);
-}
-template <> int Engine<bf16_t>::attn_fwd_dispatch(const AttnArgs& a, hipStream_t s) {
-    if (a.dh == 64 && !attn_ref_forced()) return k_attn_fwd_mfma(a, s);
-    return k_attn_fwd_ref<bf16_t>(a, s);
-}
-template <> int Engine<bf16_t>::attn_bwd_dispatch(const AttnArgs& a, hipStream_t s) {
-    if (a.dh == 64 && !attn_ref_forced()) return k_attn_bwd_mfma(a, s);
-    return k_attn_bwd_ref<bf16_t>(a, s);
-}
-
-template <> int Engine<float>::attn_fwd_pair_dispatch(const AttnArgs&, const AttnArgs&, hipStream_t) { return 0; }
-template <> int Engine<float>::attn_bwd_pair_dispatch(const AttnArgs&, const AttnArgs&, hipStream_t) { return 0; }
-template <> int Engine<sf32>::attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
-    return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_fwd_x3_pair(a0, a1, s) : 0;
-}
-template <> int Engine<sf32>::attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
-    return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_bwd_x3_pair(a0, a1, s) : 0;
-}
-template <> int Engine<bf16_t>::attn_fwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
-    return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_fwd_mfma_pair(a0, a1, s) : 0;
-}
-template <> int Engine<bf16_t>::attn_bwd_pair_dispatch(const AttnArgs& a0, const AttnArgs& a1, hipStream_t s) {
-    return (a0.dh == 64 && !attn_ref_forced()) ? k_attn_bwd_mfma_pair(a0, a1, s) : 0;
-}
-
 EngineBase* make_engine(const rgqa_config& cfg) {
     if (cfg.precision == RGQA_PRECISION_BF16) return new Engine<bf16_t>(cfg);
     if (cfg.precision == RGQA_PRECISION_BF16X3) return new Engine<sf32>(cfg);
+    if (cfg.precision == RGQA_PRECISION_BF16X3_FWD) return new Engine<sf32, true>(cfg);
     return new Engine<float>(cfg);
 }

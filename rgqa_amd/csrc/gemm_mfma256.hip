@@ -130,6 +130,11 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     const GemmProblem& P = g.p[pi];
     // tile order inside a problem: consecutive ids run over the M-tiles of one N-tile first, so neighbours stream the same B
     // operand (the wider one); blocks that share an XCD (equal id mod 8) get consecutive ids.
+    // (Round 4 measured the alternative - ONE contiguous run of the whole launch's tile list per XCD, each XCD then holding a compact
+    // sub-grid of one weight matrix: L2 hit rate of this kernel 0.39 -> 0.68, fabric requests halved (profiles/r04_pmc_tcc_hit_*.json),
+    // serialised time unchanged (3.33 -> 3.39 ms per step) and the step 0.85 ms SLOWER (11.93 -> 12.78, three interleaved rounds,
+    // profiles/r04_wgrad_cost_probe.txt): the loop is not bound by where its lines come from, and the long-contraction problems then sit
+    // on four of the eight XCDs, whose CUs the main stream's launches wait for.)
     const int tiles_m = cdiv(P.M, WMV);
     const int tix = xcd_remap256(tile - P.tile_start, tiles_m * P.tiles_n);
     const int local = (tix % tiles_m) * P.tiles_n + (tix / tiles_m);     // back to the m-major id used below

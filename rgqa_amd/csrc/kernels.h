@@ -21,12 +21,13 @@ struct FinDefer {
     void add(float* out, int qsrc, int b0, int b1) { if (out) { fo.p[nout] = out; fo.stride[nout] = 1; fo.qsrc[nout] = qsrc; fo.b0[nout] = b0; fo.b1[nout] = b1; ++nout; } }
 };
 int fin_flush(FinDefer& d, int accumulate, hipStream_t s);
+// y_b (split-f32 rows only): optional bf16 image of y at the same element offsets (the bf16x3_fwd precision's backward reads it)
 template <typename T>
-int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s);
+int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s, bf16_t* y_b = nullptr);
 // rows [0, split) use (gamma, beta), rows [split, M) use (gamma2, beta2): two modules' LayerNorms over adjacent row ranges in one launch
 template <typename T>
 int k_ln_fwd2(const T* x, int ldx, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, T* y, int ldy, float* mean, float* rstd,
-              int M, int N, float eps, hipStream_t s);
+              int M, int N, float eps, hipStream_t s, bf16_t* y_b = nullptr);
 int ln_bwd_blocks(int M, int N);
 // part: workspace of ln_bwd_blocks(M,N)*3*N floats (or null: no column sums). dzd may be null.
 template <typename T>
@@ -47,6 +48,7 @@ struct AttnArgs {
     const void* q; const void* k; const void* v;  // element (row 0, head 0, dim 0) of each operand
     int ldq, ldk, ldv;                             // row strides in elements
     void* out; int ldo;                            // fwd: context [B*Lq, nh*dh]
+    void* out_b;                                   // split-f32 forward only: optional bf16 image of `out` (same ldo), or null
     const float* mask;                             // additive key mask [B, Lk] (0 / -10000) or null
     float* lse;                                    // [B, nh, Lq] log-sum-exp of the masked, scaled scores
     // backward only
@@ -160,5 +162,7 @@ int k_set_lengths(const int* lens_host, int B, int Tn, int* lens_dev, int* cu_de
 // row(b) = cu ? cu[b] : b * stride_rows
 template <typename T> int k_gather_rows(const T* src, int lds, const int* cu, int stride_rows, T* dst, int ldd, int rows, int cols, hipStream_t s);
 template <typename T> int k_scatter_rows(const T* src, int lds, T* dst, int ldd, const int* cu, int stride_rows, int rows, int cols, hipStream_t s);
+// dst[r][c] = bf16(src[r][c]) = the hi part of every split-f32 element: the bf16 image of a tensor no kernel writes twice (embeddings, gathered rows)
+int k_sf_image(const sf32* src, int lds, bf16_t* dst, int ldd, int rows, int cols, hipStream_t s);
 template <typename T> int k_dgelu_mul(const T* dy, const T* pre, T* out, size_t n, hipStream_t s);
 template <typename T> int k_dtanh_mul(const T* dy, const T* y, T* out, size_t n, hipStream_t s);

@@ -235,6 +235,23 @@ template int k_scatter_rows<bf16_t>(const bf16_t*, int, bf16_t*, int, const int*
 template int k_gather_rows<sf32>(const sf32*, int, const int*, int, sf32*, int, int, int, hipStream_t);
 template int k_scatter_rows<sf32>(const sf32*, int, sf32*, int, const int*, int, int, int, hipStream_t);
 
+// bf16 image of a split-f32 matrix (bf16x3_fwd precision): the hi part of every element IS bf16(x); 8 elements per thread, two 16-byte accesses
+__global__ __launch_bounds__(256) void sf_image_kernel(const sf32* __restrict__ src, int lds, bf16_t* __restrict__ dst, int ldd, int rows, int cols8) {
+    const size_t n = (size_t)rows * cols8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cols8), c = (int)(i % cols8) * 8;
+        *reinterpret_cast<bf16x8*>(dst + (size_t)r * ldd + c) = *reinterpret_cast<const bf16x8*>(sf_hi(src + (size_t)r * lds + c));
+    }
+}
+int k_sf_image(const sf32* src, int lds, bf16_t* dst, int ldd, int rows, int cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return RGQA_OK;
+    RGQA_REQUIRE(cols % 8 == 0 && lds % 32 == 0 && ldd % 8 == 0 && ((uintptr_t)src % 128) == 0 && ((uintptr_t)dst % 16) == 0, "sf_image: cols %% 8, whole split-f32 lines and a 16-byte aligned image required");
+    const size_t nb = ((size_t)rows * (cols / 8) + 255) / 256;
+    hipLaunchKernelGGL(sf_image_kernel, dim3(nb > 2048 ? 2048 : (int)nb), dim3(256), 0, s, src, lds, dst, ldd, rows, cols / 8);
+    RGQA_LAUNCH_CHECK("sf_image_kernel");
+    return RGQA_OK;
+}
+
 // out[i] (+)= sum_s part[s][i]  (fixed order: deterministic split-K reduction of a weight gradient)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int S, size_t n, float* __restrict__ out, int accumulate) {
     const size_t nv = n >> 2;

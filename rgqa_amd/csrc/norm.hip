@@ -10,7 +10,7 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const float* gamma,
                                                      const float* beta, T* __restrict__ y, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int N, float eps,
-                                                     int split, const float* __restrict__ gamma2, const float* __restrict__ beta2) {
+                                                     int split, const float* __restrict__ gamma2, const float* __restrict__ beta2, bf16_t* __restrict__ yb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
             store4(y + (size_t)row * ldy + c * 4, o);
+            if (yb) store4(yb + (size_t)row * ldy + c * 4, o);
         }
     }
     if (lane == 0) {
@@ -62,24 +63,39 @@ __device__ __forceinline__ float half_sum(float v) {
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-template <int NC>
-__global__ __launch_bounds__(256) void ln_fwd16_kernel(const bf16_t* __restrict__ x, int ldx, const float* gamma, const float* beta, bf16_t* __restrict__ y, int ldy,
+// 8 consecutive elements (first index a multiple of 8) of a bf16 / split-f32 row: one / two 16-byte accesses per lane
+__device__ __forceinline__ void ld8(const bf16_t* p, float v[8]) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+}
+__device__ __forceinline__ void ld8(const sf32* p, float v[8]) { sf_load8(p, v); }
+__device__ __forceinline__ void st8(bf16_t* p, const float v[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+__device__ __forceinline__ void st8(sf32* p, const float v[8]) { sf_store8(p, v); }
+// T = bf16_t or sf32 (round 4: the split-f32 rows of the bf16x3 precisions ran on the generic kernel's 8-byte accesses); yb: optional bf16
+// image of a split-f32 result (bf16x3_fwd precision)
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_fwd16_kernel(const T* __restrict__ x, int ldx, const float* gamma, const float* beta, T* __restrict__ y, int ldy,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int M, float eps, int split,
-                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2) {
+                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2, bf16_t* __restrict__ yb) {
     constexpr int N = 256 * NC;
     const int hl = threadIdx.x & 31;
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (row >= M) return;                                   // a whole half-wave leaves: the shuffles below stay inside a half
     if (row >= split) { gamma = gamma2; beta = beta2; }
-    bf16x8 raw[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) raw[i] = *reinterpret_cast<const bf16x8*>(x + (size_t)row * ldx + (hl + 32 * i) * 8);
     float v[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) ld8(x + (size_t)row * ldx + (hl + 32 * i) * 8, v[i]);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v[i][j] = (float)raw[i][j]; s += v[i][j]; }
+        for (int j = 0; j < 8; ++j) s += v[i][j];
     const float mu = half_sum(s) * (1.0f / (float)N);
     float q = 0.f;
 #pragma unroll
@@ -90,13 +106,13 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = (hl + 32 * i) * 8;
-        float g[8], b[8];
+        float g[8], b[8], o[8];
         load4(gamma + c, g); load4(gamma + c + 4, g + 4);
         load4(beta + c, b); load4(beta + c + 4, b + 4);
-        bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((v[i][j] - mu) * rs * g[j] + b[j]);
-        *reinterpret_cast<bf16x8*>(y + (size_t)row * ldy + c) = o;
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+        st8(y + (size_t)row * ldy + c, o);
+        if (yb) st8(yb + (size_t)row * ldy + c, o);
     }
     if (hl == 0) {
         if (mean) mean[row] = mu;
@@ -431,18 +447,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 
 template <typename T>
 int k_ln_fwd2(const T* x, int ldx, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, T* y, int ldy, float* mean, float* rstd,
-              int M, int N, float eps, hipStream_t s) {
+              int M, int N, float eps, hipStream_t s, bf16_t* y_b) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: N=%d must be a multiple of 4 and <= %d", N, LN_MAXV * 256);
+    RGQA_REQUIRE(y_b == nullptr || (std::is_same<T, sf32>::value && ((uintptr_t)y_b % 16) == 0 && ldy % 8 == 0), "layernorm: the bf16 image goes with split-f32 rows (16-byte aligned, ldy %% 8)");
     if (M <= 0) return RGQA_OK;
-    if (std::is_same<T, bf16_t>::value && (N == 768 || N == 1536) && ldx % 8 == 0 && ldy % 8 == 0 &&
-        ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0) {
-        const bf16_t* xb = reinterpret_cast<const bf16_t*>(x); bf16_t* yb = reinterpret_cast<bf16_t*>(y);
-        if (N == 768) hipLaunchKernelGGL(ln_fwd16_kernel<3>, dim3(cdiv(M, 8)), dim3(256), 0, s, xb, ldx, gamma, beta, yb, ldy, mean, rstd, M, eps, split, gamma2, beta2);
-        else hipLaunchKernelGGL(ln_fwd16_kernel<6>, dim3(cdiv(M, 8)), dim3(256), 0, s, xb, ldx, gamma, beta, yb, ldy, mean, rstd, M, eps, split, gamma2, beta2);
-        RGQA_LAUNCH_CHECK("ln_fwd16_kernel");
-        return RGQA_OK;
+    if constexpr (!std::is_same<T, float>::value) {
+        constexpr int AL = std::is_same<T, sf32>::value ? 128 : 16, LDM = std::is_same<T, sf32>::value ? 32 : 8;
+        if ((N == 768 || N == 1536) && ldx % LDM == 0 && ldy % LDM == 0 && ((uintptr_t)x % AL) == 0 && ((uintptr_t)y % AL) == 0) {
+            if (N == 768) hipLaunchKernelGGL((ln_fwd16_kernel<T, 3>), dim3(cdiv(M, 8)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, eps, split, gamma2, beta2, y_b);
+            else hipLaunchKernelGGL((ln_fwd16_kernel<T, 6>), dim3(cdiv(M, 8)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, eps, split, gamma2, beta2, y_b);
+            RGQA_LAUNCH_CHECK("ln_fwd16_kernel");
+            return RGQA_OK;
+        }
     }
-#define LN_FWD(NVV) hipLaunchKernelGGL((ln_fwd_kernel<T, NVV>), dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, split, gamma2, beta2)
+#define LN_FWD(NVV) hipLaunchKernelGGL((ln_fwd_kernel<T, NVV>), dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, split, gamma2, beta2, y_b)
     const int nvl = cdiv(N / 4, 64);
     if (nvl <= 1) LN_FWD(1); else if (nvl == 2) LN_FWD(2); else if (nvl == 3) LN_FWD(3); else if (nvl == 4) LN_FWD(4);
     else if (nvl <= 6) LN_FWD(6); else LN_FWD(8);
@@ -451,8 +469,8 @@ int k_ln_fwd2(const T* x, int ldx, const float* gamma, const float* beta, const 
     return RGQA_OK;
 }
 template <typename T>
-int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s) {
-    return k_ln_fwd2<T>(x, ldx, gamma, beta, gamma, beta, M, y, ldy, mean, rstd, M, N, eps, s);
+int k_ln_fwd(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean, float* rstd, int M, int N, float eps, hipStream_t s, bf16_t* y_b) {
+    return k_ln_fwd2<T>(x, ldx, gamma, beta, gamma, beta, M, y, ldy, mean, rstd, M, N, eps, s, y_b);
 }
 
 // waves per block: narrow rows live on occupancy (16 waves = 4 per SIMD at <= 128 VGPRs with 2-byte elements); the 4-byte element types (f32,
@@ -564,12 +582,12 @@ int k_colsum(const T* x, int ldx, float* part, float* out, int accumulate, int M
     return k_colsum_finalize(part, nblk, 1, N, fo, accumulate, s);
 }
 
-template int k_ln_fwd2<float>(const float*, int, const float*, const float*, const float*, const float*, int, float*, int, float*, float*, int, int, float, hipStream_t);
-template int k_ln_fwd2<bf16_t>(const bf16_t*, int, const float*, const float*, const float*, const float*, int, bf16_t*, int, float*, float*, int, int, float, hipStream_t);
-template int k_ln_fwd2<sf32>(const sf32*, int, const float*, const float*, const float*, const float*, int, sf32*, int, float*, float*, int, int, float, hipStream_t);
-template int k_ln_fwd<float>(const float*, int, const float*, const float*, float*, int, float*, float*, int, int, float, hipStream_t);
-template int k_ln_fwd<bf16_t>(const bf16_t*, int, const float*, const float*, bf16_t*, int, float*, float*, int, int, float, hipStream_t);
-template int k_ln_fwd<sf32>(const sf32*, int, const float*, const float*, sf32*, int, float*, float*, int, int, float, hipStream_t);
+template int k_ln_fwd2<float>(const float*, int, const float*, const float*, const float*, const float*, int, float*, int, float*, float*, int, int, float, hipStream_t, bf16_t*);
+template int k_ln_fwd2<bf16_t>(const bf16_t*, int, const float*, const float*, const float*, const float*, int, bf16_t*, int, float*, float*, int, int, float, hipStream_t, bf16_t*);
+template int k_ln_fwd2<sf32>(const sf32*, int, const float*, const float*, const float*, const float*, int, sf32*, int, float*, float*, int, int, float, hipStream_t, bf16_t*);
+template int k_ln_fwd<float>(const float*, int, const float*, const float*, float*, int, float*, float*, int, int, float, hipStream_t, bf16_t*);
+template int k_ln_fwd<bf16_t>(const bf16_t*, int, const float*, const float*, bf16_t*, int, float*, float*, int, int, float, hipStream_t, bf16_t*);
+template int k_ln_fwd<sf32>(const sf32*, int, const float*, const float*, sf32*, int, float*, float*, int, int, float, hipStream_t, bf16_t*);
 template int k_ln_bwd2<float>(const float*, int, const float*, int, const float*, const float*, float*, float*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
 template int k_ln_bwd2<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, bf16_t*, bf16_t*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
 template int k_ln_bwd2<sf32>(const sf32*, int, const sf32*, int, const float*, const float*, sf32*, sf32*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);

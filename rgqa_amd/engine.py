@@ -9,7 +9,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import Config, check, ptr, PREC_BF16, PREC_BF16X3, PREC_F32
+from ._lib import Config, check, ptr, PREC_BF16, PREC_BF16X3, PREC_BF16X3_FWD, PREC_F32
 
 
 def _stream():
@@ -54,10 +54,11 @@ class Engine:
         self.lib = _lib.load()
         self.precision = precision
         # "bf16x3": split-f32 operands, three bf16 MFMA products per f32 product - the fast mode inside the reference's 1e-3 logits bound;
+        # "bf16x3_fwd": that forward pass (same kernels, same logits) with the bf16 backward pass - BASELINE config 3 prescribes a bf16 backward;
         # "bf16": BASELINE config 3's mode (outside that bound); "f32": exact f32 FMA arithmetic on the vector ALU (slow; the on-device reference)
-        precision = {"fp32": "f32", "x3": "bf16x3"}.get(precision, precision)
+        precision = {"fp32": "f32", "x3": "bf16x3", "x3fwd": "bf16x3_fwd"}.get(precision, precision)
         self.precision = precision
-        prec = {"bf16": PREC_BF16, "f32": PREC_F32, "bf16x3": PREC_BF16X3}[precision]
+        prec = {"bf16": PREC_BF16, "f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x3_fwd": PREC_BF16X3_FWD}[precision]
         self.cfg = Config(vocab_size, hidden, heads, inter, max_pos, type_vocab, l_layers, x_layers, r_layers, feat_dim,
                           pos_dim, num_answers, prec, ln_eps, hidden_dropout, attn_dropout, arch, emb_dim)
         h = C.c_void_p()
@@ -115,6 +116,9 @@ class Engine:
         elif self.precision == "bf16x3":     # split-f32 operand copies: 4 bytes per element slot (csrc/common.h sf32), opaque to torch
             self.params_lp = torch.zeros(n, dtype=torch.int32, device=device)
             self.params_lp_t = torch.zeros(n, dtype=torch.int32, device=device)
+        elif self.precision == "bf16x3_fwd":     # forward operand copy split f32, the backward's (transposed) copy bf16
+            self.params_lp = torch.zeros(n, dtype=torch.int32, device=device)
+            self.params_lp_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
         self.shape = None
         return self
 
@@ -305,7 +309,7 @@ class Engine:
             for i, (a, b) in enumerate(rngs):
                 check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
         self._seg_sumsq_valid = False
-        lp_split = 1 if self.precision == "bf16x3" else 0
+        lp_split = 1 if self.precision in ("bf16x3", "bf16x3_fwd") else 0
         for a, b in rngs:
             lp = ptr(self.params_lp[a:b]) if self.params_lp is not None else None
             check(self.lib.rgqa_bertadam_step(ptr(self.params[a:b]), ptr(self.grads[a:b]), ptr(self.adam_m[a:b]), ptr(self.adam_v[a:b]),

@@ -228,7 +228,7 @@ class BertAdam(Optimizer):
                     eng = _engine.engine_of(r["p0"])
                     if eng is not None and eng.params_lp is not None and r["g0"] - eng.grads.data_ptr() == r["p0"] - eng.params.data_ptr():
                         off = (r["p0"] - eng.params.data_ptr()) // 4
-                        lp_split = 1 if eng.precision == "bf16x3" else 0
+                        lp_split = 1 if eng.precision in ("bf16x3", "bf16x3_fwd") else 0
                         lp = C.c_void_p(eng.params_lp.data_ptr() + off * eng.params_lp.element_size())
                         ent = touched.setdefault(id(eng), [eng, 0, None])
                         ent[1] += sum(p.numel() for p in r["params"])
