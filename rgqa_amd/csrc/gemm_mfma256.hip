@@ -130,6 +130,11 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     const GemmProblem& P = g.p[pi];
     // tile order inside a problem: consecutive ids run over the M-tiles of one N-tile first, so neighbours stream the same B
     // operand (the wider one); blocks that share an XCD (equal id mod 8) get consecutive ids.
+    // Round 4 measured two alternatives, both removed (profiles/r04_wgrad_cost_probe.txt, profiles/r04_pmc_tcc_hit_*.json): (1) ONE contiguous
+    // run of the whole launch's tile list per XCD, each XCD holding a compact sub-grid of one weight matrix: L2 hit rate 0.39 -> 0.68, fabric
+    // requests halved, serialised time unchanged (3.33 -> 3.39 ms per step) and the step 0.85 ms SLOWER (the long-contraction problems then
+    // sit on four of the eight XCDs, whose CUs the main stream's launches wait for); (2) a five-slot ring of 32-row K-steps (three K-steps in
+    // flight instead of one): +0.35 ms per step.  The loop is bound neither by where its lines come from nor by how early they are requested.
     // (Round 4 measured the alternative - ONE contiguous run of the whole launch's tile list per XCD, each XCD then holding a compact
     // sub-grid of one weight matrix: L2 hit rate of this kernel 0.39 -> 0.68, fabric requests halved (profiles/r04_pmc_tcc_hit_*.json),
     // serialised time unchanged (3.33 -> 3.39 ms per step) and the step 0.85 ms SLOWER (11.93 -> 12.78, three interleaved rounds,

@@ -421,8 +421,9 @@ def test_mixed_cfg3_b256_fwd_bwd_vs_oracle():
 
 def test_mixed_train_steps_follow_the_bf16x3_run():
     """Three optimizer steps (dropout off) of the bf16x3_fwd engine next to the bf16x3 engine from the same weights.  BertAdam's update is
-    m / (sqrt(v) + eps): a sign-like +-lr per step, so an element whose tiny gradient changes sign under bf16 rounding moves the other way -
-    the two runs can differ by at most 2 lr per element and step, and the logits of the fourth forward stay close."""
+    m / (sqrt(v) + eps) without bias correction: sign-like, up to 0.1 / sqrt(0.001) = 3.2 lr per element in the first steps, so an element whose
+    tiny gradient changes sign under bf16 rounding moves the other way - the two runs can differ by ~6 lr per element and step; the logits of
+    the fourth forward stay close."""
     B, T, O = 6, 12, 10
     raw = synth.synth_batch(B, T, O=O, F=MED["feat_dim"], NA=MED["num_answers"], vocab=MED["vocab_size"], seed=5, min_len=2)
     b = dev(raw)
@@ -441,8 +442,8 @@ def test_mixed_train_steps_follow_the_bf16x3_run():
     dl = float((res["bf16x3"][0] - res["bf16x3_fwd"][0]).abs().max())
     dp = float((res["bf16x3"][1] - res["bf16x3_fwd"][1]).abs().max())
     _report("bf16x3_fwd vs bf16x3 after 3 steps (medium config)", logits_diff=dl, weights_diff=dp)
-    assert dp <= 3 * 2 * lr * 1.1, dp
-    assert dl < 5e-3, dl
+    assert dp <= 3 * 2 * 3.2 * lr * 1.05, dp
+    assert dl < 1e-2, dl
 
 
 def test_dropout_train_mode_is_deterministic_and_consistent():
