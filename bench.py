@@ -214,7 +214,7 @@ def supervise(n_self_launch):
     return rc
 
 
-def dp_selfcheck(dist, mode, device):
+def dp_selfcheck(dist, mode, device, precision="bf16"):
     """Every collective the chosen exchange needs, once, on 1 MB, checked numerically - so that a broken or hanging collective is a fast
     non-zero exit (the process group carries a short timeout) before any warm-up step, not a silent hang of the timed region."""
     W, r = dist.get_world_size(), dist.get_rank()
@@ -223,14 +223,17 @@ def dp_selfcheck(dist, mode, device):
     t = torch.full((n,), float(r + 1), device=device)
     dist.all_reduce(t)
     ok = bool((t == want).all())
-    if mode == "allreduce_bf16":
+    from rgqa_amd.parallel import payload_dtype
+    kind, _, forced = mode.partition("_")
+    pdt = payload_dtype(precision, forced or None)          # what this exchange puts on the wire: bf16 or f32 by the engine's precision
+    if kind == "allreduce" and pdt == torch.bfloat16:
         tb = torch.full((n,), float(r + 1), device=device, dtype=torch.bfloat16)
         dist.all_reduce(tb)
         ok = ok and bool((tb.float() == want).all())
-    if mode == "sharded":
+    if kind == "sharded":
         s = n // W
-        send = torch.full((W * s,), float(r + 1), device=device, dtype=torch.bfloat16)
-        recv = torch.zeros(W * s, device=device, dtype=torch.bfloat16)
+        send = torch.full((W * s,), float(r + 1), device=device, dtype=pdt)
+        recv = torch.zeros(W * s, device=device, dtype=pdt)
         dist.all_to_all_single(recv, send)
         ok = ok and bool((recv.view(W, s).float() == torch.arange(1, W + 1, device=device, dtype=torch.float32)[:, None]).all())
         full = torch.zeros(W * s, device=device, dtype=torch.bfloat16)
@@ -254,7 +257,7 @@ def launch_check(world, rank, fail_rank, fail_mode):
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
     t = torch.ones(1)
     if world > 1:
-        dp_selfcheck(dist, "allreduce" if mode == "sharded" else mode, torch.device("cpu"))      # (gloo has no all_to_all on CPU tensors in every build)
+        dp_selfcheck(dist, "allreduce" if mode.startswith("sharded") else mode, torch.device("cpu"), "f32")      # (gloo has no all_to_all on CPU tensors in every build)
         dist.all_reduce(t)
         seen = dist.get_world_size()
     else:
@@ -439,7 +442,7 @@ def main():
         else:       # rehearsal only: RCCL refuses two ranks on one device; gloo stages the same collectives through the host
             dist.init_process_group("gloo", timeout=tmo)
         if dist.get_backend() == "nccl":
-            dp_selfcheck(dist, dp_mode, torch.device("cuda", local))
+            dp_selfcheck(dist, dp_mode, torch.device("cuda", local), args.precision)
     elif os.environ.get("RGQA_BENCH_RCCL_REHEARSAL") == "1":
         # one-GPU rehearsal of the N > 1 path ON RCCL: a process group of ONE rank, so every collective of the chosen exchange runs through
         # the library (group creation with device_id and timeout, the bf16 all-to-all, the in-place all-gather, the scalar all-reduce) and
@@ -448,7 +451,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
                                 device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=120))
-        dp_selfcheck(dist, dp_mode, torch.device("cuda", local))
+        dp_selfcheck(dist, dp_mode, torch.device("cuda", local), args.precision)
 
     from rgqa_amd.engine import Engine
     from rgqa_amd import synth
@@ -500,9 +503,12 @@ def main():
             dev.update(feats=f2, boxes=b2, target=t2, input_ids=ids2, input_mask=mask2, segment_ids=seg2)
     e.ensure_shape(MB, T, O)
     e.sync_weights()
-    comm = make_exchange(e, dist, mode=dp_mode) if dist is not None else None      # RGQA_DP_MODE: sharded (default) | allreduce | allreduce_bf16
+    comm = make_exchange(e, dist, mode=dp_mode) if dist is not None else None      # RGQA_DP_MODE: sharded (default) | allreduce, payload by precision (rgqa_amd/parallel.py)
     if dist is None and not args.butd:
         e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
+    # (under an exchange the norm belongs to the REDUCED gradients: the sharded exchange takes each owner's share while it sums the shards,
+    # so backward's per-segment sums of the local gradients are left off - 21 launches of side-stream time; the collective-free legs below
+    # switch them on)
     t_total = 10000
     state = dict(step=0, lengths=lengths, comm=comm)
 
@@ -573,6 +579,8 @@ def main():
             dp_legs["alt_ms_per_step"] = round(timed_leg(n2), 3)
             alt.release()
         state["comm"] = None
+        if not args.butd:
+            e.enable_segment_sumsq(True)          # local gradients, whole-arena optimizer: the single-GPU step
         for _ in range(2):
             step(exchange=False)
         local_ms = timed_leg(n2, exchange=False)

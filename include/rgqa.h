@@ -191,6 +191,11 @@ int rgqa_cast_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
 int rgqa_split_f32(const float* src, void* dst_split, size_t n, void* stream);
 int rgqa_unsplit_f32(const void* src_split, float* dst, size_t n, void* stream);
 int rgqa_sum_bf16_parts(const void* parts_bf16, size_t part_stride, int nparts, float* dst, size_t n, void* stream);
+/* The general form: parts are bf16 (parts_f32 = 0: the payload of bf16 / bf16x3_fwd engines) or f32 (1: f32 / bf16x3 engines, whose gradients
+ * are exact beyond bf16); with sq_ws (>= 1025 floats of scratch, any content) and sumsq_accum (device scalar) the kernel also ADDS
+ * sum(dst^2) to *sumsq_accum - the owner's share of clip_grad_norm_'s norm (tasks/gqa_conf.py:201) without a second pass. */
+int rgqa_sum_parts(const void* parts, int parts_f32, size_t part_stride, int nparts, float* dst, size_t n, float* sq_ws, float* sumsq_accum,
+                   void* stream);
 
 /* ---- batch construction: replaces the host loop of RoI-mixup (tasks/gqa_mixup_vis.py:134-181).
  * feats [2B,O,F] / boxes [2B,O,4] with rows [0,B) filled; partner [B] i32; take_pos [B,O] u8 (1 = RoI taken from

@@ -57,6 +57,7 @@ SIGNATURES = {
     "rgqa_split_f32": [_vp, _vp, _sz, _vp],
     "rgqa_unsplit_f32": [_vp, _vp, _sz, _vp],
     "rgqa_sum_bf16_parts": [_vp, _sz, _i, _vp, _sz, _vp],
+    "rgqa_sum_parts": [_vp, _i, _sz, _i, _vp, _sz, _vp, _vp, _vp],
     "rgqa_mixup_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_mixup_perturb": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "rgqa_mixup_weighted_sum": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -208,6 +208,10 @@ int rgqa_sum_bf16_parts(const void* parts_bf16, size_t part_stride, int nparts, 
     RGQA_REQUIRE(parts_bf16 && dst && nparts >= 1, "sum_bf16_parts: bad argument");
     return k_sum_bf16_parts(parts_bf16, part_stride, nparts, dst, n, S(stream));
 }
+int rgqa_sum_parts(const void* parts, int parts_f32, size_t part_stride, int nparts, float* dst, size_t n, float* sq_ws, float* sumsq_accum, void* stream) {
+    RGQA_REQUIRE(parts && dst && nparts >= 1, "sum_parts: bad argument");
+    return k_sum_parts(parts, parts_f32, part_stride, nparts, dst, n, sq_ws, sumsq_accum, S(stream));
+}
 int rgqa_mixup_gather(float* feats, float* boxes, const int32_t* partner, const uint8_t* take_pos, int B, int O, int F, int mode_v3, void* stream) {
     RGQA_REQUIRE(feats && boxes && partner && take_pos, "mixup_gather: null argument");
     return k_mixup_gather(feats, boxes, partner, take_pos, B, O, F, mode_v3, S(stream));

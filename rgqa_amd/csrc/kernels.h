@@ -139,6 +139,7 @@ int k_cast_transpose(const void* src, int src_is_bf16, void* dst, int dst_split,
 int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 int k_cast_split(const float* src, void* dst_split, size_t n, hipStream_t s);
 int k_sum_bf16_parts(const void* parts, size_t stride, int nparts, float* dst, size_t n, hipStream_t s);
+int k_sum_parts(const void* parts, int parts_f32, size_t stride, int nparts, float* dst, size_t n, float* sq_ws /* >= 1025 floats or null */, float* sq_out /* += sum(dst^2), or null */, hipStream_t s);
 
 // ---- misc.hip
 // RoI-mixup gather (gqa_mixup_vis.py:134-181): rows [B,2B) of feats/boxes built from partner + positive rows

@@ -24,17 +24,20 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     __syncthreads();
     int* ticket = reinterpret_cast<int*>(partial + 1024);
     if (threadIdx.x == 0) {
-        __hip_atomic_store(partial + blockIdx.x, red[0] + red[1] + red[2] + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1 store: visible beyond this CU's L2 slice
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Hand-off without fences.  Round 3 bracketed it with agent-scope release / acquire fences: a release is a write-back of the XCD's
+        // whole L2 - per block, 1024 blocks per launch, 21 launches per step beside the GEMMs whose results were sitting there: 0.33 ms of
+        // the train step (tools/sumsq_probe.py).  Now every access to a partial is a RETURNING read-modify-write atomic at agent scope
+        // (performed at the memory side, never served from a CU's L1 or another XCD's L2), and the publishing lane's exchange has returned -
+        // i.e. has been performed - before it draws its ticket; the block whose ticket is last reads behind the workgroup barrier.
+        const unsigned old = __hip_atomic_exchange(reinterpret_cast<unsigned*>(partial) + blockIdx.x, __float_as_uint(red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" :: "v"(old) : "memory");               // the returned value is waited for here
         last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
     }
     __syncthreads();
     if (!last) return;                                          // block-uniform
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
     double t = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+        t += (double)__uint_as_float(__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(partial) + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
     __shared__ double redd[4];
@@ -197,34 +200,78 @@ int k_cast_split(const float* src, void* dst, size_t n, hipStream_t s) {
 }
 
 // Data-parallel exchange (rgqa_amd/parallel.py): dst[i] = sum_r f32(parts[r * stride + i]), r ascending (f32 accumulation of the
-// bf16 gradient shards every rank received for the range it owns - deterministic, unlike an in-network bf16 reduction)
-__global__ __launch_bounds__(256) void sum_bf16_parts_kernel(const bf16_t* __restrict__ parts, size_t stride, int nparts, float* __restrict__ dst, size_t n) {
+// gradient shards every rank received for the range it owns - deterministic, unlike an in-network reduction).  PT = bf16_t (bf16 /
+// bf16x3_fwd engines: bf16 payload) or float (f32 / bf16x3 engines).  With sq_out the kernel also leaves sum(dst^2) behind - the owner's share
+// of the clip norm, taken while every element is in registers instead of by a second pass over the range: per-block partials, the last
+// block (agent-scope ticket at sq_ws[1024], zeroed on the stream by the launcher) folds them in index order and ADDS to *sq_out.
+__device__ __forceinline__ void ld8p(const bf16_t* p, float v[8]) {         // one 16-byte access
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+}
+__device__ __forceinline__ void ld8p(const float* p, float v[8]) { load4(p, v); load4(p + 4, v + 4); }
+template <typename PT>
+__global__ __launch_bounds__(256) void sum_parts_kernel(const PT* __restrict__ parts, size_t stride, int nparts, float* __restrict__ dst, size_t n,
+                                                        float* __restrict__ sq_ws, float* __restrict__ sq_out) {
     const size_t nv = n >> 3;
+    float sq = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < nparts; ++r) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(parts + (size_t)r * stride + i * 8);
+            float v[8];
+            ld8p(parts + (size_t)r * stride + i * 8, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sq += acc[j] * acc[j];
         store4(dst + i * 8, acc); store4(dst + i * 8 + 4, acc + 4);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
         const size_t i = (nv << 3) + threadIdx.x;
         float a = 0.f;
-        for (int r = 0; r < nparts; ++r) a += (float)parts[(size_t)r * stride + i];
+        for (int r = 0; r < nparts; ++r) a += to_f32(parts[(size_t)r * stride + i]);
         dst[i] = a;
+        sq += a * a;
     }
+    if (sq_out == nullptr) return;
+    __shared__ float red[4];
+    __shared__ int last;
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    int* ticket = reinterpret_cast<int*>(sq_ws + 1024);
+    if (threadIdx.x == 0) {
+        // as in sumsq_kernel: returning agent-scope atomics on the partials, no fences
+        const unsigned old = __hip_atomic_exchange(reinterpret_cast<unsigned*>(sq_ws) + blockIdx.x, __float_as_uint(red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" :: "v"(old) : "memory");
+        last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last) return;                                          // block-uniform
+    double t = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+        t += (double)__uint_as_float(__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(sq_ws) + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    __shared__ double redd[4];
+    if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) *sq_out += (float)(redd[0] + redd[1] + redd[2] + redd[3]);
 }
-int k_sum_bf16_parts(const void* parts, size_t stride, int nparts, float* dst, size_t n, hipStream_t s) {
+int k_sum_parts(const void* parts, int parts_f32, size_t stride, int nparts, float* dst, size_t n, float* sq_ws, float* sq_out, hipStream_t s) {
     if (n == 0) return RGQA_OK;
-    RGQA_REQUIRE(((uintptr_t)parts % 16) == 0 && ((uintptr_t)dst % 16) == 0 && (stride % 8) == 0, "sum_bf16_parts: 16-byte alignment / stride %% 8 required");
+    RGQA_REQUIRE(((uintptr_t)parts % 16) == 0 && ((uintptr_t)dst % 16) == 0 && (stride % 8) == 0, "sum_parts: 16-byte alignment / stride %% 8 required");
+    RGQA_REQUIRE((sq_out == nullptr) == (sq_ws == nullptr), "sum_parts: the norm share needs both its scratch (>= 1025 floats) and its output");
     size_t nb = (n / 8 + 255) / 256;
-    int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
-    hipLaunchKernelGGL(sum_bf16_parts_kernel, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(parts), stride, nparts, dst, n);
-    RGQA_LAUNCH_CHECK("sum_bf16_parts_kernel");
+    int nblk = nb > 1024 ? 1024 : (nb < 1 ? 1 : (int)nb);
+    if (sq_ws) RGQA_HIP(hipMemsetAsync(sq_ws + 1024, 0, sizeof(int), s));
+    if (parts_f32) hipLaunchKernelGGL(sum_parts_kernel<float>, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const float*>(parts), stride, nparts, dst, n, sq_ws, sq_out);
+    else hipLaunchKernelGGL(sum_parts_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(parts), stride, nparts, dst, n, sq_ws, sq_out);
+    RGQA_LAUNCH_CHECK("sum_parts_kernel");
     return RGQA_OK;
 }
+int k_sum_bf16_parts(const void* parts, size_t stride, int nparts, float* dst, size_t n, hipStream_t s) { return k_sum_parts(parts, 0, stride, nparts, dst, n, nullptr, nullptr, s); }
 
 // Batched cast + transpose of every linear weight: dst[k][n] = bf16(src[n][k]); TRANSPOSE_TILE^2 (64x64) tiles through LDS:
 // float4 reads of 256-B row pieces, 8-B writes of full 128-B destination lines (the 32x32 / 2-B-store version ran at 58 % of

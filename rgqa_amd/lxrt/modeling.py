@@ -426,12 +426,17 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
             b.ensure(device)
 
     def _dp_exchange(self):
-        """The gradient exchange of this module's engine (rgqa_amd.parallel; RGQA_DP_MODE=allreduce_bf16 halves the payload)."""
+        """The gradient exchange of this module's engine (rgqa_amd.parallel): an all-reduce - the unchanged trainer owns the optimizer object,
+        which steps every parameter, so the sharded-optimizer exchange of bench.py does not apply here - whose payload follows the engine's
+        precision exactly as there (bf16 under bf16 / bf16x3_fwd, f32 under f32 / bf16x3; RGQA_DP_MODE=allreduce_bf16 / allreduce_f32 force one)."""
         ex = self.__dict__.get("_dp_ex")
         if ex is None or ex.e is not self._binding.engine:
             import torch.distributed as dist
-            from ..parallel import GradAllReduce
-            ex = GradAllReduce(self._binding.engine, dist, bf16=os.environ.get("RGQA_DP_MODE", "allreduce") == "allreduce_bf16")
+            from ..parallel import make_exchange
+            mode = os.environ.get("RGQA_DP_MODE", "allreduce")
+            if mode.startswith("sharded"):
+                mode = "allreduce" + mode[len("sharded"):]
+            ex = make_exchange(self._binding.engine, dist, mode=mode)
             self.__dict__["_dp_ex"] = ex
         return ex
 

@@ -3,14 +3,18 @@ on ROCm; "gloo" in the CPU / single-GPU tests).
 
 Replaces the reference's single-process nn.DataParallel (lxrt/entry.py:102-103): samples are independent through the whole
 forward, so each rank runs its own shard of the batch and the only exchange per step is the gradient arena.
-Three modes (`make_exchange`, env RGQA_DP_MODE; RGQA_DP_OVERLAP=0 issues any of them after backward instead of beside it):
+THE PAYLOAD FOLLOWS THE ENGINE'S PRECISION in every mode (payload_dtype): bf16 under `bf16` and `bf16x3_fwd` engines, whose gradients carry
+bf16 rounding anyway (410 MB); f32 under `f32` and `bf16x3` engines, whose gradients are exact to 1e-5 and must not be rounded to 8 bits on
+the wire (819 MB).  The suffixes _bf16 / _f32 force one.  Modes (`make_exchange`, env RGQA_DP_MODE; RGQA_DP_OVERLAP=0 issues any of them
+after backward instead of beside it):
 
-  allreduce        f32 SUM all-reduce of the live arena ranges (819 MB), buckets of >= 64 MB issued from a side stream as backward
-                   finalises them; every rank then clips and runs BertAdam over the whole arena (round 1).
-  allreduce_bf16   the same exchange with a bf16 payload (410 MB): cast -> SUM all-reduce -> back to f32.
-  sharded          (default) reduce-scatter as ONE all-to-all per chunk with a bf16 payload: rank r receives every rank's bf16 copy
-                   of the 1/N range it owns and accumulates them in f32 in rank order (rgqa_sum_bf16_parts: deterministic, no
-                   bf16 running sum); clip + BertAdam then touch only that 1/N (sum(g^2) of the shards is one scalar
+  allreduce        SUM all-reduce of the live arena ranges, buckets of >= 64 MB issued from a side stream as backward finalises them;
+                   every rank then clips and runs BertAdam over the whole arena (round 1).  The drop-in modules' default: the
+                   unchanged trainer owns the optimizer object, which steps every parameter.
+  sharded          (bench.py's default) reduce-scatter as ONE all-to-all per chunk: rank r receives every rank's copy
+                   of the 1/N range it owns and accumulates them in f32 in rank order (rgqa_sum_parts: deterministic, no
+                   low-precision running sum) - the same pass leaves the owner's share of sum(g^2) behind, so the clip norm costs no second
+                   read; clip + BertAdam then touch only that 1/N (the shares meet in one scalar
                    all-reduce), and the updated weights are all-gathered into every rank's forward copy (bf16 engines: the bf16
                    copy, plus - in f32 - what the forward reads from the masters: biases, LayerNorm parameters, embedding tables;
                    f32 / bf16x3 engines: the f32 masters).  The chunks are the gradient segments backward finalises (merged
@@ -29,6 +33,15 @@ import os
 import torch
 
 from ._lib import check, ptr
+
+
+def payload_dtype(precision, forced=None):
+    """what goes on the wire: bf16 for engines whose gradients carry bf16 rounding anyway, f32 for the others; forced = 'bf16' / 'f32'"""
+    if forced == "bf16":
+        return torch.bfloat16
+    if forced == "f32":
+        return torch.float32
+    return torch.bfloat16 if precision in ("bf16", "bf16x3_fwd") else torch.float32
 
 
 def bucket_ranges(ranges, bucket_elems):
@@ -92,8 +105,9 @@ class _HipOps:
     def cast_bf16(self, dst, src):
         check(self.lib.rgqa_cast_bf16(ptr(src), ptr(dst), src.numel(), self._s()))
 
-    def sum_parts(self, dst, parts, stride, nparts):
-        check(self.lib.rgqa_sum_bf16_parts(ptr(parts), stride, nparts, ptr(dst), dst.numel(), self._s()))
+    def sum_parts(self, dst, parts, stride, nparts, sq_ws=None, sq_out=None):
+        check(self.lib.rgqa_sum_parts(ptr(parts), 1 if parts.dtype == torch.float32 else 0, stride, nparts, ptr(dst), dst.numel(),
+                                      ptr(sq_ws) if sq_out is not None else None, ptr(sq_out), self._s()))
 
 
 class GradAllReduce:
@@ -102,7 +116,9 @@ class GradAllReduce:
     def release(self):
         pass
 
-    def __init__(self, engine, dist, bucket_mb=64, overlap=None, bf16=False, ops=None):
+    def __init__(self, engine, dist, bucket_mb=64, overlap=None, bf16=None, ops=None):
+        if bf16 is None:           # the payload follows the engine's precision
+            bf16 = payload_dtype(getattr(engine, "precision", "f32")) == torch.bfloat16
         self.e, self.dist, self.bf16 = engine, dist, bf16
         self.ops = ops if ops is not None else (_HipOps(engine.lib) if bf16 else None)
         if overlap is None:
@@ -162,8 +178,9 @@ class ShardedExchange:
     """mode 'sharded' (module docstring).  exchange(): bf16 all-to-all reduce-scatter with f32 accumulation at the owner;
     step(): sharded clip + BertAdam, bf16 weight all-gather, transposed-copy refresh."""
 
-    def __init__(self, engine, dist, chunk_mb=256, bucket_mb=64, overlap=None, ops=None, f32_chunk_elems=1 << 18):
+    def __init__(self, engine, dist, chunk_mb=256, bucket_mb=64, overlap=None, ops=None, f32_chunk_elems=1 << 18, payload=None):
         self.e, self.dist = engine, dist
+        self.payload = payload_dtype(getattr(engine, "precision", "f32"), payload)
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.ops = ops if ops is not None else _HipOps(engine.lib)
         if overlap is None:
@@ -180,9 +197,11 @@ class ShardedExchange:
             self.events = [-1] * len(self.chunks)
         self.smax = max(s for _, _, s in self.chunks)
         dev = engine.grads.device
-        self._send = torch.zeros(self.world * self.smax, dtype=torch.bfloat16, device=dev)
-        self._recv = torch.zeros(self.world * self.smax, dtype=torch.bfloat16, device=dev)
+        self._send = torch.zeros(self.world * self.smax, dtype=self.payload, device=dev)
+        self._recv = torch.zeros(self.world * self.smax, dtype=self.payload, device=dev)
         self._sumsq = self._sqws = None
+        self._sumsq_from_exchange = False
+        self._norm_read = None
         self.side = None
         backend = dist.get_backend()
         self._host_staged = backend != "nccl"      # rehearsal on one device over gloo: collectives run on host copies
@@ -221,8 +240,8 @@ class ShardedExchange:
                 self._small_own = own[in_chunk].to(dev)
 
     def describe(self):
-        return "sharded: bf16 all-to-all reduce-scatter + sharded BertAdam + %s weight all-gather, %d chunk(s) of <= %d MB, %s" % (
-            "bf16" if self.lp else "f32", len(self.chunks), self.smax * self.world * 2 >> 20,
+        return "sharded: %s all-to-all reduce-scatter (clip-norm share taken while summing) + sharded BertAdam + %s weight all-gather, %d chunk(s) of <= %d MB, %s" % (
+            "bf16" if self.payload == torch.bfloat16 else "f32", "bf16" if self.lp else "f32", len(self.chunks), self.smax * self.world * self._send.element_size() >> 20,
             "overlapped with backward" if self.overlap else "after backward")
 
     # -- collectives (RCCL on device tensors; host-staged under gloo, where device tensors are not supported by every op)
@@ -250,16 +269,27 @@ class ShardedExchange:
         if hasattr(self.e, "invalidate_segment_sumsq"):
             self.e.invalidate_segment_sumsq()
 
+        if self._sumsq is None:
+            self._sumsq = torch.zeros(1, dtype=torch.float32, device=g.device)
+            self._sqws = torch.zeros(2048, dtype=torch.float32, device=g.device)
+
         def one(a, b, s):
             n = b - a
             send, recv = self._send[:W * s], self._recv[:W * s]
-            self.ops.cast_bf16(send[:n], g[a:b])            # part r of the chunk at send[r*s : (r+1)*s]; the ragged tail is never read
+            if self.payload == torch.bfloat16:
+                self.ops.cast_bf16(send[:n], g[a:b])        # part r of the chunk at send[r*s : (r+1)*s]; the ragged tail is never read
+            elif n == W * s:
+                send = g[a:b]                               # f32 payload, whole parts: straight from the gradient arena
+            else:
+                send[:n].copy_(g[a:b])
             self._a2a(recv, send)
             lo, hi = owned((a, b, s), self.rank)
             if hi > lo:
-                self.ops.sum_parts(g[lo:hi], recv, s, W)    # f32 accumulation in rank order
+                self.ops.sum_parts(g[lo:hi], recv, s, W, self._sqws, self._sumsq)    # f32 accumulation in rank order + this range's sum(g^2)
 
+        self._sumsq_from_exchange = True
         if not (self.overlap and g.is_cuda):
+            self._sumsq.zero_()
             for c in self.chunks:
                 one(*c)
             return
@@ -268,7 +298,10 @@ class ShardedExchange:
         if self.side is None:
             self.side = torch.cuda.Stream(device=g.device)
         cur = torch.cuda.current_stream()
+        if self._norm_read is not None:
+            self.side.wait_event(self._norm_read)       # the previous step's optimizer has read the norm before it is cleared
         with torch.cuda.stream(self.side):
+            self._sumsq.zero_()
             for c, ev in zip(self.chunks, self.events):
                 self.e.wait_grad_event(ev, self.side)
                 one(*c)
@@ -293,9 +326,11 @@ class ShardedExchange:
         mine = [(lo, hi) for lo, hi in mine if hi > lo]
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev.type == "cuda" else None
         if clip:
-            self._sumsq.zero_()
-            for lo, hi in mine:
-                self._local_sumsq(lo, hi, s)
+            if not self._sumsq_from_exchange:        # gradients that did not come through exchange() (tests, a caller's own reduction)
+                self._sumsq.zero_()
+                for lo, hi in mine:
+                    self._local_sumsq(lo, hi, s)
+            self._sumsq_from_exchange = False
             if self._host_staged and self._sumsq.is_cuda:
                 t = self._sumsq.cpu()
                 self.dist.all_reduce(t)
@@ -304,6 +339,10 @@ class ShardedExchange:
                 self.dist.all_reduce(self._sumsq)        # sum over ranks of the shards' sum(g^2) = the global norm^2
         for lo, hi in mine:
             self._local_adam(lo, hi, lr_t, b1, b2, eps, weight_decay, clip, max_norm, 1.0 / W, s)
+        if dev.type == "cuda":
+            if self._norm_read is None:
+                self._norm_read = torch.cuda.Event()
+            self._norm_read.record()
         # updated weights -> every rank's forward copy
         for ci, (a, b, sz) in enumerate(self.chunks):
             f32c = ci in self.f32_chunks                  # bf16 engine, chunk with a large f32-read tensor: gather the masters, re-make the copy
@@ -377,11 +416,16 @@ class ShardedExchange:
                 p[a:b].copy_(buf[:n])
 
 
-def make_exchange(engine, dist, mode=None, **kw):
-    """mode: 'sharded' (default), 'allreduce', 'allreduce_bf16'; env RGQA_DP_MODE overrides the default."""
-    mode = mode or os.environ.get("RGQA_DP_MODE", "sharded")
-    if mode == "sharded":
-        return ShardedExchange(engine, dist, **kw)
-    if mode in ("allreduce", "allreduce_bf16"):
-        return GradAllReduce(engine, dist, bf16=(mode == "allreduce_bf16"), **kw)
-    raise ValueError("RGQA_DP_MODE must be sharded, allreduce or allreduce_bf16 (got %r)" % mode)
+MODES = ("sharded", "sharded_bf16", "sharded_f32", "allreduce", "allreduce_bf16", "allreduce_f32")
+
+
+def make_exchange(engine, dist, mode=None, default="sharded", **kw):
+    """mode: 'sharded' | 'allreduce', payload by the engine's precision (payload_dtype), or with a forcing suffix _bf16 / _f32; env RGQA_DP_MODE
+    overrides `default` (bench.py: 'sharded'; the drop-in modules: 'allreduce' - the trainer's own optimizer steps every parameter)."""
+    mode = mode or os.environ.get("RGQA_DP_MODE", default)
+    if mode not in MODES:
+        raise ValueError("RGQA_DP_MODE must be one of %s (got %r)" % (", ".join(MODES), mode))
+    kind, _, forced = mode.partition("_")
+    if kind == "sharded":
+        return ShardedExchange(engine, dist, payload=forced or None, **kw)
+    return GradAllReduce(engine, dist, bf16=(payload_dtype(getattr(engine, "precision", "f32"), forced or None) == torch.bfloat16), **kw)

@@ -227,11 +227,13 @@ class _TorchOps:
     def cast_bf16(self, dst, src):
         dst.copy_(src)
 
-    def sum_parts(self, dst, parts, stride, nparts):
+    def sum_parts(self, dst, parts, stride, nparts, sq_ws=None, sq_out=None):
         acc = torch.zeros_like(dst)
         for r in range(nparts):
             acc += parts[r * stride:r * stride + dst.numel()].float()
         dst.copy_(acc)
+        if sq_out is not None:
+            sq_out += (acc.double() ** 2).sum().float()
 
 
 def _fake_engine(n, rank, precision):
