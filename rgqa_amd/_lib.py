@@ -93,6 +93,8 @@ def load():
                            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
+        if os.environ.get("RGQA_LIB") and not hasattr(lib, name):
+            continue              # an older build named by RGQA_LIB (tools/ab_lib.sh): entry points added since are simply absent
         fn = getattr(lib, name)   # AttributeError here = header / library mismatch
         fn.argtypes = args
         fn.restype = _RESTYPES.get(name, C.c_int)

@@ -62,7 +62,14 @@ __device__ __forceinline__ const unsigned char* sf_hi(const sf32* p) {
     return reinterpret_cast<const unsigned char*>((a & ~(uintptr_t)127) + ((a & 127) >> 1));      // lo part: + 64
 }
 __device__ __forceinline__ unsigned char* sf_hi(sf32* p) { return const_cast<unsigned char*>(sf_hi(const_cast<const sf32*>(p))); }
-__device__ __forceinline__ void sf_split(float x, bf16_t& hi, bf16_t& lo) { hi = (bf16_t)x; lo = (bf16_t)(x - (float)hi); }
+// (no contraction here: with x = a * b produced just before, "x - hi" would otherwise fuse into fma(a, b, -hi) in SOME instantiations of a
+// kernel and not in others - e.g. when x has a second use - and two epilogue variants of the same GEMM would differ in the last bit of lo)
+__device__ __forceinline__ void sf_split(float x, bf16_t& hi, bf16_t& lo) {
+#pragma clang fp contract(off)
+    hi = (bf16_t)x;
+    const float r = x - (float)hi;
+    lo = (bf16_t)r;
+}
 __device__ __forceinline__ float sf_load1(const sf32* p) {
     const unsigned char* h = sf_hi(p);
     return (float)*reinterpret_cast<const bf16_t*>(h) + (float)*reinterpret_cast<const bf16_t*>(h + 64);
