@@ -32,6 +32,18 @@ template <typename T>
 class ButdEngine : public EngineBase {
 public:
     static constexpr bool LP = !std::is_same<T, float>::value;
+    static constexpr bool X3 = std::is_same<T, sf32>::value;       // split-f32 activations and effective-weight copies (bf16x3 precision)
+    static constexpr int LDM = X3 ? 32 : 8;                          // row pitches: whole 128-byte lines of split f32, 16 bytes of bf16
+    static int nt_gemm(GemmGroup& g, int out_f32, int trans_b, hipStream_t s) {
+        if constexpr (X3) return launch_gemm_nt_x3(g, out_f32, s);
+        else if constexpr (LP) return launch_gemm_nt_bf16(g, out_f32, s);
+        else return launch_gemm_f32(g, 0, trans_b, s);
+    }
+    static int tn_gemm(GemmGroup& g, hipStream_t s) {
+        if constexpr (X3) return launch_gemm_tn_x3(g, s);
+        else if constexpr (LP) return launch_gemm_tn_bf16(g, 1, s);
+        else return launch_gemm_f32(g, 1, 1, s);
+    }
     size_t emb = 0;
     BLin wih, whh, ip, qp, lin, qproj, iproj, c0, c3;
     std::vector<BLin*> lins;
@@ -42,6 +54,7 @@ public:
     const float* in_feats = nullptr; const float* in_boxes = nullptr; const int64_t* in_toks = nullptr;
     int last_train = 0; uint64_t last_seed = 0; bool have_fwd = false;
     // workspace
+    float *c3_bias_pad = nullptr;        // bf16x3: ans_classifier.3.bias zero-padded to op entries
     float *sumsq = nullptr, *sumsq_scr = nullptr, *partial = nullptr, *wlin_eff = nullptr, *att = nullptr, *logits = nullptr, *dwscr = nullptr, *dw_part = nullptr, *db_part = nullptr, *loss_dev = nullptr;
     T *X = nullptr, *GI = nullptr, *GH = nullptr, *Hall = nullptr, *Rg = nullptr, *Zg = nullptr, *Ng = nullptr, *GHN = nullptr;
     T *IF = nullptr, *IP = nullptr, *QP = nullptr, *IE = nullptr, *QR = nullptr, *IR = nullptr, *J = nullptr, *C1 = nullptr, *dlogits = nullptr;
@@ -50,7 +63,7 @@ public:
 
     explicit ButdEngine(const rgqa_config& c) {
         cfg = c;
-        H = c.hidden; E = c.emb_dim; Ep = (int)rupb(E, 8); D = c.feat_dim + c.pos_dim; Dp = (int)rupb(D, 8); NA = c.num_answers; NAp = (int)rupb(NA, 64);
+        H = c.hidden; E = c.emb_dim; Ep = (int)rupb(E, LDM); D = c.feat_dim + c.pos_dim; Dp = (int)rupb(D, LDM); NA = c.num_answers; NAp = (int)rupb(NA, 64);
         size_t cur = 0;
         auto add = [&](const std::string& name, long d0, long d1, int nd) {
             cur = rupb(cur, 64);
@@ -62,7 +75,7 @@ public:
         emb = add("w_emb.emb.weight", c.vocab_size, E, 2);
         int nnorm = 0;
         auto plain = [&](BLin& l, const std::string& wname, const std::string& bname, int o, int i) {
-            l.out = o; l.in = i; l.kp = (int)rupb(i, 8); l.op = (int)rupb(o, 64); l.wn = false; l.g = 0; l.norm = -1;
+            l.out = o; l.in = i; l.kp = (int)rupb(i, LDM); l.op = (int)rupb(o, 64); l.wn = false; l.g = 0; l.norm = -1;
             l.v = add(wname, o, i, 2);
             (void)bname;
         };
@@ -71,7 +84,7 @@ public:
         wih.b = add("q_enc.rnn.bias_ih_l0", 3 * H, 0, 1);
         whh.b = add("q_enc.rnn.bias_hh_l0", 3 * H, 0, 1);
         auto wn = [&](BLin& l, const std::string& name, int o, int i) {
-            l.out = o; l.in = i; l.kp = (int)rupb(i, 8); l.op = (int)rupb(o, 64); l.wn = true; l.norm = nnorm++;
+            l.out = o; l.in = i; l.kp = (int)rupb(i, LDM); l.op = (int)rupb(o, 64); l.wn = true; l.norm = nnorm++;
             l.b = add(name + ".bias", o, 0, 1);
             l.g = add(name + ".weight_g", 0, 0, 0);
             l.v = add(name + ".weight_v", o, i, 2);
@@ -101,10 +114,10 @@ public:
         sumsq = take<float>(64); loss_dev = take<float>(64); sumsq_scr = take<float>(1088);      // k_sumsq's partials + ticket: not shared with the column-sum scratch
         { size_t pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp; partial = take<float>(256 * pw); }
         for (BLin* l : lins) {
-            l->eff = ws_used; take<T>((size_t)l->out * l->kp);
+            l->eff = ws_used; take<T>((size_t)l->op * l->kp);          // op >= out rows: the rows past `out` stay zero (bf16x3: the logits GEMM runs over op columns)
             l->efft = ws_used; take<T>((size_t)l->kp * l->op);
         }
-        wlin_eff = take<float>(H);
+        wlin_eff = take<float>(H); c3_bias_pad = take<float>(c3.op);
         X = take<T>((size_t)B * L * Ep); GI = take<T>((size_t)B * L * 3 * H); GH = take<T>((size_t)B * 3 * H);
         Hall = take<T>((size_t)(L + 1) * B * H);
         Rg = take<T>((size_t)L * B * H); Zg = take<T>((size_t)L * B * H); Ng = take<T>((size_t)L * B * H); GHN = take<T>((size_t)L * B * H);
@@ -139,7 +152,7 @@ public:
         RGQA_REQUIRE(P != nullptr, "sync_weights: engine not bound");
         if (!eff_zeroed) {   // padding rows / columns of the effective copies must be exact zeros
             for (BLin* l : lins) {
-                CKB(rgqa_check_hip(hipMemsetAsync(effp(*l), 0, sizeof(T) * (size_t)l->out * l->kp, s), "zero eff"));
+                CKB(rgqa_check_hip(hipMemsetAsync(effp(*l), 0, sizeof(T) * (size_t)l->op * l->kp, s), "zero eff"));
                 CKB(rgqa_check_hip(hipMemsetAsync(efftp(*l), 0, sizeof(T) * (size_t)l->kp * l->op, s), "zero efft"));
             }
             eff_zeroed = true;
@@ -153,6 +166,10 @@ public:
             CKB(kb_wn_eff<T>(P + l->v, g, ss, effp(*l), l->kp, LP ? efftp(*l) : nullptr, l->op, l->out, l->in, s));
         }
         CKB(kb_wn_eff<float>(P + lin.v, P + lin.g, sumsq + lin.norm, wlin_eff, H, nullptr, 0, 1, H, s));
+        if (X3) {
+            CKB(rgqa_check_hip(hipMemsetAsync(c3_bias_pad, 0, sizeof(float) * c3.op, s), "zero padded bias"));
+            CKB(rgqa_check_hip(hipMemcpyAsync(c3_bias_pad, P + c3.b, sizeof(float) * c3.out, hipMemcpyDeviceToDevice, s), "padded bias"));
+        }
         return RGQA_OK;
     }
     int sync_transposed(hipStream_t s) override { return sync_weights(s); }
@@ -163,14 +180,14 @@ public:
         GemmGroup g; ginit(g); g.drop = drop;
         GemmProblem& p = g.p[0];
         p.A = x; p.lda = ldx; p.B = effp(l); p.ldb = l.kp; p.C = C; p.ldc = ldc; p.M = M; p.N = l.out; p.K = l.kp; p.bias = P + l.b; p.epi = epi; p.drop_site = site;
-        return LP ? launch_gemm_nt_bf16(g, out_f32, s) : launch_gemm_f32(g, 0, 0, s);
+        return nt_gemm(g, out_f32, 0, s);
     }
     // dx[M, kp] = dy[M, out(op)] @ Weff
     int gemm_dgrad(const void* dy, int lddy, int M, const BLin& l, void* dx, int lddx, int epi, const void* aux, int ldaux, DropCfg drop, hipStream_t s) {
         GemmGroup g; ginit(g); g.drop = drop;
         GemmProblem& p = g.p[0];
         p.A = dy; p.lda = lddy; p.C = dx; p.ldc = lddx; p.M = M; p.N = l.kp; p.epi = epi; p.aux = aux; p.ldaux = ldaux;
-        if (LP) { p.B = efftp(l); p.ldb = l.op; p.K = (int)rupb(l.out, 8) > l.op ? l.op : (int)rupb(l.out, 8); return launch_gemm_nt_bf16(g, 0, s); }
+        if (LP) { p.B = efftp(l); p.ldb = l.op; p.K = (int)rupb(l.out, LDM) > l.op ? l.op : (int)rupb(l.out, LDM); return nt_gemm(g, 0, 1, s); }
         p.B = effp(l); p.ldb = l.kp; p.K = l.out;
         return launch_gemm_f32(g, 0, 1, s);
     }
@@ -179,7 +196,7 @@ public:
         GemmGroup g; ginit(g);
         GemmProblem& p = g.p[0];
         p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.C = dwscr; p.ldc = l.kp; p.M = l.out; p.N = l.kp; p.K = rows; p.epi = EPI_BIAS;
-        CKB(LP ? launch_gemm_tn_bf16(g, 1, s) : launch_gemm_f32(g, 1, 1, s));
+        CKB(tn_gemm(g, s));
         CKB(kb_wn_bwd(dwscr, l.kp, P + l.v, l.wn ? P + l.g : nullptr, l.wn ? sumsq + l.norm : nullptr, partial, G + l.v, l.wn ? G + l.g : nullptr, l.out, l.in, accumulate, s));
         // bias gradient: column sums of dy (its padded columns are exact zeros) into scratch, then the first `out` of them
         CKB(k_colsum<T>((const T*)dy, lddy, partial, dwscr, 0, rows, (int)rupb(l.out, 4), s));
@@ -217,6 +234,12 @@ public:
         CKB(gemm_fwd(IE, Dp, B, iproj, IR, H, EPI_RELU, 0, nd, 0, s));
         CKB(kb_mul_fwd<T>(QR, IR, J, (size_t)B * H, s));
         CKB(gemm_fwd(J, H, B, c0, C1, 2 * H, EPI_RELU_DROP, 0, drop_raw(cfg.hidden_dropout), 2, s));
+        if (X3) {       // the split-f32 kernels want N % 8 == 0: all op = round_up(NA, 64) columns (zero weight rows, zero-padded bias: exact zeros)
+            GemmGroup g; ginit(g);
+            GemmProblem& p = g.p[0];
+            p.A = C1; p.lda = 2 * H; p.B = effp(c3); p.ldb = c3.kp; p.C = logits; p.ldc = NAp; p.M = B; p.N = c3.op; p.K = c3.kp; p.bias = c3_bias_pad; p.epi = EPI_BIAS;
+            CKB(nt_gemm(g, 1, 0, s));
+        } else
         CKB(gemm_fwd(C1, 2 * H, B, c3, logits, NAp, EPI_BIAS, 1, nd, 0, s));
         if (pooled_out) CKB(k_to_f32<T>(J, H, pooled_out, H, B, H, s));
         if (logits_out) CKB(k_fill_rows<float>(logits_out, ld_logits, logits, NAp, B, NA, s));
@@ -299,5 +322,6 @@ public:
 
 EngineBase* make_butd_engine(const rgqa_config& cfg) {
     if (cfg.precision == RGQA_PRECISION_BF16) return new ButdEngine<bf16_t>(cfg);
+    if (cfg.precision == RGQA_PRECISION_BF16X3) return new ButdEngine<sf32>(cfg);
     return new ButdEngine<float>(cfg);
 }

@@ -10,14 +10,14 @@ template <typename T>
 __global__ void butd_embed_fwd_kernel(const int64_t* __restrict__ toks, const float* __restrict__ table, T* __restrict__ out, int E, int Ep) {
     const int row = blockIdx.x;
     const int64_t id = toks[row];
-    for (int c = threadIdx.x; c < Ep; c += blockDim.x) out[(size_t)row * Ep + c] = from_f32<T>(c < E ? table[(size_t)id * E + c] : 0.f);
+    for (int c = threadIdx.x; c < Ep; c += blockDim.x) st_elem(out + ((size_t)row * Ep + c), c < E ? table[(size_t)id * E + c] : 0.f);
 }
 template <typename T>
 __global__ void butd_embed_bwd_kernel(const int64_t* __restrict__ toks, const T* __restrict__ dx, float* __restrict__ dtable, int E, int Ep, int pad_idx) {
     const int row = blockIdx.x;
     const int64_t id = toks[row];
     if (id == pad_idx) return;           // nn.Embedding(padding_idx=ntoken): no gradient (butd.py:36)
-    for (int c = threadIdx.x; c < E; c += blockDim.x) atomicAdd(dtable + (size_t)id * E + c, to_f32(dx[(size_t)row * Ep + c]));
+    for (int c = threadIdx.x; c < E; c += blockDim.x) atomicAdd(dtable + (size_t)id * E + c, ld_elem(dx + ((size_t)row * Ep + c)));
 }
 
 // ---------------------------------------------------------------- GRU gates (gate order r, z, n as torch.nn.GRU)
@@ -31,13 +31,13 @@ __global__ void gru_gate_fwd_kernel(const T* __restrict__ gi, long ldgi, const T
     const int b = i / H, h = i % H;
     const T* gib = gi + (size_t)b * ldgi;
     const T* ghb = gh + (size_t)b * 3 * H;
-    const float r = sigm(to_f32(gib[h]) + to_f32(ghb[h]));
-    const float z = sigm(to_f32(gib[H + h]) + to_f32(ghb[H + h]));
-    const float gn = to_f32(ghb[2 * H + h]);
-    const float n = tanhf(to_f32(gib[2 * H + h]) + r * gn);
-    const float hp = to_f32(hprev[i]);
-    hnew[i] = from_f32<T>((1.f - z) * n + z * hp);
-    rs[i] = from_f32<T>(r); zs[i] = from_f32<T>(z); ns[i] = from_f32<T>(n); ghn[i] = from_f32<T>(gn);
+    const float r = sigm(ld_elem(gib + (h)) + ld_elem(ghb + (h)));
+    const float z = sigm(ld_elem(gib + (H + h)) + ld_elem(ghb + (H + h)));
+    const float gn = ld_elem(ghb + (2 * H + h));
+    const float n = tanhf(ld_elem(gib + (2 * H + h)) + r * gn);
+    const float hp = ld_elem(hprev + (i));
+    st_elem(hnew + (i), (1.f - z) * n + z * hp);
+    st_elem(rs + (i), r); st_elem(zs + (i), z); st_elem(ns + (i), n); st_elem(ghn + (i), gn);
 }
 // given dh (gradient w.r.t. h_t): dgi / dgh for this step and the direct part of dh_{t-1} (= dh * z)
 template <typename T>
@@ -47,15 +47,15 @@ __global__ void gru_gate_bwd_kernel(const T* __restrict__ dh, const T* __restric
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, h = i % H;
-    const float d = to_f32(dh[i]), r = to_f32(rs[i]), z = to_f32(zs[i]), n = to_f32(ns[i]), gn = to_f32(ghn[i]), hp = to_f32(hprev[i]);
+    const float d = ld_elem(dh + (i)), r = ld_elem(rs + (i)), z = ld_elem(zs + (i)), n = ld_elem(ns + (i)), gn = ld_elem(ghn + (i)), hp = ld_elem(hprev + (i));
     const float dn = d * (1.f - z) * (1.f - n * n);
     const float dz = d * (hp - n) * z * (1.f - z);
     const float dr = dn * gn * r * (1.f - r);
     T* gi = dgi + (size_t)b * lddgi;
     T* gh = dgh + (size_t)b * 3 * H;
-    gi[h] = from_f32<T>(dr); gi[H + h] = from_f32<T>(dz); gi[2 * H + h] = from_f32<T>(dn);
-    gh[h] = from_f32<T>(dr); gh[H + h] = from_f32<T>(dz); gh[2 * H + h] = from_f32<T>(dn * r);
-    dhprev[i] = from_f32<T>(d * z);
+    st_elem(gi + (h), dr); st_elem(gi + (H + h), dz); st_elem(gi + (2 * H + h), dn);
+    st_elem(gh + (h), dr); st_elem(gh + (H + h), dz); st_elem(gh + (2 * H + h), dn * r);
+    st_elem(dhprev + (i), d * z);
 }
 
 // ---------------------------------------------------------------- image features = cat(feat, pos), padded to a multiple of 8 columns
@@ -66,7 +66,7 @@ __global__ void concat_cast_kernel(const float* __restrict__ feat, const float* 
         float v = 0.f;
         if (c < F) v = feat[(size_t)row * F + c];
         else if (c < F + Pd) v = pos[(size_t)row * Pd + (c - F)];
-        out[(size_t)row * Dp + c] = from_f32<T>(v);
+        st_elem(out + ((size_t)row * Dp + c), v);
     }
 }
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void butd_attend_fwd_kernel(const T* __restric
     for (int k = wave; k < O; k += 4) {
         float s = 0.f;
         for (int h = lane; h < H; h += 64) {
-            const float j = to_f32(ipb[(size_t)k * H + h]) * to_f32(qp[(size_t)b * H + h]);
+            const float j = ld_elem(ipb + ((size_t)k * H + h)) * ld_elem(qp + ((size_t)b * H + h));
             s += drop_apply(drop, (uint32_t)((b * O + k) * H + h), j) * wlin[h];
         }
         s = wave_sum(s);
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void butd_attend_fwd_kernel(const T* __restric
     const T* fb = imgf + (size_t)b * O * Dp;
     for (int f = threadIdx.x; f < Dp; f += 256) {
         float s = 0.f;
-        for (int k = 0; k < O; ++k) s = fmaf(lg[k], to_f32(fb[(size_t)k * Dp + f]), s);
-        img_enc[(size_t)b * Dp + f] = from_f32<T>(s);
+        for (int k = 0; k < O; ++k) s = fmaf(lg[k], ld_elem(fb + ((size_t)k * Dp + f)), s);
+        st_elem(img_enc + ((size_t)b * Dp + f), s);
     }
 }
 
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void butd_attend_bwd_kernel(const T* __restric
     const T* fb = imgf + (size_t)b * O * Dp;
     for (int k = wave; k < O; k += 4) {
         float s = 0.f;
-        for (int f = lane; f < Dp; f += 64) s = fmaf(to_f32(dimg[(size_t)b * Dp + f]), to_f32(fb[(size_t)k * Dp + f]), s);
+        for (int f = lane; f < Dp; f += 64) s = fmaf(ld_elem(dimg + ((size_t)b * Dp + f)), ld_elem(fb + ((size_t)k * Dp + f)), s);
         s = wave_sum(s);
         if (lane == 0) dl[k] = s;                 // d att_k
     }
@@ -132,17 +132,17 @@ __global__ __launch_bounds__(256) void butd_attend_bwd_kernel(const T* __restric
     const T* ipb = ip + (size_t)b * O * H;
     T* dipb = dip + (size_t)b * O * H;
     for (int h = threadIdx.x; h < H; h += 256) {
-        const float q = to_f32(qp[(size_t)b * H + h]), w = wlin[h];
+        const float q = ld_elem(qp + ((size_t)b * H + h)), w = wlin[h];
         float dq = 0.f, dw = 0.f;
         for (int k = 0; k < O; ++k) {
-            const float x = to_f32(ipb[(size_t)k * H + h]);
+            const float x = ld_elem(ipb + ((size_t)k * H + h));
             const float keep = drop_apply(drop, (uint32_t)((b * O + k) * H + h), 1.0f);
             const float dj = dl[k] * w * keep;      // d joint[k][h]
             dq = fmaf(dj, x, dq);
             dw = fmaf(dl[k] * keep, x * q, dw);
-            dipb[(size_t)k * H + h] = from_f32<T>(x > 0.f ? dj * q : 0.f);     // through the ReLU of image_proj
+            st_elem(dipb + ((size_t)k * H + h), x > 0.f ? dj * q : 0.f);     // through the ReLU of image_proj
         }
-        dqp[(size_t)b * H + h] = from_f32<T>(q > 0.f ? dq : 0.f);               // through the ReLU of question_proj
+        st_elem(dqp + ((size_t)b * H + h), q > 0.f ? dq : 0.f);               // through the ReLU of question_proj
         dw_part[(size_t)b * H + h] = dw;
     }
 }
@@ -150,14 +150,14 @@ __global__ __launch_bounds__(256) void butd_attend_bwd_kernel(const T* __restric
 // ---------------------------------------------------------------- joint = q_repr * img_repr (both post-ReLU)
 template <typename T>
 __global__ void mul_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = from_f32<T>(to_f32(a[i]) * to_f32(b[i]));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_elem(out + (i), ld_elem(a + (i)) * ld_elem(b + (i)));
 }
 template <typename T>
 __global__ void mul_relu_bwd_kernel(const T* __restrict__ dj, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ da, T* __restrict__ db, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float d = to_f32(dj[i]), x = to_f32(a[i]), y = to_f32(b[i]);
-        da[i] = from_f32<T>(x > 0.f ? d * y : 0.f);
-        db[i] = from_f32<T>(y > 0.f ? d * x : 0.f);
+        const float d = ld_elem(dj + (i)), x = ld_elem(a + (i)), y = ld_elem(b + (i));
+        st_elem(da + (i), x > 0.f ? d * y : 0.f);
+        st_elem(db + (i), y > 0.f ? d * x : 0.f);
     }
 }
 
@@ -174,14 +174,14 @@ __global__ __launch_bounds__(256) void wn_eff_kernel(const float* __restrict__ v
         const int n = n0 + ty + r * 8, k = k0 + tx;
         const float x = (n < N && k < K) ? v[(size_t)n * K + k] * scale : 0.f;
         tile[ty + r * 8][tx] = x;
-        if (n < N && k < ldo) w[(size_t)n * ldo + k] = from_f32<T>(x);
+        if (n < N && k < ldo) st_elem(w + ((size_t)n * ldo + k), x);
     }
     if (wt == nullptr) return;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int k = k0 + ty + r * 8, n = n0 + tx;
-        if (k < K && n < ldt) wt[(size_t)k * ldt + n] = from_f32<T>(tile[tx][ty + r * 8]);
+        if (k < K && n < ldt) st_elem(wt + ((size_t)k * ldt + n), tile[tx][ty + r * 8]);
     }
 }
 __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int N, int K, float* __restrict__ partial) {
@@ -290,3 +290,4 @@ int kb_wn_bwd(const float* dw, int lddw, const float* v, const float* g, const f
     template int kb_wn_eff<T>(const float*, const float*, const float*, T*, int, T*, int, int, int, hipStream_t);
 INST(float)
 INST(bf16_t)
+INST(sf32)       // bf16x3 precision: element access through ld_elem / st_elem (rows are whole split-f32 lines: every ld a multiple of 32)

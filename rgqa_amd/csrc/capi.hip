@@ -39,7 +39,9 @@ int rgqa_engine_create(const rgqa_config* cfg, rgqa_engine** out) {
     if (cfg->arch == 1) {
         RGQA_REQUIRE(cfg->hidden > 0 && cfg->hidden % 64 == 0 && cfg->emb_dim > 0 && cfg->vocab_size > 1 && cfg->num_answers > 0 && cfg->feat_dim % 4 == 0 &&
                      cfg->pos_dim >= 1 && cfg->pos_dim <= 4, "engine_create (BUTD): hidden %% 64, emb_dim, vocab_size, num_answers, feat_dim %% 4 required");
-        RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16, "engine_create: unknown precision %d", cfg->precision);
+        RGQA_REQUIRE(cfg->precision == RGQA_PRECISION_F32 || cfg->precision == RGQA_PRECISION_BF16 || cfg->precision == RGQA_PRECISION_BF16X3,
+                     "engine_create (BUTD): precision %d unsupported (f32, bf16, bf16x3)", cfg->precision);
+        if (cfg->precision == RGQA_PRECISION_BF16X3) RGQA_REQUIRE(cfg->hidden % 64 == 0, "engine_create (BUTD): bf16x3 precision needs hidden %% 64 == 0");
         RGQA_REQUIRE(cfg->hidden_dropout >= 0.f && cfg->hidden_dropout < 1.f && cfg->attn_dropout >= 0.f && cfg->attn_dropout < 1.f, "engine_create: dropout out of range");
         rgqa_engine* eb = new (std::nothrow) rgqa_engine;
         if (!eb) { rgqa_set_error("engine_create: out of host memory"); return RGQA_ERR_STATE; }

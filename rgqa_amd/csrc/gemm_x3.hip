@@ -45,6 +45,9 @@ int launch_gemm_nt_x3(GemmGroup& g, int out_f32, hipStream_t s) {
         case EPI_DGELU: return launch256_mt<sf32, EPI_DGELU, true>(g, mt, s);
         case EPI_ADD: return launch256_mt<sf32, EPI_ADD, true>(g, mt, s);
         case EPI_DTANH: return launch256_mt<sf32, EPI_DTANH, true>(g, mt, s);
+        case EPI_RELU: return launch256_mt<sf32, EPI_RELU, true>(g, mt, s);                     // BUTD (butd.py:8-26, 170-178)
+        case EPI_RELU_DROP: return launch256_mt<sf32, EPI_RELU_DROP, true>(g, mt, s);
+        case EPI_DRELU_DROP: return launch256_mt<sf32, EPI_DRELU_DROP, true>(g, mt, s);
         default: rgqa_set_error("gemm_x3: no kernel for epilogue %d", epi); return RGQA_ERR_ARG;
     }
 }

@@ -34,7 +34,7 @@ def build(precision, dropout=False):
     return m.cuda(), c, filled
 
 
-@pytest.mark.parametrize("precision,tol,gtol", [("f32", 2e-4, 3e-3), ("bf16", 8e-2, 6e-2)])
+@pytest.mark.parametrize("precision,tol,gtol", [("f32", 2e-4, 3e-3), ("bf16", 8e-2, 6e-2), ("bf16x3", 1e-3, 3e-3)])      # bf16x3 (round 4): inside the north star's 1e-3
 def test_butd_vs_reference_golden(golden_dir, precision, tol, gtol):
     g = np.load(os.path.join(golden_dir, "g7_butd.npz"))
     m, c, filled = build(precision)
@@ -62,6 +62,41 @@ def test_butd_vs_reference_golden(golden_dir, precision, tol, gtol):
         assert np.abs(got - ref).max() <= 3 * gtol * max(np.abs(ref).max(), 1e-6) + 1e-7, k
     print("butd %s: worst gradient-norm rel err %.3e, worst sampled-entry err / max %.3e, loss rel %.3e" % (precision, wn, ws, abs(loss.item() - g["loss"]) / abs(g["loss"])))
     assert float(dict(m.named_parameters())["w_emb.emb.weight"].grad[-1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 5e-4), ("bf16x3", 1e-3)])
+def test_butd_weight_norm_follows_the_weights_over_several_steps(precision, tol):
+    """Several forward / backward passes at hidden 1024 against the oracle: the weight-norm scale ||V||_F must be re-taken from
+    the CURRENT weights on every forward pass.  Round 3's one-launch sum-of-squares kept its ticket word in the scratch that backward's
+    column sums also use, so from the second training step on the norm stayed at its first value.  Between the passes every weight_v grows
+    by 25 % and the biases move (the same edit on both sides, after a real backward pass has used the scratch): W = g V / ||V|| is unchanged
+    by the scaling only if the norm is taken again."""
+    from oracle import butd_ref as BR
+    m, c, filled = build(precision)
+    m.eval()          # dropout off; gradients still flow
+    b = synth.synth_batch(len(BUTD_SENTS), 8, O=36, F=2048, NA=23, vocab=64, seed=606, uq_frac=0.2)
+    feat, pos, target = (torch.from_numpy(b[k]) for k in ("feats", "boxes", "target"))
+    toks = m.tokenize(BUTD_SENTS)
+    P = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in filled.items()}
+    fg, pg, tg = feat.cuda(), pos.cuda(), target.cuda()
+    first = None
+    for step in range(4):
+        lo = BR.butd_forward(P, c, feat, pos, toks)
+        lg = m(fg, pg, BUTD_SENTS)
+        err = float((lg.detach().cpu() - lo).abs().max())
+        print("butd %s pass %d: logits max err %.3e (|logits| max %.3e)" % (precision, step, err, float(lo.abs().max())))
+        assert err < tol, (step, err)
+        first = lo if first is None else first
+        loss = torch.nn.BCEWithLogitsLoss()(lg, tg) * lg.size(1)
+        m.zero_grad()
+        loss.backward()          # the engine's backward pass runs its column sums through the shared scratch
+        with torch.no_grad():
+            for k, p_ in m.named_parameters():
+                if k.endswith("weight_v"):
+                    p_ *= 1.25; P[k] *= 1.25
+                elif k.endswith(".bias"):
+                    p_ += 0.01; P[k] += 0.01
+    assert float((lo - first).abs().max()) > 10 * tol       # the passes are not all the same computation (the biases moved)
 
 
 def test_butd_train_step_runs_with_dropout():
