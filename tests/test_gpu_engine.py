@@ -446,6 +446,47 @@ def test_mixed_train_steps_follow_the_bf16x3_run():
     assert dl < 1e-2, dl
 
 
+@pytest.mark.parametrize("precision,tol,gtol", [("f32", 1e-4, 2e-3), ("bf16x3", 2e-4, 2e-3), ("bf16x3_fwd", 2e-4, 3.5e-2)])
+def test_roi_mixup_train_step_vs_oracle(precision, tol, gtol):
+    """BASELINE config 4's step (tasks/gqa_mixup_vis.py:134-181, 250-259) end to end: RoIMixup('mixup_v1', Beta(1, 5)) doubles a B = 8
+    loader batch on the device (the six constructions themselves are pinned bit-exactly to the reference's by test_roi_mixup_entry_vs_golden),
+    `sent = sent + sent`, then ONE engine step on the 16 rows: logits, loss (BCE x NA over 2B rows) and every gradient tensor against the
+    oracle on the same doubled batch; packed language rows as bench.py --mixup runs them."""
+    import random
+    from rgqa_amd.mixup import RoIMixup
+    B, T, O = 8, 12, 10
+    raw = synth.synth_batch(B, T, O=O, F=MED["feat_dim"], NA=MED["num_answers"], vocab=MED["vocab_size"], seed=91, min_len=2, uq_frac=0.25)
+    d = dev(raw)
+    random.seed(5); np.random.seed(5)
+    mixer = RoIMixup("mixup_v1", alpha=1.0, beta=5.0)
+    f2, b2, t2 = mixer(d["feats"], d["boxes"], d["target"], list(range(B)))
+    assert f2.shape[0] == 2 * B and float((t2[B:] - d["target"]).abs().max()) > 0          # targets of the mixed rows are scaled by prop
+    ids2, mask2, seg2 = (torch.cat([d[k], d[k]], 0).contiguous() for k in ("input_ids", "input_mask", "segment_ids"))
+    doubled = dict(feats=f2.cpu().numpy(), boxes=b2.cpu().numpy(), target=t2.cpu().numpy(), input_ids=ids2.cpu().numpy(),
+                   input_mask=mask2.cpu().numpy(), segment_ids=seg2.cpu().numpy())
+    lg_r, pl_r, loss_r, Pr = oracle_run(MED, doubled)
+    e = make_engine(MED, precision)
+    e.ensure_shape(2 * B, T, O)
+    e.sync_weights()
+    lens = np.ascontiguousarray(np.tile(raw["lengths"], 2), dtype=np.int32)
+    lg, pl = e.forward(f2, b2, ids2, mask2, seg2, train=False, lengths=lens)
+    lerr = float((lg.cpu() - lg_r).abs().max())
+    loss = e.loss_backward(t2).item()
+    gworst = 0.0
+    for sp in e.specs:
+        got = e.view(e.grads, sp).cpu()
+        ref = Pr[sp.name].grad
+        if ref is None or sp.dead:
+            assert float(got.abs().max()) == 0.0, sp.name
+            continue
+        den = float(ref.norm())
+        if den < 1e-8:
+            continue
+        gworst = max(gworst, float((got - ref).norm()) / den)
+    _report("RoI-mixup step (medium config, 16 rows) %s vs oracle" % precision, logits_max=lerr, loss_rel=abs(loss - loss_r) / abs(loss_r), worst_tensor_rel=gworst)
+    assert lerr < tol and abs(loss - loss_r) < 50 * tol and gworst < gtol
+
+
 def test_dropout_train_mode_is_deterministic_and_consistent():
     """Train mode (dropout 0.1 regenerated from (seed, site, index) in backward): same seed -> bit-identical results,
     different seed -> different; the analytic gradient agrees with a finite difference of the loss along a direction."""
