@@ -643,6 +643,11 @@ public:
             const GemmProblem& p = g.p[i];
             flops += 2.0 * p.M * p.N * p.K;
             bytes += sizeof(T) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+            // the operands of the fused epilogue are algorithmic bytes of the launch too: the residual / gelu' / activation it reads and
+            // the second output it writes would be moved by a separate element-wise kernel otherwise (twice: that kernel would re-read C)
+            if (epi_needs_aux(p.epi) && p.aux != nullptr) bytes += sizeof(T) * (double)p.M * p.N;
+            if (p.C2 != nullptr) bytes += (p.c2_lp ? 2.0 : (double)sizeof(T)) * (double)p.M * p.N;
+            if (p.Cb != nullptr) bytes += 2.0 * (double)p.M * p.N;
         }
     }
     int run_fwd(GemmGroup& g, hipStream_t s, int out_f32 = 0, int a_f32 = 0) {
