@@ -222,6 +222,35 @@ def test_trainer_step_fused_clip_and_operand_copies(env, precision):
     assert worst < 1e-4
 
 
+def test_clip_fast_path_rejects_a_foreign_gradient_tensor(env):
+    """after one recognised call the patched clip_grad_norm_ re-validates EVERY parameter's .grad, not only the first: a gradient
+    tensor that was re-bound afterwards (here: a scaled clone in place of the arena view) sends the call to torch's implementation, which
+    clips the tensors it was given - the foreign one included - instead of rescaling the engine's arena behind their back."""
+    import lxrt.entry  # noqa: F401
+    from lxrt.optimization import clip_grad_norm_ as fast_clip
+    feats, boxes, target = batch(20)
+    m, _ = build("bf16", 20)
+    m.train()
+    params = list(m.parameters())
+
+    def fwd_bwd():
+        m.zero_grad()
+        logit = m(feats.cuda(), boxes.cuda(), SENTS)
+        (torch.nn.functional.binary_cross_entropy_with_logits(logit, target.cuda()) * logit.size(1)).backward()
+
+    fwd_bwd()
+    n0 = float(fast_clip(params, 1e9))                           # recognised: the engine's fast path, now cached
+    fwd_bwd()
+    victim = [p for p in params if p.grad is not None and p.grad.numel() > 1000][-1]
+    victim.grad = victim.grad.clone() * 3.0                       # a foreign tensor in place of the arena view
+    ref = [None if p.grad is None else p.grad.detach().clone() for p in params]
+    want = float(sum(float((r.double() ** 2).sum()) for r in ref if r is not None) ** 0.5)
+    got = float(fast_clip(params, 0.25))
+    assert abs(got - want) <= 1e-4 * want and got > n0 * (1 + 1e-4)          # the norm counts the foreign (x 3) tensor
+    coef = 0.25 / (got + 1e-6)
+    assert torch.allclose(victim.grad, ref[next(i for i, p in enumerate(params) if p is victim)] * coef, rtol=1e-4, atol=1e-9)      # ... and it was clipped in place
+
+
 def test_train_mode_runs_and_is_seeded(env):
     """model.train(): dropout 0.1 active (reference BertConfig defaults); different forward calls draw different masks."""
     import rgqa_amd.lxrt.modeling as M
