@@ -109,7 +109,7 @@ def test_engine_f32_small_vs_golden(golden_dir, tag, T, packed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec,packed", [("f32", False), ("f32", True), ("bf16", True), ("bf16x3", True), ("bf16x3", False)])
+@pytest.mark.parametrize("prec,packed", [("f32", False), ("f32", True), ("bf16", True), ("bf16x3", True), ("bf16x3", False), ("bf16x3_fwd", True)])
 def test_engine_full_config_vs_golden(golden_dir, prec, packed):
     """bert-base UNITER: 12 layers over 56-token sequences. f32 and split-f32 (bf16x3) operands: logits within the north-star 1e-3 of the
     reference's CPU path; bf16: within the tolerance the LXMERT bf16 path is held to."""
