@@ -55,7 +55,9 @@ const char* rgqa_last_error_string(void);
 int rgqa_version(void);
 /* test switches: key 0: 1 forces the 128x128 register-staged GEMM kernels everywhere; key 1: forces the NT tile height (16-row
  * m-tiles per wave: 2, 4..8; 0 = cost model); key 2: 1 runs the deferred weight-gradient launches on the caller's stream instead of
- * the side stream; key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots; key 8: 0 computes
+ * the side stream; key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots (one tile per block);
+ * key 5 (measurement only): 1 skips the deferred weight-gradient launches; key 6: periods of backward whose weight-gradient problems go into
+ * one launch (1..4; 0 = default); key 8: 0 computes
  * the last language FFN on every row (as the reference does), 1 on the [CLS] rows only (default), -1 = environment RGQA_CLS_TAIL;
  * key 16: 0 launches the two attention problems of a stage separately, 1 as one launch (default). */
 int rgqa_debug_set(int key, int value);
@@ -254,6 +256,11 @@ int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const voi
 /* C[M,N] f32 = A[K,M]^T B[K,N]   (wgrad form); dtype of A and B */
 int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int dtype, void* stream);
+/* One grouped wgrad launch as the engine issues it (<= 32 problems): C_i[M_i,N_i] (+)= A_i[K_i,M_i]^T B_i[K_i,N_i] and, where colsum_i is not
+ * NULL, colsum_i[m] (+)= sum_k A_i[k][m] (the bias gradient); dtype 1 bf16 / 2 split f32.  Kernel parity tests and tools/wgrad_lab.py. */
+int rgqa_op_matmul_tn_group(int count, const void* const* A, const void* const* B, float* const* C, float* const* colsum,
+                            const int* M, const int* N, const int* K, const int* lda, const int* ldb, const int* ldc,
+                            int accumulate, int dtype, void* stream);
 int rgqa_op_layernorm(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       int M, int N, float eps, int dtype, void* stream);
 int rgqa_op_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "rgqa_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rgqa_op_linear_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "rgqa_op_matmul_tn": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rgqa_op_matmul_tn_group": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "rgqa_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
     "rgqa_op_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "rgqa_op_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -21,6 +21,7 @@ extern int g_rgqa_tn_mtw;
 extern int g_rgqa_cls_tail;
 extern int g_rgqa_attn_pair;
 extern int g_rgqa_skip_wgrad;
+extern int g_rgqa_wgrad_merge;
 // debug / test switches (include/rgqa.h)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -28,6 +29,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 2) { g_rgqa_wgrad_serial = value; return RGQA_OK; }
     if (key == 4) { g_rgqa_tn_mtw = value; return RGQA_OK; }
     if (key == 5) { g_rgqa_skip_wgrad = value; return RGQA_OK; }
+    if (key == 6) { g_rgqa_wgrad_merge = value; return RGQA_OK; }
     if (key == 8) { g_rgqa_cls_tail = value; return RGQA_OK; }
     if (key == 16) { g_rgqa_attn_pair = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
@@ -276,6 +278,20 @@ int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int 
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.epi = EPI_BIAS;
     if (dtype == 2) return launch_gemm_tn_x3(g, S(stream));
     return dtype == 1 ? launch_gemm_tn_bf16(g, 1, S(stream)) : launch_gemm_f32(g, 1, 1, S(stream));
+}
+// grouped wgrad launch as the engine issues it: C_i[M_i,N_i] (+)= A_i[K_i,M_i]^T B_i[K_i,N_i], colsum_i[m] (+)= sum_k A_i[k][m] (or null)
+int rgqa_op_matmul_tn_group(int count, const void* const* A, const void* const* B, float* const* C, float* const* colsum, const int* M, const int* N, const int* K,
+                            const int* lda, const int* ldb, const int* ldc, int accumulate, int dtype, void* stream) {
+    RGQA_REQUIRE(count >= 1 && count <= GEMM_MAX_PROBLEMS && A && B && C && M && N && K && lda && ldb && ldc, "op_matmul_tn_group: bad argument (1..%d problems)", GEMM_MAX_PROBLEMS);
+    RGQA_REQUIRE(dtype == 1 || dtype == 2, "op_matmul_tn_group: dtype 1 (bf16) or 2 (split f32)");
+    GemmGroup g; memset(&g, 0, sizeof g);
+    g.count = count; g.drop = make_drop(0.f, 0, 0);
+    for (int i = 0; i < count; ++i) {
+        GemmProblem& p = g.p[i];
+        p.A = A[i]; p.B = B[i]; p.C = C[i]; p.colsum_out = colsum ? colsum[i] : nullptr; p.M = M[i]; p.N = N[i]; p.K = K[i];
+        p.lda = lda[i]; p.ldb = ldb[i]; p.ldc = ldc[i]; p.epi = accumulate ? EPI_ACCUM : EPI_BIAS;
+    }
+    return dtype == 2 ? launch_gemm_tn_x3(g, S(stream)) : launch_gemm_tn_bf16(g, 1, S(stream));
 }
 int rgqa_op_layernorm(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int N, float eps, int dtype, void* stream) {
     if (dtype == 2) return k_ln_fwd<sf32>((const sf32*)x, N, gamma, beta, (sf32*)y, N, mean, rstd, M, N, eps, S(stream));

@@ -148,11 +148,14 @@ static void build_params(const rgqa_config& c, std::vector<ParamInfo>& tab, Mode
 // ahead of the side stream; behind the cross-modality layers the four language-only layers have short chains, and the main stream then
 // sat 0.17 ms per step waiting for the set of two periods ago (profiles/r02_timeline_b256.txt); with four it runs on and the side stream
 // catches up beside the longer chains of the paired layers that follow.
-#define NPAR 4
+#define NPAR 8
+#define WGRAD_MERGE_MAX 4      // periods of backward whose weight-gradient problems may share one launch (NPAR >= 2 * WGRAD_MERGE_MAX)
 #define SUMSQ_WS_STRIDE 1088     // k_sumsq_owned: 1024 block partials + the ticket word, per gradient segment
 #define LNPART_BLOCKS 1536     // per layer: <= 3 LayerNorm-backward launches of <= 512 blocks
 int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad launches on the main stream
 int g_rgqa_skip_wgrad = 0;     // rgqa_debug_set(5, v): MEASUREMENT ONLY - the deferred weight-gradient launches are not issued (gradients are then wrong)
+int g_rgqa_wgrad_merge = 0;    // rgqa_debug_set(6, v): periods per weight-gradient launch (1 .. WGRAD_MERGE_MAX); 0 = default
+#define WGRAD_MERGE_DEFAULT 3
 int g_rgqa_attn_pair = 1;      // rgqa_debug_set(16, v): 0 = the two attention problems of a stage as two launches (the bit-identity test's other arm)
 
 // RGQA_ATTN_REF (test switch: the plain attention kernels instead of the MFMA ones), read once
@@ -296,29 +299,61 @@ public:
     // Launches the collected weight-gradient GEMMs of one layer on the side stream, ordered after everything the main
     // stream has enqueued for that layer; records the DP segment event there (the segment is final once both the main
     // stream's bias / LayerNorm gradients and these GEMMs are done).
-    int flush_wgrad(GemmGroup& wg, int par, hipStream_t s, bool layer_done = true) {
-        static const bool serial = getenv("RGQA_WGRAD_SERIAL") != nullptr;
-        if (serial || g_rgqa_wgrad_serial || profiling) {
-            if (int r = fin_flush(fin, fin_accumulate, s)) return r;
-            if (int r = run_wgrad(wg, s)) return r;
-            gg_init(wg);
-            return layer_done ? mark_segment(s) : RGQA_OK;
-        }
-        if (s_w == nullptr) {
-            RGQA_HIP(hipStreamCreateWithFlags(&s_w, hipStreamNonBlocking));
-            for (int i = 0; i < NPAR; ++i) {
-                RGQA_HIP(hipEventCreateWithFlags(&ev_chain[i], hipEventDisableTiming));
-                RGQA_HIP(hipEventCreateWithFlags(&ev_wdone[i], hipEventDisableTiming));
-            }
-        }
-        RGQA_HIP(hipEventRecord(ev_chain[par], s));
-        RGQA_HIP(hipStreamWaitEvent(s_w, ev_chain[par], 0));
-        if (int r = fin_flush(fin, fin_accumulate, s_w)) return r;
-        if (int r = run_wgrad(wg, s_w)) return r;
+    // A layer's launch groups problems whose contraction lengths differ 4x (3,140 language rows, 9,216 vision rows, 12,356 rows of the shared
+    // cross-attention weights) and whose 256 x 256 output tiles number about one per CU: the launch lasts as long as its longest contraction
+    // (193 K-steps) while the CUs of the short ones idle (344 us for work that, spread evenly, is 150 us per CU).  With the problems of two
+    // periods in ONE launch the dispatcher hands the second period's tiles to the CUs the first one's short contractions free: 260 us per
+    // layer (tools/wgrad_lab.py, profiles/r04_wgrad_lab.txt).  The periods wait in `wgm` until the launch is due; their gradient-buffer
+    // sets stay untouched meanwhile (NPAR sets, used round-robin).
+    // (Round 4 also measured stream-K scheduling of these launches - equal shares of (tile, K-step) units per CU, tiles cut by a share's
+    // boundary summed through partial slabs in a fixed order: correct and bit-repeatable, but 423 us per layer instead of 344: with all 256
+    // CUs streaming unshared operand rows the loop is bound by what the fabric delivers, 22 GB/s per CU instead of 46; docs/MEASUREMENTS.md.)
+    GemmGroup wgm; int pend_n = 0, pend_marks = 0; int pend_par[WGRAD_MERGE_MAX] = {}; FinDefer pend_fin[WGRAD_MERGE_MAX]; int pend_acc[WGRAD_MERGE_MAX] = {};
+    static int wgrad_merge() { const int m = g_rgqa_wgrad_merge > 0 ? g_rgqa_wgrad_merge : WGRAD_MERGE_DEFAULT; return m > WGRAD_MERGE_MAX ? WGRAD_MERGE_MAX : m; }
+    bool set_pending(int par) const { for (int k = 0; k < pend_n; ++k) if (pend_par[k] == par) return true; return false; }
+    // Collects the weight-gradient GEMMs of one period; once enough periods wait (or `force`), launches them on the side stream, ordered after
+    // everything the main stream has enqueued so far; records the DP segment events there (a segment is final once both the main stream's
+    // bias / LayerNorm gradients and these GEMMs are done).
+    int flush_wgrad(GemmGroup& wg, int par, hipStream_t s, bool layer_done = true, bool force = false) {
+        if (pend_n == 0) gg_init(wgm);
+        RGQA_REQUIRE(wgm.count + wg.count <= GEMM_MAX_PROBLEMS && pend_n < WGRAD_MERGE_MAX, "flush_wgrad: too many pending problems (%d + %d)", wgm.count, wg.count);
+        for (int i = 0; i < wg.count; ++i) wgm.p[wgm.count++] = wg.p[i];
         gg_init(wg);
-        if (layer_done) if (int r = mark_segment(s_w)) return r;
-        RGQA_HIP(hipEventRecord(ev_wdone[par], s_w));
-        wdone_valid[par] = true;
+        pend_par[pend_n] = par; pend_fin[pend_n] = fin; pend_acc[pend_n] = fin_accumulate; ++pend_n;
+        fin.blk = 0; fin.nout = 0; fin.fo = FinOut{};        // handed over: the period's column sums are folded with the launch
+        if (layer_done) ++pend_marks;
+        // a period adds at most 10 problems (paired FFN + two attention stages)
+        if (!force && pend_n < wgrad_merge() && wgm.count + 10 <= GEMM_MAX_PROBLEMS) return RGQA_OK;
+        return launch_pending(s);
+    }
+    int launch_pending(hipStream_t s) {
+        if (pend_n == 0) return RGQA_OK;
+        static const bool serial = getenv("RGQA_WGRAD_SERIAL") != nullptr;
+        const bool on_main = serial || g_rgqa_wgrad_serial || profiling;
+        hipStream_t st = s;
+        if (!on_main) {
+            if (s_w == nullptr) {
+                RGQA_HIP(hipStreamCreateWithFlags(&s_w, hipStreamNonBlocking));
+                for (int i = 0; i < NPAR; ++i) {
+                    RGQA_HIP(hipEventCreateWithFlags(&ev_chain[i], hipEventDisableTiming));
+                    RGQA_HIP(hipEventCreateWithFlags(&ev_wdone[i], hipEventDisableTiming));
+                }
+            }
+            const int par = pend_par[pend_n - 1];
+            RGQA_HIP(hipEventRecord(ev_chain[par], s));
+            RGQA_HIP(hipStreamWaitEvent(s_w, ev_chain[par], 0));
+            st = s_w;
+        }
+        for (int k = 0; k < pend_n; ++k) if (int r = fin_flush(pend_fin[k], pend_acc[k], st)) return r;
+        if (int r = run_wgrad(wgm, st)) return r;
+        gg_init(wgm);
+        for (int k = 0; k < pend_marks; ++k) if (int r = mark_segment(st)) return r;
+        if (!on_main)
+            for (int k = 0; k < pend_n; ++k) {
+                RGQA_HIP(hipEventRecord(ev_wdone[pend_par[k]], s_w));
+                wdone_valid[pend_par[k]] = true;
+            }
+        pend_n = 0; pend_marks = 0;
         return RGQA_OK;
     }
     static int wgrad_sets() { return NPAR; }
@@ -1054,8 +1089,8 @@ public:
         int flushes = 0;
         // phase_ffn: the first launch holds the last layer's FFN only (no layer is complete yet); every later one completes the layer above
         auto flush_after = [&](const Stage& st) { return phase_ffn ? st.kind == ST_FFN : st.layer_first != 0; };
-        auto flush_layer = [&](hipStream_t ss) -> int {
-            int r = flush_wgrad(wg, par, ss, !phase_ffn || flushes > 0);
+        auto flush_layer = [&](hipStream_t ss, bool force = false) -> int {
+            int r = flush_wgrad(wg, par, ss, !phase_ffn || flushes > 0, force);
             ++flushes; par = (par + 1) % wgrad_sets(); layer_open = false;
             return r;
         };
@@ -1063,6 +1098,7 @@ public:
             Stage& st = stages[si];
             prof_block = si < n_lr_stages ? PB_LR : PB_X;
             if (!layer_open) {     // first stage (in backward order) of a layer
+                if (set_pending(par)) CK(launch_pending(s));       // (cannot happen while NPAR >= 2 * WGRAD_MERGE_MAX)
                 CK(wait_wgrad(par, s)); layer_open = true;
                 fin_accumulate = accumulate;
                 fin.begin(lnpart_s[par], LNPART_BLOCKS, H);     // LayerNorm-backward column sums: folded once per layer, with the layer's wgrad launch
@@ -1206,7 +1242,7 @@ public:
             // the first layer's attention wgrads are the launch nothing of the encoder runs beside: start them here, beside this stage's
             // own QKV dgrad and the embedding backward (they read dqkv / dz, which are final), not after the dgrad
             // (-0.02 ms bf16, -0.12 ms bf16x3 per step, round 3)
-            if (si == 0 && phase_ffn && layer_open) CK(flush_layer(s));
+            if (si == 0 && phase_ffn && layer_open) CK(flush_layer(s, true));
             // input gradient: dx = dqkv @ Wqkv + dz (residual path)
             gg_init(g);
             if (shared_all) {
@@ -1226,7 +1262,8 @@ public:
             if (flush_after(st)) CK(flush_layer(s));
         }
         prof_block = PB_LR;
-        if (phase_ffn && layer_open) CK(flush_layer(s));        // the first layer's attention wgrads: the only launch nothing of the encoder runs beside
+        if (phase_ffn && layer_open) CK(flush_layer(s, true));        // the first layer's attention wgrads: the only launch nothing of the encoder runs beside
+        CK(launch_pending(s));
         CK(fin_flush(fin, fin_accumulate, s));
         fin.begin(nullptr, 0, 0);
         CK(run_wgrad(wg, s));

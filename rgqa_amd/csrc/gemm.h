@@ -38,7 +38,10 @@ struct GemmProblem {
     int epi;            // GemmEpi
 };
 
-#define GEMM_MAX_PROBLEMS 12
+// 32 (3,888 bytes of kernel arguments): two or three layers' weight-gradient problems go into one launch (engine.hip, flush_wgrad)
+#define GEMM_MAX_PROBLEMS 32
+// NT launches (forward, dgrad) group at most 12: their kernels look a tile's problem up in a loop over this many entries, once per tile
+#define GEMM_NT_MAX_PROBLEMS 12
 struct GemmGroup {
     int count;
     int total_tiles;

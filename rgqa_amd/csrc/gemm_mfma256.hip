@@ -10,6 +10,7 @@ int g_rgqa_force_mt = 0;      // rgqa_debug_set key 1
 
 // true when every problem of the group can run on the LDS-DMA kernel
 bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
+    if (g.count > GEMM_NT_MAX_PROBLEMS) return false;
     if (g.a_f32) return false;
     const int epi = g.p[0].epi;
     if (out_f32) {      // f32 result: only the plain-bias epilogue on 64-row tiles (deep-ring kernel), e.g. the logits GEMM

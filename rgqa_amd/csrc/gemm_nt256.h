@@ -109,7 +109,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
         const int tile = xcd_remap256(vt, g.total_tiles);
         int p = 0;
 #pragma unroll
-        for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+        for (int i = 1; i < GEMM_NT_MAX_PROBLEMS; ++i)
             if (i < g.count && tile >= g.p[i].tile_start) p = i;
         const GemmProblem& P = g.p[p];
         const int local = tile - P.tile_start;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
     const int tile = xcd_remap256(blockIdx.x, g.total_tiles);
     int pi = 0;
 #pragma unroll
-    for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+    for (int i = 1; i < GEMM_NT_MAX_PROBLEMS; ++i)
         if (i < g.count && tile >= g.p[i].tile_start) pi = i;
     const GemmProblem& P = g.p[pi];
     const int local = tile - P.tile_start;

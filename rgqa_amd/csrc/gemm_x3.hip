@@ -14,7 +14,7 @@
 static bool x3_aligned(const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 127) == 0 && (ld % 32) == 0); }
 
 int launch_gemm_nt_x3(GemmGroup& g, int out_f32, hipStream_t s) {
-    RGQA_REQUIRE(g.count >= 1 && g.count <= GEMM_MAX_PROBLEMS, "gemm_x3: bad problem count %d", g.count);
+    RGQA_REQUIRE(g.count >= 1 && g.count <= GEMM_NT_MAX_PROBLEMS, "gemm_x3: bad problem count %d", g.count);
     const int epi = g.p[0].epi;
     for (int i = 0; i < g.count; ++i) {
         const GemmProblem& p = g.p[i];

@@ -143,6 +143,50 @@ def test_matmul_tn_bf16_both_tile_heights(lib, mtw, M, N, K):
     assert float((got - ref).abs().max()) < 1e-2 * math.sqrt(K)
 
 
+def tn_group(lib, probs, dtype, accumulate=0, C=None, cs=None):
+    """One grouped wgrad launch (rgqa_op_matmul_tn_group): probs = [(A [K,lda], B [K,ldb], M, N, with_colsum, K, lda, ldb)]; returns (C list, colsum list)."""
+    import ctypes
+    n = len(probs)
+    Cs = C if C is not None else [torch.zeros(p[2], p[3], device="cuda") for p in probs]
+    css = cs if cs is not None else [torch.zeros(p[2], device="cuda") if p[4] else None for p in probs]
+    vp = ctypes.c_void_p * n; ia = ctypes.c_int * n
+    arr = lambda ts: vp(*[t.data_ptr() if t is not None else None for t in ts])
+    ck(lib.rgqa_op_matmul_tn_group(n, arr([p[0] for p in probs]), arr([p[1] for p in probs]), arr(Cs), arr(css),
+                                   ia(*[p[2] for p in probs]), ia(*[p[3] for p in probs]), ia(*[p[5] for p in probs]),
+                                   ia(*[p[6] for p in probs]), ia(*[p[7] for p in probs]), ia(*[c.shape[1] for c in Cs]), accumulate, dtype, S()))
+    torch.cuda.synchronize()
+    return Cs, css
+
+
+# two layers' launch in miniature (the engine merges the weight-gradient problems of up to three periods of backward into one launch):
+# contraction lengths 4 : 3 : 1 with tails, 14 problems, bias sums on some
+_TN_GROUP = [(768, 768, 12356, True), (2304, 768, 9216, True), (768, 3072, 3140, False), (3072, 768, 3140, True), (768, 768, 9216, False),
+             (768, 768, 3140, True), (2304, 768, 12356, True)] * 2
+
+
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_matmul_tn_group_bf16(lib, accumulate):
+    """A grouped wgrad launch of 14 problems against f32 matmuls of the same bf16 operands; a second launch gives bit-identical results."""
+    probs, refs, csr = [], [], []
+    for i, (M, N, K, cs) in enumerate(_TN_GROUP):
+        A = rnd(K, M, seed=10 + i).bfloat16(); Bm = rnd(K, N, seed=30 + i).bfloat16()
+        probs.append((A, Bm, M, N, cs, K, M, N))
+        refs.append(A.float().t() @ Bm.float()); csr.append(A.float().sum(0))
+    init = lambda: ([torch.full((p[2], p[3]), 0.5, device="cuda") for p in probs], [torch.full((p[2],), -1.0, device="cuda") if p[4] else None for p in probs])
+    C1, c1 = init(); C2, c2 = init()
+    tn_group(lib, probs, 1, accumulate, C1, c1)
+    tn_group(lib, probs, 1, accumulate, C2, c2)
+    for i, p in enumerate(probs):
+        off = 0.5 if accumulate else 0.0
+        rel = float((C1[i] - off - refs[i]).norm() / refs[i].norm())
+        assert rel < 1e-3, (i, rel)
+        assert torch.equal(C1[i], C2[i])
+        if p[4]:
+            offc = -1.0 if accumulate else 0.0
+            assert float((c1[i] - offc - csr[i]).abs().max()) < 1e-2 * math.sqrt(p[5])
+            assert torch.equal(c1[i], c2[i])
+
+
 @pytest.mark.parametrize("M,N,K", [(144, 208, 192), (1024, 1536, 192), (1024, 1536, 197), (1024, 1536, 33), (1024, 1536, 65)])
 def test_matmul_tn_exact_integers(lib, M, N, K):
     A = ((torch.arange(K * M).reshape(K, M) * 5 + 1) % 7 - 3).float().cuda().bfloat16()
@@ -338,6 +382,23 @@ def test_matmul_tn_x3(lib, M, N, K):
     assert rel < 2e-5
     if ldc > N:
         assert float((Cc[:, N:] - 5.0).abs().max()) == 0.0
+
+
+def test_matmul_tn_group_x3(lib):
+    """The split-f32 grouped wgrad launch (14 problems) against f64 matmuls"""
+    probs, refs, csr = [], [], []
+    for i, (M, N, K, cs) in enumerate(_TN_GROUP):
+        A, Bm = rnd(K, M, seed=10 + i), rnd(K, N, seed=30 + i)
+        As, Bs = split(lib, A), split(lib, Bm)
+        A, Bm = unsplit(lib, As), unsplit(lib, Bs)
+        probs.append((As, Bs, M, N, cs, K, M, N))
+        refs.append(A.double().t() @ Bm.double()); csr.append(A.double().sum(0))
+    C1, c1 = tn_group(lib, probs, 2)
+    for i, p in enumerate(probs):
+        rel = float((C1[i].double() - refs[i]).norm() / refs[i].norm())
+        assert rel < 2e-5, (i, rel)
+        if p[4]:
+            assert float((c1[i].double() - csr[i]).abs().max()) < 1e-4 * math.sqrt(p[5])
 
 
 def test_matmul_tn_x3_exact_integers(lib):
