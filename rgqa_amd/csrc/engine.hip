@@ -308,6 +308,7 @@ public:
     // (Round 4 also measured stream-K scheduling of these launches - equal shares of (tile, K-step) units per CU, tiles cut by a share's
     // boundary summed through partial slabs in a fixed order: correct and bit-repeatable, but 423 us per layer instead of 344: with all 256
     // CUs streaming unshared operand rows the loop is bound by what the fabric delivers, 22 GB/s per CU instead of 46; docs/MEASUREMENTS.md.)
+    GemmGroup wg_head;          // head / pooler weight-gradient problems, handed to the encoder's first deferred launch
     GemmGroup wgm; int pend_n = 0, pend_marks = 0; int pend_par[WGRAD_MERGE_MAX] = {}; FinDefer pend_fin[WGRAD_MERGE_MAX]; int pend_acc[WGRAD_MERGE_MAX] = {};
     static int wgrad_merge() { const int m = g_rgqa_wgrad_merge > 0 ? g_rgqa_wgrad_merge : WGRAD_MERGE_DEFAULT; return m > WGRAD_MERGE_MAX ? WGRAD_MERGE_MAX : m; }
     bool set_pending(int par) const { for (int k = 0; k < pend_n; ++k) if (pend_par[k] == par) return true; return false; }
@@ -327,7 +328,11 @@ public:
         return launch_pending(s);
     }
     int launch_pending(hipStream_t s) {
-        if (pend_n == 0) return RGQA_OK;
+        if (pend_n == 0) {       // nothing collected (an encoder without stages): only the segment marks are due
+            for (int k = 0; k < pend_marks; ++k) if (int r = mark_segment(s)) return r;
+            pend_marks = 0;
+            return RGQA_OK;
+        }
         static const bool serial = getenv("RGQA_WGRAD_SERIAL") != nullptr;
         const bool on_main = serial || g_rgqa_wgrad_serial || profiling;
         hipStream_t st = s;
@@ -1019,13 +1024,16 @@ public:
         // ---- head
         // padded columns of dlogits are exact zeros and the bias slot reserves round_up(NA, 64) elements
         CKP(PC_OTHER, colsum_bias(dlogits, NAp, mp.head3, 0, NAp, B, accumulate, s));
-        gg_init(g); add_wgrad(g, dlogits, NAp, mp.head3, 0, NA, sv(h2), 2 * H, B, accumulate); CK(run_wgrad(g, s));
+        // the head's and the pooler's weight gradients ride in the encoder's first deferred launch: their operands (dlogits, gp3, gp1 and
+        // forward tensors) are not written again during backward
+        gg_init(wg_head);
+        add_wgrad(wg_head, dlogits, NAp, mp.head3, 0, NA, sv(h2), 2 * H, B, accumulate);
         gg_init(g); add_dgrad(g, dlogits, NAp, mp.head3, 0, NA, gp1, 2 * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
         CKP(PC_LN, k_ln_bwd<TB>(gp1, 2 * H, sv(h1), 2 * H, P + mp.head_ln.w, hd_mean, hd_rstd, gp2, nullptr, 2 * H, part, G + mp.head_ln.w, G + mp.head_ln.b, nullptr,
                        accumulate, B, 2 * H, nodrop, nodrop, 1.0f, s));
         CKP(PC_OTHER, k_dgelu_mul<TB>(gp2, sv(h1pre), gp3, (size_t)B * 2 * H, s));
         CKP(PC_OTHER, colsum_bias(gp3, 2 * H, mp.head0, 0, 2 * H, B, accumulate, s));
-        gg_init(g); add_wgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, sv(pooled), H, B, accumulate); CK(run_wgrad(g, s));
+        add_wgrad(wg_head, gp3, 2 * H, mp.head0, 0, 2 * H, sv(pooled), H, B, accumulate);
         gg_init(g); add_dgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, gp1, H, B, EPI_DTANH, sv(pooled), H); CK(run_dgrad(g, s));   // gp1[B,H] = d(pooler pre-tanh)
         return backward_encoder(accumulate, s);
     }
@@ -1042,6 +1050,7 @@ public:
         }
         CKP(PC_OTHER, k_cast_pad<TB>(dpooled, ld, gp2, H, B, H, 1.0f, s));
         CKP(PC_OTHER, k_dtanh_mul<TB>(gp2, sv(pooled), gp1, (size_t)B * H, s));
+        gg_init(wg_head);
         return backward_encoder(accumulate, s);
     }
 
@@ -1054,7 +1063,7 @@ public:
         GemmGroup g;
         CKP(PC_OTHER, colsum_bias(gp1, H, mp.pooler, 0, H, B, accumulate, s));
         const int* cu = fwd_varlen ? cu_dev : nullptr;
-        gg_init(g); add_wgrad(g, gp1, H, mp.pooler, 0, H, sv(pool_in), H, B, accumulate); CK(run_wgrad(g, s));
+        add_wgrad(wg_head, gp1, H, mp.pooler, 0, H, sv(pool_in), H, B, accumulate);
         // gradient w.r.t. the final hidden states: zero except the [CLS] rows of lang
         // Gradient w.r.t. the current stage's output, one pointer per modality: a stage moves only the modalities it computes to
         // the other buffer, so a modality that merely passes through (vision under the language-only layers) stays where it is
@@ -1077,10 +1086,11 @@ public:
         const bool tail = !stages.empty() && cls_tail(stages.back());
         if (!tail) CKP(PC_OTHER, k_scatter_rows<TB>(gp2, H, dyp[0], H, cu, Tn, B, H, s));     // tail: the last FFN stage takes gp2 [B,H] as it is
         seg_cursor = 0;
-        CK(mark_segment(s));     // head + pooler gradients are final
+        pend_n = 0; gg_init(wgm);      // (a backward pass that failed half-way leaves nothing behind)
+        pend_marks = 1;          // head + pooler gradients are final with the first deferred launch, which carries their weight gradients
 
         // ---- encoder stages in reverse; weight-gradient GEMMs are collected per layer and launched once
-        GemmGroup wg; gg_init(wg);
+        GemmGroup wg = wg_head; gg_init(wg_head);
         int par = 0; bool layer_open = false;
         // Where a layer's deferred wgrad GEMMs are launched: after every FFN stage - the launch then holds the attention wgrads of the layer
         // above and this layer's FFN wgrads, and runs beside this layer's LayerNorm / attention kernels instead of beside the next layer's FFN
@@ -1263,6 +1273,7 @@ public:
         }
         prof_block = PB_LR;
         if (phase_ffn && layer_open) CK(flush_layer(s, true));        // the first layer's attention wgrads: the only launch nothing of the encoder runs beside
+        if (wg.count > 0) CK(flush_wgrad(wg, par, s, false, true));   // (an encoder without stages: the head's problems alone)
         CK(launch_pending(s));
         CK(fin_flush(fin, fin_accumulate, s));
         fin.begin(nullptr, 0, 0);
