@@ -22,6 +22,7 @@ extern int g_rgqa_cls_tail;
 extern int g_rgqa_attn_pair;
 extern int g_rgqa_skip_wgrad;
 extern int g_rgqa_wgrad_merge;
+extern int g_rgqa_nt_splitk;
 // debug / test switches (include/rgqa.h)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -30,6 +31,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 4) { g_rgqa_tn_mtw = value; return RGQA_OK; }
     if (key == 5) { g_rgqa_skip_wgrad = value; return RGQA_OK; }
     if (key == 6) { g_rgqa_wgrad_merge = value; return RGQA_OK; }
+    if (key == 7) { g_rgqa_nt_splitk = value; return RGQA_OK; }
     if (key == 8) { g_rgqa_cls_tail = value; return RGQA_OK; }
     if (key == 16) { g_rgqa_attn_pair = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
@@ -270,6 +272,19 @@ int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const voi
     p.A = A; p.B = W; p.C = C; p.C2 = C2; p.bias = bias; p.aux = aux; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.ldaux = ldaux;
     p.epi = epilogue; p.drop_site = 17u;
     return dtype == 2 ? launch_gemm_nt_x3(g, 0, S(stream)) : launch_gemm_nt_bf16(g, 0, S(stream));
+}
+// the same bf16 problem with split-K scratch (ws_floats floats): problems of M <= 256 rows and K >= 1536 are cut along the contraction
+// (csrc/gemm_mfma256.hip); out_f32: C is float (plain-bias epilogue only)
+int rgqa_op_linear_splitk(const void* A, const void* W, const float* bias, const void* aux, void* C, void* C2, int M, int N, int K, int lda, int ldw, int ldc,
+                          int ldaux, int epilogue, float drop_p, int out_f32, float* ws, size_t ws_floats, void* stream) {
+    RGQA_REQUIRE(epilogue >= 0 && epilogue <= EPI_DRELU_DROP && epilogue != EPI_ACCUM, "op_linear_splitk: bad epilogue %d", epilogue);
+    RGQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f && ws != nullptr, "op_linear_splitk: bad argument");
+    GemmGroup g; memset(&g, 0, sizeof g);
+    g.count = 1; g.drop = make_drop(drop_p, 0x1234567ull, 0); g.splitk_ws = ws; g.splitk_floats = ws_floats;
+    GemmProblem& p = g.p[0];
+    p.A = A; p.B = W; p.C = C; p.C2 = C2; p.bias = bias; p.aux = aux; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.ldaux = ldaux;
+    p.epi = epilogue; p.drop_site = 17u;
+    return launch_gemm_nt_bf16(g, out_f32, S(stream));
 }
 int rgqa_op_matmul_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {
     GemmGroup g; memset(&g, 0, sizeof g);

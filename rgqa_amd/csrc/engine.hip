@@ -252,6 +252,7 @@ public:
     TB *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
     static constexpr bool ln_merge = true;   // one LayerNorm launch over [language | vision] rows
     float* lnpart_s[NPAR] = {}; FinDefer fin; int fin_accumulate = 0;   // LayerNorm-backward column sums of the open layer (finalised with its wgrad launch)
+    size_t part_floats = 0;
     float* part = nullptr; TransDesc* tdesc = nullptr; int n_tdesc = 0, tdesc_tiles = 0;
     void* lang_final = nullptr;
     std::vector<TransDesc> tdesc_host;
@@ -526,7 +527,8 @@ public:
             }
         gp1 = take<TB>((size_t)B * 2 * H); gp2 = take<TB>((size_t)B * 2 * H); gp3 = take<TB>((size_t)B * 2 * H);
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
-        part = take<float>((size_t)512 * 10 * pw);
+        part_floats = (size_t)512 * 10 * pw;
+        part = take<float>(part_floats);
         for (int par = 0; par < NPAR; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
         sumsq_ws_segs = (int)grad_segs.size(); sumsq_ws = take<float>((size_t)sumsq_ws_segs * SUMSQ_WS_STRIDE);
         if (joint) {
@@ -690,22 +692,26 @@ public:
             if (p.Cb != nullptr) bytes += 2.0 * (double)p.M * p.N;
         }
     }
-    int run_fwd(GemmGroup& g, hipStream_t s, int out_f32 = 0, int a_f32 = 0) {
+    // cls_rows: the launch is one of those whose rows are the B [CLS] rows (tail of the last layer, pooler, answer head): skinny whatever the
+    // batch - it may take the split-K path.  Chosen by call site, not by shape: a sample's arithmetic must not depend on the batch it is in.
+    int run_fwd(GemmGroup& g, hipStream_t s, int out_f32 = 0, int a_f32 = 0, bool cls_rows = false) {
         if (g.count == 0) return RGQA_OK;
         g.a_f32 = a_f32;
         if (out_f32) for (int i = 0; i < g.count; ++i) g.p[i].Cb = nullptr;      // f32 results (the logits) have no image
         double f, b; gemm_work(g, f, b);
         char tg[48];
         prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "");
+        if constexpr (std::is_same<T, bf16_t>::value) { if (cls_rows) { g.splitk_ws = part; g.splitk_floats = part_floats; } }
         int r = nt_gemm(g, out_f32, 0, s);
         prof_end(s);
         return r;
     }
-    int run_dgrad(GemmGroup& g, hipStream_t s) {
+    int run_dgrad(GemmGroup& g, hipStream_t s, bool cls_rows = false) {
         if (g.count == 0) return RGQA_OK;
         double f, b; gemm_work(g, f, b);
         char tg[48];
         prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "");
+        if constexpr (std::is_same<TB, bf16_t>::value) { if (cls_rows) { g.splitk_ws = part; g.splitk_floats = part_floats; } }
         int r = nt_gemm_b(g, 0, 1, s);
         prof_end(s);
         return r;
@@ -755,10 +761,10 @@ public:
             CKP(PC_OTHER, k_gather_rows<T>((const T*)st.sb[0].x_in, H, cu, Tn, tail_x, H, B, H, s));      // the [CLS] row of every sample
             CK(image_of(tail_x, H, B, H, s));
             add_fwd(g, tail_x, H, st.ffn[0]->up, 0, I, st.sb[0].h, I, B, EPI_GELU, nullptr, 0, st.sb[0].hpre, 0);
-            CK(run_fwd(g, s));
+            CK(run_fwd(g, s, 0, 0, true));
             gg_init(g); g.drop = drop_base(pd);
             add_fwd(g, st.sb[0].h, I, st.ffn[0]->down, 0, H, st.sb[0].z, H, B, EPI_RESID_DROP, tail_x, H, nullptr, st.site + 1);
-            CK(run_fwd(g, s));
+            CK(run_fwd(g, s, 0, 0, true));
             CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.ffn[0]->ln.w, P + st.ffn[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, B, H, cfg.ln_eps, s, img(st.sb[0].y)));
             return RGQA_OK;
         }
@@ -970,16 +976,16 @@ public:
             if (!stages.empty() && cls_tail(stages.back())) pool_in = (T*)lang_final;      // already the B compact [CLS] rows
             else { CKP(PC_OTHER, k_gather_rows<T>((const T*)lang_final, H, cu, Tn, cls_rows, H, B, H, s)); CK(image_of(cls_rows, H, B, H, s)); }     // the [CLS] row of every sample
             add_fwd(g, pool_in, H, mp.pooler, 0, H, pooled, H, B, EPI_TANH, nullptr, 0, nullptr, 0);
-            CK(run_fwd(g, s));
+            CK(run_fwd(g, s, 0, 0, true));
             gg_init(g);
             add_fwd(g, pooled, H, mp.head0, 0, 2 * H, h1, 2 * H, B, EPI_GELU, nullptr, 0, h1pre, 0);
-            CK(run_fwd(g, s));
+            CK(run_fwd(g, s, 0, 0, true));
             CKP(PC_LN, k_ln_fwd<T>(h1, 2 * H, P + mp.head_ln.w, P + mp.head_ln.b, h2, 2 * H, hd_mean, hd_rstd, B, 2 * H, cfg.ln_eps, s, img(h2)));
             gg_init(g);
             // N = NAp (a multiple of 64): the arena slots of logit_fc.3.weight / .bias are zero-padded up to NAp rows, so the extra
             // logits columns come out as exact zeros and the GEMM runs on the LDS-DMA kernel
             add_fwd(g, h2, 2 * H, mp.head3, 0, LP ? NAp : cfg.num_answers, logits, NAp, B, EPI_BIAS, nullptr, 0, nullptr, 0);
-            CK(run_fwd(g, s, 1));
+            CK(run_fwd(g, s, 1, 0, true));
         }
         if (pooled_out) CKP(PC_OTHER, k_to_f32<T>(pooled, H, pooled_out, H, B, H, s));
         if (logits_out) CKP(PC_OTHER, k_fill_rows<float>(logits_out, ld_logits, logits, NAp, B, cfg.num_answers, s));
@@ -1028,13 +1034,13 @@ public:
         // forward tensors) are not written again during backward
         gg_init(wg_head);
         add_wgrad(wg_head, dlogits, NAp, mp.head3, 0, NA, sv(h2), 2 * H, B, accumulate);
-        gg_init(g); add_dgrad(g, dlogits, NAp, mp.head3, 0, NA, gp1, 2 * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
+        gg_init(g); add_dgrad(g, dlogits, NAp, mp.head3, 0, NA, gp1, 2 * H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s, true));
         CKP(PC_LN, k_ln_bwd<TB>(gp1, 2 * H, sv(h1), 2 * H, P + mp.head_ln.w, hd_mean, hd_rstd, gp2, nullptr, 2 * H, part, G + mp.head_ln.w, G + mp.head_ln.b, nullptr,
                        accumulate, B, 2 * H, nodrop, nodrop, 1.0f, s));
         CKP(PC_OTHER, k_dgelu_mul<TB>(gp2, sv(h1pre), gp3, (size_t)B * 2 * H, s));
         CKP(PC_OTHER, colsum_bias(gp3, 2 * H, mp.head0, 0, 2 * H, B, accumulate, s));
         add_wgrad(wg_head, gp3, 2 * H, mp.head0, 0, 2 * H, sv(pooled), H, B, accumulate);
-        gg_init(g); add_dgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, gp1, H, B, EPI_DTANH, sv(pooled), H); CK(run_dgrad(g, s));   // gp1[B,H] = d(pooler pre-tanh)
+        gg_init(g); add_dgrad(g, gp3, 2 * H, mp.head0, 0, 2 * H, gp1, H, B, EPI_DTANH, sv(pooled), H); CK(run_dgrad(g, s, true));   // gp1[B,H] = d(pooler pre-tanh)
         return backward_encoder(accumulate, s);
     }
 
@@ -1082,7 +1088,7 @@ public:
             return RGQA_OK;
         };
         CK(rgqa_check_hip(hipMemsetAsync(dyp[0], 0, (size_t)R * H * sizeof(TB), s), "zero dy"));
-        gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, gp2, H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
+        gg_init(g); add_dgrad(g, gp1, H, mp.pooler, 0, H, gp2, H, B, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s, true));
         const bool tail = !stages.empty() && cls_tail(stages.back());
         if (!tail) CKP(PC_OTHER, k_scatter_rows<TB>(gp2, H, dyp[0], H, cu, Tn, B, H, s));     // tail: the last FFN stage takes gp2 [B,H] as it is
         seg_cursor = 0;
@@ -1124,10 +1130,10 @@ public:
                 CKP(PC_LN, k_ln_bwd<TB>(gp2, H, sv(st.sb[0].z), H, P + f.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b,
                                accumulate, B, H, d, nodrop, 1.0f, s, &fin));
                 TB* gzm = d.thresh ? gzd : gz;
-                gg_init(g); add_dgrad(g, gzm, H, f.down, 0, H, gh, I, B, EPI_DGELU, sv(st.sb[0].hpre), I); CK(run_dgrad(g, s));
+                gg_init(g); add_dgrad(g, gzm, H, f.down, 0, H, gh, I, B, EPI_DGELU, sv(st.sb[0].hpre), I); CK(run_dgrad(g, s, true));
                 add_wgrad(wg, gzm, H, f.down, 0, H, sv(st.sb[0].h), I, B, accumulate);
                 add_wgrad(wg, gh, I, f.up, 0, I, sv(tail_x), H, B, accumulate, true);
-                gg_init(g); add_dgrad(g, gh, I, f.up, 0, I, tail_dx, H, B, EPI_ADD, gz, H); CK(run_dgrad(g, s));
+                gg_init(g); add_dgrad(g, gh, I, f.up, 0, I, tail_dx, H, B, EPI_ADD, gz, H); CK(run_dgrad(g, s, true));
                 CK(rgqa_check_hip(hipMemsetAsync(dxp[0], 0, (size_t)Rl * H * sizeof(TB), s), "zero tail dx"));
                 CKP(PC_OTHER, k_scatter_rows<TB>(tail_dx, H, dxp[0], H, cu, Tn, B, H, s));
                 { TB* t = dyp[0]; dyp[0] = dxp[0]; dxp[0] = t; }

@@ -48,6 +48,8 @@ struct GemmGroup {
     int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
     const void* zeros;  // TN LDS-DMA kernel: >= 16 zero bytes on the device (source of the contraction tail's A rows)
     unsigned long long* stamps;   // clock probe only (rgqa_probe_gemm: separately instantiated, stamped kernels): 8 words per block
+    float* splitk_ws;   // bf16 NT launches: scratch for the split-K path of skinny problems (gemm_mfma256.hip), splitk_floats floats, or null
+    size_t splitk_floats;
     DropCfg drop;
     GemmProblem p[GEMM_MAX_PROBLEMS];
 };

@@ -296,11 +296,12 @@ int g_rgqa_force_gemm128 = 0;
 bool gemm_nt256_eligible(const GemmGroup& g, int out_f32);
 int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s);
 int launch_gemm_nt256_f32out(GemmGroup& g, hipStream_t s);
+int launch_gemm_nt256_any(GemmGroup& g, int out_f32, hipStream_t s);
 
 int launch_gemm_nt_bf16(GemmGroup& g, int out_f32, hipStream_t s) {
     int r = check_group(g, false);
     if (r) return r;
-    if (!g_rgqa_force_gemm128 && gemm_nt256_eligible(g, out_f32)) return out_f32 ? launch_gemm_nt256_f32out(g, s) : launch_gemm_nt256_bf16(g, s);
+    if (!g_rgqa_force_gemm128 && gemm_nt256_eligible(g, out_f32)) return launch_gemm_nt256_any(g, out_f32, s);
     static const bool log_fb = getenv("RGQA_GEMM_LOG_FALLBACK") != nullptr;       // which launches still take the 128x128 register-staged kernel
     if (log_fb && !g_rgqa_force_gemm128)
         for (int i = 0; i < g.count; ++i)

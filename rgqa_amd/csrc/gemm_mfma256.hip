@@ -94,6 +94,68 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
     }
 }
 
+// ============================================================================ split-K for skinny NT problems
+// The [CLS]-row tail of the last layer, the pooler and the answer head are GEMMs of M = B <= 256 rows: 3-12 tiles on a 256-CU chip, each
+// walking a contraction of 1,536-3,072 alone (42 us for 1.2 GFLOP).  Their contraction is cut into S <= 12 slices that run as the S problems
+// of ONE grouped launch of the f32-result kernel (64-row tiles: 4 x N/256 x S blocks, 4-5 K-steps each) into f32 partial tiles, and one pass
+// sums the slices in slice order - a fixed order: bit-reproducible - and applies the epilogue (bias, activation, dropout, residual, second
+// output) with the shared element-wise epilogue of gemm.h.  Two launches of ~6 us for one of 25-42.
+int g_rgqa_nt_splitk = 1;     // rgqa_debug_set key 7: 0 = skinny problems stay whole
+template <typename OutT>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmProblem P, const DropCfg drop, const float* __restrict__ part, int S, int ldp, size_t slice_stride) {
+    const int nq = P.N >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)P.M * nq) return;
+    const int m = (int)(i / nq), n0 = (int)(i % nq) << 2;
+    const float* src = part + (size_t)m * ldp + n0;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        float t[4]; load4(src + (size_t)s * slice_stride, t);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    gemm_epilogue4_e<OutT, bf16_t>(P, P.epi, drop, m, n0, v);
+}
+static int splitk_slices(const GemmGroup& g, int out_f32) {
+    if (!g_rgqa_nt_splitk || g.count != 1 || g.a_f32 || g.splitk_ws == nullptr || g.stamps != nullptr) return 0;
+    const GemmProblem& p = g.p[0];
+    if (p.M > 256 || p.K < 1536 || (p.K % TK) != 0 || (p.N % 8) != 0 || (p.ldc % 4) != 0 || p.Cb != nullptr) return 0;
+    if (out_f32 && p.epi != EPI_BIAS) return 0;
+    if (p.epi == EPI_ACCUM || (epi_needs_aux(p.epi) && (p.aux == nullptr || (p.ldaux % 4) != 0))) return 0;
+    int S = (p.K / TK) / 4;
+    if (S > GEMM_NT_MAX_PROBLEMS) S = GEMM_NT_MAX_PROBLEMS;
+    if (S < 2 || (size_t)S * p.M * p.N > g.splitk_floats) return 0;
+    return S;
+}
+static int launch_gemm_nt_splitk(GemmGroup& g, int S, int out_f32, hipStream_t s) {
+    const GemmProblem P = g.p[0];
+    const int steps = P.K / TK, ldp = P.N;
+    const size_t stride = (size_t)P.M * ldp;
+    GemmGroup g2; memset(&g2, 0, sizeof g2);
+    g2.count = S; g2.drop = g.drop;
+    for (int i = 0, k0 = 0; i < S; ++i) {
+        const int ks = (steps / S + (i < steps % S ? 1 : 0)) * TK;
+        GemmProblem& q = g2.p[i];
+        q.A = reinterpret_cast<const bf16_t*>(P.A) + k0; q.lda = P.lda;
+        q.B = reinterpret_cast<const bf16_t*>(P.B) + k0; q.ldb = P.ldb;
+        q.C = g.splitk_ws + (size_t)i * stride; q.ldc = ldp;
+        q.M = P.M; q.N = P.N; q.K = ks; q.epi = EPI_BIAS;
+        k0 += ks;
+    }
+    RGQA_REQUIRE(gemm_nt256_eligible(g2, 1), "gemm split-K: internal eligibility mismatch");
+    if (int r = launch_gemm_nt256_f32out(g2, s)) return r;
+    const long n4 = (long)P.M * (P.N >> 2);
+    const int blocks = (int)((n4 + 255) / 256);
+    if (out_f32) hipLaunchKernelGGL((splitk_finish_kernel<float>), dim3(blocks), dim3(256), 0, s, P, g.drop, g.splitk_ws, S, ldp, stride);
+    else hipLaunchKernelGGL((splitk_finish_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, P, g.drop, g.splitk_ws, S, ldp, stride);
+    RGQA_LAUNCH_CHECK("splitk_finish_kernel");
+    return RGQA_OK;
+}
+// the bf16 NT entry of the LDS-DMA kernels: skinny single problems take the split-K path when the caller provides scratch
+int launch_gemm_nt256_any(GemmGroup& g, int out_f32, hipStream_t s) {
+    if (const int S = splitk_slices(g, out_f32)) return launch_gemm_nt_splitk(g, S, out_f32, s);
+    return out_f32 ? launch_gemm_nt256_f32out(g, s) : launch_gemm_nt256_bf16(g, s);
+}
+
 // ============================================================================ TN (wgrad) with LDS-DMA
 //   C[M,N] (f32) (+)= A[K,M]^T * B[K,N],  K % 64 == 0:  dW[n,k] = sum_rows dY[row,n] X[row,k]
 // 128 x 256 output tile, 8 waves (2 x 4, 64x64 each), 3-stage ring x (A 64x128 + B 64x256) bf16 = 144 KiB.

@@ -143,6 +143,47 @@ def test_matmul_tn_bf16_both_tile_heights(lib, mtw, M, N, K):
     assert float((got - ref).abs().max()) < 1e-2 * math.sqrt(K)
 
 
+@pytest.mark.parametrize("M", [256, 4, 77])
+@pytest.mark.parametrize("N,K,epi", [(768, 3072, 3), (768, 3072, 5), (3072, 1536, 1), (768, 1536, 7), (1536, 1856, 0), (768, 2304, 2), (3072, 1536, 4)])
+def test_linear_splitk_matches_the_whole_problem(lib, M, N, K, epi):
+    """Skinny bf16 problems (M <= 256, K >= 1536) cut along the contraction (rgqa_op_linear_splitk) against the same problem run whole
+    (rgqa_op_linear_ex) - same epilogue, same dropout stream; the two differ by the order of the f32 additions, i.e. by bf16 rounding of the
+    result - and against an f32 matmul."""
+    A = rnd(M, K, seed=1).bfloat16(); W = (rnd(N, K, seed=2) * 0.05).bfloat16(); b = rnd(N, seed=3)
+    aux = rnd(M, N, seed=4).bfloat16()
+    ws = torch.empty(12 * M * N, device="cuda")
+    outs = []
+    for split in (True, False):
+        Cc = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); C2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        if split:
+            ck(lib.rgqa_op_linear_splitk(P(A), P(W), P(b), P(aux), P(Cc), P(C2), M, N, K, K, K, N, N, epi, 0.1 if epi == 3 else 0.0, 0, P(ws), ws.numel(), S()))
+        else:
+            ck(lib.rgqa_op_linear_ex(P(A), P(W), P(b), P(aux), P(Cc), P(C2), M, N, K, K, K, N, N, epi, 0.1 if epi == 3 else 0.0, 1, S()))
+        outs.append((Cc.float(), C2.float()))
+    (c1, g1), (c0, g0) = outs
+    tol = 2.0 ** -7
+    assert float(((c1 - c0).abs() - tol * c0.abs()).max()) <= 2e-2, float((c1 - c0).abs().max())
+    if epi == 3:
+        assert float(((c1 == aux.float()) != (c0 == aux.float())).float().mean()) < 1e-3      # the same elements dropped
+    if epi == 1:
+        assert float((g1 - g0).abs().max()) <= 2e-2
+    pre = A.float() @ W.float().t() + b
+    ref = {0: pre, 1: torch.nn.functional.gelu(pre), 2: torch.tanh(pre), 4: pre * aux.float(), 5: pre + aux.float(), 7: pre * (1 - aux.float() ** 2)}.get(epi)
+    if ref is not None:
+        assert float((c1 - ref).norm() / ref.norm()) < 1e-2
+
+
+def test_linear_splitk_f32_result(lib):
+    """the logits GEMM's shape: f32 result, plain bias"""
+    M, N, K = 256, 1856, 1536
+    A = rnd(M, K, seed=1).bfloat16(); W = (rnd(N, K, seed=2) * 0.05).bfloat16(); b = rnd(N, seed=3)
+    ws = torch.empty(12 * M * N, device="cuda")
+    Cc = torch.zeros(M, N, device="cuda")
+    ck(lib.rgqa_op_linear_splitk(P(A), P(W), P(b), None, P(Cc), None, M, N, K, K, K, N, N, 0, 0.0, 1, P(ws), ws.numel(), S()))
+    ref = A.float() @ W.float().t() + b
+    assert float((Cc - ref).abs().max()) < 1e-3
+
+
 def tn_group(lib, probs, dtype, accumulate=0, C=None, cs=None):
     """One grouped wgrad launch (rgqa_op_matmul_tn_group): probs = [(A [K,lda], B [K,ldb], M, N, with_colsum, K, lda, ldb)]; returns (C list, colsum list)."""
     import ctypes

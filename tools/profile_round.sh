@@ -10,7 +10,7 @@ BENCH="python3 bench.py --steps 5 --warmup 2 --lean"
 STEPS=7
 # 0. the box and its step
 BOXMS=$(python3 bench.py --lean --steps 60 --warmup 15 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])")
-BOXID=$( (rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id" | head -1 | sed 's/.*: *//') || true)
+BOXID=$( (rocm-smi --showuniqueid 2>/dev/null | grep "GPU\[" | grep -i "unique id" | head -1 | sed 's/.*: *//') || true)
 BOX="gpu ${BOXID:-unknown} host $(hostname) bf16 lean step ${BOXMS:-?} ms ($(date -u +%Y-%m-%dT%H:%MZ))"
 echo "$BOX" > $OUT/${TAG}_box.txt; echo "box: $BOX"
 stamp() { python3 tools/stamp_box.py "$BOX" "$@"; }
@@ -67,6 +67,8 @@ rm -rf $OUT/${TAG}_p_stats $OUT/${TAG}_p_stats_serial $OUT/${TAG}_p_stats_x3 $OU
 timeout -k 10 200 python3 tools/nt_stamps.py > $OUT/${TAG}_nt_stamps.txt 2>/dev/null; echo "stamps rc=$?"
 timeout -k 10 300 python3 tools/vendor_gemm.py > $OUT/${TAG}_vendor_gemm.txt 2>/dev/null; echo "vendor rc=$?"
 timeout -k 10 200 python3 tools/wgrad_probe.py 30 3 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_wgrad_probe.txt; echo "wgrad probe rc=$?"
+timeout -k 10 200 python3 tools/wgrad_lab.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_wgrad_lab.txt; echo "wgrad lab rc=$?"
+timeout -k 10 300 python3 tools/ab_debug.py 6 "1 2 3 4" 3 bf16 2>/dev/null | grep key > $OUT/${TAG}_wgrad_merge_ab.txt; echo "wgrad merge ab rc=$?"
 timeout -k 10 200 python3 tools/sumsq_probe.py bf16 3 2>/dev/null | grep median > $OUT/${TAG}_sumsq_probe.txt; echo "sumsq probe rc=$?"
-stamp $OUT/${TAG}_nt_stamps.txt $OUT/${TAG}_vendor_gemm.txt $OUT/${TAG}_wgrad_probe.txt $OUT/${TAG}_sumsq_probe.txt
+stamp $OUT/${TAG}_nt_stamps.txt $OUT/${TAG}_vendor_gemm.txt $OUT/${TAG}_wgrad_probe.txt $OUT/${TAG}_sumsq_probe.txt $OUT/${TAG}_wgrad_lab.txt $OUT/${TAG}_wgrad_merge_ab.txt
 ls $OUT | grep "^${TAG}_"
