@@ -42,7 +42,10 @@ struct GemmProblem {
 #define GEMM_MAX_PROBLEMS 32
 // NT launches (forward, dgrad) group at most 12: their kernels look a tile's problem up in a loop over this many entries, once per tile
 #define GEMM_NT_MAX_PROBLEMS 12
-struct GemmGroup {
+// NP problems; the NT kernels take the 12-problem prefix of a group as their argument (1.5 KB of kernel arguments instead of 3.9), the
+// TN kernels the whole group
+template <int NP>
+struct GemmGroupT {
     int count;
     int total_tiles;
     int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
@@ -51,8 +54,11 @@ struct GemmGroup {
     float* splitk_ws;   // bf16 NT launches: scratch for the split-K path of skinny problems (gemm_mfma256.hip), splitk_floats floats, or null
     size_t splitk_floats;
     DropCfg drop;
-    GemmProblem p[GEMM_MAX_PROBLEMS];
+    GemmProblem p[NP];
 };
+using GemmGroup = GemmGroupT<GEMM_MAX_PROBLEMS>;
+using GemmGroupNT = GemmGroupT<GEMM_NT_MAX_PROBLEMS>;
+static inline const GemmGroupNT& nt_prefix(const GemmGroup& g) { return reinterpret_cast<const GemmGroupNT&>(g); }
 
 // Epilogue on 4 consecutive columns n0..n0+3 of row m. OutT = float or bf16_t; AuxT = act type.
 template <typename OutT, typename AuxT>

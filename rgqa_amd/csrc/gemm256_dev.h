@@ -50,7 +50,7 @@ __device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch
 // the next tile's first K-steps - runs after the last of them (compiler-tracked loads issued behind the untracked LDS-DMA would make
 // every aux wait drain the DMA as well).
 template <typename OutT, int EPI, int MT, typename F>
-__device__ __forceinline__ void nt256_epilogue(const GemmGroup& g, const GemmProblem& P, unsigned char* lds, int wave, int lane,
+__device__ __forceinline__ void nt256_epilogue(const GemmGroupNT& g, const GemmProblem& P, unsigned char* lds, int wave, int lane,
                                                int m0, int n0, int wm, int wn, f32x4 (&acc)[MT][4], F&& after_loads) {
     const int M = P.M, N = P.N;
     const int fr = lane & 15, fq = lane >> 4;

@@ -44,7 +44,7 @@ static int launch_probe(GemmGroup& g, hipStream_t s) {
             RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<bf16_t, EPI, MT, NSD, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
             attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_nt256d_kernel<bf16_t, EPI, MT, NSD, false, true>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, g);
+        hipLaunchKernelGGL((gemm_nt256d_kernel<bf16_t, EPI, MT, NSD, false, true>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, nt_prefix(g));
     } else {
         constexpr int LDS_BYTES = NT256_LDS(MT);
         if (!attr_set) {
@@ -53,7 +53,7 @@ static int launch_probe(GemmGroup& g, hipStream_t s) {
         }
         int grid = g.total_tiles;
         if (grid > rgqa_num_cus()) grid = rgqa_num_cus();
-        hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI, MT, false, true>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
+        hipLaunchKernelGGL((gemm_nt256_kernel<bf16_t, EPI, MT, false, true>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, nt_prefix(g));
     }
     RGQA_LAUNCH_CHECK("gemm_nt256 probe");
     return RGQA_OK;
@@ -185,26 +185,32 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_tn_dma_kernel(const GemmGro
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int tile = blockIdx.x;
+    // Block id -> tile.  The launcher sorts the problems by contraction length; problems of equal length form a class, and the ids of a class
+    // are re-dealt so that the blocks of one XCD (equal id mod 8, dispatched in id order) walk ONE contiguous run of the class's tile list:
+    // a run is a compact piece of one weight matrix - M-tiles of one N-tile first - whose tiles stream the same operand rows at the same time
+    // through that XCD's L2.  (Per problem instead of per class, the runs were 3-5 tiles: L2 hit rate 0.39.)  Every XCD gets an eighth of
+    // every class, so the XCDs stay balanced whatever the mix of lengths.
+    const int tile0 = blockIdx.x;
+    int p0 = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+        if (i < g.count && tile0 >= g.p[i].tile_start) p0 = i;
+    const int K0 = g.p[p0].K;
+    int c_lo = g.p[p0].tile_start, c_hi = g.total_tiles;
+#pragma unroll
+    for (int i = 0; i < GEMM_MAX_PROBLEMS; ++i)
+        if (i < g.count) {
+            if (g.p[i].K == K0) c_lo = min(c_lo, g.p[i].tile_start);
+            else if (g.p[i].K < K0) c_hi = min(c_hi, g.p[i].tile_start);
+        }
+    const int tile = c_lo + xcd_remap256(tile0 - c_lo, c_hi - c_lo);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
         if (i < g.count && tile >= g.p[i].tile_start) pi = i;
     const GemmProblem& P = g.p[pi];
-    // tile order inside a problem: consecutive ids run over the M-tiles of one N-tile first, so neighbours stream the same B
-    // operand (the wider one); blocks that share an XCD (equal id mod 8) get consecutive ids.
-    // Round 4 measured two alternatives, both removed (profiles/r04_wgrad_cost_probe.txt, profiles/r04_pmc_tcc_hit_*.json): (1) ONE contiguous
-    // run of the whole launch's tile list per XCD, each XCD holding a compact sub-grid of one weight matrix: L2 hit rate 0.39 -> 0.68, fabric
-    // requests halved, serialised time unchanged (3.33 -> 3.39 ms per step) and the step 0.85 ms SLOWER (the long-contraction problems then
-    // sit on four of the eight XCDs, whose CUs the main stream's launches wait for); (2) a five-slot ring of 32-row K-steps (three K-steps in
-    // flight instead of one): +0.35 ms per step.  The loop is bound neither by where its lines come from nor by how early they are requested.
-    // (Round 4 measured the alternative - ONE contiguous run of the whole launch's tile list per XCD, each XCD then holding a compact
-    // sub-grid of one weight matrix: L2 hit rate of this kernel 0.39 -> 0.68, fabric requests halved (profiles/r04_pmc_tcc_hit_*.json),
-    // serialised time unchanged (3.33 -> 3.39 ms per step) and the step 0.85 ms SLOWER (11.93 -> 12.78, three interleaved rounds,
-    // profiles/r04_wgrad_cost_probe.txt): the loop is not bound by where its lines come from, and the long-contraction problems then sit
-    // on four of the eight XCDs, whose CUs the main stream's launches wait for.)
     const int tiles_m = cdiv(P.M, WMV);
-    const int tix = xcd_remap256(tile - P.tile_start, tiles_m * P.tiles_n);
+    const int tix = tile - P.tile_start;
     const int local = (tix % tiles_m) * P.tiles_n + (tix / tiles_m);     // back to the m-major id used below
     const int m0 = (local / P.tiles_n) * WMV, n0 = (local % P.tiles_n) * WN;
     // contraction length need not be a multiple of the K-step (packed language rows): in the last, partial step the A rows

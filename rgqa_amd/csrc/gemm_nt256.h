@@ -84,7 +84,7 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
 // under this loop), 4 s_memrealtime when the first tile's first operands have landed, 5 at the end of its K loop, 6 after its epilogue
 // (stores issued, not drained), 7 the number of tiles the block walked.
 template <typename OutT, int EPI, int MT, bool X3, bool STAMP = false>
-__global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroup g) {
+__global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroupNT g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned long long st_c0 = 0, st_r0 = 0, st_r1 = 0, st_r2 = 0, st_r3 = 0, st_nt = 0;
     if (STAMP && threadIdx.x == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
 // the ring: NS = 4 slots for MT = 2 (40 KiB each) - three K-steps in flight under counted vmcnt waits; the epilogue scratch
 // aliases the ring once the last step has been consumed.
 template <typename OutT, int EPI, int MT, int NS, bool X3, bool STAMP = false>
-__global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGroup g) {
+__global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGroupNT g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned long long st_c0 = 0, st_r0 = 0, st_r1 = 0, st_r2 = 0;
     if (STAMP && threadIdx.x == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -330,7 +330,7 @@ static int launch256(GemmGroup& g, hipStream_t s) {
             RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
             attr_set_d = true;
         }
-        hipLaunchKernelGGL((gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, g);
+        hipLaunchKernelGGL((gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, nt_prefix(g));
         RGQA_LAUNCH_CHECK("gemm_nt256d_kernel");
         return RGQA_OK;
     } else {
@@ -341,7 +341,7 @@ static int launch256(GemmGroup& g, hipStream_t s) {
         }
         int grid = g.total_tiles;
         if (grid > rgqa_num_cus()) grid = rgqa_num_cus();     // one persistent block per CU
-        hipLaunchKernelGGL((gemm_nt256_kernel<OutT, EPI, MT, X3>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, g);
+        hipLaunchKernelGGL((gemm_nt256_kernel<OutT, EPI, MT, X3>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, nt_prefix(g));
         RGQA_LAUNCH_CHECK("gemm_nt256_kernel");
         return RGQA_OK;
     }
