@@ -585,6 +585,39 @@ def test_side_stream_wgrad_matches_serial():
         assert torch.equal(grads(0), ref)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "f32"])
+def test_merged_wgrad_launches_give_the_same_gradients(prec):
+    """The weight-gradient problems of 1, 2, 3 or 4 backward periods in one launch (rgqa_debug_set key 6): the kernel per output tile is the
+    same whatever shares the launch, so the gradients - including an accumulating second backward - are bit-identical."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    cfg = FULL if prec != "f32" else MED
+    B, T, O = (32, 20, 36) if prec != "f32" else (6, 12, 10)
+    b = dev(synth.synth_batch(B, T, O=O, F=cfg["feat_dim"], NA=cfg["num_answers"], vocab=cfg["vocab_size"], seed=5, min_len=3))
+    e = make_engine(cfg, prec, dropout=0.1)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)      # the embedding tables are scatter-added with f32 atomics
+
+    def grads(merge):
+        assert L.rgqa_debug_set(6, merge) == 0
+        try:
+            run(e, b, True, 77)
+            e.loss_backward(b["target"])
+            one = e.grads[first:].clone()
+            e.loss_backward(b["target"], accumulate=True)
+            torch.cuda.synchronize()
+            return one, e.grads[first:].clone()
+        finally:
+            L.rgqa_debug_set(6, 0)
+
+    ref1, ref2 = grads(1)
+    assert float(ref1.abs().max()) > 0 and float((ref2 - 2 * ref1).abs().max()) <= 1e-5 * float(ref1.abs().max())
+    for merge in (2, 3, 4):
+        g1, g2 = grads(merge)
+        assert torch.equal(g1, ref1) and torch.equal(g2, ref2), merge
+
+
 @pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("tag,T,prec,tol", [("small", 5, "f32", 2e-5), ("small", 8, "f32", 2e-5), ("full", 20, "f32", 1e-4), ("full", 20, "bf16x3", 1e-4),
                                             ("full", 20, "bf16", 3e-2)])
