@@ -270,6 +270,10 @@ class _EngineFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, owner, feats, boxes, ids, mask, seg, want_logits):
         lg, pl = owner._engine_forward(feats, boxes, ids, mask, seg, train=owner.training)
+        # an output the loss does not depend on gets None for its gradient, not a tensor of zeros: backward() can tell which of the two paths
+        # (logits / pooled output) carries a gradient without reading device memory (a `(dpooled != 0).any()` here was a host
+        # synchronisation in every training step: the CPU could not enqueue the backward pass before the forward pass had finished)
+        ctx.set_materialize_grads(False)
         ctx.owner = owner
         ctx.in_shapes = (tuple(feats.shape), tuple(boxes.shape))
         ctx.want_logits = want_logits
@@ -318,7 +322,7 @@ class _EngineFunction(torch.autograd.Function):
             dlogits = None if dlogits is None else dlogits * (1.0 / world)
             dpooled = None if dpooled is None else dpooled * (1.0 / world)
         try:
-            two = ctx.want_logits and dlogits is not None and dpooled is not None and bool((dpooled != 0).any())
+            two = ctx.want_logits and dlogits is not None and dpooled is not None
             if two and (want_f or want_b):
                 raise RuntimeError("rgqa: input gradients through both the logits and the pooled output of one forward are not supported")
             if ctx.want_logits and dlogits is not None:
