@@ -57,7 +57,7 @@ int rgqa_version(void);
  * m-tiles per wave: 2, 4..8; 0 = cost model); key 2: 1 runs the deferred weight-gradient launches on the caller's stream instead of
  * the side stream; key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots (one tile per block);
  * key 5 (measurement only): 1 skips the deferred weight-gradient launches; key 6: periods of backward whose weight-gradient problems go into
- * one launch (1..4; 0 = default); key 7: 0 = skinny GEMMs (M <= 256, K >= 1536) run whole instead of split along K; key 8: 0 computes
+ * one launch (1..4; 0 = default); key 7: 0 = skinny GEMMs (M <= 256, K >= 1536) run whole instead of split along K; key 9: NT tile numbering: 0 = row-major, -1 = panels of N-tiles sized to the L2 (default), n = panel width n; key 8: 0 computes
  * the last language FFN on every row (as the reference does), 1 on the [CLS] rows only (default), -1 = environment RGQA_CLS_TAIL;
  * key 16: 0 launches the two attention problems of a stage separately, 1 as one launch (default). */
 int rgqa_debug_set(int key, int value);

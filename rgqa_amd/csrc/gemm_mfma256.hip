@@ -7,6 +7,7 @@
 #include "gemm_nt256.h"
 
 int g_rgqa_force_mt = 0;      // rgqa_debug_set key 1
+int g_rgqa_nt_panel = -1;     // rgqa_debug_set key 9
 
 // true when every problem of the group can run on the LDS-DMA kernel
 bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
@@ -36,6 +37,7 @@ bool gemm_nt256_eligible(const GemmGroup& g, int out_f32) {
 template <int EPI, int MT>
 static int launch_probe(GemmGroup& g, hipStream_t s) {
     gemm_group_finalize(g, 32 * MT, TN);
+    nt_set_panels<false>(g);
     static bool attr_set = false;
     if constexpr (MT == 2 || MT == 5) {
         constexpr int NSD = MT == 2 ? 4 : 3;

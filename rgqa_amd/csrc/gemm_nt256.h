@@ -21,6 +21,22 @@
 // before their use, which is what the compiler makes of the plain loop (every group of 8 MFMAs then starts behind a full LDS round trip
 // that only the SIMD's other wave can cover).  Measured in situ (B=256 train step): ring 3 -0.18 ms; depth 4 = depth 3; depth 2 within
 // noise of 3; iglp_opt on the plain loop +1..3 % against the ring.
+// tile id inside a problem -> tile coordinates.  P.tiles_n carries the number of N-tiles in its low 16 bits and the PANEL width in its high 16
+// (set by the NT launchers, nt_set_panels): tiles are numbered panel by panel - a panel = `pw` adjacent N-tiles over all M-tiles, N fastest
+// inside it - so that the contiguous run of tile ids an XCD walks (xcd_remap256) stays inside one panel over its rounds: the panel's weight
+// rows (pw x 256 x K elements, sized to fit the XCD's 4-MB L2 beside the streamed A rows) are fetched once instead of once per round, and
+// a round's 32 tiles still share their A rows pw ways.  pw == tiles_n is the plain row-major numbering.
+__device__ __forceinline__ void nt_tile_coords(const GemmProblem& P, int local, int tm_rows, int& m0, int& n0) {
+    const int tn_ = P.tiles_n & 0xFFFF, pw = P.tiles_n >> 16;
+    if (pw <= 0 || pw >= tn_) { m0 = (local / tn_) * tm_rows; n0 = (local % tn_) * TN; return; }
+    const int tiles_m = cdiv(P.M, tm_rows), full = tn_ / pw;          // full panels
+    int pnl = local / (tiles_m * pw);
+    if (pnl > full) pnl = full;                                          // (cannot exceed: the last, narrower panel is index `full`)
+    const int r = local - pnl * tiles_m * pw;
+    const int w = pnl < full ? pw : tn_ - full * pw;                    // width of this panel
+    m0 = (r / w) * tm_rows; n0 = (pnl * pw + r % w) * TN;
+}
+
 #define RGQA_NT_PIPE 3
 template <int MT, bool X3>
 __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsigned char* w, int wm, int wn, int fr, int fq, f32x4 (&acc)[MT][4]) {
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             if (i < g.count && tile >= g.p[i].tile_start) p = i;
         const GemmProblem& P = g.p[p];
         const int local = tile - P.tile_start;
-        pi = p; m0 = (local / P.tiles_n) * TM; n0 = (local % P.tiles_n) * TN; nkt = P.K * KV / TK;
+        pi = p; nt_tile_coords(P, local, TM, m0, n0); nkt = P.K * KV / TK;
         const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
         const bf16_t* W = reinterpret_cast<const bf16_t*>(P.B);
 #pragma unroll
@@ -215,7 +231,9 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
         if (i < g.count && tile >= g.p[i].tile_start) pi = i;
     const GemmProblem& P = g.p[pi];
     const int local = tile - P.tile_start;
-    const int m0 = (local / P.tiles_n) * TM, n0 = (local % P.tiles_n) * TN, nkt = P.K * KV / TK;
+    int m0, n0;
+    nt_tile_coords(P, local, TM, m0, n0);
+    const int nkt = P.K * KV / TK;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
     const bf16_t* W = reinterpret_cast<const bf16_t*>(P.B);
     const bf16_t* asrc[AG];
@@ -314,6 +332,29 @@ static inline int pick_mt(const GemmGroup& g, long& tiles_out) {
 }
 
 extern int g_rgqa_force_mt;      // rgqa_debug_set key 1 (kernel parity tests: every tile height)
+extern int g_rgqa_nt_panel;      // rgqa_debug_set key 9: 0 = row-major tile numbering everywhere, -1 = default, n > 0 = panel width n
+
+// panel width per problem (see nt_tile_coords): the widest panel whose weight rows fit ~1.6 MB (split f32: 2.4 MB - three tiles at K = 768,
+// the measured best), preferring one that divides the N-tile count; narrower than three tiles a panel shares too little inside a round -
+// such problems keep the row-major numbering.  In the train step (tools/ab_debug.py 9): bf16 11.43 -> 11.39 ms, bf16x3 22.88 -> 22.81.
+template <bool X3>
+static inline void nt_set_panels(GemmGroup& g) {
+    for (int i = 0; i < g.count; ++i) {
+        GemmProblem& p = g.p[i];
+        const int tn_ = p.tiles_n & 0xFFFF;
+        int pw = tn_;
+        if (g_rgqa_nt_panel > 0) pw = g_rgqa_nt_panel < tn_ ? g_rgqa_nt_panel : tn_;
+        else if (g_rgqa_nt_panel < 0) {
+            const size_t wblock = (size_t)TN * p.K * (X3 ? 4 : 2);
+            const int fit = (int)(((X3 ? 2400u : 1600u) << 10) / wblock);
+            if (fit >= 3 && tn_ > fit) {
+                pw = fit;
+                for (int c = fit; c >= 3; --c) if (tn_ % c == 0) { pw = c; break; }
+            }
+        }
+        p.tiles_n = tn_ | (pw << 16);
+    }
+}
 
 // Launch of one grouped problem set at tile height MT.  64-, 128- and 160-row tiles take the deep-ring kernel (4 / 3 LDS slots,
 // one tile per block): measured IN SITU (operands arriving from MALL/HBM) -4..-25 % on those launches against the two-slot loop;
@@ -322,6 +363,7 @@ template <typename OutT, int EPI, int MT, bool X3>
 static int launch256(GemmGroup& g, hipStream_t s) {
     constexpr int LDS_BYTES = NT256_LDS(MT);
     gemm_group_finalize(g, 32 * MT, TN);
+    nt_set_panels<X3>(g);
     if constexpr (MT == 2 || MT == 4 || MT == 5) {
         constexpr int NSD = MT == 2 ? 4 : 3;
         constexpr int LDS_D = NSD * (32 * MT * TK * 2 + TN * TK * 2);

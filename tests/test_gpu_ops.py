@@ -184,6 +184,29 @@ def test_linear_splitk_f32_result(lib):
     assert float((Cc - ref).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(2000, 3072, 768), (5000, 2304, 768), (700, 1280, 256)])
+def test_linear_tile_numbering_does_not_change_results(lib, dtype, M, N, K):
+    """The NT kernels number their tiles panel by panel (rgqa_debug_set key 9; csrc/gemm_nt256.h nt_tile_coords): whatever the panel width -
+    dividing the N-tile count or not - every output tile is computed exactly as under the row-major numbering."""
+    A = rnd(M, K, seed=1); W = rnd(N, K, seed=2) * 0.05; b = rnd(N, seed=3)
+    if dtype == 1:
+        Ad, Wd = A.bfloat16(), W.bfloat16()
+    else:
+        Ad, Wd = split(lib, A), split(lib, W)
+    outs = []
+    try:
+        for pw in (0, -1, 2, 3, 4, 5, 7):
+            assert lib.rgqa_debug_set(9, pw) == 0
+            Cc = torch.zeros(M, N, dtype=torch.bfloat16 if dtype == 1 else torch.int32, device="cuda")
+            ck(lib.rgqa_op_linear_ex(P(Ad), P(Wd), P(b), None, P(Cc), None, M, N, K, K, K, N, N, 0, 0.0, dtype, S()))
+            outs.append(Cc)
+    finally:
+        lib.rgqa_debug_set(9, -1)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def tn_group(lib, probs, dtype, accumulate=0, C=None, cs=None):
     """One grouped wgrad launch (rgqa_op_matmul_tn_group): probs = [(A [K,lda], B [K,ldb], M, N, with_colsum, K, lda, ldb)]; returns (C list, colsum list)."""
     import ctypes
