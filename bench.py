@@ -223,9 +223,9 @@ def dp_selfcheck(dist, mode, device, precision="bf16"):
     t = torch.full((n,), float(r + 1), device=device)
     dist.all_reduce(t)
     ok = bool((t == want).all())
-    from rgqa_amd.parallel import payload_dtype
-    kind, _, forced = mode.partition("_")
-    pdt = payload_dtype(precision, forced or None)          # what this exchange puts on the wire: bf16 or f32 by the engine's precision
+    from rgqa_amd.parallel import exchange_payload
+    kind = mode.partition("_")[0]
+    pdt = exchange_payload(mode, precision)          # what this exchange puts on the wire (sharded: by the engine's precision; all-reduce: f32 unless _bf16)
     if kind == "allreduce" and pdt == torch.bfloat16:
         tb = torch.full((n,), float(r + 1), device=device, dtype=torch.bfloat16)
         dist.all_reduce(tb)
@@ -503,7 +503,7 @@ def main():
             dev.update(feats=f2, boxes=b2, target=t2, input_ids=ids2, input_mask=mask2, segment_ids=seg2)
     e.ensure_shape(MB, T, O)
     e.sync_weights()
-    comm = make_exchange(e, dist, mode=dp_mode) if dist is not None else None      # RGQA_DP_MODE: sharded (default) | allreduce, payload by precision (rgqa_amd/parallel.py)
+    comm = make_exchange(e, dist, mode=dp_mode) if dist is not None else None      # RGQA_DP_MODE: sharded (default, payload by precision) | allreduce (f32; _bf16 opts in) (rgqa_amd/parallel.py)
     if dist is None and not args.butd:
         e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
     # (under an exchange the norm belongs to the REDUCED gradients: the sharded exchange takes each owner's share while it sums the shards,

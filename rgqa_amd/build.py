@@ -52,6 +52,11 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    # objects whose source is gone (a deleted or renamed unit) would still travel to the GPU box: prune them
+    live = {os.path.basename(s)[:-4] + ".o" for s in srcs}
+    for o in glob.glob(os.path.join(OBJ, "*.o")):
+        if os.path.basename(o) not in live:
+            os.remove(o)
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in res]

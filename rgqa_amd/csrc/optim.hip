@@ -9,6 +9,30 @@
 // rgqa_grad_sumsq); k_sumsq_owned is for a scratch that only these launches ever touch and that its owner zeroed once (the engine's
 // per-segment slots: 21 launches per step without a memset node each).  (Round 2 ran this as two launches per gradient segment: 42 launches
 // per step, the second one 5 us of pure launch latency.)
+// The cross-block hand-off of sumsq_kernel / sum_parts_kernel: one lane parks its block's partial and draws a ticket; the block whose ticket
+// is last reads every partial.  What makes it correct ON THIS TARGET (and cheap):
+//   * every access to a partial - the publish AND the last block's reads - is a RETURNING agent-scope read-modify-write: on gfx950 such an
+//     atomic is performed at the memory side (MI355X_MICROARCH.md, "atomic DROP it"), never served from a CU's L1 or another XCD's L2, and its
+//     return value exists only once it has been performed;
+//   * the publishing lane WAITS for that return (hardware: s_waitcnt vmcnt(0), forced by the workgroup-scope release fence below - which emits
+//     the wait and NO L2 write-back, unlike an agent-scope release, round 3's 0.33 ms per train step) before it draws its ticket, so the ticket
+//     order is a happens-after order of the publishes at the memory side;
+//   * the last block's reads sit behind a workgroup-scope acquire fence + the workgroup barrier.
+// The LLVM memory model alone gives no happens-before between relaxed agent atomics on different addresses: the argument above is a
+// property of gfx942 / gfx950 with coarse-grained hipMalloc memory, so the file refuses to build for anything else, and
+// tests/test_gpu_ops.py::test_sumsq_handoff_under_load checks the result against a two-pass sum beside GEMMs on all eight XCDs.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "optim.hip: the fence-free partial hand-off is verified on gfx942 / gfx950 only; use agent-scope release / acquire fences elsewhere"
+#endif
+__device__ __forceinline__ bool publish_partial_draw_ticket(unsigned* slot, unsigned bits, int* ticket, int nblocks) {
+    const unsigned old = __hip_atomic_exchange(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" :: "v"(old) : "memory");                          // the returned value is waited for here
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // s_waitcnt only (no buffer_wbl2): the exchange above has been performed
+    const bool last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // the partial reads of the last block are not hoisted above its ticket
+    return last;
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial, float* __restrict__ out, int accumulate) {
     __shared__ float red[4];
     __shared__ int last;
@@ -38,14 +62,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     __syncthreads();
     int* ticket = reinterpret_cast<int*>(partial + 1024);
     if (threadIdx.x == 0) {
-        // Hand-off without fences.  Round 3 bracketed it with agent-scope release / acquire fences: a release is a write-back of the XCD's
-        // whole L2 - per block, 1024 blocks per launch, 21 launches per step beside the GEMMs whose results were sitting there: 0.33 ms of
-        // the train step (tools/sumsq_probe.py).  Now every access to a partial is a RETURNING read-modify-write atomic at agent scope
-        // (performed at the memory side, never served from a CU's L1 or another XCD's L2), and the publishing lane's exchange has returned -
-        // i.e. has been performed - before it draws its ticket; the block whose ticket is last reads behind the workgroup barrier.
-        const unsigned old = __hip_atomic_exchange(reinterpret_cast<unsigned*>(partial) + blockIdx.x, __float_as_uint(red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" :: "v"(old) : "memory");               // the returned value is waited for here
-        last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+        // hand-off without agent-scope fences: publish_partial_draw_ticket above
+        last = publish_partial_draw_ticket(reinterpret_cast<unsigned*>(partial) + blockIdx.x, __float_as_uint(red[0] + red[1] + red[2] + red[3]), ticket, (int)gridDim.x);
     }
     __syncthreads();
     if (!last) return;                                          // block-uniform
@@ -256,10 +274,8 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const PT* __restrict__ p
     __syncthreads();
     int* ticket = reinterpret_cast<int*>(sq_ws + 1024);
     if (threadIdx.x == 0) {
-        // as in sumsq_kernel: returning agent-scope atomics on the partials, no fences
-        const unsigned old = __hip_atomic_exchange(reinterpret_cast<unsigned*>(sq_ws) + blockIdx.x, __float_as_uint(red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" :: "v"(old) : "memory");
-        last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+        // as in sumsq_kernel
+        last = publish_partial_draw_ticket(reinterpret_cast<unsigned*>(sq_ws) + blockIdx.x, __float_as_uint(red[0] + red[1] + red[2] + red[3]), ticket, (int)gridDim.x);
     }
     __syncthreads();
     if (!last) return;                                          // block-uniform

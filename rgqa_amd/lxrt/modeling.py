@@ -431,8 +431,9 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
 
     def _dp_exchange(self):
         """The gradient exchange of this module's engine (rgqa_amd.parallel): an all-reduce - the unchanged trainer owns the optimizer object,
-        which steps every parameter, so the sharded-optimizer exchange of bench.py does not apply here - whose payload follows the engine's
-        precision exactly as there (bf16 under bf16 / bf16x3_fwd, f32 under f32 / bf16x3; RGQA_DP_MODE=allreduce_bf16 / allreduce_f32 force one)."""
+        which steps every parameter, so the sharded-optimizer exchange of bench.py does not apply here - with an f32 payload whatever the engine's
+        precision (what the reference's nn.DataParallel reduces; RCCL keeps the running sum in the payload type); RGQA_DP_MODE=allreduce_bf16 opts in
+        to the 410-MB payload."""
         ex = self.__dict__.get("_dp_ex")
         if ex is None or ex.e is not self._binding.engine:
             import torch.distributed as dist

@@ -3,9 +3,11 @@ on ROCm; "gloo" in the CPU / single-GPU tests).
 
 Replaces the reference's single-process nn.DataParallel (lxrt/entry.py:102-103): samples are independent through the whole
 forward, so each rank runs its own shard of the batch and the only exchange per step is the gradient arena.
-THE PAYLOAD FOLLOWS THE ENGINE'S PRECISION in every mode (payload_dtype): bf16 under `bf16` and `bf16x3_fwd` engines, whose gradients carry
+THE SHARDED MODE'S PAYLOAD FOLLOWS THE ENGINE'S PRECISION (payload_dtype): bf16 under `bf16` and `bf16x3_fwd` engines, whose gradients carry
 bf16 rounding anyway (410 MB); f32 under `f32` and `bf16x3` engines, whose gradients are exact to 1e-5 and must not be rounded to 8 bits on
-the wire (819 MB).  The suffixes _bf16 / _f32 force one.  Modes (`make_exchange`, env RGQA_DP_MODE; RGQA_DP_OVERLAP=0 issues any of them
+the wire (819 MB) - the owner adds the N shards in f32 in rank order, so a bf16 payload costs one rounding per contribution and no more.  An
+ALL-REDUCE keeps its running sum in the payload type, so plain `allreduce` is f32 for every engine (what the reference's nn.DataParallel
+reduces); `allreduce_bf16` opts in.  The suffixes _bf16 / _f32 force a payload in either mode.  Modes (`make_exchange`, env RGQA_DP_MODE; RGQA_DP_OVERLAP=0 issues any of them
 after backward instead of beside it):
 
   allreduce        SUM all-reduce of the live arena ranges, buckets of >= 64 MB issued from a side stream as backward finalises them;
@@ -42,6 +44,15 @@ def payload_dtype(precision, forced=None):
     if forced == "f32":
         return torch.float32
     return torch.bfloat16 if precision in ("bf16", "bf16x3_fwd") else torch.float32
+
+
+def exchange_payload(mode, precision):
+    """dtype on the wire for a full RGQA_DP_MODE string: the sharded exchange follows the engine's precision, an all-reduce is f32 unless the
+    mode says _bf16 (its running sum lives in the payload type); a suffix forces either"""
+    kind, _, forced = mode.partition("_")
+    if kind == "sharded":
+        return payload_dtype(precision, forced or None)
+    return torch.bfloat16 if forced == "bf16" else torch.float32
 
 
 def bucket_ranges(ranges, bucket_elems):
@@ -117,8 +128,8 @@ class GradAllReduce:
         pass
 
     def __init__(self, engine, dist, bucket_mb=64, overlap=None, bf16=None, ops=None):
-        if bf16 is None:           # the payload follows the engine's precision
-            bf16 = payload_dtype(getattr(engine, "precision", "f32")) == torch.bfloat16
+        if bf16 is None:           # f32 on the wire, as the reference's nn.DataParallel reduces f32 gradients; bf16 is opt-in (allreduce_bf16)
+            bf16 = False
         self.e, self.dist, self.bf16 = engine, dist, bf16
         self.ops = ops if ops is not None else (_HipOps(engine.lib) if bf16 else None)
         if overlap is None:
@@ -325,12 +336,12 @@ class ShardedExchange:
         mine = [owned(c, self.rank) for c in self.chunks]
         mine = [(lo, hi) for lo, hi in mine if hi > lo]
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev.type == "cuda" else None
-        if clip:
-            if not self._sumsq_from_exchange:        # gradients that did not come through exchange() (tests, a caller's own reduction)
+        from_exchange, self._sumsq_from_exchange = self._sumsq_from_exchange, False      # consumed by THIS step whatever `clip` says (a stale flag
+        if clip:                                                                           # would make a later step reuse an old norm: ADVICE r4)
+            if not from_exchange:                    # gradients that did not come through exchange() (tests, a caller's own reduction)
                 self._sumsq.zero_()
                 for lo, hi in mine:
                     self._local_sumsq(lo, hi, s)
-            self._sumsq_from_exchange = False
             if self._host_staged and self._sumsq.is_cuda:
                 t = self._sumsq.cpu()
                 self.dist.all_reduce(t)
@@ -428,4 +439,7 @@ def make_exchange(engine, dist, mode=None, default="sharded", **kw):
     kind, _, forced = mode.partition("_")
     if kind == "sharded":
         return ShardedExchange(engine, dist, payload=forced or None, **kw)
-    return GradAllReduce(engine, dist, bf16=(payload_dtype(getattr(engine, "precision", "f32"), forced or None) == torch.bfloat16), **kw)
+    # all-reduce: RCCL would keep a bf16 RUNNING sum across the ranks (error grows with the world size and depends on the reduction order), where
+    # the sharded mode adds the N bf16 shards in f32 in rank order.  So the plain 'allreduce' is f32 whatever the engine's precision; the bf16
+    # payload is opt-in by name.
+    return GradAllReduce(engine, dist, bf16=(forced == "bf16"), **kw)

@@ -572,6 +572,47 @@ def test_bertadam_and_clip_vs_oracle(lib, golden_dir):
             np.testing.assert_allclose(pp[:n].cpu().numpy(), gd["p%d.%s" % (step, k)].reshape(-1), rtol=1e-4, atol=2e-6)
 
 
+def test_sumsq_handoff_under_load(lib):
+    """The cross-block hand-off of sumsq_kernel / sum_parts_kernel carries no agent-scope fence (csrc/optim.hip, publish_partial_draw_ticket:
+    returning agent-scope atomics + a workgroup-scope wait): here it runs on a side stream while grouped GEMMs keep all eight XCDs busy
+    and dirty their L2s on the main stream - the train step's situation - 200 launches over segments of different sizes, each checked
+    against a two-pass f64 sum of the same data, and repeated launches on one segment must agree bit for bit (fixed folding order)."""
+    M, N, K = 12356, 2304, 768
+    A = rnd(M, K, seed=1).bfloat16()
+    W = rnd(N, K, seed=2, scale=0.05).bfloat16()
+    Cc = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    segs = [torch.randn(n, device="cuda", generator=g) * 3.0 for n in (28 * 1024 * 1024 // 4, 7087872, 100003 * 4, 4096, 1 << 22)]
+    want = [float((s.double() ** 2).sum()) for s in segs]
+    ws = [torch.zeros(2048, device="cuda") for _ in segs]
+    out = torch.zeros(len(segs), 40, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for it in range(40):
+        for _ in range(3):                                  # main stream: the GEMMs whose results sit dirty in the eight L2s
+            ck(lib.rgqa_op_linear(P(A), P(W), None, P(Cc), M, N, K, K, K, N, 0, 1, S()))
+        with torch.cuda.stream(side):
+            for k, s in enumerate(segs):
+                ck(lib.rgqa_grad_sumsq(P(s), s.numel(), P(ws[k]), P(out[k, it:it + 1]), 0, C.c_void_p(side.cuda_stream)))
+    torch.cuda.synchronize()
+    got = out.cpu().double().numpy()
+    for k in range(len(segs)):
+        np.testing.assert_allclose(got[k], want[k], rtol=2e-6)
+        assert (got[k] == got[k][0]).all(), "launches of one segment differ: the hand-off dropped or re-ordered a partial"
+    # the data-parallel shard sum takes its norm share through the same hand-off
+    parts = (torch.randn(4, 1 << 20, device="cuda", generator=g)).bfloat16()
+    dst = torch.empty(1 << 20, device="cuda"); sq = torch.zeros(1, device="cuda"); w2 = torch.zeros(2048, device="cuda")
+    for _ in range(3):
+        ck(lib.rgqa_op_linear(P(A), P(W), None, P(Cc), M, N, K, K, K, N, 0, 1, S()))
+    with torch.cuda.stream(side):
+        ck(lib.rgqa_sum_parts(P(parts), 0, 1 << 20, 4, P(dst), 1 << 20, P(w2), P(sq), C.c_void_p(side.cuda_stream)))
+    torch.cuda.synchronize()
+    pf = parts.float()
+    ref = ((pf[0] + pf[1]) + pf[2]) + pf[3]              # rank order, f32: the kernel's order
+    assert torch.equal(dst, ref)
+    np.testing.assert_allclose(sq.item(), float((ref.double() ** 2).sum()), rtol=2e-6)
+
+
 @pytest.mark.parametrize("mode", ["mixup_v1", "mixup_v3"])
 def test_mixup_gather_vs_golden(lib, golden_dir, mode):
     from rgqa_amd import synth
