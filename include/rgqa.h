@@ -57,9 +57,10 @@ int rgqa_version(void);
  * m-tiles per wave: 2, 4..8; 0 = cost model); key 2: 1 runs the deferred weight-gradient launches on the caller's stream instead of
  * the side stream; key 4: forces the wgrad (TN) tile height: 4 = 128 rows / 3-slot ring, 8 = 256 rows / 2 slots (one tile per block);
  * key 5 (measurement only): 1 skips the deferred weight-gradient launches; key 6: periods of backward whose weight-gradient problems go into
- * one launch (1..4; 0 = default); key 7: 0 = skinny GEMMs (M <= 256, K >= 1536) run whole instead of split along K; key 9: NT tile numbering: 0 = row-major, -1 = panels of N-tiles sized to the L2 (default), n = panel width n; key 8: 0 computes
+ * one launch (1..4; 0 = default); key 7: 0 = the [CLS]-row GEMMs (K >= 1536) run whole instead of split along K; key 9: NT tile numbering: 0 = row-major, -1 = panels of N-tiles sized to the L2 (default), n = panel width n; key 8: 0 computes
  * the last language FFN on every row (as the reference does), 1 on the [CLS] rows only (default), -1 = environment RGQA_CLS_TAIL;
- * key 16: 0 launches the two attention problems of a stage separately, 1 as one launch (default). */
+ * key 16: 0 launches the two attention problems of a stage separately, 1 as one launch (default); key 17: gradient-buffer sets planned by
+ * the NEXT rgqa_engine_bind (2 x key 6 .. 8; 0 = that minimum). */
 int rgqa_debug_set(int key, int value);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over
@@ -253,8 +254,9 @@ int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int
  * NULL when the epilogue does not use them.  Kernel parity tests and tools/lab only. */
 int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const void* aux, void* C, void* C2, int M, int N,
                       int K, int lda, int ldw, int ldc, int ldaux, int epilogue, float drop_p, int dtype, void* stream);
-/* The same bf16 problem with split-K scratch: problems of M <= 256 rows and K >= 1536 are cut into <= 12 slices along the contraction, run
- * as one grouped launch into f32 partial tiles in ws (>= 12 * M * N floats) and folded in slice order with the epilogue applied once.
+/* The same bf16 problem with split-K scratch: problems of K >= 1536 are cut into <= 12 slices along the contraction (the count depends on K
+ * alone), run as one grouped launch into f32 partial tiles in ws (>= 12 * min(M, 256) * N floats) and folded in slice order with the epilogue
+ * applied once; more than 256 rows run as row groups of 256, so a row's arithmetic does not depend on M.
  * out_f32 != 0: C is float (epilogue 0 only). */
 int rgqa_op_linear_splitk(const void* A, const void* W, const float* bias, const void* aux, void* C, void* C2, int M, int N,
                           int K, int lda, int ldw, int ldc, int ldaux, int epilogue, float drop_p, int out_f32, float* ws,

@@ -156,6 +156,7 @@ int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad l
 int g_rgqa_skip_wgrad = 0;     // rgqa_debug_set(5, v): MEASUREMENT ONLY - the deferred weight-gradient launches are not issued (gradients are then wrong)
 int g_rgqa_wgrad_merge = 0;    // rgqa_debug_set(6, v): periods per weight-gradient launch (1 .. WGRAD_MERGE_MAX); 0 = default
 #define WGRAD_MERGE_DEFAULT 3
+int g_rgqa_wgrad_sets = 0;     // rgqa_debug_set(17, v): gradient-buffer sets planned at the next bind (2 * periods-per-launch .. NPAR); 0 = default (the minimum)
 int g_rgqa_attn_pair = 1;      // rgqa_debug_set(16, v): 0 = the two attention problems of a stage as two launches (the bit-identity test's other arm)
 
 // RGQA_ATTN_REF (test switch: the plain attention kernels instead of the MFMA ones), read once
@@ -217,7 +218,7 @@ public:
         if constexpr (MIXED) return img(p);
         else return reinterpret_cast<const TB*>(p);
     }
-    size_t mirror_off = 0;
+    size_t mirror_off = 0, fwd_end = 0;
     int image_of(const void* p, int ld, int rows, int cols, hipStream_t s) {        // one-off tensors: the image by a copy kernel
         if constexpr (MIXED) return k_sf_image(reinterpret_cast<const sf32*>(p), ld, img(p), ld, rows, cols, s);
         else return RGQA_OK;
@@ -311,7 +312,11 @@ public:
     // CUs streaming unshared operand rows the loop is bound by what the fabric delivers, 22 GB/s per CU instead of 46; docs/MEASUREMENTS.md.)
     GemmGroup wg_head;          // head / pooler weight-gradient problems, handed to the encoder's first deferred launch
     GemmGroup wgm; int pend_n = 0, pend_marks = 0; int pend_par[WGRAD_MERGE_MAX] = {}; FinDefer pend_fin[WGRAD_MERGE_MAX]; int pend_acc[WGRAD_MERGE_MAX] = {};
-    static int wgrad_merge() { const int m = g_rgqa_wgrad_merge > 0 ? g_rgqa_wgrad_merge : WGRAD_MERGE_DEFAULT; return m > WGRAD_MERGE_MAX ? WGRAD_MERGE_MAX : m; }
+    // periods per weight-gradient launch: what the debug key asks for, within the gradient-buffer sets the workspace was planned with (two per period
+    // of a launch: the main stream fills one launch's sets while the side stream still reads the previous launch's)
+    static int wgrad_merge_wanted() { const int m = g_rgqa_wgrad_merge > 0 ? g_rgqa_wgrad_merge : WGRAD_MERGE_DEFAULT; return m > WGRAD_MERGE_MAX ? WGRAD_MERGE_MAX : m; }
+    int nsets = 2 * WGRAD_MERGE_DEFAULT;
+    int wgrad_merge() const { const int m = wgrad_merge_wanted(); return m > nsets / 2 ? nsets / 2 : m; }
     bool set_pending(int par) const { for (int k = 0; k < pend_n; ++k) if (pend_par[k] == par) return true; return false; }
     // Collects the weight-gradient GEMMs of one period; once enough periods wait (or `force`), launches them on the side stream, ordered after
     // everything the main stream has enqueued so far; records the DP segment events there (a segment is final once both the main stream's
@@ -362,7 +367,7 @@ public:
         pend_n = 0; pend_marks = 0;
         return RGQA_OK;
     }
-    static int wgrad_sets() { return NPAR; }
+    int wgrad_sets() const { return nsets; }
     // every launch on the side stream has joined `s` (the side stream is in order: the newest event covers the older ones); `next` = the set the
     // next period would use
     int join_wgrad(int next, hipStream_t s) {
@@ -514,13 +519,23 @@ public:
         visn_final = cur[1];
         pooled = take<T>((size_t)B * H); h1pre = take<T>((size_t)B * 2 * H); h1 = take<T>((size_t)B * 2 * H); h2 = take<T>((size_t)B * 2 * H);
         hd_mean = take<float>(B); hd_rstd = take<float>(B);
-        logits = take<float>((size_t)B * NAp); dlogits = take<TB>((size_t)B * NAp); loss_dev = take<float>(64);
+        logits = take<float>((size_t)B * NAp);
+        if (joint) {      // UNITER front-end: its forward tensors (they have bf16 images under MIXED) before the mark below
+            const size_t ni = (size_t)B * Oi;
+            u_zf = take<T>(ni * H); u_zp = take<T>(ni * H); u_a1 = take<T>(ni * H); u_a2 = take<T>(ni * H); u_x3 = take<T>(ni * H);
+            feats_lp = LP ? take<T>(ni * cfg.feat_dim) : nullptr;
+        }
+        fwd_end = ws_used;        // everything img() / sv() may be asked for lies below: the bf16 image mirror covers [0, fwd_end) only
+        dlogits = take<TB>((size_t)B * NAp); loss_dev = take<float>(64);
         gA = take<TB>((size_t)RC * H); gB = take<TB>((size_t)RC * H); gctx = take<TB>((size_t)RC * H); gemb = take<TB>((size_t)RC * H);
         // one set of per-stage gradient buffers per stage slot of a layer: the weight-gradient GEMMs of a whole layer are
         // deferred into ONE grouped launch (432-504 tiles: fills the 256 CUs), so their operands must outlive the stage
         // ... and two such sets (layer parity): layer i's wgrad launch reads its set on the side stream while layer i-1
         // already overwrites the other one on the main stream
-        for (int par = 0; par < NPAR; ++par)
+        nsets = 2 * wgrad_merge_wanted();
+        if (g_rgqa_wgrad_sets > nsets) nsets = g_rgqa_wgrad_sets < NPAR ? g_rgqa_wgrad_sets : NPAR;
+        // (8 sets were planned whatever the merge depth: +2.4 GB bf16 / +4.8 GB split f32 at B = 256)
+        for (int par = 0; par < nsets; ++par)
             for (int k = 0; k < 3; ++k) {
                 gz_s[par][k] = take<TB>((size_t)RC * H); gzd_s[par][k] = take<TB>((size_t)RC * H);
                 gqkv_s[par][k] = take<TB>((size_t)RC * 3 * H); gh_s[par][k] = take<TB>((size_t)RC * I);
@@ -529,20 +544,18 @@ public:
         size_t pw = 2 * (size_t)H; if ((size_t)I > pw) pw = I; if (3 * (size_t)H > pw) pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp;
         part_floats = (size_t)512 * 10 * pw;
         part = take<float>(part_floats);
-        for (int par = 0; par < NPAR; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
+        for (int par = 0; par < nsets; ++par) lnpart_s[par] = take<float>((size_t)LNPART_BLOCKS * 3 * H);
         sumsq_ws_segs = (int)grad_segs.size(); sumsq_ws = take<float>((size_t)sumsq_ws_segs * SUMSQ_WS_STRIDE);
         if (joint) {
             const size_t ni = (size_t)B * Oi, nt = (size_t)B * Tt;
             tlens_dev = take<int>(B); tcu_dev = take<int>(B + 1); trow_src_dev = take<int>(nt); text_dst_dev = take<int>(nt); img_dst_dev = take<int>(ni);
-            u_zf = take<T>(ni * H); u_zp = take<T>(ni * H); u_a1 = take<T>(ni * H); u_a2 = take<T>(ni * H); u_x3 = take<T>(ni * H);
             u_g = take<TB>(ni * H); u_dx3 = take<TB>(ni * H); u_dz = take<TB>(ni * H); u_gt = take<TB>(nt * H); u_de = take<TB>(nt * H);
             u_st = take<float>(6 * ni);
-            feats_lp = LP ? take<T>(ni * cfg.feat_dim) : nullptr;
         }
         tdesc = take<TransDesc>(n_tdesc + 1);
-        if (MIXED) {          // the bf16 images: a half-size mirror of everything planned above (img())
-            mirror_off = rup(ws_used, 256);
-            ws_used = mirror_off + rup(mirror_off / 2, 256);
+        if (MIXED) {          // the bf16 images: a half-size mirror of the forward tensors planned above (img()); gradient buffers, f32 scratch and
+            mirror_off = rup(ws_used, 256);      // index arrays have no image (the mirror used to cover the whole plan, +40 %)
+            ws_used = mirror_off + rup(fwd_end / 2, 256);
         }
     }
     int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr; T* tail_x = nullptr; TB* tail_dx = nullptr; T* pool_in = nullptr;

@@ -97,59 +97,68 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
 }
 
 // ============================================================================ split-K for skinny NT problems
-// The [CLS]-row tail of the last layer, the pooler and the answer head are GEMMs of M = B <= 256 rows: 3-12 tiles on a 256-CU chip, each
-// walking a contraction of 1,536-3,072 alone (42 us for 1.2 GFLOP).  Their contraction is cut into S <= 12 slices that run as the S problems
+// The [CLS]-row tail of the last layer, the pooler and the answer head are GEMMs of M = B rows (256 in training): 3-12 tiles on a 256-CU chip,
+// each walking a contraction of 1,536-3,072 alone (42 us for 1.2 GFLOP).  Their contraction is cut into S <= 12 slices that run as the S problems
 // of ONE grouped launch of the f32-result kernel (64-row tiles: 4 x N/256 x S blocks, 4-5 K-steps each) into f32 partial tiles, and one pass
 // sums the slices in slice order - a fixed order: bit-reproducible - and applies the epilogue (bias, activation, dropout, residual, second
 // output) with the shared element-wise epilogue of gemm.h.  Two launches of ~6 us for one of 25-42.
+// S depends on K alone and the path is chosen by CALL SITE (the caller hands scratch over), never by M: a batch of more than 256 rows runs as
+// row groups of <= 256 rows, each with the same S, so a sample's arithmetic does not depend on the batch it is in (eval at B = 1024 and
+// training at B = 256 fold the same slices in the same order; tests/test_gpu_engine.py::test_full_size_batch_independence...).
+#define SPLITK_ROWS 256
 int g_rgqa_nt_splitk = 1;     // rgqa_debug_set key 7: 0 = skinny problems stay whole
 template <typename OutT>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmProblem P, const DropCfg drop, const float* __restrict__ part, int S, int ldp, size_t slice_stride) {
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmProblem P, const DropCfg drop, const float* __restrict__ part, int S, int ldp, size_t slice_stride,
+                                                            int m_base, int rows) {
     const int nq = P.N >> 2;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)P.M * nq) return;
-    const int m = (int)(i / nq), n0 = (int)(i % nq) << 2;
-    const float* src = part + (size_t)m * ldp + n0;
+    if (i >= (long)rows * nq) return;
+    const int ml = (int)(i / nq), n0 = (int)(i % nq) << 2;
+    const float* src = part + (size_t)ml * ldp + n0;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < S; ++s) {
         float t[4]; load4(src + (size_t)s * slice_stride, t);
         v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
     }
-    gemm_epilogue4_e<OutT, bf16_t>(P, P.epi, drop, m, n0, v);
+    gemm_epilogue4_e<OutT, bf16_t>(P, P.epi, drop, m_base + ml, n0, v);     // global row: addresses and the dropout stream are those of the whole problem
 }
 static int splitk_slices(const GemmGroup& g, int out_f32) {
     if (!g_rgqa_nt_splitk || g.count != 1 || g.a_f32 || g.splitk_ws == nullptr || g.stamps != nullptr) return 0;
     const GemmProblem& p = g.p[0];
-    if (p.M > 256 || p.K < 1536 || (p.K % TK) != 0 || (p.N % 8) != 0 || (p.ldc % 4) != 0 || p.Cb != nullptr) return 0;
+    if (p.K < 1536 || (p.K % TK) != 0 || (p.N % 8) != 0 || (p.ldc % 4) != 0 || p.Cb != nullptr) return 0;
     if (out_f32 && p.epi != EPI_BIAS) return 0;
     if (p.epi == EPI_ACCUM || (epi_needs_aux(p.epi) && (p.aux == nullptr || (p.ldaux % 4) != 0))) return 0;
     int S = (p.K / TK) / 4;
     if (S > GEMM_NT_MAX_PROBLEMS) S = GEMM_NT_MAX_PROBLEMS;
-    if (S < 2 || (size_t)S * p.M * p.N > g.splitk_floats) return 0;
+    const int rows = p.M < SPLITK_ROWS ? p.M : SPLITK_ROWS;
+    if (S < 2 || (size_t)S * rows * p.N > g.splitk_floats) return 0;
     return S;
 }
 static int launch_gemm_nt_splitk(GemmGroup& g, int S, int out_f32, hipStream_t s) {
     const GemmProblem P = g.p[0];
     const int steps = P.K / TK, ldp = P.N;
-    const size_t stride = (size_t)P.M * ldp;
-    GemmGroup g2; memset(&g2, 0, sizeof g2);
-    g2.count = S; g2.drop = g.drop;
-    for (int i = 0, k0 = 0; i < S; ++i) {
-        const int ks = (steps / S + (i < steps % S ? 1 : 0)) * TK;
-        GemmProblem& q = g2.p[i];
-        q.A = reinterpret_cast<const bf16_t*>(P.A) + k0; q.lda = P.lda;
-        q.B = reinterpret_cast<const bf16_t*>(P.B) + k0; q.ldb = P.ldb;
-        q.C = g.splitk_ws + (size_t)i * stride; q.ldc = ldp;
-        q.M = P.M; q.N = P.N; q.K = ks; q.epi = EPI_BIAS;
-        k0 += ks;
+    for (int m0 = 0; m0 < P.M; m0 += SPLITK_ROWS) {         // row groups: the scratch is reused, the launches are ordered by the stream
+        const int rows = P.M - m0 < SPLITK_ROWS ? P.M - m0 : SPLITK_ROWS;
+        const size_t stride = (size_t)rows * ldp;
+        GemmGroup g2; memset(&g2, 0, sizeof g2);
+        g2.count = S; g2.drop = g.drop;
+        for (int i = 0, k0 = 0; i < S; ++i) {
+            const int ks = (steps / S + (i < steps % S ? 1 : 0)) * TK;
+            GemmProblem& q = g2.p[i];
+            q.A = reinterpret_cast<const bf16_t*>(P.A) + (size_t)m0 * P.lda + k0; q.lda = P.lda;
+            q.B = reinterpret_cast<const bf16_t*>(P.B) + k0; q.ldb = P.ldb;
+            q.C = g.splitk_ws + (size_t)i * stride; q.ldc = ldp;
+            q.M = rows; q.N = P.N; q.K = ks; q.epi = EPI_BIAS;
+            k0 += ks;
+        }
+        RGQA_REQUIRE(gemm_nt256_eligible(g2, 1), "gemm split-K: internal eligibility mismatch");
+        if (int r = launch_gemm_nt256_f32out(g2, s)) return r;
+        const long n4 = (long)rows * (P.N >> 2);
+        const int blocks = (int)((n4 + 255) / 256);
+        if (out_f32) hipLaunchKernelGGL((splitk_finish_kernel<float>), dim3(blocks), dim3(256), 0, s, P, g.drop, g.splitk_ws, S, ldp, stride, m0, rows);
+        else hipLaunchKernelGGL((splitk_finish_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, P, g.drop, g.splitk_ws, S, ldp, stride, m0, rows);
+        RGQA_LAUNCH_CHECK("splitk_finish_kernel");
     }
-    RGQA_REQUIRE(gemm_nt256_eligible(g2, 1), "gemm split-K: internal eligibility mismatch");
-    if (int r = launch_gemm_nt256_f32out(g2, s)) return r;
-    const long n4 = (long)P.M * (P.N >> 2);
-    const int blocks = (int)((n4 + 255) / 256);
-    if (out_f32) hipLaunchKernelGGL((splitk_finish_kernel<float>), dim3(blocks), dim3(256), 0, s, P, g.drop, g.splitk_ws, S, ldp, stride);
-    else hipLaunchKernelGGL((splitk_finish_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, P, g.drop, g.splitk_ws, S, ldp, stride);
-    RGQA_LAUNCH_CHECK("splitk_finish_kernel");
     return RGQA_OK;
 }
 // the bf16 NT entry of the LDS-DMA kernels: skinny single problems take the split-K path when the caller provides scratch

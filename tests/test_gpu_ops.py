@@ -143,10 +143,10 @@ def test_matmul_tn_bf16_both_tile_heights(lib, mtw, M, N, K):
     assert float((got - ref).abs().max()) < 1e-2 * math.sqrt(K)
 
 
-@pytest.mark.parametrize("M", [256, 4, 77])
+@pytest.mark.parametrize("M", [256, 4, 77, 600])
 @pytest.mark.parametrize("N,K,epi", [(768, 3072, 3), (768, 3072, 5), (3072, 1536, 1), (768, 1536, 7), (1536, 1856, 0), (768, 2304, 2), (3072, 1536, 4)])
 def test_linear_splitk_matches_the_whole_problem(lib, M, N, K, epi):
-    """Skinny bf16 problems (M <= 256, K >= 1536) cut along the contraction (rgqa_op_linear_splitk) against the same problem run whole
+    """Skinny bf16 problems (K >= 1536; more than 256 rows as row groups) cut along the contraction (rgqa_op_linear_splitk) against the same problem run whole
     (rgqa_op_linear_ex) - same epilogue, same dropout stream; the two differ by the order of the f32 additions, i.e. by bf16 rounding of the
     result - and against an f32 matmul."""
     A = rnd(M, K, seed=1).bfloat16(); W = (rnd(N, K, seed=2) * 0.05).bfloat16(); b = rnd(N, seed=3)
@@ -171,6 +171,14 @@ def test_linear_splitk_matches_the_whole_problem(lib, M, N, K, epi):
     ref = {0: pre, 1: torch.nn.functional.gelu(pre), 2: torch.tanh(pre), 4: pre * aux.float(), 5: pre + aux.float(), 7: pre * (1 - aux.float() ** 2)}.get(epi)
     if ref is not None:
         assert float((c1 - ref).norm() / ref.norm()) < 1e-2
+    if M > 256 and epi != 3:
+        # a row's arithmetic does not depend on the batch it is in: rows 300..555 run as a problem of their own come out bit for bit the same
+        # (the slice count depends on K alone, more than 256 rows run as row groups; epi 3's dropout stream is keyed by the row index)
+        r0, r1 = 300, 556
+        Cs = torch.zeros(r1 - r0, N, dtype=torch.bfloat16, device="cuda"); C2s = torch.zeros(r1 - r0, N, dtype=torch.bfloat16, device="cuda")
+        As, auxs = A[r0:r1].contiguous(), aux[r0:r1].contiguous()
+        ck(lib.rgqa_op_linear_splitk(P(As), P(W), P(b), P(auxs), P(Cs), P(C2s), r1 - r0, N, K, K, K, N, N, epi, 0.0, 0, P(ws), ws.numel(), S()))
+        assert torch.equal(Cs.float(), c1[r0:r1])
 
 
 def test_linear_splitk_f32_result(lib):
