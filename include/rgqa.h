@@ -161,6 +161,9 @@ int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* 
  * single-modality layers, 2 cross-modality layers (LXRTXLayer, lxrt/modeling.py:439-488: the block the north-star roofline target
  * names), 3 pooler + answer head + loss; ms = sum of kernel durations, flops = GEMM + attention FLOPs */
 int rgqa_engine_profile_blocks(rgqa_engine* e, double* ms, double* flops, int nblock);
+/* per category of the last profile_read: the bytes of the GEMM operands alone (A + B + C), i.e. `bytes` without the operands of the fused
+ * epilogues (residual / gelu' read, second output written): bench.py reports its traffic ratio against both denominators */
+int rgqa_engine_profile_operand_bytes(rgqa_engine* e, double* bytes, int ncat);
 
 /* GEMM probe (roofline.peak_sustained in bench.py; tools/nt_stamps.py): `launches` back-to-back launches of the bf16 NT GEMM
  * C[M,N] = A[M,K] W[N,K]^T (K % 64 == 0, N % 8 == 0; dense row-major bf16; gelu != 0: GELU epilogue, C2 = its second output) on separately

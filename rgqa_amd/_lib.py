@@ -49,6 +49,7 @@ SIGNATURES = {
     "rgqa_engine_profile": [_vp, _i],
     "rgqa_engine_profile_read": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _i],
     "rgqa_engine_profile_blocks": [_vp, _vp, _vp, _i],
+    "rgqa_engine_profile_operand_bytes": [_vp, _vp, _i],
     "rgqa_probe_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "rgqa_grad_sumsq": [_vp, _sz, _vp, _vp, _i, _vp],
     "rgqa_clip_scale": [_vp, _sz, _vp, _f, _vp],

@@ -180,6 +180,12 @@ int rgqa_engine_profile_blocks(rgqa_engine* e, double* ms, double* flops, int nb
     for (int i = 0; i < PB_COUNT; ++i) { ms[i] = e->impl->last_blk_ms[i]; flops[i] = e->impl->last_blk_flops[i]; }
     return RGQA_OK;
 }
+int rgqa_engine_profile_operand_bytes(rgqa_engine* e, double* bytes, int ncat) {
+    NEED(e);
+    RGQA_REQUIRE(bytes && ncat >= PC_COUNT, "profile_operand_bytes: need room for %d categories", PC_COUNT);
+    for (int i = 0; i < PC_COUNT; ++i) bytes[i] = e->impl->last_cat_obytes[i];
+    return RGQA_OK;
+}
 int rgqa_grad_sumsq(const float* grads, size_t n, float* partial_ws, float* sumsq_out, int accumulate, void* stream) {
     RGQA_REQUIRE(grads && partial_ws && sumsq_out, "grad_sumsq: null argument");
     return k_sumsq(grads, n, partial_ws, sumsq_out, accumulate, S(stream));

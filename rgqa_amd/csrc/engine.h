@@ -49,7 +49,7 @@ struct Stage {
 // Optional per-launch timing with HIP events on the launch stream (bench.py's live roofline figures).
 enum ProfCat { PC_GEMM_NT = 0, PC_GEMM_TN = 1, PC_ATTN_FWD = 2, PC_ATTN_BWD = 3, PC_LN = 4, PC_OTHER = 5, PC_COUNT = 6 };
 enum ProfBlock { PB_EMBED = 0, PB_LR = 1, PB_X = 2, PB_HEAD = 3, PB_COUNT = 4 };   // input embeddings | l/r layers | cross-modality layers | pooler + head + loss
-struct ProfRec { hipEvent_t a, b; int cat; int block; double flops, bytes; char tag[48]; };
+struct ProfRec { hipEvent_t a, b; int cat; int block; double flops, bytes, obytes; char tag[48]; };
 struct ProfSummary { double ms[PC_COUNT]; double flops[PC_COUNT]; double bytes[PC_COUNT]; long launches[PC_COUNT]; };
 
 class EngineBase {
@@ -58,6 +58,7 @@ public:
     bool profiling = false;
     int prof_block = PB_EMBED;                 // which part of the model the launches being enqueued belong to
     double last_blk_ms[PB_COUNT] = {0, 0, 0, 0}, last_blk_flops[PB_COUNT] = {0, 0, 0, 0};   // filled by prof_collect
+    double last_cat_obytes[PC_COUNT] = {0, 0, 0, 0, 0, 0};   // per category: the GEMM operands alone (A + B + C), without the fused epilogues' operands
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
@@ -65,9 +66,10 @@ public:
         if (prof_used == prof_pool.size()) { hipEvent_t e; hipEventCreate(&e); prof_pool.push_back(e); }
         return prof_pool[prof_used++];
     }
-    void prof_begin(int cat, double flops, double bytes, hipStream_t s, const char* tag = "") {
+    void prof_begin(int cat, double flops, double bytes, hipStream_t s, const char* tag = "", double operand_bytes = -1.0) {
         if (!profiling) return;
         ProfRec r; r.a = prof_event(); r.b = prof_event(); r.cat = cat; r.block = prof_block; r.flops = flops; r.bytes = bytes;
+        r.obytes = operand_bytes < 0 ? bytes : operand_bytes;
         snprintf(r.tag, sizeof r.tag, "%s", tag);
         hipEventRecord(r.a, s);
         prof_recs.push_back(r);
@@ -78,12 +80,14 @@ public:
     void prof_collect(ProfSummary& out) {
         memset(&out, 0, sizeof out);
         for (int i = 0; i < PB_COUNT; ++i) { last_blk_ms[i] = 0; last_blk_flops[i] = 0; }
+        for (int i = 0; i < PC_COUNT; ++i) last_cat_obytes[i] = 0;
         const char* dump = getenv("RGQA_PROF_DUMP");          // per-launch records (category, FLOPs, bytes, ms) for offline analysis
         FILE* df = dump ? fopen(dump, "a") : nullptr;
         for (auto& r : prof_recs) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
                 out.ms[r.cat] += ms; out.flops[r.cat] += r.flops; out.bytes[r.cat] += r.bytes; out.launches[r.cat]++;
+                last_cat_obytes[r.cat] += r.obytes;
                 if (r.block >= 0 && r.block < PB_COUNT) { last_blk_ms[r.block] += ms; last_blk_flops[r.block] += r.flops; }
                 if (df) fprintf(df, "%d %d %.6e %.6e %.6f %s\n", r.cat, r.block, r.flops, r.bytes, ms, r.tag[0] ? r.tag : "-");
             }

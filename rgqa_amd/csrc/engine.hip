@@ -692,12 +692,14 @@ public:
         else snprintf(buf, sizeof buf, "n1_e%d_%dx%dx%d", g.p[0].epi, g.p[0].M, g.p[0].N, g.p[0].K);
         return buf;
     }
-    void gemm_work(const GemmGroup& g, double& flops, double& bytes) const {
+    double last_obytes = 0;        // gemm_work: the operands alone (A + B + C) of the group it was last called for
+    void gemm_work(const GemmGroup& g, double& flops, double& bytes) {
         flops = 0; bytes = 0;
         for (int i = 0; i < g.count; ++i) {
             const GemmProblem& p = g.p[i];
             flops += 2.0 * p.M * p.N * p.K;
             bytes += sizeof(T) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+            last_obytes = (i == 0 ? 0.0 : last_obytes) + sizeof(T) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
             // the operands of the fused epilogue are algorithmic bytes of the launch too: the residual / gelu' / activation it reads and
             // the second output it writes would be moved by a separate element-wise kernel otherwise (twice: that kernel would re-read C)
             if (epi_needs_aux(p.epi) && p.aux != nullptr) bytes += sizeof(T) * (double)p.M * p.N;
@@ -713,7 +715,7 @@ public:
         if (out_f32) for (int i = 0; i < g.count; ++i) g.p[i].Cb = nullptr;      // f32 results (the logits) have no image
         double f, b; gemm_work(g, f, b);
         char tg[48];
-        prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "");
+        prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "", last_obytes);
         if constexpr (std::is_same<T, bf16_t>::value) { if (cls_rows) { g.splitk_ws = part; g.splitk_floats = part_floats; } }
         int r = nt_gemm(g, out_f32, 0, s);
         prof_end(s);
@@ -723,7 +725,7 @@ public:
         if (g.count == 0) return RGQA_OK;
         double f, b; gemm_work(g, f, b);
         char tg[48];
-        prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "");
+        prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "", last_obytes);
         if constexpr (std::is_same<TB, bf16_t>::value) { if (cls_rows) { g.splitk_ws = part; g.splitk_floats = part_floats; } }
         int r = nt_gemm_b(g, 0, 1, s);
         prof_end(s);

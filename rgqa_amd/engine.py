@@ -250,6 +250,13 @@ class Engine:
         check(self.lib.rgqa_engine_profile_blocks(self.h, ms, fl, n))
         return {b: dict(ms=ms[i], flops=fl[i]) for i, b in enumerate(self.PROFILE_BLOCKS)}
 
+    def profile_operand_bytes(self):
+        """{category: bytes of the GEMM operands alone (A + B + C)} of the last profile_read(): `bytes` without the fused epilogues' operands."""
+        n = len(self.PROFILE_CATS)
+        by = (C.c_double * n)()
+        check(self.lib.rgqa_engine_profile_operand_bytes(self.h, by, n))
+        return {c: by[i] for i, c in enumerate(self.PROFILE_CATS)}
+
     def grad_segments(self):
         """[(begin, end, event)] gradient-arena ranges in the order backward finalises them (dead range excluded)."""
         n = C.c_int()
