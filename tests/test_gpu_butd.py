@@ -99,6 +99,59 @@ def test_butd_weight_norm_follows_the_weights_over_several_steps(precision, tol)
     assert float((lo - first).abs().max()) > 10 * tol       # the passes are not all the same computation (the biases moved)
 
 
+@pytest.mark.parametrize("precision,ltol,lrel,gtol", [("bf16x3", 1e-3, 1e-2, 3e-3), ("bf16", 1e-2, 1.5e-1, 8e-2), ("f32", 5e-4, 2e-3, 3e-3)])
+def test_butd_step_at_config5_size_vs_oracle(precision, ltol, lrel, gtol):
+    """BASELINE config 5 at its per-GPU size: B = 256 QA pairs, 40 front-padded tokens over a dictionary of 3000 words, 36
+    RoIs, 1842 answers, through the engine as bench.py --butd drives it (rgqa_config.arch = 1).  Forward: the logits of ALL 256 rows and the
+    loss against the oracle (butd/butd.py:195-221 restated; the BUTD model is ~0.5 GFLOP per sample, the host does all rows in seconds).
+    Backward: every gradient tensor against the oracle's on the full batch."""
+    from oracle import butd_ref as BR
+    from rgqa_amd.engine import Engine
+    from tests.test_oracle_golden import butd_fill
+    B, L, O, NA, NT = 256, 40, 36, 1842, 3000
+    c = BR.ButdConfig(ntoken=NT, num_answers=NA)
+    filled = butd_fill(c)
+    e = Engine(arch=1, vocab_size=NT + 1, hidden=1024, emb_dim=300, feat_dim=2048, pos_dim=4, num_answers=NA, precision=precision,
+               hidden_dropout=0.0, attn_dropout=0.0, heads=1, inter=8, l_layers=0, x_layers=0, r_layers=0).allocate("cuda")
+    assert {sp.name for sp in e.specs} == set(filled)
+    for sp in e.specs:
+        e.view(e.params, sp).copy_(torch.from_numpy(np.asarray(filled[sp.name]).reshape(sp.shape)))
+    b = synth.synth_batch(B, L, seed=515, uq_frac=0.25, vocab=NT)
+    rng = np.random.RandomState(3)
+    toks = np.full((B, L), NT, dtype=np.int64)                     # front padding with the padding index (butd.py:180-193)
+    for r in range(B):
+        n = int(rng.randint(1, L + 1)) if r else L                # a full-length question and 1-token questions occur
+        toks[r, L - n:] = rng.randint(0, NT, size=n)
+    feat, pos, target, tk = torch.from_numpy(b["feats"]), torch.from_numpy(b["boxes"]), torch.from_numpy(b["target"]), torch.from_numpy(toks)
+    e.ensure_shape(B, L, O)
+    e.sync_weights()
+    fg, pg, tg, kg = feat.cuda(), pos.cuda(), target.cuda(), tk.cuda()
+    lg, _ = e.forward(fg, pg, kg, kg, None, train=False)
+    lg = lg.clone()
+    loss = e.loss_backward(tg).item()
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    P = {k: torch.from_numpy(np.asarray(v)).clone().requires_grad_(True) for k, v in filled.items()}
+    lo = BR.butd_forward(P, c, feat, pos, tk)
+    lr = torch.nn.functional.binary_cross_entropy_with_logits(lo, target) * NA
+    lr.backward()
+    lr = lr.detach()
+    err = (lg.cpu() - lo.detach()).abs()
+    worst, wname, num, den = 0.0, "", 0.0, 0.0
+    for sp in e.specs:
+        got, ref = e.view(e.grads, sp).float().cpu(), P[sp.name].grad.reshape(sp.shape)
+        dd, rr = float((got - ref).norm()), float(ref.norm())
+        num += dd * dd
+        den += rr * rr
+        if rr > 1e-9 and dd / rr > worst:
+            worst, wname = dd / rr, sp.name
+    print("butd %s at B=256 / 40 tokens / 3000 words: logits max err %.3e mean %.3e, loss rel %.3e, gradients rel %.3e, worst tensor %s %.3e" % (
+        precision, float(err.max()), float(err.mean()), abs(loss - lr.item()) / abs(lr.item()), (num / den) ** 0.5, wname, worst))
+    assert float(err.max()) < min(ltol, lrel * float(lo.detach().abs().max())), (float(err.max()), float(lo.detach().abs().max()))     # (the filler's logits are small: |z| <= 0.05)
+    assert abs(loss - lr.item()) < (2e-3 if precision == "bf16" else 5e-5) * abs(lr.item())
+    assert (num / den) ** 0.5 < gtol / 2 and worst < gtol, (wname, worst)
+    assert float(e.view(e.grads, [sp for sp in e.specs if sp.name == "w_emb.emb.weight"][0])[NT].abs().max()) == 0.0       # the padding row gets no gradient
+
+
 def test_butd_train_step_runs_with_dropout():
     from rgqa_amd.lxrt.optimization import BertAdam
     m, c, _ = build("bf16", dropout=True)

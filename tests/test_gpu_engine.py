@@ -487,6 +487,76 @@ def test_roi_mixup_train_step_vs_oracle(precision, tol, gtol):
     assert lerr < tol and abs(loss - loss_r) < 50 * tol and gworst < gtol
 
 
+@pytest.mark.parametrize("precision,ltol,gtol", [("bf16x3", 1e-3, 3e-3), ("bf16", 1.0e-1, 6e-2)])
+def test_roi_mixup_step_at_config4_size_vs_oracle(precision, ltol, gtol):
+    """BASELINE config 4 at its per-GPU size on the FULL architecture: a loader batch of 256 QA pairs doubled by
+    RoIMixup('mixup_v1', Beta(1, 5)) to 512 model rows (tasks/gqa_mixup_vis.py:134-181), packed language rows as bench.py runs them.
+    Forward: the logits of ALL 512 rows and the loss (BCE x NA over 512 rows) against the CPU oracle's forward on the same doubled batch
+    (bf16x3: inside the north star's 1e-3; bf16: the headline mode's gates).  Backward: samples are independent, so a backward pass whose
+    incoming gradient is non-zero on 6 spread rows only - exactly those rows' share (sigmoid(z) - t) / 512 of the step's dlogits - must give
+    the oracle's gradients of the 6-row sub-batch scaled by 6 / 512: every kernel runs at the 512-row size, every tensor is compared."""
+    import random
+    from oracle import lxmert_ref as R
+    from rgqa_amd.mixup import RoIMixup
+    B, T, O = 256, 20, 36
+    raw = synth.synth_batch(B, T, seed=4242, uq_frac=0.25)
+    d = dev(raw)
+    random.seed(11); np.random.seed(11)
+    f2, b2, t2 = RoIMixup("mixup_v1", alpha=1.0, beta=5.0)(d["feats"], d["boxes"], d["target"], list(range(B)))
+    assert f2.shape == (2 * B, O, 2048) and t2.shape == (2 * B, 1842)
+    ids2, mask2, seg2 = (torch.cat([d[k], d[k]], 0).contiguous() for k in ("input_ids", "input_mask", "segment_ids"))
+    lens = np.ascontiguousarray(np.tile(raw["lengths"], 2), dtype=np.int32)
+    e = make_engine(FULL, precision)
+    e.ensure_shape(2 * B, T, O)
+    e.sync_weights()
+    lg, _ = e.forward(f2, b2, ids2, mask2, seg2, train=False, lengths=lens)
+    lg = lg.clone()
+    loss = e.loss_backward(t2).item()
+    gn_full = e.grad_norm().item()
+    assert np.isfinite(loss) and np.isfinite(gn_full) and gn_full > 0
+    # ---- the oracle's forward on all 512 rows (no graph: ~10 s on the GPU box's host cores)
+    cfg = R.RefConfig(**FULL)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    Pn = synth.fill_state_dict(R.param_shapes(cfg))
+    cpu = dict(feats=f2.cpu(), boxes=b2.cpu(), ids=ids2.cpu(), mask=mask2.cpu(), seg=seg2.cpu(), target=t2.cpu())
+    with torch.no_grad():
+        Pd = {k: torch.from_numpy(v) for k, v in Pn.items()}
+        lg_r, _ = R.gqa_forward(Pd, cfg, cpu["feats"], cpu["boxes"], cpu["ids"], cpu["mask"], cpu["seg"])
+        loss_r = R.bce_loss(lg_r, cpu["target"]).item()
+    err = (lg.cpu() - lg_r).abs()
+    # ---- backward restricted to 6 rows (3 loader rows, 3 mixed rows)
+    pick = [0, 101, 255, 256, 300, 511]
+    dl = torch.zeros(2 * B, 1842, device="cuda")
+    dl[pick] = (torch.sigmoid(lg[pick]) - t2[pick]) / (2 * B)
+    e.forward(f2, b2, ids2, mask2, seg2, train=False, lengths=lens)
+    e.backward(dl)
+    P6 = {k: torch.from_numpy(v).requires_grad_(True) for k, v in Pn.items()}
+    lg6, _ = R.gqa_forward(P6, cfg, cpu["feats"][pick], cpu["boxes"][pick], cpu["ids"][pick], cpu["mask"][pick], cpu["seg"][pick])
+    R.bce_loss(lg6, cpu["target"][pick]).backward()
+    scale = len(pick) / (2.0 * B)
+    num = den = 0.0
+    worst, wname = 0.0, ""
+    for sp in e.specs:
+        ref = P6[sp.name].grad
+        got = e.view(e.grads, sp).float().cpu()
+        if ref is None or sp.dead:
+            assert float(got.abs().max()) == 0.0, sp.name
+            continue
+        ref = ref * scale
+        dd, rr = float((got - ref).norm()), float(ref.norm())
+        num += dd * dd
+        den += rr * rr
+        if rr > 1e-7 and dd / rr > worst:
+            worst, wname = dd / rr, sp.name
+    overall = (num / den) ** 0.5
+    _report("RoI-mixup step at config 4's size (512 rows, full config) %s vs oracle" % precision, logits_max=float(err.max()), logits_mean=float(err.mean()),
+            loss_rel=abs(loss - loss_r) / abs(loss_r), grads_rel=overall, worst_tensor_rel=worst)
+    print("   worst tensor:", wname)
+    assert float(err.max()) < ltol, float(err.max())
+    assert abs(loss - loss_r) < (1e-4 if precision == "bf16" else 2e-5) * abs(loss_r)
+    assert overall < gtol / 3 and worst < gtol, (overall, wname, worst)
+
+
 def test_dropout_train_mode_is_deterministic_and_consistent():
     """Train mode (dropout 0.1 regenerated from (seed, site, index) in backward): same seed -> bit-identical results,
     different seed -> different; the analytic gradient agrees with a finite difference of the loss along a direction."""
