@@ -21,6 +21,9 @@ res = {v: [] for v in vals}
 for r in range(rounds):
     for v in vals:
         _lib.check(lib.rgqa_debug_set(key, v))
+        if key == 17:       # a plan-time switch (gradient-buffer sets): re-bind the engine so that the workspace is planned with it
+            e.shape = None
+            e.ensure_shape(256, 20, 36); e.sync_weights(); e.enable_segment_sumsq(True)
         for _ in range(8): step()
         torch.cuda.synchronize()
         a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
