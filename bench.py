@@ -64,6 +64,38 @@ def _cpu_model():
     return "unknown"
 
 
+_T0 = time.time()
+
+
+def note(msg):
+    """progress on stderr (the one JSON line owns stdout): which leg of the run is on, with the seconds since start"""
+    sys.stderr.write("bench.py [%6.1f s] %s\n" % (time.time() - _T0, msg))
+    sys.stderr.flush()
+
+
+def cpu_budget():
+    """(CPUs in this process's affinity mask, CPUs the cgroup's quota allows or None, CPUs of the machine): a container may see every CPU of the
+    host in its mask and still be throttled to a few of them - threads beyond the quota only contend"""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2: "max 100000" or "<quota> <period>"
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return aff, quota, os.cpu_count() or aff
+
+
 def cpu_baseline(T, sample_b, iters, warm=2, extra=True, check=None):
     """The oracle (CPU restatement pinned to the reference's golden vectors) timed on this box's host cores: `warm` untimed +
     `iters` timed full train steps at B=sample_b (the headline entry), plus SURVEY §8 D4's other cases in `cases`: BASELINE config 1
@@ -73,13 +105,12 @@ def cpu_baseline(T, sample_b, iters, warm=2, extra=True, check=None):
     from oracle import lxmert_ref as R
     from rgqa_amd import synth
     cfg = R.RefConfig(**FULL)
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except Exception:
-        ncpu = os.cpu_count() or 1
-    # every CPU this process may run on (the host's cores, stated): the affinity mask IS the box's share for this job; the JSON
-    # carries the mask's size and the machine's CPU count next to the thread count used (rounds 1-4 capped the threads at 16)
-    torch.set_num_threads(max(1, int(os.environ.get("RGQA_BENCH_CPU_THREADS", ncpu))))
+    # every CPU this process may USE (the host's cores, stated): the affinity mask, cut to the cgroup's CPU quota when there is one;
+    # the JSON carries mask, quota and the machine's CPU count next to the thread count (rounds 1-4 capped the threads at 16)
+    ncpu, quota, host = cpu_budget()
+    use = ncpu if quota is None else max(1, min(ncpu, int(quota + 0.5)))
+    torch.set_num_threads(max(1, int(os.environ.get("RGQA_BENCH_CPU_THREADS", use))))
+    note("cpu_baseline: %d threads (affinity mask %d CPUs, cgroup quota %s, machine %d)" % (torch.get_num_threads(), ncpu, "none" if quota is None else "%.1f" % quota, host))
     # the deterministic filler of the golden fixtures (biases / LayerNorm parameters non-trivial, |logit| ~ 1)
     P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(R.param_shapes(cfg)).items()}
     opt = R.BertAdamRef(list(P.values()), lr=1e-5, warmup=0.1, t_total=1000)
@@ -109,18 +140,26 @@ def cpu_baseline(T, sample_b, iters, warm=2, extra=True, check=None):
             lg = []
             te = timed(lambda: lg.append(R.gqa_forward(Pd, cfg, batch["feats"], batch["boxes"], batch["input_ids"], batch["input_mask"], batch["segment_ids"])[0]), 0, 2)
         out_cases["eval_forward_B256"] = dict(value=round(256 / te, 2), unit="QA-pairs/s", sample="BASELINE config 2: eval forward B=256 T=%d, 2 timed, median %.2fs" % (T, te))
+        note("cpu_baseline: eval forward B=256 %.2f s" % te)
         if check is not None:
             checked = check({k: v.detach().clone() for k, v in P.items()}, b, lg[-1].detach())
-    t = train_case(sample_b, warm, iters)
-    out = dict(value=sample_b / t, unit="QA-pairs/s", cores=torch.get_num_threads(), affinity_cpus=ncpu, host_cpus=os.cpu_count(), kind="port", cpu_model=_cpu_model(),
+    slow_host = extra and te > 25.0          # (4 s on the 16 host cores of a GPU box: a host this slow would spend minutes on the larger cases below)
+    t = train_case(sample_b, warm if not slow_host else 1, iters if not slow_host else 2)
+    note("cpu_baseline: train step B=%d %.2f s" % (sample_b, t))
+    out = dict(value=sample_b / t, unit="QA-pairs/s", cores=torch.get_num_threads(), affinity_cpus=ncpu, cgroup_quota_cpus=quota, host_cpus=host, kind="port", cpu_model=_cpu_model(),
                sample="full train step (fwd+BCE+bwd+clip+BertAdam), B=%d T=%d, fp32, %d warm-up + %d timed iters, median %.2fs" % (sample_b, T, warm, iters, t))
     if extra:
         t4 = train_case(4, 1, 3)
         out_cases["train_step_B4"] = dict(value=round(4 / t4, 2), unit="QA-pairs/s", sample="BASELINE config 1: full train step B=4 T=%d, 1 warm-up + 3 timed, median %.2fs" % (T, t4))
-        t64 = train_case(64, 1, 3)
-        out_cases["train_step_B64"] = dict(value=round(64 / t64, 2), unit="QA-pairs/s", sample="full train step B=64 T=%d, 1 warm-up + 3 timed, median %.2fs" % (T, t64))
-        t256 = train_case(256, 0, 2)
-        out_cases["train_step_B256"] = dict(value=round(256 / t256, 2), unit="QA-pairs/s", sample="full train step B=256 T=%d (the headline's batch), 2 timed, median %.2fs" % (T, t256))
+        note("cpu_baseline: train step B=4 %.2f s" % t4)
+        if slow_host:
+            out_cases["skipped"] = "train steps at B=64 and B=256: the B=256 eval forward took %.1f s on this host (bounded sample)" % te
+        else:
+            t64 = train_case(64, 1, 3)
+            out_cases["train_step_B64"] = dict(value=round(64 / t64, 2), unit="QA-pairs/s", sample="full train step B=64 T=%d, 1 warm-up + 3 timed, median %.2fs" % (T, t64))
+            note("cpu_baseline: train step B=64 %.2f s" % t64)
+            t256 = train_case(256, 0, 2)
+            out_cases["train_step_B256"] = dict(value=round(256 / t256, 2), unit="QA-pairs/s", sample="full train step B=256 T=%d (the headline's batch), 2 timed, median %.2fs" % (T, t256))
         out["cases"] = out_cases
     return out, checked
 
@@ -587,6 +626,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    note("warm-up (%d steps) + timed region (%d steps)" % (args.warmup, args.steps))
     for _ in range(args.warmup):
         step()
     fence()
@@ -595,6 +635,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    note("timed region: %.3f ms per step" % (dt / args.steps * 1e3))
     if dist is not None:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -661,6 +702,7 @@ def main():
     prof = None
     blocks = None
     if rank == 0:
+        note("live per-launch timing (%d steps)" % args.profile_steps)
         e.profile(True)
         for _ in range(args.profile_steps):
             step(exchange=False)      # rank-0-only kernel timing AFTER the timed region: no collective (the other ranks are at the barrier below)
@@ -712,6 +754,7 @@ def main():
     if extra_legs:
         # ---- the tolerance-compliant mode on the same workload: second engine, same weights, same batch
         n2 = max(5, min(args.steps, 20))
+        note("leg: bf16x3 train step")
         ex = Engine(precision="bf16x3", **FULL).allocate("cuda")
         ex.params.copy_(e.params)
         ex.ensure_shape(B, T, O)
@@ -722,6 +765,7 @@ def main():
         tol = dict(precision="bf16x3", ms_per_step=round(xms, 3), value=round(B / xms * 1e3, 1), unit="QA-pairs/s", steps=n2,
                    note="same workload, weights and batch as the headline; split-f32 operands, 3 bf16 MFMA products per f32 product (rgqa.h RGQA_PRECISION_BF16X3)")
         # ---- the same forward pass with the bf16 backward pass (BASELINE config 3 prescribes a bf16 backward): logits identical to bf16x3's
+        note("leg: bf16x3_fwd train step")
         exf = Engine(precision="bf16x3_fwd", **FULL).allocate("cuda")
         exf.params.copy_(e.params)
         exf.ensure_shape(B, T, O)
@@ -735,12 +779,14 @@ def main():
                             "the bf16 mode's loss / gradient-norm / sampled-gradient gates (tests/test_gpu_engine.py::test_mixed_*)")
         # ---- BASELINE config 2: forward-only inference at B=256
         fwd_only = {}
+        note("leg: forward-only B=256, three precisions")
         for name, en in engines.items():
             fms = time_steps(lambda en=en: en.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=False, lengths=lengths), n2, 3)
             fwd_only[name] = dict(ms=round(fms, 3), value=round(B / fms * 1e3, 1), unit="QA-pairs/s",
                                   reference_equivalent_tflops=round(B / fms * 1e3 * FWD_GFLOP.get(T, FWD_GFLOP[20]) / 1e3, 1))
         # ---- the reference trainer's statements through the drop-in modules
         try:
+            note("leg: drop-in trainer step")
             dms = dropin_step_leg(B, T, n2, "bf16")
             dropin = dict(ms_per_step=round(dms, 3), value=round(B / dms * 1e3, 1), unit="QA-pairs/s", steps=n2, vs_headline=round(dms / ms, 3),
                           what="GQAModel(feats, boxes, list_of_str) + BCE x NA + backward + nn.utils.clip_grad_norm_ + BertAdam.step (tasks/gqa_conf.py:174-202) on a fresh "
@@ -753,6 +799,7 @@ def main():
         other = {}
         try:
             n3 = 10
+            note("leg: RoI-mixup step (config 4), 2 x %d rows" % B)
             mms = mixup_leg(e, dev, lengths, B, T, O, n3, rank)
             other["roi_mixup_b256"] = dict(ms_per_step=round(mms, 3), loader_qa_per_s=round(B / mms * 1e3, 1), model_rows_per_s=round(2 * B / mms * 1e3, 1), steps=n3, dtype="bf16",
                                            what="BASELINE config 4 on one GPU: RoI-mixup finetune step (tasks/gqa_mixup_vis.py:134-181, 250-259; mixup_v1, Beta(1,5)): host draws + one "
@@ -762,6 +809,7 @@ def main():
         except Exception as exn:
             other["roi_mixup_b256"] = dict(error=repr(exn))
         try:
+            note("leg: BUTD step (config 5)")
             bms = butd_leg(B, 10, "bf16", rank)
             other["butd_b256"] = dict(ms_per_step=round(bms, 3), value=round(B / bms * 1e3, 1), unit="QA-pairs/s", steps=10, dtype="bf16",
                                       what="BASELINE config 5 on one GPU: BUTD backbone train step (butd/butd.py:195-221): GRU over 40 tokens x 1024, region attention over 36 RoIs, "
@@ -789,7 +837,9 @@ def main():
                 en.params.copy_(keep)
                 en.sync_weights()
             return res
+        note("leg: CPU baseline (the oracle on the host cores) + logits check of the GPU engines")
         cpu, checked = cpu_baseline(T, args.cpu_sample, 5, extra=not args.butd, check=check)
+        note("CPU baseline done")
         if checked and tol is not None:
             tol.update(logits_max_err=checked["bf16x3"]["logits_max_err"], logits_mean_err=checked["bf16x3"]["logits_mean_err"], bound=1e-3,
                        within_bound=bool(checked["bf16x3"]["logits_max_err"] <= 1e-3),

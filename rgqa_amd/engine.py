@@ -16,6 +16,15 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_RAW_GRAD = torch.Tensor.grad          # the C-level .grad descriptor
+
+
+def raw_grad(p):
+    """p.grad WITHOUT side effects: what the engine-side bookkeeping (arena bindings, the drop-in optimizer and clip) reads.  The `.grad` property
+    of rgqa_amd's parameters (lxrt.modeling.ArenaParameter) first materialises a deferred clip_grad_norm_."""
+    return _RAW_GRAD.__get__(p, type(p))
+
+
 # engines by the address of their f32 parameter arena: lets the drop-in optimizer / clip helpers (rgqa_amd.lxrt.optimization) recognise
 # parameters that are views of an engine's arena and use its fused kernels and operand copies
 ARENAS = weakref.WeakValueDictionary()
@@ -83,6 +92,7 @@ class Engine:
         self.adam_m = self.adam_v = None
         self._seg_sumsq = None
         self._seg_sumsq_valid = False
+        self._pending_clip = None        # max_norm of a deferred clip_grads_ (lxrt.optimization.clip_grad_norm_ -> BertAdam.step), else None
         self._sharded_owner = None       # set by parallel.ShardedExchange while the f32 masters / Adam moments are valid on their owner rank only
         self.shape = None
         self._io = {}
@@ -187,6 +197,8 @@ class Engine:
         """BCE x NA loss on the last forward's logits + backward into the gradient arena. Returns the loss (device scalar)."""
         if target.dtype != torch.float32 or target.stride(1) != 1:
             raise ValueError("target must be f32 with unit inner stride")
+        if self._pending_clip is not None:
+            self.flush_deferred_clip() if accumulate else self.drop_deferred_clip()
         check(self.lib.rgqa_engine_loss_backward(self.h, ptr(target), target.stride(0), ptr(self._io["loss"]), grad_scale,
                                                  1 if accumulate else 0, _stream()))
         self._seg_sumsq_valid = self._seg_sumsq is not None
@@ -299,6 +311,8 @@ class Engine:
         """clip_grad_norm_(params, max_norm) + BertAdam.step over every parameter that receives a gradient
         (gqa_conf.py:201-202), on the caller's stream; the same kernel re-writes the operand copy of the weights (bf16 / split f32)
         and the transposed copies follow."""
+        if self._pending_clip is not None:
+            self.flush_deferred_clip()
         if self._sharded_owner is not None:
             raise RuntimeError("adam_step: the optimizer state of this engine is sharded over the data-parallel ranks "
                                "(ShardedExchange); step through the exchange, or call its gather_master() / release() first")
@@ -325,10 +339,28 @@ class Engine:
         if self.params_lp is not None:
             check(self.lib.rgqa_engine_sync_transposed(self.h, s))
 
-    def clip_grads_(self, max_norm):
+    def flush_deferred_clip(self):
+        """Materialises a deferred clip_grads_(..., defer=True): the gradient arena is scaled in place now (one kernel; no traffic when the
+        norm was below max_norm)."""
+        mn, self._pending_clip = getattr(self, "_pending_clip", None), None
+        if mn is not None:
+            s = _stream()
+            for a, b in self.live_ranges():
+                check(self.lib.rgqa_clip_scale(ptr(self.grads[a:b]), b - a, ptr(self._sumsq), float(mn), s))
+
+    def drop_deferred_clip(self):
+        self._pending_clip = None
+
+    def clip_grads_(self, max_norm, defer=False):
         """nn.utils.clip_grad_norm_(params, max_norm) (tasks/gqa_conf.py:201) on the gradient arena, in place: the norm from the per-segment
         sums backward left behind when they are valid (enable_segment_sumsq), else from one pass over the live ranges; the gradients are
-        rescaled by one kernel only when the norm exceeds max_norm.  Returns the total norm (device scalar), as torch does."""
+        rescaled by one kernel only when the norm exceeds max_norm.  Returns the total norm (device scalar), as torch does.
+        defer=True (the drop-in clip_grad_norm_): the norm is taken and returned, the rescale is left PENDING (`_pending_clip` = max_norm, the sum
+        of squares stays in `_sumsq`): lxrt.optimization.BertAdam.step folds the coefficient into its update kernel - as adam_step does - and
+        whoever reads a .grad first (ArenaParameter.grad) or accumulates onto the gradients gets it materialised by flush_deferred_clip()."""
+        if getattr(self, "_pending_clip", None) is not None:
+            self.flush_deferred_clip()              # two clips in a row: the second one measures the scaled gradients
+            self._seg_sumsq_valid = False
         if getattr(self, "_sumsq", None) is None:
             self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._sq_ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
@@ -340,6 +372,9 @@ class Engine:
             for i, (a, b) in enumerate(rngs):
                 check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
         self._seg_sumsq_valid = False            # the gradients change below (or may have: the caller owns them from here on)
+        if defer:
+            self._pending_clip = float(max_norm)
+            return self._sumsq.sqrt().reshape(())
         for a, b in rngs:
             check(self.lib.rgqa_clip_scale(ptr(self.grads[a:b]), b - a, ptr(self._sumsq), float(max_norm), s))
         return self._sumsq.sqrt().reshape(())

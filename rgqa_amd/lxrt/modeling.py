@@ -19,7 +19,7 @@ import os
 import torch
 from torch import nn
 
-from ..engine import Engine
+from ..engine import Engine, raw_grad, _RAW_GRAD
 
 logger = logging.getLogger(__name__)
 
@@ -142,6 +142,32 @@ def _build_tree(root, specs, prefix):
     return leaves
 
 
+class ArenaParameter(nn.Parameter):
+    """nn.Parameter whose data / .grad are views of an engine's arenas.  The ONLY behavioural difference to nn.Parameter: reading `.grad` first
+    materialises a deferred `clip_grad_norm_` (lxrt.optimization.clip_grad_norm_ leaves the clip coefficient with the engine so that
+    BertAdam.step can fold it into the update kernel instead of one read-modify-write of the 820-MB gradient arena; anybody who LOOKS at a
+    gradient between the two calls - a logger, a test, a foreign optimizer - gets the scaled values, as after torch's in-place clip).
+    Parameters become ArenaParameters by class assignment when a module tree is bound to an engine (ArenaBinding.bind): identity, registration,
+    state_dict keys, isinstance(p, nn.Parameter) are untouched."""
+
+    @property
+    def grad(self):
+        ref = self.__dict__.get("_rgqa_binding")
+        if ref is not None:
+            b = ref()
+            if b is not None and b.engine is not None and getattr(b.engine, "_pending_clip", None) is not None:
+                b.engine.flush_deferred_clip()
+        return _RAW_GRAD.__get__(self, type(self))
+
+    @grad.setter
+    def grad(self, value):
+        _RAW_GRAD.__set__(self, value)
+
+    @grad.deleter
+    def grad(self):
+        _RAW_GRAD.__delete__(self)
+
+
 class ArenaBinding(object):
     """Keeps the nn.Parameters of a module tree as views of the engine's flat f32 arena (and their .grad as views of
     the gradient arena), re-packing when the module was moved / re-materialised, and re-casting the bf16 weight copies
@@ -161,7 +187,12 @@ class ArenaBinding(object):
         for sp in engine.specs:
             if sp.name not in byname:
                 raise KeyError("parameter %s missing from the module tree" % sp.name)
-            self.params.append((sp, byname[sp.name]))
+            p = byname[sp.name]
+            if type(p) is nn.Parameter:          # (a caller's own Parameter subclass keeps its class: its reads simply never defer)
+                p.__class__ = ArenaParameter
+            if isinstance(p, ArenaParameter):
+                p.__dict__["_rgqa_binding"] = weakref.ref(self)
+            self.params.append((sp, p))
 
     def materialize(self, device, init_fn=None):
         """(Re)allocates the arenas on `device` and points every parameter at its slice, preserving current values."""
@@ -208,7 +239,7 @@ class ArenaBinding(object):
     def grads_untouched(self):
         """no .grad was written in place since attach_grads() (the per-segment sums of squares backward took are still those of .grad)"""
         gv = getattr(self, "_grad_versions", None)
-        return gv is not None and gv == sum(p.grad._version for sp, p in self.params if not sp.dead and p.grad is not None)
+        return gv is not None and gv == sum(g._version for g in (raw_grad(p) for sp, p in self.params if not sp.dead) if g is not None)
 
     def _views(self):
         """the gradient-arena view of every live parameter, made once per gradient arena: re-attaching them after the trainer's
@@ -232,7 +263,7 @@ class ArenaBinding(object):
             if v is None:
                 continue
             live += 1
-            g = p.grad
+            g = raw_grad(p)
             if g is None:
                 none += 1
             elif g is v or g.data_ptr() == base + 4 * sp.offset:
@@ -249,9 +280,10 @@ class ArenaBinding(object):
         for (sp, p), v in zip(self.params, gv):
             if v is None:
                 continue
-            if p.grad is None:
-                p.grad = v
-            ver += p.grad._version
+            g = raw_grad(p)
+            if g is None:
+                p.grad = g = v
+            ver += g._version
         self._grad_versions = ver
 
 
@@ -293,6 +325,12 @@ class _EngineFunction(torch.autograd.Function):
             raise RuntimeError("rgqa: parameter .grad tensors were replaced by foreign tensors; use zero_grad() / set_to_none")
         acc = state == "views"
         e = b.engine
+        if getattr(e, "_pending_clip", None) is not None:
+            # a deferred clip_grad_norm_ nobody consumed: it scales the gradients this pass accumulates ONTO, or concerns gradients about to be overwritten
+            if acc:
+                e.flush_deferred_clip()
+            else:
+                e.drop_deferred_clip()
         # gradients w.r.t. the RoI features / boxes when the caller asked for them (ODIN: tasks/gqa_odin.py:97-121)
         want_f, want_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         dfeats = torch.empty(ctx.in_shapes[0][0] * ctx.in_shapes[0][1], ctx.in_shapes[0][2], dtype=torch.float32, device=e.device) if want_f else None

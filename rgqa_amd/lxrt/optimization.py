@@ -8,6 +8,7 @@ arena (rgqa_amd models) are updated by one kernel launch per contiguous run inst
 import ctypes as C
 import logging
 import math
+import os
 
 import torch
 from torch.optim import Optimizer
@@ -15,6 +16,7 @@ from torch.optim.optimizer import required
 
 from .. import _lib
 from .. import engine as _engine
+from ..engine import raw_grad
 
 logger = logging.getLogger(__name__)
 
@@ -43,7 +45,7 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
                 eng = None
             else:
                 for p, want in zip(params, cached[2]):
-                    g = p.grad
+                    g = raw_grad(p)
                     if (g is None) != (want is None) or (g is not None and g.data_ptr() != want):
                         eng = None
                         break
@@ -54,14 +56,19 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
             if eng is not None:
                 import weakref
                 _CLIP_CACHE.clear()
-                _CLIP_CACHE[sig[0]] = (sig, weakref.ref(eng), [None if p.grad is None else p.grad.data_ptr() for p in params], eng.grads.data_ptr())
+                _CLIP_CACHE[sig[0]] = (sig, weakref.ref(eng), [None if raw_grad(p) is None else raw_grad(p).data_ptr() for p in params], eng.grads.data_ptr())
     if eng is None:
         return _torch_clip_grad_norm_(params, max_norm, norm_type=norm_type, error_if_nonfinite=error_if_nonfinite, foreach=foreach)
     binding = getattr(eng, "_binding_ref", None)
     binding = binding() if binding is not None else None
     if binding is None or not binding.grads_untouched():
         eng.invalidate_segment_sumsq()           # someone wrote to a .grad since backward: take the norm from the arena itself
-    return eng.clip_grads_(max_norm)
+    # The in-place rescale is DEFERRED (default): the norm is taken and returned now, the coefficient stays with the engine; the drop-in
+    # BertAdam.step folds it into its update kernel (as the engine-direct adam_step does: identical arithmetic, g * coef in f32 either way),
+    # and anything that reads a .grad before that (ArenaParameter.grad) or accumulates onto the gradients materialises it first.  What differs
+    # from torch: AFTER BertAdam.step the .grad views hold the unclipped gradients (the reference's loops call zero_grad() next).
+    # RGQA_DEFER_CLIP=0: scale in place here, as torch does (0.3 ms per step at the full model while clipping is active).
+    return eng.clip_grads_(max_norm, defer=os.environ.get("RGQA_DEFER_CLIP", "1") != "0")
 
 
 _CLIP_CACHE = {}
@@ -72,14 +79,15 @@ def engine_view_offset(eng, p):
     off = p.data_ptr() - eng.params.data_ptr()
     if off < 0 or off % 4 or off // 4 + p.numel() > eng.arena_elems or p.dtype != torch.float32:
         return None
-    if p.grad is not None and p.grad.data_ptr() != eng.grads.data_ptr() + off:
+    g = raw_grad(p)
+    if g is not None and g.data_ptr() != eng.grads.data_ptr() + off:
         return None
     return off // 4
 
 
 def _arena_engine_of(params):
     """the engine all of `params` belong to (every gradient-carrying one a full arena view, all live ranges covered), or None"""
-    live = [p for p in params if p.grad is not None]
+    live = [p for p in params if raw_grad(p) is not None]
     if not live or not live[0].is_cuda:
         return None
     eng = _engine.engine_of(live[0].data_ptr())
@@ -87,7 +95,7 @@ def _arena_engine_of(params):
         return None
     covered = 0
     for p in live:
-        if engine_view_offset(eng, p) is None or not p.grad.is_contiguous():
+        if engine_view_offset(eng, p) is None or not raw_grad(p).is_contiguous():
             return None
         covered += p.numel()
     # every tensor that backward writes must be among them: otherwise the arena norm would count gradients the caller did not pass
@@ -157,24 +165,29 @@ class BertAdam(Optimizer):
     def _build_runs(self, gi, plist):
         runs, cur = [], None
         for p in sorted(plist, key=lambda q: q.data_ptr()):
-            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.grad.dtype == torch.float32):
+            g = raw_grad(p)
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() and g.dtype == torch.float32):
                 raise RuntimeError("BertAdam (rgqa_amd): parameters and gradients must be contiguous f32 tensors on the MI355X; "
                                    "there is no CPU path")
             st = self.state[p]
             if cur is not None:
                 gap_p = p.data_ptr() - cur["p_end"]
-                gap_g = p.grad.data_ptr() - cur["g_end"]
+                gap_g = g.data_ptr() - cur["g_end"]
                 if 0 <= gap_p == gap_g <= 252 and st.get("step", 0) == cur["step"] and p.device == cur["dev"] and ("next_m" in st) == cur["has_state"]:
                     cur["params"].append(p)
                     cur["p_end"] = p.data_ptr() + 4 * p.numel()
-                    cur["g_end"] = p.grad.data_ptr() + 4 * p.numel()
+                    cur["g_end"] = g.data_ptr() + 4 * p.numel()
                     continue
-            cur = dict(params=[p], p0=p.data_ptr(), g0=p.grad.data_ptr(), p_end=p.data_ptr() + 4 * p.numel(),
-                       g_end=p.grad.data_ptr() + 4 * p.numel(), step=st.get("step", 0), dev=p.device, has_state="next_m" in st)
+            cur = dict(params=[p], p0=p.data_ptr(), g0=g.data_ptr(), p_end=p.data_ptr() + 4 * p.numel(),
+                       g_end=g.data_ptr() + 4 * p.numel(), step=st.get("step", 0), dev=p.device, has_state="next_m" in st)
             runs.append(cur)
+        import weakref
         for r in runs:
             n = (r["p_end"] - r["p0"]) // 4
             r["n"] = n
+            r["numel"] = sum(p.numel() for p in r["params"])
+            eng = _engine.engine_of(r["p0"])
+            r["eng"] = weakref.ref(eng) if eng is not None else None
             if not r["has_state"]:
                 r["m"] = torch.zeros(n, dtype=torch.float32, device=r["dev"])
                 r["v"] = torch.zeros(n, dtype=torch.float32, device=r["dev"])
@@ -195,22 +208,42 @@ class BertAdam(Optimizer):
         lib = _lib.load()
         stream = None
         warned_for_t_total = False
+        # ---- pass 1: the runs of every group (cached by the (data, grad) addresses) and how much of each engine's arena they cover
+        work, cover = [], {}
         for gi, group in enumerate(self.param_groups):
-            plist = [p for p in group['params'] if p.grad is not None]
+            plist = [p for p in group['params'] if raw_grad(p) is not None]
             if not plist:
                 continue
             for p in plist:
-                if p.grad.is_sparse:
+                if raw_grad(p).is_sparse:
                     raise RuntimeError('Adam does not support sparse gradients, please consider SparseAdam instead')
-            sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+            sig = tuple((p.data_ptr(), raw_grad(p).data_ptr()) for p in plist)
             cached = self._runs.get(gi)
             if cached is None or cached[0] != sig:
                 cached = (sig, self._build_runs(gi, plist))
                 self._runs[gi] = cached
+            work.append((group, cached[1]))
+            for r in cached[1]:
+                eng = self._run_engine(r) if r["m"] is not None else None      # (per-tensor state, e.g. restored from a checkpoint: not the fused path)
+                if eng is not None:
+                    ent = cover.setdefault(id(eng), [eng, 0])
+                    ent[1] += r["numel"]
+        # ---- a clip_grad_norm_ that was deferred to this step (clip_grad_norm_ above): folded into the update kernel when this call updates
+        # EVERY gradient-carrying parameter of the engine (then no gradient is left behind unscaled), materialised in place otherwise
+        fold = {}
+        for key, (eng, n_cov) in cover.items():
+            if getattr(eng, "_pending_clip", None) is None:
+                continue
+            if n_cov == self._live_numel(eng):
+                fold[key] = (_lib.ptr(eng._sumsq), float(eng._pending_clip))
+            else:
+                eng.flush_deferred_clip()
+        # ---- pass 2: the update launches
+        for group, runs in work:
             if stream is None:
                 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             touched = {}
-            for r in cached[1]:
+            for r in runs:
                 step = self.state[r["params"][0]]["step"]
                 if group['t_total'] != -1:
                     progress = step / group['t_total']
@@ -225,24 +258,27 @@ class BertAdam(Optimizer):
                     # a run inside an engine's arena: the same kernel also re-writes the engine's operand copy of these weights (bf16 / split
                     # f32), so the next forward need not re-cast the whole arena
                     lp, lp_split = None, 0
-                    eng = _engine.engine_of(r["p0"])
-                    if eng is not None and eng.params_lp is not None and r["g0"] - eng.grads.data_ptr() == r["p0"] - eng.params.data_ptr():
+                    sumsq, max_norm = None, 0.0
+                    eng = self._run_engine(r)
+                    if eng is not None:
+                        sumsq, max_norm = fold.get(id(eng), (None, 0.0))
+                    if eng is not None and eng.params_lp is not None:
                         off = (r["p0"] - eng.params.data_ptr()) // 4
                         lp_split = 1 if eng.precision in ("bf16x3", "bf16x3_fwd") else 0
                         lp = C.c_void_p(eng.params_lp.data_ptr() + off * eng.params_lp.element_size())
                         ent = touched.setdefault(id(eng), [eng, 0, None])
-                        ent[1] += sum(p.numel() for p in r["params"])
+                        ent[1] += r["numel"]
                         if ent[2] is None:
                             b = getattr(eng, "_binding_ref", None)
                             b = b() if b is not None else None
                             ent[2] = b if (b is not None and b.in_sync()) else False
                     _lib.check(lib.rgqa_bertadam_step(C.c_void_p(r["p0"]), C.c_void_p(r["g0"]), _lib.ptr(r["m"]), _lib.ptr(r["v"]), lp, lp_split,
                                                       r["n"], lr_scheduled, group['b1'], group['b2'], group['e'], group['weight_decay'],
-                                                      None, 0.0, 1.0, stream))
+                                                      sumsq, max_norm, 1.0, stream))
                 else:
                     for p in r["params"]:
                         st = self.state[p]
-                        _lib.check(lib.rgqa_bertadam_step(_lib.ptr(p.data), _lib.ptr(p.grad), _lib.ptr(st["next_m"]), _lib.ptr(st["next_v"]),
+                        _lib.check(lib.rgqa_bertadam_step(_lib.ptr(p.data), _lib.ptr(raw_grad(p)), _lib.ptr(st["next_m"]), _lib.ptr(st["next_v"]),
                                                           None, 0, p.numel(), lr_scheduled, group['b1'], group['b2'], group['e'],
                                                           group['weight_decay'], None, 0.0, 1.0, stream))
                 for p in r["params"]:
@@ -254,7 +290,27 @@ class BertAdam(Optimizer):
             for eng, n_upd, binding in touched.values():
                 # every live parameter of the engine went through the fused path and its copies were current before: finish them (the
                 # transposed copies) and tell the binding, instead of a full re-cast at the next forward
-                if binding and n_upd == sum(sp.numel for sp in eng.specs if not sp.dead):
+                if binding and n_upd == self._live_numel(eng):
                     eng.sync_transposed()
                     binding.mark_synced()
+        for key in fold:
+            cover[key][0].drop_deferred_clip()          # consumed: the update used g * coef; the .grad views keep the unclipped gradients
         return loss
+
+    @staticmethod
+    def _live_numel(eng):
+        n = getattr(eng, "_live_numel_cache", None)
+        if n is None:
+            n = eng._live_numel_cache = sum(sp.numel for sp in eng.specs if not sp.dead)
+        return n
+
+    @staticmethod
+    def _run_engine(r):
+        """the engine whose arenas the run lies in - parameters in its parameter arena, gradients at the same offsets of its gradient arena - or None"""
+        ref = r.get("eng")
+        eng = ref() if ref is not None else None
+        if eng is None or eng.params is None or eng.grads is None:
+            return None
+        if r["g0"] - eng.grads.data_ptr() != r["p0"] - eng.params.data_ptr():
+            return None
+        return eng

@@ -178,7 +178,7 @@ def test_encoder_alone_under_a_foreign_head(env):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
-def test_trainer_step_fused_clip_and_operand_copies(env, precision):
+def test_trainer_step_fused_clip_and_operand_copies(env, precision, monkeypatch):
     """The unchanged trainer's `nn.utils.clip_grad_norm_` + `BertAdam.step` (tasks/gqa_conf.py:201-202) through the drop-in's fast paths:
     importing lxrt.entry routes torch.nn.utils.clip_grad_norm_ through lxrt.optimization.clip_grad_norm_ (norm from the sums backward
     left per gradient segment, one rescale kernel), and BertAdam.step lets the update kernel re-write the engine's operand copies.
@@ -189,7 +189,10 @@ def test_trainer_step_fused_clip_and_operand_copies(env, precision):
     assert torch.nn.utils.clip_grad_norm_ is fast_clip
     feats, boxes, target = batch(20)
     res = {}
-    for which in ("fast", "torch"):
+    for which in ("fast", "inplace", "torch"):
+        # "fast": the default - the rescale is deferred and folded into BertAdam's update kernel; "inplace": RGQA_DEFER_CLIP=0, the fast norm with
+        # the rescale kernel run at the clip call (rounds 3-4); "torch": torch's own clip_grad_norm_
+        monkeypatch.setenv("RGQA_DEFER_CLIP", "0" if which == "inplace" else "1")
         m, _ = build(precision, 20)
         m.train()
         # (dropout is off in the config these models are built with: the two runs can be compared exactly)
@@ -201,9 +204,11 @@ def test_trainer_step_fused_clip_and_operand_copies(env, precision):
             logit = m(feats.cuda(), boxes.cuda(), SENTS)
             loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, target.cuda()) * logit.size(1)
             loss.backward()
-            clip = torch.nn.utils.clip_grad_norm_ if which == "fast" else torch_clip
-            norms.append(float(clip(m.parameters(), 0.5)))          # small max_norm: the rescale kernel really runs
+            clip = torch_clip if which == "torch" else torch.nn.utils.clip_grad_norm_
+            norms.append(float(clip(m.parameters(), 0.5)))          # small max_norm: the rescale really happens
+            assert (eng._pending_clip == 0.5) == (which == "fast")
             optim.step()
+            assert eng._pending_clip is None                        # consumed by the update kernel
         m.eval()
         with torch.no_grad():
             lg_a = m(feats.cuda(), boxes.cuda(), SENTS).clone()
@@ -213,6 +218,8 @@ def test_trainer_step_fused_clip_and_operand_copies(env, precision):
         res[which] = (norms, {k: v.detach().clone() for k, v in m.named_parameters()}, lg_a, lg_b, in_sync)
     nf, pf, la, lb, sync_f = res["fast"]
     nt, pt, _, _, _ = res["torch"]
+    ni, pi_, _, _, _ = res["inplace"]
+    assert nf == ni and all(torch.equal(pf[k], pi_[k]) for k in pf)      # folding the coefficient into the update = scaling in place, bit for bit
     assert sync_f                                   # the fused optimizer path left the copies current: no re-cast happened at the forward
     assert torch.equal(la, lb)                      # ... and they are exactly what a full re-cast produces
     np.testing.assert_allclose(nf, nt, rtol=2e-5)
@@ -220,6 +227,111 @@ def test_trainer_step_fused_clip_and_operand_copies(env, precision):
     worst = max(float((pf[k] - pt[k]).abs().max()) / max(1e-12, float(pt[k].abs().max())) for k in pt)
     print("fused clip vs torch clip (%s): norms %s vs %s, worst relative parameter difference %.2e" % (precision, nf, nt, worst))
     assert worst < 1e-4
+
+
+def test_deferred_clip_is_seen_by_every_reader_of_grad(env):
+    """`clip_grad_norm_` leaves the clip coefficient with the engine (BertAdam.step folds it in), yet whoever READS a `.grad`
+    after the clip sees the scaled values, as after torch's in-place clip (the parameters are ArenaParameters: their `.grad` property
+    materialises the pending rescale first).  Also: an optimizer that steps only SOME parameters cannot fold (the others' gradients would stay
+    unscaled): the rescale is materialised; a second clip measures the scaled gradients; a backward that accumulates onto clipped gradients
+    materialises first; a backward that overwrites them drops the pending rescale."""
+    import lxrt.entry  # noqa: F401
+    from lxrt.optimization import BertAdam
+    from rgqa_amd.engine import raw_grad
+    from rgqa_amd.lxrt.modeling import ArenaParameter
+    feats, boxes, target = batch(20)
+    m, _ = build("bf16", 20)
+    m.train()
+    eng = m.lxrt_encoder.model._binding.engine
+    params = list(m.parameters())
+    assert all(isinstance(p, ArenaParameter) and isinstance(p, torch.nn.Parameter) for p in params)
+    assert set(dict(m.named_parameters())) == set(m.state_dict())
+
+    def fwd_bwd(zero=True):
+        if zero:
+            m.zero_grad()
+        logit = m(feats.cuda(), boxes.cuda(), SENTS)
+        (torch.nn.functional.binary_cross_entropy_with_logits(logit, target.cuda()) * logit.size(1)).backward()
+
+    fwd_bwd()
+    live = [p for p in params if raw_grad(p) is not None]
+    before = [raw_grad(p).clone() for p in live]
+    norm = float(torch.nn.utils.clip_grad_norm_(params, 0.5))
+    want = float(sum(float((g.double() ** 2).sum()) for g in before) ** 0.5)
+    assert abs(norm - want) < 1e-4 * want and norm > 0.5
+    assert eng._pending_clip == 0.5 and torch.equal(raw_grad(live[3]), before[3])       # nothing has moved yet
+    coef = 0.5 / (norm + 1e-6)
+    seen = live[3].grad                                                                    # a reader: the rescale happens now, for every gradient
+    assert eng._pending_clip is None
+    for p, g0 in zip(live, before):
+        assert torch.allclose(raw_grad(p), g0 * coef, rtol=1e-5, atol=1e-12)
+    assert seen is raw_grad(live[3])
+    # a second clip measures the scaled gradients (norm = 0.5), deferred again; an optimizer over HALF of the parameters cannot fold it
+    n2 = float(torch.nn.utils.clip_grad_norm_(params, 0.25))
+    assert abs(n2 - 0.5) < 1e-3 and eng._pending_clip == 0.25
+    half = BertAdam(live[: len(live) // 2], lr=1e-3, warmup=0.1, t_total=20)
+    half.step()
+    assert eng._pending_clip is None
+    c2 = 0.25 / (n2 + 1e-6)
+    for p, g0 in zip(live, before):
+        assert torch.allclose(raw_grad(p), g0 * (coef * c2), rtol=2e-5, atol=1e-12)          # every gradient scaled in place, stepped or not
+    # accumulation onto clipped gradients: materialise, then add
+    fwd_bwd()
+    g1 = [raw_grad(p).clone() for p in live]
+    n3 = float(torch.nn.utils.clip_grad_norm_(params, 0.5))
+    assert eng._pending_clip == 0.5
+    fwd_bwd(zero=False)                                                                    # same batch, no dropout in this config: adds g1 again
+    assert eng._pending_clip is None
+    c3 = 0.5 / (n3 + 1e-6)
+    for p, g in zip(live, g1):
+        assert torch.allclose(raw_grad(p), g * c3 + g, rtol=2e-2, atol=1e-6)               # (bf16 backward: the second pass rounds on its own)
+    # a backward that overwrites the gradients drops a pending rescale
+    torch.nn.utils.clip_grad_norm_(params, 0.5)
+    assert eng._pending_clip == 0.5
+    fwd_bwd()
+    assert eng._pending_clip is None
+    for p, g in zip(live, g1):
+        assert torch.allclose(raw_grad(p), g, rtol=2e-2, atol=1e-6)
+
+
+def test_clip_patch_leaves_foreign_models_to_torch(env):
+    """importing the drop-in `lxrt.entry` routes `torch.nn.utils.clip_grad_norm_` through lxrt.optimization.clip_grad_norm_ for the
+    process.  The contract: a parameter set that is not exactly one engine's arena views goes to torch's own implementation untouched - a
+    foreign model in the same process (CPU or GPU), a mix of an rgqa model's and foreign parameters, a generator argument, norm_type != 2,
+    error_if_nonfinite - and gives torch's results."""
+    import lxrt.entry  # noqa: F401
+    from lxrt.optimization import clip_grad_norm_ as fast_clip, _torch_clip_grad_norm_ as torch_clip
+    assert torch.nn.utils.clip_grad_norm_ is fast_clip
+    for dev_ in ("cpu", "cuda"):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3)).to(dev_)
+        net(torch.randn(5, 8, device=dev_)).pow(2).sum().backward()
+        ref = [p.grad.clone() for p in net.parameters()]
+        want = float(torch_clip(net.parameters(), 1e9))                                                          # torch's norm (no scaling at 1e9)
+        got = float(torch.nn.utils.clip_grad_norm_(net.parameters(), 0.1))                                        # a generator, as the trainers pass
+        assert abs(got - want) < 1e-6 * max(1.0, want)
+        coef = min(1.0, 0.1 / (got + 1e-6))
+        for p, r in zip(net.parameters(), ref):
+            assert torch.allclose(p.grad, r * coef, rtol=1e-6, atol=1e-12)
+        assert float(torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0, norm_type=1.0)) > 0               # other norms: torch's code
+    # an rgqa model's parameters TOGETHER with a foreign module's: not one arena -> torch's implementation over all of them, in place
+    feats, boxes, target = batch(20)
+    m, _ = build("bf16", 20)
+    m.train()
+    eng = m.lxrt_encoder.model._binding.engine
+    extra = torch.nn.Linear(4, 4).cuda()
+    extra(torch.randn(2, 4, device="cuda")).sum().backward()
+    logit = m(feats.cuda(), boxes.cuda(), SENTS)
+    (torch.nn.functional.binary_cross_entropy_with_logits(logit, target.cuda()) * logit.size(1)).backward()
+    allp = list(m.parameters()) + list(extra.parameters())
+    ref = [None if p.grad is None else p.grad.detach().clone() for p in allp]
+    want = float(sum(float((r.double() ** 2).sum()) for r in ref if r is not None) ** 0.5)
+    got = float(torch.nn.utils.clip_grad_norm_(allp, 0.5))
+    assert abs(got - want) < 1e-4 * want and eng._pending_clip is None              # nothing deferred: torch scaled every tensor in place
+    coef = 0.5 / (got + 1e-6)
+    for p, r in zip(allp, ref):
+        if r is not None:
+            assert torch.allclose(p.grad, r * coef, rtol=1e-4, atol=1e-10)
 
 
 def test_clip_fast_path_rejects_a_foreign_gradient_tensor(env):

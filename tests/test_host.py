@@ -236,20 +236,24 @@ class _TorchOps:
             sq_out += (acc.double() ** 2).sum().float()
 
 
-def _fake_engine(n, rank, precision):
-    base = (torch.arange(n) % 64).float()
+def _fake_engine(n, rank, precision, mod=64):
+    base = (torch.arange(n) % mod).float()
     return types.SimpleNamespace(grads=base * (rank + 1), params=torch.ones(n), params_lp=torch.ones(n, dtype=torch.bfloat16), adam_m=None, adam_v=None,
                                  precision=precision, live_ranges=lambda: [(0, 296), (360, n)], lib=None, h=None, _sharded_owner=None)
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, mod=64):
     import torch.distributed as dist
     from rgqa_amd.parallel import GradAllReduce, ShardedExchange
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     n = 1000
     out = {}
+    if world > 2:       # bench.py's pre-flight check of every collective the exchanges need, at this world size (all-to-all and in-place all-gather included)
+        import bench
+        for mode, prec in (("sharded", "f32"), ("allreduce", "f32")):
+            bench.dp_selfcheck(dist, mode, torch.device("cpu"), prec)
     for name, bf16 in (("allreduce", False), ("allreduce_bf16", True)):
-        eng = _fake_engine(n, rank, "f32")
+        eng = _fake_engine(n, rank, "f32", mod)
         GradAllReduce(eng, dist, bucket_mb=1, bf16=bf16, ops=_TorchOps()).all_reduce()
         out[name] = eng.grads.numpy().copy()
 
@@ -266,7 +270,7 @@ def _dp_worker(rank, world, port, q):
             pass
 
     for prec in ("bf16", "f32"):
-        eng = _fake_engine(n, rank, prec)
+        eng = _fake_engine(n, rank, prec, mod)
         local = eng.grads.clone()
         ex = CpuSharded(eng, dist, ops=_TorchOps())
         ex.chunks = __import__("rgqa_amd.parallel", fromlist=["shard_layout"]).shard_layout(eng.live_ranges(), world, 256)    # several chunks, two of them ragged
@@ -283,23 +287,31 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gradient_exchange_modes_gloo_world2():
-    """DP exchange on CPU/gloo, world_size 2: all-reduce (f32 and bf16 payload) sums the live ranges and leaves the
-    dead range alone; the sharded mode leaves each rank the SUM over its own 1/N of every chunk (ragged chunks included), takes the
-    global norm from one scalar all-reduce, and after step() every rank holds the same updated weights."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradient_exchange_modes_gloo(world):
+    """DP exchange on CPU/gloo at world size 2 and at the size the driver's node has, 8 (the shard arithmetic had
+    only ever run with two ranks): all-reduce (f32 and bf16 payload) sums the live ranges and leaves the dead range alone; the sharded mode
+    leaves each rank the SUM over its own 1/N of every chunk - ragged chunks, parts aligned to 8 elements and, at world 8, owners whose part of
+    a ragged chunk is EMPTY included - takes the global norm from one scalar all-reduce, and after step() every rank holds the same updated
+    weights.  At world 8 the workers also run bench.py's collective self-check (all-to-all + in-place all-gather) first."""
     import torch.multiprocessing as mp
     from rgqa_amd.parallel import bucket_ranges, shard_layout, owned
     assert bucket_ranges([(0, 10), (20, 25)], 4) == [(0, 4), (4, 8), (8, 10), (20, 24), (24, 25)]
     assert shard_layout([(0, 100)], 4, 64) == [(0, 64, 16), (64, 100, 16)]
     assert [owned((64, 100, 16), r) for r in range(4)] == [(64, 80), (80, 96), (96, 100), (100, 100)]
+    # the layout the workers use at world 8: the chunk (256, 296) is cut into parts of 8 (5 rounded up to the alignment): ranks 5..7 own nothing of it
+    lay8 = shard_layout([(0, 296), (360, 1000)], 8, 256)
+    assert lay8 == [(0, 256, 32), (256, 296, 8), (360, 616, 32), (616, 872, 32), (872, 1000, 16)]
+    assert [owned(lay8[1], r) for r in range(8)] == [(256, 264), (264, 272), (272, 280), (280, 288), (288, 296), (296, 296), (296, 296), (296, 296)]
+    mod = 64 if world == 2 else 8          # integers whose sums over the ranks (x 36 at world 8) stay exact in bf16: every check below is an equality
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, mod), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     try:
-        res = dict(q.get(timeout=120) for _ in range(2))
+        res = dict(q.get(timeout=240) for _ in range(world))
         for p in procs:
             p.join(60)
     finally:
@@ -308,33 +320,39 @@ def test_gradient_exchange_modes_gloo_world2():
                 p.terminate()
     assert all(p.exitcode == 0 for p in procs)
     n = 1000
-    base = (torch.arange(n) % 64).float()
+    tot = world * (world + 1) // 2          # sum over ranks of (rank + 1)
+    base = (torch.arange(n) % mod).float()
     live = torch.zeros(n, dtype=torch.bool)
     live[:296] = True
     live[360:] = True
-    for r in range(2):
+    for r in range(world):
         for mode in ("allreduce", "allreduce_bf16"):
             g = torch.from_numpy(res[r][mode])
-            assert torch.equal(g[live], base[live] * 3), mode
+            assert torch.equal(g[live], base[live] * tot), mode
             assert torch.equal(g[~live], base[~live] * (r + 1)), mode
         for prec in ("bf16", "f32"):
             o = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in res[r]["sharded_" + prec].items()}
-            assert len(o["chunks"]) == 5 and any((b - a) != 2 * s for a, b, s in o["chunks"])
+            assert len(o["chunks"]) == 5 and any((b - a) != world * s for a, b, s in o["chunks"])
             own = torch.zeros(n, dtype=torch.bool)
             for lo, hi in o["mine"]:
                 own[lo:hi] = True
-            assert torch.equal(o["grads"][own], base[own] * 3)                 # reduced where this rank is the owner
+            assert torch.equal(o["grads"][own], base[own] * tot)               # reduced where this rank is the owner
             assert torch.equal(o["grads"][~own], o["local"][~own])             # untouched elsewhere (dead range included)
-            assert abs(o["sumsq"] - float(((base[live] * 3) ** 2).sum())) < 1e-3 * o["sumsq"]
+            assert abs(o["sumsq"] - float(((base[live] * tot) ** 2).sum())) < 1e-3 * o["sumsq"]
             want = torch.ones(n)
-            want[live] -= 0.5 * 0.5 * 3 * base[live]
+            want[live] -= 0.5 * (1.0 / world) * tot * base[live]
             assert torch.equal(o["params"], want)                               # after gather_master every rank has every range
             if prec == "bf16":
                 assert torch.equal(o["params_lp"][live], want[live].bfloat16().float())
     for prec in ("bf16", "f32"):
-        own0 = set(map(tuple, res[0]["sharded_" + prec]["mine"]))
-        own1 = set(map(tuple, res[1]["sharded_" + prec]["mine"]))
-        assert not (own0 & own1)
+        owns = [set(map(tuple, res[r]["sharded_" + prec]["mine"])) for r in range(world)]
+        cover = torch.zeros(n, dtype=torch.int32)
+        for r in range(world):
+            for lo, hi in owns[r]:
+                cover[lo:hi] += 1
+        assert torch.equal(cover, live.int())                                   # the owners tile the live ranges exactly once
+        if world == 8:
+            assert any(hi == lo for lo, hi in res[7]["sharded_" + prec]["mine"])   # rank 7 owns an EMPTY part of the ragged chunk
 
 
 def test_bench_launches_its_own_ranks_when_no_launcher_is_present():

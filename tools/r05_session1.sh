@@ -2,7 +2,8 @@
 # round-5 GPU session 1: the test suite on the round's first build, the default bench line, where BUTD's and the drop-in step's time goes
 set -u
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-python3 -m pytest tests -m gpu -x -q > $OUT/s1_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/s1_pytest.log
+python3 -c "from rgqa_amd import _lib; _lib.load()" || { echo "stale library in the snapshot"; exit 1; }
+python3 -m pytest tests -m gpu -q --maxfail=8 > $OUT/s1_pytest.log 2>&1; echo "pytest rc=$?"; tail -12 $OUT/s1_pytest.log
 python3 __graft_entry__.py --smoke > $OUT/s1_smoke.log 2>&1; echo "smoke rc=$?"
 python3 bench.py > $OUT/s1_bench.json 2> $OUT/s1_bench.err; echo "bench rc=$?"
 python3 tools/show_bench.py $OUT/s1_bench.json 2>/dev/null | head -60
