@@ -415,7 +415,7 @@ def dropin_step_leg(B, T, n_steps, precision):
             optim.step()
             state["i"] = i + 1
 
-        ms = time_steps(step, n_steps, 3)
+        ms = time_steps(step, n_steps, 8)
         del model, optim, batcher
         torch.cuda.empty_cache()
         return ms

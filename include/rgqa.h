@@ -151,6 +151,14 @@ int rgqa_engine_set_grad_sumsq_slots(rgqa_engine* e, float* slots, int n);
 int rgqa_engine_num_grad_segments(const rgqa_engine* e, int* out);
 int rgqa_engine_grad_segment(const rgqa_engine* e, int k, size_t* begin, size_t* end, int* event);
 int rgqa_engine_wait_grad_event(rgqa_engine* e, int event, void* stream);
+/* the opposite direction (the sharded data-parallel exchange all-gathers the updated weights chunk by chunk on a side stream WHILE the next forward
+ * pass already runs; replaces the per-step weight re-broadcast of nn.DataParallel, lxrt/entry.py:102-103): the first launch of the next forward pass
+ * that reads the weights of gradient segment `segment_event` (ids as in rgqa_engine_grad_segment) waits for hip_event (a hipEvent_t recorded by the
+ * caller once those weights - operand copy and f32 masters alike - are in place); the next backward pass waits for the event given to
+ * set_backward_event before its first launch (the transposed dgrad operand copies).  One-shot: consumed by the pass that waits; NULL clears.  The
+ * event must stay alive until that pass has been enqueued. */
+int rgqa_engine_set_weight_event(rgqa_engine* e, int segment_event, void* hip_event);
+int rgqa_engine_set_backward_event(rgqa_engine* e, void* hip_event);
 
 /* measurement: time every GEMM / attention launch with HIP events on the launch stream. profile_read synchronises
  * on the recorded events; categories: 0 gemm NT (fwd + dgrad), 1 gemm TN (wgrad), 2 attention fwd, 3 attention bwd,

@@ -166,6 +166,20 @@ int rgqa_engine_wait_grad_event(rgqa_engine* e, int event, void* stream) {
     RGQA_HIP(hipStreamWaitEvent(S(stream), e->impl->seg_events[event], 0));
     return RGQA_OK;
 }
+int rgqa_engine_set_weight_event(rgqa_engine* e, int segment_event, void* hip_event) {
+    NEED(e);
+    const int n = e->impl->num_weight_segments();
+    RGQA_REQUIRE(segment_event >= 0 && segment_event < n, "set_weight_event: segment event %d outside 0..%d (this engine's forward waits for none)", segment_event, n - 1);
+    if ((int)e->impl->wready.size() < n) e->impl->wready.resize(n, nullptr);
+    e->impl->wready[segment_event] = reinterpret_cast<hipEvent_t>(hip_event);
+    return RGQA_OK;
+}
+int rgqa_engine_set_backward_event(rgqa_engine* e, void* hip_event) {
+    NEED(e);
+    RGQA_REQUIRE(e->impl->num_weight_segments() > 0, "set_backward_event: not supported by this engine");
+    e->impl->bwd_wait = reinterpret_cast<hipEvent_t>(hip_event);
+    return RGQA_OK;
+}
 int rgqa_engine_profile(rgqa_engine* e, int enable) { NEED(e); e->impl->profiling = enable != 0; return RGQA_OK; }
 int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* bytes, int64_t* launches, int ncat) {
     NEED(e);

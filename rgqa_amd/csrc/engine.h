@@ -113,6 +113,28 @@ public:
     struct GradSeg { size_t begin, end; int event; };
     std::vector<GradSeg> grad_segs;
     std::vector<hipEvent_t> seg_events;
+    // Weights that arrive while the forward pass is already running (the sharded data-parallel exchange all-gathers the updated weights chunk by
+    // chunk on a side stream, rgqa_amd/parallel.py): wready[k] = event the first launch that reads the weights of gradient segment k waits for;
+    // bwd_wait = event the next backward pass waits for (the transposed dgrad operand copies are refreshed behind the last chunk).  One-shot.
+    std::vector<hipEvent_t> wready;
+    hipEvent_t bwd_wait = nullptr;
+    int wait_wready(int seg, hipStream_t s) {
+        if (seg >= 0 && seg < (int)wready.size() && wready[seg] != nullptr) {
+            const hipError_t r = hipStreamWaitEvent(s, wready[seg], 0);
+            wready[seg] = nullptr;
+            if (r != hipSuccess) { rgqa_set_error("forward: waiting for the weights of segment %d: %s", seg, hipGetErrorString(r)); return RGQA_ERR_HIP; }
+        }
+        return RGQA_OK;
+    }
+    int wait_bwd(hipStream_t s) {
+        if (bwd_wait != nullptr) {
+            const hipError_t r = hipStreamWaitEvent(s, bwd_wait, 0);
+            bwd_wait = nullptr;
+            if (r != hipSuccess) { rgqa_set_error("backward: waiting for the transposed operand copies: %s", hipGetErrorString(r)); return RGQA_ERR_HIP; }
+        }
+        return RGQA_OK;
+    }
+    virtual int num_weight_segments() const { return 0; }      // engines whose forward honours wready (0: none)
     virtual int get_activation(const char* name, float* out, size_t cap_elems, hipStream_t s) = 0;
     virtual int get_cross_attention(int, int, float*, size_t, hipStream_t) { rgqa_set_error("get_cross_attention: this engine has no cross-modality layers"); return RGQA_ERR_ARG; }
     // per-segment sum of squared gradients, written as each segment becomes final during backward (null = off)

@@ -270,6 +270,7 @@ public:
     // Every layer occupies one contiguous arena range, so each segment is an element range + the event recorded when
     // its last gradient kernel has been enqueued.
     int n_seg_events = 0;
+    int num_weight_segments() const override { return n_seg_events; }
     void build_grad_segments() {
         grad_segs.clear();
         int ev = 0;
@@ -532,8 +533,12 @@ public:
         // deferred into ONE grouped launch (432-504 tiles: fills the 256 CUs), so their operands must outlive the stage
         // ... and two such sets (layer parity): layer i's wgrad launch reads its set on the side stream while layer i-1
         // already overwrites the other one on the main stream
-        nsets = 2 * wgrad_merge_wanted();
-        if (g_rgqa_wgrad_sets > nsets) nsets = g_rgqa_wgrad_sets < NPAR ? g_rgqa_wgrad_sets : NPAR;
+        // two per period of a launch - the main stream fills the next launch's sets while the side stream reads the previous launch's - plus one
+        // spare pair: with exactly 2 x 3 the main stream waits now and then for the launch in flight (A/B on one box, rgqa_debug_set key 17,
+        // three interleaved rounds: 6 sets 11.556 ms per step, 8 sets 11.516; profiles/r05_wgrad_sets_ab.txt)
+        const int min_sets = 2 * wgrad_merge_wanted();
+        nsets = min_sets + 2 < NPAR ? min_sets + 2 : NPAR;
+        if (g_rgqa_wgrad_sets >= min_sets) nsets = g_rgqa_wgrad_sets < NPAR ? g_rgqa_wgrad_sets : NPAR;
         // (8 sets were planned whatever the merge depth: +2.4 GB bf16 / +4.8 GB split f32 at B = 256)
         for (int par = 0; par < nsets; ++par)
             for (int k = 0; k < 3; ++k) {
@@ -770,6 +775,7 @@ public:
     // one stage (self-attention / cross-attention / FFN sub-block) of the forward pass for the modalities st.active[] marks, on stream s
     int forward_stage(Stage& st, const int* cu, hipStream_t s) {
         const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh;
+        CK(wait_wready(st.seg_event, s));             // this layer's weights may still be arriving from their owner rank (sharded exchange)
         const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
         if (st.kind == ST_FFN && cls_tail(st)) {
             GemmGroup g; gg_init(g);
@@ -951,6 +957,7 @@ public:
             fwd_cls_tail = cls_tail_wanted();
         }
         const int* cu = fwd_varlen ? cu_dev : nullptr;
+        CK(wait_wready(n_seg_events - 1, s));         // embedding tables, visual projection (the segment backward finishes last)
         if (joint) CK(forward_joint_embeddings(feats, boxes, ids, seg, mask, s));
         else {
         if (!fwd_varlen) CKP(PC_OTHER, k_make_mask(mask, maskf, Rl, s));
@@ -985,6 +992,7 @@ public:
         }
         // ---- BertPooler (modeling.py:575-581) + answer head (gqa_model.py:22-27)
         prof_block = PB_HEAD;
+        CK(wait_wready(0, s));                        // pooler + answer head
         {
             GemmGroup g; gg_init(g);
             pool_in = cls_rows;
@@ -1033,6 +1041,7 @@ public:
 
     int backward_impl(int accumulate, hipStream_t s) {
         prof_block = PB_HEAD;
+        CK(wait_bwd(s));
         const int H = cfg.hidden, I = cfg.inter, nh = cfg.heads, dh = H / nh, NA = cfg.num_answers;
         const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
         const DropCfg nodrop = make_drop(0.f, 0, 0);
@@ -1064,6 +1073,7 @@ public:
         RGQA_REQUIRE(have_fwd, "backward_pooled: no forward pass recorded");
         RGQA_REQUIRE(G != nullptr && dpooled != nullptr, "backward_pooled: null gradient arena / dpooled");
         const int H = cfg.hidden;
+        CK(wait_bwd(s));
         if (!accumulate) {
             CK(rgqa_check_hip(hipMemsetAsync(G + mp.word, 0, sizeof(float) * (mp.emb_ln.w - mp.word), s), "zero embedding grads"));
             if (dead_end > dead_begin) CK(rgqa_check_hip(hipMemsetAsync(G + dead_begin, 0, sizeof(float) * (dead_end - dead_begin), s), "zero dead grads"));

@@ -284,6 +284,15 @@ class Engine:
         """Makes torch stream `stream` wait until the gradient segment(s) tagged `event` of the last backward are final."""
         check(self.lib.rgqa_engine_wait_grad_event(self.h, event, C.c_void_p(stream.cuda_stream)))
 
+    def set_weight_event(self, segment_event, event):
+        """The next forward pass waits for torch event `event` (recorded once the weights of gradient segment `segment_event` are in place) before
+        the first launch that reads those weights (rgqa_engine_set_weight_event; one-shot).  The caller keeps `event` alive until then."""
+        check(self.lib.rgqa_engine_set_weight_event(self.h, int(segment_event), C.c_void_p(event.cuda_event) if event is not None else None))
+
+    def set_backward_event(self, event):
+        """the next backward pass waits for `event` before its first launch (the transposed operand copies are refreshed behind it); one-shot"""
+        check(self.lib.rgqa_engine_set_backward_event(self.h, C.c_void_p(event.cuda_event) if event is not None else None))
+
     def enable_segment_sumsq(self, on=True):
         """Single-GPU training loops: let backward leave sum(g^2) of every gradient segment behind (rgqa_engine_set_grad_sumsq_slots),
         so adam_step(clip=True) adds ~20 numbers instead of re-reading the gradient arena. Anything that changes the gradients after

@@ -207,6 +207,9 @@ class ShardedExchange:
             self.chunks = shard_layout(engine.live_ranges(), self.world, chunk_mb * (1 << 20) // 2)
             self.events = [-1] * len(self.chunks)
         self.smax = max(s for _, _, s in self.chunks)
+        # gradient-segment ids whose weights each chunk holds (the engine's forward waits per segment: step() below)
+        segs = engine.grad_segments() if hasattr(engine, "grad_segments") else []
+        self.chunk_segs = [sorted({ev for sb, se, ev in segs if sb < b and se > a}) for a, b, _ in self.chunks]
         dev = engine.grads.device
         self._send = torch.zeros(self.world * self.smax, dtype=self.payload, device=dev)
         self._recv = torch.zeros(self.world * self.smax, dtype=self.payload, device=dev)
@@ -219,6 +222,13 @@ class ShardedExchange:
         # what is all-gathered after the update: the bf16 operand copy (bf16 engines), else the f32 masters (a split-f32 copy cannot be
         # cut at arbitrary element offsets: a 128-byte line holds the hi and the lo parts of 32 elements; it is re-made from the masters)
         self.lp = engine.precision == "bf16"
+        # The weight all-gather beside the NEXT forward pass: chunks gathered on the side stream in FORWARD order (embeddings first,
+        # head last), one event per chunk; the engine's forward waits, per layer, for the event of the chunk that holds the layer's weights, its
+        # backward for the transposed copies refreshed behind the last chunk.  bf16 engines on a real device only (a split-f32 operand copy is
+        # re-made from the gathered masters as a whole); RGQA_DP_GATHER_OVERLAP=0 keeps the gather on the step's stream.
+        self.gather_overlap = (self.overlap and self.lp and dev.type == "cuda" and hasattr(engine, "set_weight_event")
+                               and os.environ.get("RGQA_DP_GATHER_OVERLAP", "1") != "0")
+        self._wevents = []
         # bf16 engines: the forward reads biases, LayerNorm parameters, the embedding tables and the K = 4 box projection from the F32 masters
         # (ParamSpec.f32_read), which the bf16 all-gather does not carry.  Chunks that hold a large such tensor (the embedding tables) are
         # gathered in f32 and their bf16 copy re-made from the result; the small tensors elsewhere travel as one packed f32 all-reduce in which
@@ -355,23 +365,10 @@ class ShardedExchange:
                 self._norm_read = torch.cuda.Event()
             self._norm_read.record()
         # updated weights -> every rank's forward copy
-        for ci, (a, b, sz) in enumerate(self.chunks):
-            f32c = ci in self.f32_chunks                  # bf16 engine, chunk with a large f32-read tensor: gather the masters, re-make the copy
-            wts = e.params_lp if (self.lp and not f32c) else e.params
-            staged = self.lp and not f32c                  # the bf16 staging buffers fit a bf16 chunk only
-            n = b - a
-            lo, hi = owned((a, b, sz), self.rank)
-            if n == W * sz:
-                self._ag(wts[a:b], wts[lo:hi])            # in place: part r of the output is this rank's own input
-            else:                                           # ragged chunk: through a padded buffer
-                buf = self._recv[:W * sz] if staged else torch.empty(W * sz, dtype=wts.dtype, device=dev)
-                mine_pad = self._send[:sz] if staged else torch.zeros(sz, dtype=wts.dtype, device=dev)
-                if hi > lo:
-                    mine_pad[:hi - lo].copy_(wts[lo:hi])
-                self._ag(buf, mine_pad)
-                wts[a:b].copy_(buf[:n])
-            if f32c:
-                self.ops.cast_bf16(e.params_lp[a:b], e.params[a:b])
+        if self.gather_overlap:
+            return self._gather_beside_forward(s)
+        for ci in range(len(self.chunks)):
+            self._gather_chunk(ci)
         if self._small_idx is not None and self._small_idx.numel():
             pack = e.params[self._small_idx] * self._small_own
             if self._host_staged and pack.is_cuda:
@@ -382,6 +379,73 @@ class ShardedExchange:
                 self.dist.all_reduce(pack)                  # exactly one rank contributes a non-zero to each element: the sum IS the owner's value
             e.params[self._small_idx] = pack
         self._after_weights(s)
+
+    def _gather_chunk(self, ci):
+        """all-gather of chunk ci's updated weights into this rank's forward copy, on the current stream"""
+        e, W, dev = self.e, self.world, self.e.grads.device
+        a, b, sz = self.chunks[ci]
+        f32c = ci in self.f32_chunks                  # bf16 engine, chunk with a large f32-read tensor: gather the masters, re-make the copy
+        wts = e.params_lp if (self.lp and not f32c) else e.params
+        staged = self.lp and not f32c                  # the bf16 staging buffers fit a bf16 chunk only
+        n = b - a
+        lo, hi = owned((a, b, sz), self.rank)
+        if n == W * sz:
+            self._ag(wts[a:b], wts[lo:hi])            # in place: part r of the output is this rank's own input
+        else:                                           # ragged chunk: through a padded buffer
+            buf = self._recv[:W * sz] if staged else torch.empty(W * sz, dtype=wts.dtype, device=dev)
+            mine_pad = self._send[:sz] if staged else torch.zeros(sz, dtype=wts.dtype, device=dev)
+            if hi > lo:
+                mine_pad[:hi - lo].copy_(wts[lo:hi])
+            self._ag(buf, mine_pad)
+            wts[a:b].copy_(buf[:n])
+        if f32c:
+            self.ops.cast_bf16(e.params_lp[a:b], e.params[a:b])
+
+    def _gather_beside_forward(self, s):
+        """step()'s tail with the gather off the critical path.  On the caller's stream only what EVERY layer of the next forward reads from the
+        f32 masters (biases, LayerNorm parameters: one small packed all-reduce); then, on the side stream and behind the optimizer, the chunks in
+        forward order - the last chunk backward finished (embeddings, first layers) first, the head's last - each followed by an event the
+        engine's forward waits for where it first reads that chunk's weights, and the transposed copies (backward's operand) at the very end."""
+        e = self.e
+        cur = torch.cuda.current_stream()
+        if self._small_idx is not None and self._small_idx.numel():
+            pack = e.params[self._small_idx] * self._small_own
+            if self._host_staged and pack.is_cuda:
+                t = pack.cpu()
+                self.dist.all_reduce(t)
+                pack.copy_(t)
+            else:
+                self.dist.all_reduce(pack)
+            e.params[self._small_idx] = pack
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=e.grads.device)
+        updated = torch.cuda.Event()
+        updated.record(cur)
+        evs = []
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(updated)
+            for ci in reversed(range(len(self.chunks))):          # chunks are in backward's completion order: forward reads them back to front
+                self._gather_chunk(ci)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                evs.append(ev)
+                for seg in self.chunk_segs[ci]:
+                    e.set_weight_event(seg, ev)
+            check(e.lib.rgqa_engine_sync_transposed(e.h, C.c_void_p(self.side.cuda_stream)))
+            ev_t = torch.cuda.Event()
+            ev_t.record(self.side)
+            evs.append(ev_t)
+            e.set_backward_event(ev_t)
+        self._wevents = evs            # alive until the passes that wait for them have been enqueued (the next step() replaces them)
+        self._gather_done = ev_t
+        # a caller that reads the weights outside the engine (state_dict, a checkpoint, another exchange object) first joins the side stream:
+        # gather_master() / release() below do; the engine's own passes wait per segment
+
+    def _join_gather(self):
+        ev = getattr(self, "_gather_done", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._gather_done = None
 
     # -- local arithmetic (HIP, through the C ABI)
     def _after_weights(self, s):
@@ -412,6 +476,7 @@ class ShardedExchange:
 
     def gather_master(self, arena=None):
         """All-gathers the f32 master weights (each range is current only on its owner): before state_dict() / checkpoints."""
+        self._join_gather()
         p = self.e.params if arena is None else arena
         for a, b, sz in self.chunks:
             n = b - a

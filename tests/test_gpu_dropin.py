@@ -219,7 +219,13 @@ def test_trainer_step_fused_clip_and_operand_copies(env, precision, monkeypatch)
     nf, pf, la, lb, sync_f = res["fast"]
     nt, pt, _, _, _ = res["torch"]
     ni, pi_, _, _, _ = res["inplace"]
-    assert nf == ni and all(torch.equal(pf[k], pi_[k]) for k in pf)      # folding the coefficient into the update = scaling in place, bit for bit
+    # folding the coefficient into the update = scaling in place: the same f32 arithmetic (g * coef, then the moments).  bf16: bit for bit.  bf16x3: the
+    # two RUNS differ in the last bits by themselves (f32-precise gradients scatter-added into the embedding tables by atomics, in arrival order)
+    if precision == "bf16":
+        assert nf == ni and all(torch.equal(pf[k], pi_[k]) for k in pf)
+    else:
+        np.testing.assert_allclose(nf, ni, rtol=1e-6)
+        assert all(torch.allclose(pf[k], pi_[k], rtol=2e-6, atol=1e-8) for k in pf)
     assert sync_f                                   # the fused optimizer path left the copies current: no re-cast happened at the forward
     assert torch.equal(la, lb)                      # ... and they are exactly what a full re-cast produces
     np.testing.assert_allclose(nf, nt, rtol=2e-5)
