@@ -49,7 +49,15 @@ __device__ __forceinline__ int off256(int row, int ch) { return row * 128 + ((ch
 // NOT all requested up front (twice the registers): they are loaded pass by pass, and `after_loads` - the persistent kernel's DMA of
 // the next tile's first K-steps - runs after the last of them (compiler-tracked loads issued behind the untracked LDS-DMA would make
 // every aux wait drain the DMA as well).
-template <typename OutT, int EPI, int MT, typename F>
+// WT (tools/lab/ffn_chain.hip only; the product launches pass false): the bf16 result rows are stored WRITE-THROUGH (sc1) from inline asm, so that
+// another workgroup of the same launch may read them after a counter hand-off without an L2 write-back (MI355X_MICROARCH.md, visibility: R1).
+// Such stores are invisible to hipcc's s_waitcnt bookkeeping: the caller drains them (s_waitcnt vmcnt(0)) before it signals.
+template <bool WT>
+__device__ __forceinline__ void nt256_store16(bf16_t* p, const bf16x8& v) {
+    if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<bf16x8*>(p) = v;
+}
+template <typename OutT, int EPI, int MT, bool WT = false, typename F>
 __device__ __forceinline__ void nt256_epilogue(const GemmGroupNT& g, const GemmProblem& P, unsigned char* lds, int wave, int lane,
                                                int m0, int n0, int wm, int wn, f32x4 (&acc)[MT][4], F&& after_loads) {
     const int M = P.M, N = P.N;
@@ -176,8 +184,8 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroupNT& g, const GemmP
 #pragma unroll
             for (int j = 0; j < 8; ++j) { o[j] = (bf16_t)v[j]; op[j] = (bf16_t)pre[j]; }
             bf16_t* cp = reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + nb;
-            *reinterpret_cast<bf16x8*>(cp) = o;
-            if (EPI == EPI_GELU && P.C2 != nullptr) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(P.C2) + (size_t)m * P.ldc + nb) = op;
+            nt256_store16<WT>(cp, o);
+            if (EPI == EPI_GELU && P.C2 != nullptr) nt256_store16<WT>(reinterpret_cast<bf16_t*>(P.C2) + (size_t)m * P.ldc + nb, op);
         }
     }
     if (AUX && SF) after_loads();
