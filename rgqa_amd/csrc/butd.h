@@ -15,3 +15,12 @@ template <typename T> int kb_mul_relu_bwd(const T* dj, const T* a, const T* b, T
 template <typename T> int kb_wn_eff(const float* v, const float* g, const float* sumsq, T* w, int ldo, T* wt, int ldt, int N, int K, hipStream_t s);
 // gradient of V (and g) from the gradient of the effective weight; plain copy when g == null. partial: >= 256 floats
 int kb_wn_bwd(const float* dw, int lddw, const float* v, const float* g, const float* sumsq, float* partial, float* dv, float* dg, int N, int K, int accumulate, hipStream_t s);
+
+// the GRU recurrence as one persistent launch per direction (butd_gru.hip): bf16, H = 1024, B <= 256; counters: gru_persist_counter_ints(B, L) ints
+// of device memory owned by these launches (the error word behind the counters is zeroed once by the owner)
+bool gru_persist_ok(int B, int H);
+size_t gru_persist_counter_ints(int B, int L);
+int k_gru_fwd_persist(const bf16_t* GI, long ldgi, const bf16_t* W, int ldw, const float* bhh, bf16_t* Hall, bf16_t* Rg, bf16_t* Zg, bf16_t* Ng, bf16_t* GHN,
+                      int B, int L, int H, int* counters, hipStream_t s);
+int k_gru_bwd_persist(const bf16_t* dH, const bf16_t* Hall, const bf16_t* Rg, const bf16_t* Zg, const bf16_t* Ng, const bf16_t* GHN, bf16_t* dGI, long lddgi, bf16_t* dGH,
+                      const bf16_t* WT, int ldwt, int B, int L, int H, int* counters, hipStream_t s);

@@ -131,7 +131,10 @@ public:
         size_t mw = 0;
         for (BLin* l : lins) { size_t n = (size_t)l->out * l->kp; if (n > mw) mw = n; }
         dwscr = take<float>(mw); dw_part = take<float>((size_t)B * H); db_part = take<float>(B);
+        gru_cnt = take<int>(gru_persist_counter_ints(B, L));
     }
+    int* gru_cnt = nullptr;
+    bool gru_persist() const { if constexpr (LP && !X3) return gru_persist_ok(B, H); else return false; }
     size_t workspace_bytes(int B_, int L_, int O_) override { dry = true; plan(B_, L_, O_); dry = false; return ws_used + 256; }
     int bind(float* p, float* g, void*, void*, void* w, size_t wb, int B_, int L_, int O_) override {
         RGQA_REQUIRE(p != nullptr && w != nullptr, "bind: null parameter arena or workspace");
@@ -140,6 +143,7 @@ public:
         if (wb < need) { rgqa_set_error("bind: workspace too small (%zu < %zu bytes)", wb, need); return RGQA_ERR_WORKSPACE; }
         P = p; G = g; ws = (char*)w;
         plan(B_, L_, O_);
+        RGQA_HIP(hipMemset(gru_cnt, 0, sizeof(int) * gru_persist_counter_ints(B, L)));       // incl. the error word of the persistent GRU launches
         have_fwd = false; eff_zeroed = false;
         return RGQA_OK;
     }
@@ -219,12 +223,19 @@ public:
         CKB(kb_embed_fwd<T>(toks, P + emb, X, B * L, E, Ep, s));
         CKB(gemm_fwd(X, Ep, B * L, wih, GI, 3 * H, EPI_BIAS, 0, nd, 0, s));
         CKB(rgqa_check_hip(hipMemsetAsync(Hall, 0, sizeof(T) * (size_t)B * H, s), "h0"));
+        if constexpr (LP && !X3) {
+            if (gru_persist()) {      // the whole recurrence in one launch, W_hh resident in LDS (butd_gru.hip)
+                CKB(k_gru_fwd_persist(GI, (long)L * 3 * H, effp(whh), whh.kp, P + whh.b, Hall, Rg, Zg, Ng, GHN, B, L, H, gru_cnt, s));
+                goto gru_done;
+            }
+        }
         for (int t = 0; t < L; ++t) {
             T* hp = Hall + (size_t)t * B * H;
             CKB(gemm_fwd(hp, H, B, whh, GH, 3 * H, EPI_BIAS, 0, nd, 0, s));
             CKB(kb_gru_fwd<T>(GI + (size_t)t * 3 * H, (long)L * 3 * H, GH, hp, hp + (size_t)B * H, Rg + (size_t)t * B * H, Zg + (size_t)t * B * H,
                               Ng + (size_t)t * B * H, GHN + (size_t)t * B * H, B, H, s));
         }
+    gru_done:
         const T* q = Hall + (size_t)L * B * H;
         CKB(kb_concat<T>(feats, boxes, IF, B * O, cfg.feat_dim, cfg.pos_dim, Dp, s));
         CKB(gemm_fwd(IF, Dp, B * O, ip, IP, H, EPI_RELU, 0, nd, 0, s));
@@ -289,6 +300,14 @@ public:
         CKB(gemm_dgrad(dQP, H, B, qp, dHa, H, EPI_ADD, dq, H, nd, s));          // dHa = d q_enc = both question paths
         // GRU, back through time
         T* dh = dHa; T* dhn = dHb;
+        bool gru_host = true;
+        if constexpr (LP && !X3) {
+            if (gru_persist()) {
+                CKB(k_gru_bwd_persist(dHa, Hall, Rg, Zg, Ng, GHN, dGI, (long)L * 3 * H, dGH, efftp(whh), whh.op, B, L, H, gru_cnt, s));
+                gru_host = false;
+            }
+        }
+        if (gru_host)
         for (int t = L - 1; t >= 0; --t) {
             const T* hp = Hall + (size_t)t * B * H;
             T* dgh_t = dGH + (size_t)t * B * 3 * H;

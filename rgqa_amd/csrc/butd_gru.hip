@@ -1,0 +1,248 @@
+// The GRU recurrence of the BUTD question encoder (reference src/butd/butd.py:48-73: nn.GRU(300, 1024, 1, batch_first=True) from h0 = 0, output[:, -1];
+// BASELINE config 5) as ONE persistent launch per direction, bf16.
+//
+// Until round 5 the host drove the recurrence: per time step one M = B GEMM (h W_hh^T, then dgh W_hh) and one gate kernel - 160 launches of 5-30 us
+// for 40 tokens, 2.2 of the step's 4.5 ms (profiles/r05_butd_kernel_stats_before.md).  Here a launch keeps W_hh on the chip for the whole sequence:
+//
+//   grid    = (row groups of 64 samples) x (H / 16 column slices); one 256-thread workgroup per CU, all co-resident (the launcher checks)
+//   LDS     = the slice's 48 weight rows (forward: rows {r, z, n} x 16 hidden units of W_hh, K = H) or its 16 rows of W_hh^T (backward: K = 3H)
+//   a step  = every wave takes the 16 rows x K operand of ITS 16 samples straight from global memory into registers (h_{t-1}; backward: dgh_t),
+//             runs 96 MFMAs against the LDS-resident slice, and finishes the gates (backward: the carry dh_{t-1}) for its 16 samples x 16 units in
+//             registers: a lane owns the same (sample, 4 units) at every step, so h_{t-1} of the own units (backward: the running dh) never leaves it.
+//   hand-off: what the OTHER slices of the row group need - h_t (forward), dgh_t (backward) - is stored write-through (sc1), every wave drains
+//             (s_waitcnt vmcnt(0)), the workgroup barrier, then ONE lane adds to the row group's counter of that step; consumers poll that counter
+//             with sc1 loads from one lane (bounded), join a workgroup barrier and read the rows with sc1 loads only - MI355X_MICROARCH.md
+//             "Valid forms", first table row (hipMalloc memory, one workgroup per CU, 8-byte sc1 stores, 16-byte sc1 loads).  Row groups are
+//             independent: a group only ever waits for its own H / 16 workgroups.
+// Counters are zeroed by the launcher on the stream before every launch; a poll that gives up (~1 s) raises the error word and the launch still ends.
+// Arithmetic: gh = h W_hh^T + b_hh stays in f32 between the MFMAs and the gates (the host loop rounded it to bf16 in between); the saved r, z, n,
+// gh_n and every h_t are bf16 as before.
+#include "kernels.h"
+#include "butd.h"
+#include "gemm_nt256.h"      // rgqa_num_cus
+
+typedef __attribute__((address_space(1))) const int gint;
+
+struct GruFwdArgs {
+    const bf16_t* GI; long ldgi;              // [B, L, 3H] input projections incl. b_ih; row stride of a sample
+    const bf16_t* W; int ldw;                 // effective W_hh [3H, ldw]
+    const float* bhh;                         // [3H]
+    bf16_t* Hall;                             // [(L + 1), B, H]; Hall[0] = 0 (set by the caller)
+    bf16_t *Rg, *Zg, *Ng, *GHN;               // [L, B, H] saved for the backward pass
+    int B, L;
+    int* cnt;                                 // [row groups][L + 1], zeroed
+    int* err;
+};
+struct GruBwdArgs {
+    const bf16_t* dH;                         // [B, H] gradient w.r.t. h_L
+    const bf16_t* Hall; const bf16_t *Rg, *Zg, *Ng, *GHN;
+    bf16_t* dGI; long lddgi;                  // [B, L, 3H]
+    bf16_t* dGH;                              // [L, B, 3H]
+    const bf16_t* WT; int ldwt;               // W_hh^T [H, ldwt >= 3H]: row k = hidden unit k, columns = the 3H gate outputs
+    int B, L;
+    int* cnt;                                 // [row groups][L], zeroed
+    int* err;
+};
+
+__device__ __forceinline__ float sigm_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// one lane polls until *p >= want (sc1 loads; the caller joins a workgroup barrier afterwards)
+__device__ __forceinline__ void gru_wait(const int* p, int want, int* err) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) { __hip_atomic_fetch_add(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const GruFwdArgs a) {
+    constexpr int KS = H / 32, PITCH = 2 * H + 16, CS = H / 16;     // K-steps of 32; LDS row pitch (16 bytes of padding: conflict-free b128 fragment reads)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int cs = blockIdx.x % CS, rg = blockIdx.x / CS;
+    const int B = a.B, L = a.L;
+    // the slice's weight rows: LDS row g * 16 + u = W_hh row g * H + cs * 16 + u
+    for (int i = tid; i < 48 * (H / 8); i += 256) {
+        const int r = i / (H / 8), c = i % (H / 8);
+        *reinterpret_cast<uint4*>(lds + r * PITCH + c * 16) = *reinterpret_cast<const uint4*>(a.W + (size_t)((r >> 4) * H + cs * 16 + (r & 15)) * a.ldw + c * 8);
+    }
+    __syncthreads();
+    const int row = rg * 64 + wave * 16 + fr;
+    const bool live = row < B;
+    const int rowc = live ? row : B - 1;
+    const int u0 = cs * 16 + fq * 4;                                 // this lane's 4 hidden units
+    float bh[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bh[g][j] = a.bhh[g * H + u0 + j];
+    float hown[4] = {0.f, 0.f, 0.f, 0.f};
+    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(a.Hall, 0, (int)((size_t)(L + 1) * B * H * 2), 0x00020000);
+    int* cnt = a.cnt + rg * (L + 1);
+    for (int t = 0; t < L; ++t) {
+        const bf16_t* gi = a.GI + (size_t)rowc * a.ldgi + (size_t)t * 3 * H + u0;
+        const bf16x4 gir = *reinterpret_cast<const bf16x4*>(gi), giz = *reinterpret_cast<const bf16x4*>(gi + H), gin = *reinterpret_cast<const bf16x4*>(gi + 2 * H);
+        if (t > 0) {                                                 // h_t of every slice of this row group is in place (Hall[0] is the caller's zero block)
+            if (tid == 0) gru_wait(cnt + t, CS, a.err);
+            __syncthreads();
+        }
+        bf16x8 af[KS];
+        const unsigned hoff = (unsigned)(((size_t)t * B + rowc) * H * 2) + fq * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_h, hoff + ks * 64, 0, 16);      // aux 16 = sc1
+            af[ks] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+        f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + (g * 16 + fr) * PITCH + (ks * 4 + fq) * 16);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[ks], acc[g], 0, 0, 0);
+            }
+        // gates (gate order r, z, n as torch.nn.GRU): acc[g][j] = (h_{t-1} W_hh^T)[sample fr of this wave][unit u0 + j] of gate g
+        bf16x4 hn, rr, zz, nn, gg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r = sigm_f((float)gir[j] + acc[0][j] + bh[0][j]);
+            const float z = sigm_f((float)giz[j] + acc[1][j] + bh[1][j]);
+            const float gn = acc[2][j] + bh[2][j];
+            const float n = tanhf((float)gin[j] + r * gn);
+            const float h = (1.f - z) * n + z * hown[j];
+            hn[j] = (bf16_t)h; rr[j] = (bf16_t)r; zz[j] = (bf16_t)z; nn[j] = (bf16_t)n; gg[j] = (bf16_t)gn;
+            hown[j] = (float)hn[j];                                  // what every other slice reads back
+        }
+        if (live) {
+            const size_t o = ((size_t)t * B + row) * H + u0;
+            *reinterpret_cast<bf16x4*>(a.Rg + o) = rr; *reinterpret_cast<bf16x4*>(a.Zg + o) = zz;
+            *reinterpret_cast<bf16x4*>(a.Ng + o) = nn; *reinterpret_cast<bf16x4*>(a.GHN + o) = gg;
+            __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned*>(&hn), rs_h,
+                                                  (unsigned)((((size_t)(t + 1) * B + row) * H + u0) * 2), 0, 16);       // write-through
+        }
+        if (t + 1 < L) {                                             // (the last h is read by later launches only)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt + t + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const GruBwdArgs a) {
+    constexpr int K3 = 3 * H, KS = H / 32, PITCH = 2 * K3 + 16, CS = H / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int cs = blockIdx.x % CS, rg = blockIdx.x / CS;
+    const int B = a.B, L = a.L;
+    // LDS row u = W_hh^T row cs * 16 + u: the 3H gate-output weights that feed hidden unit u of h_{t-1}
+    for (int i = tid; i < 16 * (K3 / 8); i += 256) {
+        const int r = i / (K3 / 8), c = i % (K3 / 8);
+        *reinterpret_cast<uint4*>(lds + r * PITCH + c * 16) = *reinterpret_cast<const uint4*>(a.WT + (size_t)(cs * 16 + r) * a.ldwt + c * 8);
+    }
+    __syncthreads();
+    const int row = rg * 64 + wave * 16 + fr;
+    const bool live = row < B;
+    const int rowc = live ? row : B - 1;
+    const int u0 = cs * 16 + fq * 4;
+    float d[4];
+    {
+        const bf16x4 d0 = *reinterpret_cast<const bf16x4*>(a.dH + (size_t)rowc * H + u0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (float)d0[j];
+    }
+    const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(a.dGH, 0, (int)((size_t)L * B * K3 * 2), 0x00020000);
+    int* cnt = a.cnt + rg * L;
+    for (int t = L - 1; t >= 0; --t) {
+        const size_t o = ((size_t)t * B + rowc) * H + u0;
+        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(a.Rg + o), z4 = *reinterpret_cast<const bf16x4*>(a.Zg + o), n4 = *reinterpret_cast<const bf16x4*>(a.Ng + o),
+                     g4 = *reinterpret_cast<const bf16x4*>(a.GHN + o), h4 = *reinterpret_cast<const bf16x4*>(a.Hall + o);
+        bf16x4 qr, qz, qn, qnr;
+        float carry[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r = (float)r4[j], z = (float)z4[j], n = (float)n4[j], gn = (float)g4[j], hp = (float)h4[j];
+            const float dn = d[j] * (1.f - z) * (1.f - n * n);
+            const float dz = d[j] * (hp - n) * z * (1.f - z);
+            const float dr = dn * gn * r * (1.f - r);
+            qr[j] = (bf16_t)dr; qz[j] = (bf16_t)dz; qn[j] = (bf16_t)dn; qnr[j] = (bf16_t)(dn * r);
+            carry[j] = d[j] * z;                                     // the direct path h_{t-1} -> h_t
+        }
+        if (live) {
+            bf16_t* gi = a.dGI + (size_t)row * a.lddgi + (size_t)t * K3 + u0;
+            *reinterpret_cast<bf16x4*>(gi) = qr; *reinterpret_cast<bf16x4*>(gi + H) = qz; *reinterpret_cast<bf16x4*>(gi + 2 * H) = qn;
+            const unsigned go = (unsigned)((((size_t)t * B + row) * K3 + u0) * 2);
+            typedef __attribute__((ext_vector_type(2))) unsigned u2;
+            __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2*>(&qr), rs_g, go, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2*>(&qz), rs_g, go + 2 * H, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2*>(&qnr), rs_g, go + 4 * H, 0, 16);
+        }
+        if (t == 0) break;                                           // h_0 is the constant zero state: nothing flows further back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gru_wait(cnt + t, CS, a.err);                            // dgh_t of every slice of this row group
+        }
+        __syncthreads();
+        // dh_{t-1}[sample][u0 + j] = carry + sum over the 3H gate outputs of dgh_t[sample][.] W_hh[., u0 + j]: three K chunks of H
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned aoff = (unsigned)(((size_t)t * B + rowc) * K3 * 2) + fq * 16;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            bf16x8 af[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_g, aoff + (c * KS + ks) * 64, 0, 16);
+                af[ks] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + fr * PITCH + ((c * KS + ks) * 4 + fq) * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[ks], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = acc[j] + carry[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- launchers
+int g_rgqa_butd_gru_persist = 1;      // rgqa_debug_set key 18: 0 = the host-driven recurrence (one GEMM + one gate kernel per token)
+
+// the persistent launches apply: bf16, H = 1024, at most four row groups, and every workgroup resident at once (one per CU)
+bool gru_persist_ok(int B, int H) {
+    return g_rgqa_butd_gru_persist != 0 && H == 1024 && B >= 1 && B <= 256 && ((B + 63) / 64) * (H / 16) <= rgqa_num_cus();
+}
+// [forward counters: row groups x (L + 1)] [backward counters: row groups x L] [error word, zeroed once by the owner] ...
+size_t gru_persist_counter_ints(int B, int L) { return (size_t)((B + 63) / 64) * (2 * L + 1) + 16; }
+
+int k_gru_fwd_persist(const bf16_t* GI, long ldgi, const bf16_t* W, int ldw, const float* bhh, bf16_t* Hall, bf16_t* Rg, bf16_t* Zg, bf16_t* Ng, bf16_t* GHN,
+                      int B, int L, int H, int* counters, hipStream_t s) {
+    RGQA_REQUIRE(gru_persist_ok(B, H), "gru_fwd_persist: B=%d H=%d not covered", B, H);
+    constexpr int HH = 1024, LDS_BYTES = 48 * (2 * HH + 16);
+    const int RG = (B + 63) / 64;
+    static bool attr = false;
+    if (!attr) { RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persist_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); attr = true; }
+    RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RG * (2 * L + 1), s));
+    GruFwdArgs a{GI, ldgi, W, ldw, bhh, Hall, Rg, Zg, Ng, GHN, B, L, counters, counters + (size_t)RG * (2 * L + 1)};
+    hipLaunchKernelGGL(gru_fwd_persist_kernel<HH>, dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    RGQA_LAUNCH_CHECK("gru_fwd_persist_kernel");
+    return RGQA_OK;
+}
+int k_gru_bwd_persist(const bf16_t* dH, const bf16_t* Hall, const bf16_t* Rg, const bf16_t* Zg, const bf16_t* Ng, const bf16_t* GHN, bf16_t* dGI, long lddgi, bf16_t* dGH,
+                      const bf16_t* WT, int ldwt, int B, int L, int H, int* counters, hipStream_t s) {
+    RGQA_REQUIRE(gru_persist_ok(B, H) && ldwt >= 3 * H, "gru_bwd_persist: B=%d H=%d ldwt=%d not covered", B, H, ldwt);
+    constexpr int HH = 1024, LDS_BYTES = 16 * (2 * 3 * HH + 16);
+    const int RG = (B + 63) / 64;
+    static bool attr = false;
+    if (!attr) { RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persist_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); attr = true; }
+    RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RG * (2 * L + 1), s));
+    GruBwdArgs a{dH, Hall, Rg, Zg, Ng, GHN, dGI, lddgi, dGH, WT, ldwt, B, L, counters + (size_t)RG * (L + 1), counters + (size_t)RG * (2 * L + 1)};
+    hipLaunchKernelGGL(gru_bwd_persist_kernel<HH>, dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    RGQA_LAUNCH_CHECK("gru_bwd_persist_kernel");
+    return RGQA_OK;
+}

@@ -25,6 +25,7 @@ extern int g_rgqa_wgrad_merge;
 extern int g_rgqa_nt_splitk;
 extern int g_rgqa_nt_panel;
 extern int g_rgqa_wgrad_sets;
+extern int g_rgqa_butd_gru_persist;
 // debug / test switches (include/rgqa.h)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -38,6 +39,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 9) { g_rgqa_nt_panel = value; return RGQA_OK; }
     if (key == 16) { g_rgqa_attn_pair = value; return RGQA_OK; }
     if (key == 17) { g_rgqa_wgrad_sets = value; return RGQA_OK; }
+    if (key == 18) { g_rgqa_butd_gru_persist = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }

@@ -11,10 +11,11 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"]))
 rows.sort()
 ngaps = int(sys.argv[2]) if len(sys.argv) > 2 else 15
-adam = [i for i, r in enumerate(rows) if "bertadam" in r[3] and r[1] - r[0] > 300000]
-if len(adam) < 3:
-    sys.exit("need >= 3 optimizer launches")
-lo, hi = adam[-3], adam[-1]          # two full steps: end of adam[-3] .. end of adam[-1]
+per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # optimizer launches per step (the drop-in BertAdam: one per contiguous run = 3)
+adam = [i for i, r in enumerate(rows) if "bertadam" in r[3] and r[1] - r[0] > (300000 if per_step == 1 else 20000)]
+if len(adam) < 2 * per_step + 1:
+    sys.exit("need >= %d optimizer launches" % (2 * per_step + 1))
+lo, hi = adam[-1 - 2 * per_step], adam[-1]          # two full steps: end of the last optimizer launch of step n-2 .. end of step n's
 t0, t1 = rows[lo][1], rows[hi][1]
 span = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 nsteps = 2
