@@ -1,6 +1,18 @@
 // BUTD path kernel launchers (butd_kernels.hip).
 #pragma once
 #include "common.h"
+// one linear layer for the grouped weight-norm launches (kb_wn_forward_group / kb_wn_backward_group): V [out, in] (+ scalar g and ||V||^2 slot when
+// weight-normed), effective copies eff [op, kp] / efft [kp, op] (element type of the engine), optional f32 copy of the effective weight, and for the
+// backward pass dW [out, lddw] (the wgrad GEMM's result), dV / dg in the gradient arena.  blk0 / nblk: this layer's blocks in the reduction /
+// element-wise launches; tile0 / tiles_x / tiles_y: its 32 x 32 tiles in the effective-weight launch.
+struct WnDesc {
+    const float* v; const float* g; float* sumsq; void* eff; void* efft; float* eff_f32;
+    const float* dw; int lddw; float* dv; float* dgp;
+    int out, in, kp, op;
+    int blk0, nblk, tile0, tiles_x, tiles_y;
+};
+int kb_wn_forward_group(const WnDesc* descs_dev, int nd, int total_blocks, int total_tiles, float* partial, int elem, hipStream_t s);
+int kb_wn_backward_group(const WnDesc* descs_dev, int nd, int total_blocks, float* partial, hipStream_t s);
 template <typename T> int kb_embed_fwd(const int64_t* toks, const float* table, T* out, int rows, int E, int Ep, hipStream_t s);
 template <typename T> int kb_embed_bwd(const int64_t* toks, const T* dx, float* dtable, int rows, int E, int Ep, int pad_idx, hipStream_t s);
 template <typename T> int kb_gru_fwd(const T* gi, long ldgi, const T* gh, const T* hprev, T* hnew, T* rs, T* zs, T* ns, T* ghn, int B, int H, hipStream_t s);

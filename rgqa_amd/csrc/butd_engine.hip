@@ -25,6 +25,7 @@ __global__ void butd_sum_small_kernel(const float* __restrict__ src, int n, floa
 struct BLin {            // one linear layer: V (or W) [out, in], optional scalar g, bias [out]
     size_t v, g, b; int out, in, kp, op; bool wn;
     size_t eff, efft;    // byte offsets of the effective-weight copies in the workspace
+    size_t dwo;          // byte offset of its dW scratch [out, kp] f32 (the grouped weight-gradient launch)
     int norm;            // index of its ||V||^2 scalar
 };
 
@@ -33,7 +34,10 @@ class ButdEngine : public EngineBase {
 public:
     static constexpr bool LP = !std::is_same<T, float>::value;
     static constexpr bool X3 = std::is_same<T, sf32>::value;       // split-f32 activations and effective-weight copies (bf16x3 precision)
-    static constexpr int LDM = X3 ? 32 : 8;                          // row pitches: whole 128-byte lines of split f32, 16 bytes of bf16
+    // row pitches / padded contraction lengths: multiples of 64 elements for the low-precision engines - whole K-steps of the LDS-DMA GEMM kernels
+    // (until round 5 bf16 padded to 8: K = 304 (GloVe), 2056 (RoI features + box) and 1848 (answers) sent four GEMMs of the step to the 128 x 128
+    // register-staged kernel, 0.38 ms) and whole 128-byte lines of split f32
+    static constexpr int LDM = LP ? 64 : 8;
     static int nt_gemm(GemmGroup& g, int out_f32, int trans_b, hipStream_t s) {
         if constexpr (X3) return launch_gemm_nt_x3(g, out_f32, s);
         else if constexpr (LP) return launch_gemm_nt_bf16(g, out_f32, s);
@@ -132,6 +136,34 @@ public:
         for (BLin* l : lins) { size_t n = (size_t)l->out * l->kp; if (n > mw) mw = n; }
         dwscr = take<float>(mw); dw_part = take<float>((size_t)B * H); db_part = take<float>(B);
         gru_cnt = take<int>(gru_persist_counter_ints(B, L));
+        for (BLin* l : lins) { l->dwo = ws_used; take<float>((size_t)l->out * l->kp); }
+        wn_dev = take<WnDesc>(16); wn_partial = take<float>(1024);
+        gemm_ws_floats = LP ? (size_t)GEMM_NT_MAX_PROBLEMS * 256 * 2112 : 0;        // split-K scratch of the M = B GEMMs (csrc/gemm_mfma256.hip)
+        gemm_ws = LP ? take<float>(gemm_ws_floats) : nullptr;
+    }
+    WnDesc* wn_dev = nullptr; float* wn_partial = nullptr; std::vector<WnDesc> wn_host; int wn_blocks = 0, wn_tiles = 0; bool wn_uploaded = false;
+    float* gemm_ws = nullptr; size_t gemm_ws_floats = 0;
+    float* dwp(const BLin& l) const { return reinterpret_cast<float*>(ws + l.dwo); }
+    // the whh weight gradient goes straight into the gradient arena (no weight norm, kp == in)
+    bool dw_direct(const BLin& l) const { return !l.wn && l.kp == l.in; }
+    void build_wn_table() {
+        wn_host.clear(); wn_blocks = 0; wn_tiles = 0;
+        for (BLin* l : lins) {
+            WnDesc d; memset(&d, 0, sizeof d);
+            d.v = P + l->v; d.g = l->wn ? P + l->g : nullptr; d.sumsq = l->wn ? sumsq + l->norm : nullptr;
+            d.eff = effp(*l); d.efft = LP ? (void*)efftp(*l) : nullptr; d.eff_f32 = (l == &lin) ? wlin_eff : nullptr;
+            const bool direct = dw_direct(*l);
+            d.dw = (G && direct) ? G + l->v : dwp(*l); d.lddw = direct ? l->in : l->kp; d.dv = G ? G + l->v : nullptr; d.dgp = (G && l->wn) ? G + l->g : nullptr;
+            d.out = l->out; d.in = l->in; d.kp = l->kp; d.op = l->op;
+            const long n = (long)l->out * l->in;
+            d.blk0 = wn_blocks; d.nblk = (int)((n + 4095) / 4096); if (d.nblk > 64) d.nblk = 64; if (d.nblk < 1) d.nblk = 1;
+            wn_blocks += d.nblk;
+            const int kk = l->kp > l->in ? l->kp : l->in, nn = LP ? (l->op > l->out ? l->op : l->out) : l->out;
+            d.tile0 = wn_tiles; d.tiles_x = cdiv(kk, 32); d.tiles_y = cdiv(nn, 32);
+            wn_tiles += d.tiles_x * d.tiles_y;
+            wn_host.push_back(d);
+        }
+        wn_uploaded = false;
     }
     int* gru_cnt = nullptr;
     bool gru_persist() const { if constexpr (LP && !X3) return gru_persist_ok(B, H); else return false; }
@@ -144,6 +176,9 @@ public:
         P = p; G = g; ws = (char*)w;
         plan(B_, L_, O_);
         RGQA_HIP(hipMemset(gru_cnt, 0, sizeof(int) * gru_persist_counter_ints(B, L)));       // incl. the error word of the persistent GRU launches
+        RGQA_REQUIRE(wn_blocks <= 1024 || true, "bind: weight-norm partial scratch");
+        build_wn_table();
+        RGQA_REQUIRE(wn_blocks <= 1024 && (int)wn_host.size() <= 16, "bind: weight-norm tables too small (%d blocks, %zu layers)", wn_blocks, wn_host.size());
         have_fwd = false; eff_zeroed = false;
         return RGQA_OK;
     }
@@ -161,16 +196,13 @@ public:
             }
             eff_zeroed = true;
         }
-        for (BLin* l : lins) {
-            const float* g = nullptr; const float* ss = nullptr;
-            if (l->wn) {
-                CKB(k_sumsq(P + l->v, (size_t)l->out * l->in, sumsq_scr, sumsq + l->norm, 0, s));
-                g = P + l->g; ss = sumsq + l->norm;
-            }
-            CKB(kb_wn_eff<T>(P + l->v, g, ss, effp(*l), l->kp, LP ? efftp(*l) : nullptr, l->op, l->out, l->in, s));
+        // every layer's ||V||^2 and effective copies in two launches (butd_kernels.hip, "weight norm ... ONE launch per phase")
+        if (!wn_uploaded) {
+            CKB(rgqa_check_hip(hipMemcpyAsync(wn_dev, wn_host.data(), sizeof(WnDesc) * wn_host.size(), hipMemcpyHostToDevice, s), "weight-norm table"));
+            wn_uploaded = true;
         }
-        CKB(kb_wn_eff<float>(P + lin.v, P + lin.g, sumsq + lin.norm, wlin_eff, H, nullptr, 0, 1, H, s));
-        if (X3) {
+        CKB(kb_wn_forward_group(wn_dev, (int)wn_host.size(), wn_blocks, wn_tiles, wn_partial, X3 ? 2 : (LP ? 1 : 0), s));
+        if (LP) {
             CKB(rgqa_check_hip(hipMemsetAsync(c3_bias_pad, 0, sizeof(float) * c3.op, s), "zero padded bias"));
             CKB(rgqa_check_hip(hipMemcpyAsync(c3_bias_pad, P + c3.b, sizeof(float) * c3.out, hipMemcpyDeviceToDevice, s), "padded bias"));
         }
@@ -184,6 +216,7 @@ public:
         GemmGroup g; ginit(g); g.drop = drop;
         GemmProblem& p = g.p[0];
         p.A = x; p.lda = ldx; p.B = effp(l); p.ldb = l.kp; p.C = C; p.ldc = ldc; p.M = M; p.N = l.out; p.K = l.kp; p.bias = P + l.b; p.epi = epi; p.drop_site = site;
+        if (M == B) { g.splitk_ws = gemm_ws; g.splitk_floats = gemm_ws_floats; }      // the per-sample GEMMs: skinny whatever the batch (call site, not shape)
         return nt_gemm(g, out_f32, 0, s);
     }
     // dx[M, kp] = dy[M, out(op)] @ Weff
@@ -191,7 +224,11 @@ public:
         GemmGroup g; ginit(g); g.drop = drop;
         GemmProblem& p = g.p[0];
         p.A = dy; p.lda = lddy; p.C = dx; p.ldc = lddx; p.M = M; p.N = l.kp; p.epi = epi; p.aux = aux; p.ldaux = ldaux;
-        if (LP) { p.B = efftp(l); p.ldb = l.op; p.K = (int)rupb(l.out, LDM) > l.op ? l.op : (int)rupb(l.out, LDM); return nt_gemm(g, 0, 1, s); }
+        if (LP) {
+            p.B = efftp(l); p.ldb = l.op; p.K = (int)rupb(l.out, LDM) > l.op ? l.op : (int)rupb(l.out, LDM);
+            if (M == B) { g.splitk_ws = gemm_ws; g.splitk_floats = gemm_ws_floats; }
+            return nt_gemm(g, 0, 1, s);
+        }
         p.B = effp(l); p.ldb = l.kp; p.K = l.out;
         return launch_gemm_f32(g, 0, 1, s);
     }
@@ -245,10 +282,11 @@ public:
         CKB(gemm_fwd(IE, Dp, B, iproj, IR, H, EPI_RELU, 0, nd, 0, s));
         CKB(kb_mul_fwd<T>(QR, IR, J, (size_t)B * H, s));
         CKB(gemm_fwd(J, H, B, c0, C1, 2 * H, EPI_RELU_DROP, 0, drop_raw(cfg.hidden_dropout), 2, s));
-        if (X3) {       // the split-f32 kernels want N % 8 == 0: all op = round_up(NA, 64) columns (zero weight rows, zero-padded bias: exact zeros)
+        if (LP) {       // the LDS-DMA kernels want N % 8 == 0: all op = round_up(NA, 64) columns (zero weight rows, zero-padded bias: exact zeros)
             GemmGroup g; ginit(g);
             GemmProblem& p = g.p[0];
             p.A = C1; p.lda = 2 * H; p.B = effp(c3); p.ldb = c3.kp; p.C = logits; p.ldc = NAp; p.M = B; p.N = c3.op; p.K = c3.kp; p.bias = c3_bias_pad; p.epi = EPI_BIAS;
+            g.splitk_ws = gemm_ws; g.splitk_floats = gemm_ws_floats;
             CKB(nt_gemm(g, 1, 0, s));
         } else
         CKB(gemm_fwd(C1, 2 * H, B, c3, logits, NAp, EPI_BIAS, 1, nd, 0, s));
@@ -274,29 +312,51 @@ public:
     }
     int backward_pooled(const float*, int, int, hipStream_t) override { rgqa_set_error("backward_pooled: not available for the BUTD engine"); return RGQA_ERR_ARG; }
 
+    // Weight gradients.  Low-precision engines, no accumulation: every layer's problem is COLLECTED while the gradient flows back (their operands
+    // live in buffers of their own until the end of the pass) and ONE grouped TN launch computes them all - longest contraction first, the bias
+    // gradients ride as column sums of the dy operands (GemmProblem::colsum_out) - followed by the two grouped weight-norm launches.  Until round 5:
+    // per layer one TN launch of 12-185 us on a mostly idle chip, a dot product, the weight-norm gradient, a column sum and a bias copy (~45 launches).
+    GemmGroup wg; bool wg_collect = false;
+    int wgrad(const void* dy, int lddy, const void* x, int ldx, int rows, const BLin& l, int accumulate, hipStream_t s) {
+        if (!wg_collect) return gemm_wgrad(dy, lddy, x, ldx, rows, l, accumulate, s);
+        RGQA_REQUIRE(wg.count < GEMM_MAX_PROBLEMS, "butd backward: too many weight-gradient problems");
+        GemmProblem& p = wg.p[wg.count++];
+        memset(&p, 0, sizeof p);
+        const bool direct = dw_direct(l);
+        p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.C = direct ? G + l.v : dwp(l); p.ldc = direct ? l.in : l.kp;
+        p.M = l.out; p.N = direct ? l.in : l.kp; p.K = rows; p.epi = EPI_BIAS; p.colsum_out = G + l.b;
+        return RGQA_OK;
+    }
+
     int backward_impl(int accumulate, hipStream_t s) {
         const DropCfg nd = make_drop(0.f, 0, 0);
         const T* q = Hall + (size_t)L * B * H;
         if (!accumulate) CKB(rgqa_check_hip(hipMemsetAsync(G + emb, 0, sizeof(float) * (size_t)cfg.vocab_size * E, s), "zero embedding grad"));
+        wg_collect = LP && !accumulate;
+        memset(&wg, 0, sizeof wg); wg.drop = make_drop(0.f, 0, 0);
         // classifier
-        CKB(gemm_wgrad(dlogits, NAp, C1, 2 * H, B, c3, accumulate, s));
+        CKB(wgrad(dlogits, NAp, C1, 2 * H, B, c3, accumulate, s));
         CKB(gemm_dgrad(dlogits, NAp, B, c3, dC1, 2 * H, EPI_DRELU_DROP, C1, 2 * H, drop_raw(cfg.hidden_dropout), s));
-        CKB(gemm_wgrad(dC1, 2 * H, J, H, B, c0, accumulate, s));
+        CKB(wgrad(dC1, 2 * H, J, H, B, c0, accumulate, s));
         CKB(gemm_dgrad(dC1, 2 * H, B, c0, dJ, H, EPI_BIAS, nullptr, 0, nd, s));
         CKB(kb_mul_relu_bwd<T>(dJ, QR, IR, dQR, dIR, (size_t)B * H, s));
         // projections
-        CKB(gemm_wgrad(dQR, H, q, H, B, qproj, accumulate, s));
+        CKB(wgrad(dQR, H, q, H, B, qproj, accumulate, s));
         CKB(gemm_dgrad(dQR, H, B, qproj, dq, H, EPI_BIAS, nullptr, 0, nd, s));
-        CKB(gemm_wgrad(dIR, H, IE, Dp, B, iproj, accumulate, s));
+        CKB(wgrad(dIR, H, IE, Dp, B, iproj, accumulate, s));
         CKB(gemm_dgrad(dIR, H, B, iproj, dIE, Dp, EPI_BIAS, nullptr, 0, nd, s));
         // attention over regions
         CKB(kb_attend_bwd<T>(dIE, IF, att, IP, QP, wlin_eff, dIP, dQP, dw_part, db_part, B, O, H, Dp, drop_for(cfg.attn_dropout, 1), s));
-        CKB(k_colsum<float>(dw_part, H, partial, dwscr, 0, B, H, s));
-        CKB(kb_wn_bwd(dwscr, H, P + lin.v, P + lin.g, sumsq + lin.norm, partial, G + lin.v, G + lin.g, 1, H, accumulate, s));
+        if (wg_collect) {
+            CKB(k_colsum<float>(dw_part, H, partial, dwp(lin), 0, B, H, s));          // dW of att.linear [1, H]: folded through its weight norm with the others
+        } else {
+            CKB(k_colsum<float>(dw_part, H, partial, dwscr, 0, B, H, s));
+            CKB(kb_wn_bwd(dwscr, H, P + lin.v, P + lin.g, sumsq + lin.norm, partial, G + lin.v, G + lin.g, 1, H, accumulate, s));
+        }
         hipLaunchKernelGGL(butd_sum_small_kernel, dim3(1), dim3(256), 0, s, db_part, B, G + lin.b, accumulate);
         RGQA_LAUNCH_CHECK("butd_sum_small_kernel");
-        CKB(gemm_wgrad(dIP, H, IF, Dp, B * O, ip, accumulate, s));
-        CKB(gemm_wgrad(dQP, H, q, H, B, qp, accumulate, s));
+        CKB(wgrad(dIP, H, IF, Dp, B * O, ip, accumulate, s));
+        CKB(wgrad(dQP, H, q, H, B, qp, accumulate, s));
         CKB(gemm_dgrad(dQP, H, B, qp, dHa, H, EPI_ADD, dq, H, nd, s));          // dHa = d q_enc = both question paths
         // GRU, back through time
         T* dh = dHa; T* dhn = dHb;
@@ -316,10 +376,15 @@ public:
             CKB(gemm_dgrad(dgh_t, 3 * H, B, whh, dhn, H, EPI_ADD, tmpH, H, nd, s));
             T* x = dh; dh = dhn; dhn = x;
         }
-        CKB(gemm_wgrad(dGH, 3 * H, Hall, H, L * B, whh, accumulate, s));
-        CKB(gemm_wgrad(dGI, 3 * H, X, Ep, B * L, wih, accumulate, s));
+        CKB(wgrad(dGH, 3 * H, Hall, H, L * B, whh, accumulate, s));
+        CKB(wgrad(dGI, 3 * H, X, Ep, B * L, wih, accumulate, s));
         CKB(gemm_dgrad(dGI, 3 * H, B * L, wih, dX, Ep, EPI_BIAS, nullptr, 0, nd, s));
         CKB(kb_embed_bwd<T>(in_toks, dX, G + emb, B * L, E, Ep, cfg.vocab_size - 1, s));
+        if (wg_collect) {
+            CKB(tn_gemm(wg, s));
+            CKB(kb_wn_backward_group(wn_dev, (int)wn_host.size(), wn_blocks, wn_partial, s));
+            wg_collect = false;
+        }
         return RGQA_OK;
     }
 

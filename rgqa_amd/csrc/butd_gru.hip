@@ -55,23 +55,27 @@ __device__ __forceinline__ void gru_wait(const int* p, int want, int* err) {
     }
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const GruFwdArgs a) {
-    constexpr int KS = H / 32, PITCH = 2 * H + 16, CS = H / 16;     // K-steps of 32; LDS row pitch (16 bytes of padding: conflict-free b128 fragment reads)
+// KSP = 1: 4 waves, each 16 samples x the whole contraction; KSP = 2: 8 waves, waves w and w + 4 share 16 samples and take one half of the contraction
+// each (twice the operand loads in flight per CU: the step is bound by the latency of those loads, not by the 96 MFMAs), the upper half hands its
+// partial sums over through LDS.
+template <int H, int KSP>
+__global__ __launch_bounds__(256 * KSP) void gru_fwd_persist_kernel(const GruFwdArgs a) {
+    constexpr int KS = H / 32, KSW = KS / KSP, PITCH = 2 * H + 16, CS = H / 16, WBYTES = 48 * PITCH;     // K-steps of 32; LDS row pitch: +16 bytes, conflict-free b128 reads
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mt = wave & 3, kh = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
     const int cs = blockIdx.x % CS, rg = blockIdx.x / CS;
     const int B = a.B, L = a.L;
     // the slice's weight rows: LDS row g * 16 + u = W_hh row g * H + cs * 16 + u
-    for (int i = tid; i < 48 * (H / 8); i += 256) {
+    for (int i = tid; i < 48 * (H / 8); i += 256 * KSP) {
         const int r = i / (H / 8), c = i % (H / 8);
         *reinterpret_cast<uint4*>(lds + r * PITCH + c * 16) = *reinterpret_cast<const uint4*>(a.W + (size_t)((r >> 4) * H + cs * 16 + (r & 15)) * a.ldw + c * 8);
     }
     __syncthreads();
-    const int row = rg * 64 + wave * 16 + fr;
-    const bool live = row < B;
-    const int rowc = live ? row : B - 1;
+    f32x4* xch = reinterpret_cast<f32x4*>(lds + WBYTES);             // [4 m-tiles][3 gates][64 lanes] partial sums of the upper K half
+    const int row = rg * 64 + mt * 16 + fr;
+    const bool live = row < B && kh == 0;
+    const int rowc = row < B ? row : B - 1;
     const int u0 = cs * 16 + fq * 4;                                 // this lane's 4 hidden units
     float bh[3][4];
 #pragma unroll
@@ -81,30 +85,48 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const GruFwdArgs a
     float hown[4] = {0.f, 0.f, 0.f, 0.f};
     const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(a.Hall, 0, (int)((size_t)(L + 1) * B * H * 2), 0x00020000);
     int* cnt = a.cnt + rg * (L + 1);
+    bf16x4 rr, zz, nn, gg;
     for (int t = 0; t < L; ++t) {
         const bf16_t* gi = a.GI + (size_t)rowc * a.ldgi + (size_t)t * 3 * H + u0;
         const bf16x4 gir = *reinterpret_cast<const bf16x4*>(gi), giz = *reinterpret_cast<const bf16x4*>(gi + H), gin = *reinterpret_cast<const bf16x4*>(gi + 2 * H);
-        if (t > 0) {                                                 // h_t of every slice of this row group is in place (Hall[0] is the caller's zero block)
-            if (tid == 0) gru_wait(cnt + t, CS, a.err);
+        if (t > 0) {
+            // what the backward pass needs of step t - 1 goes out AFTER that step's signal: these stores are nobody's hand-off
+            if (live) {
+                const size_t o = ((size_t)(t - 1) * B + row) * H + u0;
+                *reinterpret_cast<bf16x4*>(a.Rg + o) = rr; *reinterpret_cast<bf16x4*>(a.Zg + o) = zz;
+                *reinterpret_cast<bf16x4*>(a.Ng + o) = nn; *reinterpret_cast<bf16x4*>(a.GHN + o) = gg;
+            }
+            if (tid == 0) gru_wait(cnt + t, CS, a.err);              // h_t of every slice of this row group is in place (Hall[0] is the caller's zero block)
             __syncthreads();
         }
-        bf16x8 af[KS];
-        const unsigned hoff = (unsigned)(((size_t)t * B + rowc) * H * 2) + fq * 16;
+        bf16x8 af[KSW];
+        const unsigned hoff = (unsigned)(((size_t)t * B + rowc) * H * 2) + fq * 16 + kh * KSW * 64;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KSW; ++ks) {
             const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_h, hoff + ks * 64, 0, 16);      // aux 16 = sc1
             af[ks] = *reinterpret_cast<const bf16x8*>(&v);
         }
         f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + (g * 16 + fr) * PITCH + (ks * 4 + fq) * 16);
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + (g * 16 + fr) * PITCH + ((kh * KSW + ks) * 4 + fq) * 16);
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[ks], acc[g], 0, 0, 0);
             }
-        // gates (gate order r, z, n as torch.nn.GRU): acc[g][j] = (h_{t-1} W_hh^T)[sample fr of this wave][unit u0 + j] of gate g
-        bf16x4 hn, rr, zz, nn, gg;
+        if (KSP == 2) {
+            if (kh == 1) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) xch[(mt * 3 + g) * 64 + lane] = acc[g];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] += xch[(mt * 3 + g) * 64 + lane];
+            }
+        }
+        // gates (gate order r, z, n as torch.nn.GRU): acc[g][j] = (h_{t-1} W_hh^T)[sample fr of this m-tile][unit u0 + j] of gate g
+        bf16x4 hn;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float r = sigm_f((float)gir[j] + acc[0][j] + bh[0][j]);
@@ -115,38 +137,41 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const GruFwdArgs a
             hn[j] = (bf16_t)h; rr[j] = (bf16_t)r; zz[j] = (bf16_t)z; nn[j] = (bf16_t)n; gg[j] = (bf16_t)gn;
             hown[j] = (float)hn[j];                                  // what every other slice reads back
         }
-        if (live) {
-            const size_t o = ((size_t)t * B + row) * H + u0;
-            *reinterpret_cast<bf16x4*>(a.Rg + o) = rr; *reinterpret_cast<bf16x4*>(a.Zg + o) = zz;
-            *reinterpret_cast<bf16x4*>(a.Ng + o) = nn; *reinterpret_cast<bf16x4*>(a.GHN + o) = gg;
+        if (live)
             __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned*>(&hn), rs_h,
                                                   (unsigned)((((size_t)(t + 1) * B + row) * H + u0) * 2), 0, 16);       // write-through
-        }
         if (t + 1 < L) {                                             // (the last h is read by later launches only)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(cnt + t + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (live) {
+        const size_t o = ((size_t)(L - 1) * B + row) * H + u0;
+        *reinterpret_cast<bf16x4*>(a.Rg + o) = rr; *reinterpret_cast<bf16x4*>(a.Zg + o) = zz;
+        *reinterpret_cast<bf16x4*>(a.Ng + o) = nn; *reinterpret_cast<bf16x4*>(a.GHN + o) = gg;
+    }
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const GruBwdArgs a) {
-    constexpr int K3 = 3 * H, KS = H / 32, PITCH = 2 * K3 + 16, CS = H / 16;
+template <int H, int KSP>
+__global__ __launch_bounds__(256 * KSP) void gru_bwd_persist_kernel(const GruBwdArgs a) {
+    constexpr int K3 = 3 * H, KS3 = K3 / 32, KSW = KS3 / KSP, CH = 16, NCH = KSW / CH, PITCH = 2 * K3 + 16, CS = H / 16, WBYTES = 16 * PITCH;
+    static_assert(KSW % CH == 0, "chunks of 16 K-steps");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mt = wave & 3, kh = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
     const int cs = blockIdx.x % CS, rg = blockIdx.x / CS;
     const int B = a.B, L = a.L;
     // LDS row u = W_hh^T row cs * 16 + u: the 3H gate-output weights that feed hidden unit u of h_{t-1}
-    for (int i = tid; i < 16 * (K3 / 8); i += 256) {
+    for (int i = tid; i < 16 * (K3 / 8); i += 256 * KSP) {
         const int r = i / (K3 / 8), c = i % (K3 / 8);
         *reinterpret_cast<uint4*>(lds + r * PITCH + c * 16) = *reinterpret_cast<const uint4*>(a.WT + (size_t)(cs * 16 + r) * a.ldwt + c * 8);
     }
     __syncthreads();
-    const int row = rg * 64 + wave * 16 + fr;
-    const bool live = row < B;
-    const int rowc = live ? row : B - 1;
+    f32x4* xch = reinterpret_cast<f32x4*>(lds + WBYTES);             // [4 m-tiles][64 lanes]
+    const int row = rg * 64 + mt * 16 + fr;
+    const bool live = row < B && kh == 0;
+    const int rowc = row < B ? row : B - 1;
     const int u0 = cs * 16 + fq * 4;
     float d[4];
     {
@@ -156,10 +181,11 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const GruBwdArgs a
     }
     const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(a.dGH, 0, (int)((size_t)L * B * K3 * 2), 0x00020000);
     int* cnt = a.cnt + rg * L;
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    size_t o = ((size_t)(L - 1) * B + rowc) * H + u0;
+    bf16x4 r4 = *reinterpret_cast<const bf16x4*>(a.Rg + o), z4 = *reinterpret_cast<const bf16x4*>(a.Zg + o), n4 = *reinterpret_cast<const bf16x4*>(a.Ng + o),
+           g4 = *reinterpret_cast<const bf16x4*>(a.GHN + o), h4 = *reinterpret_cast<const bf16x4*>(a.Hall + o);
     for (int t = L - 1; t >= 0; --t) {
-        const size_t o = ((size_t)t * B + rowc) * H + u0;
-        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(a.Rg + o), z4 = *reinterpret_cast<const bf16x4*>(a.Zg + o), n4 = *reinterpret_cast<const bf16x4*>(a.Ng + o),
-                     g4 = *reinterpret_cast<const bf16x4*>(a.GHN + o), h4 = *reinterpret_cast<const bf16x4*>(a.Hall + o);
         bf16x4 qr, qz, qn, qnr;
         float carry[4];
 #pragma unroll
@@ -172,38 +198,47 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const GruBwdArgs a
             carry[j] = d[j] * z;                                     // the direct path h_{t-1} -> h_t
         }
         if (live) {
-            bf16_t* gi = a.dGI + (size_t)row * a.lddgi + (size_t)t * K3 + u0;
-            *reinterpret_cast<bf16x4*>(gi) = qr; *reinterpret_cast<bf16x4*>(gi + H) = qz; *reinterpret_cast<bf16x4*>(gi + 2 * H) = qn;
             const unsigned go = (unsigned)((((size_t)t * B + row) * K3 + u0) * 2);
-            typedef __attribute__((ext_vector_type(2))) unsigned u2;
             __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2*>(&qr), rs_g, go, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2*>(&qz), rs_g, go + 2 * H, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2*>(&qnr), rs_g, go + 4 * H, 0, 16);
         }
-        if (t == 0) break;                                           // h_0 is the constant zero state: nothing flows further back
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(cnt + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gru_wait(cnt + t, CS, a.err);                            // dgh_t of every slice of this row group
+        if (t > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (live) {                                                  // dgi_t (read by later launches only) and the next step's saved activations: behind the signal
+            bf16_t* gi = a.dGI + (size_t)row * a.lddgi + (size_t)t * K3 + u0;
+            *reinterpret_cast<bf16x4*>(gi) = qr; *reinterpret_cast<bf16x4*>(gi + H) = qz; *reinterpret_cast<bf16x4*>(gi + 2 * H) = qn;
+        }
+        if (t == 0) break;                                           // h_0 is the constant zero state: nothing flows further back
+        o = ((size_t)(t - 1) * B + rowc) * H + u0;
+        r4 = *reinterpret_cast<const bf16x4*>(a.Rg + o); z4 = *reinterpret_cast<const bf16x4*>(a.Zg + o); n4 = *reinterpret_cast<const bf16x4*>(a.Ng + o);
+        g4 = *reinterpret_cast<const bf16x4*>(a.GHN + o); h4 = *reinterpret_cast<const bf16x4*>(a.Hall + o);
+        if (tid == 0) gru_wait(cnt + t, CS, a.err);                  // dgh_t of every slice of this row group
         __syncthreads();
-        // dh_{t-1}[sample][u0 + j] = carry + sum over the 3H gate outputs of dgh_t[sample][.] W_hh[., u0 + j]: three K chunks of H
+        // dh_{t-1}[sample][u0 + j] = carry + sum over the 3H gate outputs of dgh_t[sample][.] W_hh[., u0 + j]
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const unsigned aoff = (unsigned)(((size_t)t * B + rowc) * K3 * 2) + fq * 16;
+        const unsigned aoff = (unsigned)(((size_t)t * B + rowc) * K3 * 2) + fq * 16 + kh * KSW * 64;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            bf16x8 af[KS];
+        for (int c = 0; c < NCH; ++c) {
+            bf16x8 af[CH];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_g, aoff + (c * KS + ks) * 64, 0, 16);
+            for (int ks = 0; ks < CH; ++ks) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_g, aoff + (c * CH + ks) * 64, 0, 16);
                 af[ks] = *reinterpret_cast<const bf16x8*>(&v);
             }
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + fr * PITCH + ((c * KS + ks) * 4 + fq) * 16);
+            for (int ks = 0; ks < CH; ++ks) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + fr * PITCH + ((kh * KSW + c * CH + ks) * 4 + fq) * 16);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[ks], acc, 0, 0, 0);
             }
+        }
+        if (KSP == 2) {
+            if (kh == 1) xch[mt * 64 + lane] = acc;
+            __syncthreads();
+            if (kh == 0) acc += xch[mt * 64 + lane];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = acc[j] + carry[j];
@@ -211,7 +246,8 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const GruBwdArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------------- launchers
-int g_rgqa_butd_gru_persist = 1;      // rgqa_debug_set key 18: 0 = the host-driven recurrence (one GEMM + one gate kernel per token)
+int g_rgqa_butd_gru_persist = 1;      // rgqa_debug_set key 18: 0 = the host-driven recurrence (one GEMM + one gate kernel per token); 1 = persistent, 8 waves
+                                      // (the contraction split over wave pairs); 2 = persistent, 4 waves
 
 // the persistent launches apply: bf16, H = 1024, at most four row groups, and every workgroup resident at once (one per CU)
 bool gru_persist_ok(int B, int H) {
@@ -223,26 +259,36 @@ size_t gru_persist_counter_ints(int B, int L) { return (size_t)((B + 63) / 64) *
 int k_gru_fwd_persist(const bf16_t* GI, long ldgi, const bf16_t* W, int ldw, const float* bhh, bf16_t* Hall, bf16_t* Rg, bf16_t* Zg, bf16_t* Ng, bf16_t* GHN,
                       int B, int L, int H, int* counters, hipStream_t s) {
     RGQA_REQUIRE(gru_persist_ok(B, H), "gru_fwd_persist: B=%d H=%d not covered", B, H);
-    constexpr int HH = 1024, LDS_BYTES = 48 * (2 * HH + 16);
+    constexpr int HH = 1024, LDS_BYTES = 48 * (2 * HH + 16) + 4 * 3 * 64 * 16;
     const int RG = (B + 63) / 64;
     static bool attr = false;
-    if (!attr) { RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persist_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); attr = true; }
+    if (!attr) {
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persist_kernel<HH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persist_kernel<HH, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr = true;
+    }
     RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RG * (2 * L + 1), s));
     GruFwdArgs a{GI, ldgi, W, ldw, bhh, Hall, Rg, Zg, Ng, GHN, B, L, counters, counters + (size_t)RG * (2 * L + 1)};
-    hipLaunchKernelGGL(gru_fwd_persist_kernel<HH>, dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    if (g_rgqa_butd_gru_persist == 2) hipLaunchKernelGGL((gru_fwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((gru_fwd_persist_kernel<HH, 2>), dim3(RG * (HH / 16)), dim3(512), LDS_BYTES, s, a);
     RGQA_LAUNCH_CHECK("gru_fwd_persist_kernel");
     return RGQA_OK;
 }
 int k_gru_bwd_persist(const bf16_t* dH, const bf16_t* Hall, const bf16_t* Rg, const bf16_t* Zg, const bf16_t* Ng, const bf16_t* GHN, bf16_t* dGI, long lddgi, bf16_t* dGH,
                       const bf16_t* WT, int ldwt, int B, int L, int H, int* counters, hipStream_t s) {
     RGQA_REQUIRE(gru_persist_ok(B, H) && ldwt >= 3 * H, "gru_bwd_persist: B=%d H=%d ldwt=%d not covered", B, H, ldwt);
-    constexpr int HH = 1024, LDS_BYTES = 16 * (2 * 3 * HH + 16);
+    constexpr int HH = 1024, LDS_BYTES = 16 * (2 * 3 * HH + 16) + 4 * 64 * 16;
     const int RG = (B + 63) / 64;
     static bool attr = false;
-    if (!attr) { RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persist_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); attr = true; }
+    if (!attr) {
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persist_kernel<HH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persist_kernel<HH, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr = true;
+    }
     RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RG * (2 * L + 1), s));
     GruBwdArgs a{dH, Hall, Rg, Zg, Ng, GHN, dGI, lddgi, dGH, WT, ldwt, B, L, counters + (size_t)RG * (L + 1), counters + (size_t)RG * (2 * L + 1)};
-    hipLaunchKernelGGL(gru_bwd_persist_kernel<HH>, dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    if (g_rgqa_butd_gru_persist == 2) hipLaunchKernelGGL((gru_bwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((gru_bwd_persist_kernel<HH, 2>), dim3(RG * (HH / 16)), dim3(512), LDS_BYTES, s, a);
     RGQA_LAUNCH_CHECK("gru_bwd_persist_kernel");
     return RGQA_OK;
 }

@@ -219,6 +219,108 @@ __global__ void copy_block_kernel(const float* __restrict__ src, int lds, float*
     }
 }
 
+// ---------------------------------------------------------------- weight norm, every linear layer of the model in ONE launch per phase (round 5)
+// Until round 5 each of the nine layers had its own sum-of-squares launch (+ the memset of its ticket), effective-weight launch, gradient dot
+// product, gradient launch, bias column sum and bias copy: ~70 launches of 2-30 us per train step, 0.8 ms of a 4.5-ms step
+// (profiles/r05_butd_kernel_stats_before.md).  Now: forward = wn_partials_group_kernel (the partial sums of squares of every weight-normed
+// layer) + wn_eff_group_kernel (every layer's effective weight and its transpose; each block first folds its layer's partials in index order:
+// deterministic, identical in every block); backward = the same pair for <dW, V> and dV / dg.
+__device__ __forceinline__ int wn_find(const WnDesc* d, int n, int b, int WnDesc::*first) {
+    int l = 0;
+    for (int i = 1; i < n; ++i) if (b >= d[i].*first) l = i;
+    return l;
+}
+// MODE 0: partial[b] = sum over the block's stripe of V^2;  MODE 1: of dW * V
+template <int MODE>
+__global__ __launch_bounds__(256) void wn_partials_group_kernel(const WnDesc* __restrict__ descs, int nd, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int l = wn_find(descs, nd, blockIdx.x, &WnDesc::blk0);
+    const WnDesc d = descs[l];
+    float acc = 0.f;
+    if (d.g != nullptr) {
+        const size_t n = (size_t)d.out * d.in;
+        for (size_t i = (size_t)(blockIdx.x - d.blk0) * 256 + threadIdx.x; i < n; i += (size_t)d.nblk * 256) {
+            const float v = d.v[i];
+            if (MODE == 0) acc = fmaf(v, v, acc);
+            else acc = fmaf(d.dw[(size_t)(i / d.in) * d.lddw + (i % d.in)], v, acc);
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float wn_fold(const float* partial, const WnDesc& d) {
+    float s = 0.f;
+    for (int i = 0; i < d.nblk; ++i) s += partial[d.blk0 + i];
+    return s;
+}
+// effective weight [op, kp] (zero padded past `in`; rows past `out` are the caller's zeros) and its transpose [kp, op]; 32 x 32 tiles
+template <typename T>
+__global__ __launch_bounds__(256) void wn_eff_group_kernel(const WnDesc* __restrict__ descs, int nd, const float* __restrict__ partial) {
+    __shared__ float tile[32][33];
+    const int l = wn_find(descs, nd, blockIdx.x, &WnDesc::tile0);
+    const WnDesc d = descs[l];
+    float scale = 1.0f;
+    if (d.g != nullptr) {
+        const float ss = wn_fold(partial, d);
+        scale = d.g[0] * rsqrtf(ss);
+        if (blockIdx.x == d.tile0 && threadIdx.x == 0) d.sumsq[0] = ss;          // the backward pass needs ||V||^2 again
+    }
+    const int lt = blockIdx.x - d.tile0;
+    const int n0 = (lt / d.tiles_x) * 32, k0 = (lt % d.tiles_x) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    T* w = reinterpret_cast<T*>(d.eff);
+    T* wt = reinterpret_cast<T*>(d.efft);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + ty + r * 8, k = k0 + tx;
+        const float x = (n < d.out && k < d.in) ? d.v[(size_t)n * d.in + k] * scale : 0.f;
+        tile[ty + r * 8][tx] = x;
+        if (n < d.out && k < d.kp) st_elem(w + ((size_t)n * d.kp + k), x);
+        if (d.eff_f32 != nullptr && n < d.out && k < d.in) d.eff_f32[(size_t)n * d.in + k] = x;
+    }
+    if (wt == nullptr) return;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + ty + r * 8, n = n0 + tx;
+        if (k < d.in && n < d.op) st_elem(wt + ((size_t)k * d.op + n), tile[tx][ty + r * 8]);
+    }
+}
+// dV = s (dW - (dot / ||V||^2) V), dg = dot / ||V||, s = g / ||V||; plain layers (g == null): dV = dW out of the padded scratch
+__global__ __launch_bounds__(256) void wn_bwd_group_kernel(const WnDesc* __restrict__ descs, int nd, const float* __restrict__ partial) {
+    const int l = wn_find(descs, nd, blockIdx.x, &WnDesc::blk0);
+    const WnDesc d = descs[l];
+    const size_t n = (size_t)d.out * d.in;
+    if (d.g == nullptr) {
+        if (d.dv == d.dw) return;                // the wgrad GEMM wrote straight into the gradient arena
+        for (size_t i = (size_t)(blockIdx.x - d.blk0) * 256 + threadIdx.x; i < n; i += (size_t)d.nblk * 256)
+            d.dv[i] = d.dw[(size_t)(i / d.in) * d.lddw + (i % d.in)];
+        return;
+    }
+    const float dot = wn_fold(partial, d), ss = d.sumsq[0], nrm = sqrtf(ss), s = d.g[0] / nrm;
+    for (size_t i = (size_t)(blockIdx.x - d.blk0) * 256 + threadIdx.x; i < n; i += (size_t)d.nblk * 256)
+        d.dv[i] = s * (d.dw[(size_t)(i / d.in) * d.lddw + (i % d.in)] - dot / ss * d.v[i]);
+    if (blockIdx.x == d.blk0 && threadIdx.x == 0) d.dgp[0] = dot / nrm;
+}
+
+int kb_wn_forward_group(const WnDesc* descs_dev, int nd, int total_blocks, int total_tiles, float* partial, int elem /* 0 f32, 1 bf16, 2 split f32 */, hipStream_t s) {
+    hipLaunchKernelGGL(wn_partials_group_kernel<0>, dim3(total_blocks), dim3(256), 0, s, descs_dev, nd, partial);
+    RGQA_LAUNCH_CHECK("wn_partials_group_kernel");
+    if (elem == 1) hipLaunchKernelGGL(wn_eff_group_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, s, descs_dev, nd, partial);
+    else if (elem == 2) hipLaunchKernelGGL(wn_eff_group_kernel<sf32>, dim3(total_tiles), dim3(256), 0, s, descs_dev, nd, partial);
+    else hipLaunchKernelGGL(wn_eff_group_kernel<float>, dim3(total_tiles), dim3(256), 0, s, descs_dev, nd, partial);
+    RGQA_LAUNCH_CHECK("wn_eff_group_kernel");
+    return RGQA_OK;
+}
+int kb_wn_backward_group(const WnDesc* descs_dev, int nd, int total_blocks, float* partial, hipStream_t s) {
+    hipLaunchKernelGGL(wn_partials_group_kernel<1>, dim3(total_blocks), dim3(256), 0, s, descs_dev, nd, partial);
+    RGQA_LAUNCH_CHECK("wn_partials_group_kernel");
+    hipLaunchKernelGGL(wn_bwd_group_kernel, dim3(total_blocks), dim3(256), 0, s, descs_dev, nd, partial);
+    RGQA_LAUNCH_CHECK("wn_bwd_group_kernel");
+    return RGQA_OK;
+}
+
 // ---------------------------------------------------------------- host wrappers
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256 > 4096 ? 4096 : ((n) + 255) / 256))
 
