@@ -453,6 +453,17 @@ def mixup_leg(e, dev, lengths_1x, B, T, O, n_steps, rank=0):
     return time_steps(step, n_steps, 3)
 
 
+def butd_tokens(B, L=40, ntoken=3000, seed=1234):
+    """BUTD question tokens as GQABUTD.tokenize builds them (butd/butd.py:180-193): dictionary indices of the words, FRONT-padded to 40 with the
+    padding index ntoken (whose embedding row is zero and receives no gradient, butd.py:36); question length ~ U{5..40}."""
+    rng = np.random.RandomState(seed)
+    toks = np.full((B, L), ntoken, dtype=np.int64)
+    for r in range(B):
+        n = int(rng.randint(5, L + 1))
+        toks[r, L - n:] = rng.randint(0, ntoken, size=n)
+    return toks
+
+
 def butd_leg(B, n_steps, precision="bf16", rank=0):
     """BASELINE config 5 on one GPU: the BUTD backbone's train step (butd/butd.py:195-221), B QA pairs, 40 tokens, dictionary of 3000 words.
     -> ms per step (n_steps timed after 3 warm-up steps)."""
@@ -467,6 +478,7 @@ def butd_leg(B, n_steps, precision="bf16", rank=0):
         if sp.name.endswith("weight_g"):
             eb.view(eb.params, sp).fill_(1.0)
     b = synth.synth_batch(B, T, seed=1234 + rank, vocab=3000)
+    b["input_ids"] = butd_tokens(B, T, 3000, seed=1234 + rank)
     d = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
     eb.ensure_shape(B, T, O)
     eb.sync_weights()
@@ -568,6 +580,8 @@ def main():
         e = Engine(precision=args.precision, **FULL).allocate("cuda")
         init_params(e, seed=0)       # identical replica on every rank
     b = synth.synth_batch(B, T, seed=1234 + rank, vocab=3000 if args.butd else (28996 if args.uniter else 30522))
+    if args.butd:
+        b["input_ids"] = butd_tokens(B, T, 3000, seed=1234 + rank)      # dictionary indices, front-padded with the padding index (not BERT word pieces)
     if args.uniter:      # 7-d region position features (x1, y1, x2, y2, w, h, area; tasks/gqa_data.py:240-250)
         bx = b["boxes"]
         w_, h_ = bx[:, :, 2] - bx[:, :, 0], bx[:, :, 3] - bx[:, :, 1]

@@ -156,7 +156,7 @@ public:
             d.dw = (G && direct) ? G + l->v : dwp(*l); d.lddw = direct ? l->in : l->kp; d.dv = G ? G + l->v : nullptr; d.dgp = (G && l->wn) ? G + l->g : nullptr;
             d.out = l->out; d.in = l->in; d.kp = l->kp; d.op = l->op;
             const long n = (long)l->out * l->in;
-            d.blk0 = wn_blocks; d.nblk = (int)((n + 4095) / 4096); if (d.nblk > 64) d.nblk = 64; if (d.nblk < 1) d.nblk = 1;
+            d.blk0 = wn_blocks; d.nblk = (int)((n + 8191) / 8192); if (d.nblk > 100) d.nblk = 100; if (d.nblk < 1) d.nblk = 1;
             wn_blocks += d.nblk;
             const int kk = l->kp > l->in ? l->kp : l->in, nn = LP ? (l->op > l->out ? l->op : l->out) : l->out;
             d.tile0 = wn_tiles; d.tiles_x = cdiv(kk, 32); d.tiles_y = cdiv(nn, 32);
@@ -176,7 +176,6 @@ public:
         P = p; G = g; ws = (char*)w;
         plan(B_, L_, O_);
         RGQA_HIP(hipMemset(gru_cnt, 0, sizeof(int) * gru_persist_counter_ints(B, L)));       // incl. the error word of the persistent GRU launches
-        RGQA_REQUIRE(wn_blocks <= 1024 || true, "bind: weight-norm partial scratch");
         build_wn_table();
         RGQA_REQUIRE(wn_blocks <= 1024 && (int)wn_host.size() <= 16, "bind: weight-norm tables too small (%d blocks, %zu layers)", wn_blocks, wn_host.size());
         have_fwd = false; eff_zeroed = false;
@@ -208,7 +207,9 @@ public:
         }
         return RGQA_OK;
     }
-    int sync_transposed(hipStream_t s) override { return sync_weights(s); }
+    // (every forward pass re-derives the effective weights - and ||V|| - from the parameters as they are then: nothing to refresh after an optimizer
+    // step.  Until round 5 this ran the whole weight-norm pass a second time per train step.)
+    int sync_transposed(hipStream_t) override { return RGQA_OK; }
 
     // ------------------------------------------------------------------ GEMM wrappers (single problem)
     static void ginit(GemmGroup& g) { memset(&g, 0, sizeof g); g.count = 1; g.drop = make_drop(0.f, 0, 0); }

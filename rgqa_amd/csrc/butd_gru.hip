@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256 * KSP) void gru_fwd_persist_kernel(const GruFwd
             const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_h, hoff + ks * 64, 0, 16);      // aux 16 = sc1
             af[ks] = *reinterpret_cast<const bf16x8*>(&v);
         }
+        __builtin_amdgcn_sched_barrier(0);       // every operand load of the step is in flight before the first MFMA waits for one
         f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
@@ -155,8 +156,9 @@ __global__ __launch_bounds__(256 * KSP) void gru_fwd_persist_kernel(const GruFwd
 
 template <int H, int KSP>
 __global__ __launch_bounds__(256 * KSP) void gru_bwd_persist_kernel(const GruBwdArgs a) {
-    constexpr int K3 = 3 * H, KS3 = K3 / 32, KSW = KS3 / KSP, CH = 16, NCH = KSW / CH, PITCH = 2 * K3 + 16, CS = H / 16, WBYTES = 16 * PITCH;
-    static_assert(KSW % CH == 0, "chunks of 16 K-steps");
+    // CH K-steps of operand fragments are requested together (4 registers each): with two waves per SIMD a wave may hold all 48 of its half
+    constexpr int K3 = 3 * H, KS3 = K3 / 32, KSW = KS3 / KSP, CH = KSP == 2 ? KSW : 32, NCH = KSW / CH, PITCH = 2 * K3 + 16, CS = H / 16, WBYTES = 16 * PITCH;
+    static_assert(KSW % CH == 0, "whole chunks");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mt = wave & 3, kh = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(256 * KSP) void gru_bwd_persist_kernel(const GruBwd
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_g, aoff + (c * CH + ks) * 64, 0, 16);
                 af[ks] = *reinterpret_cast<const bf16x8*>(&v);
             }
+            __builtin_amdgcn_sched_barrier(0);   // the chunk's loads are all in flight before the first MFMA waits for one
 #pragma unroll
             for (int ks = 0; ks < CH; ++ks) {
                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + fr * PITCH + ((kh * KSW + c * CH + ks) * 4 + fq) * 16);
