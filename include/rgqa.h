@@ -61,7 +61,7 @@ int rgqa_version(void);
  * the last language FFN on every row (as the reference does), 1 on the [CLS] rows only (default), -1 = environment RGQA_CLS_TAIL;
  * key 16: 0 launches the two attention problems of a stage separately, 1 as one launch (default); key 17: gradient-buffer sets planned by
  * the NEXT rgqa_engine_bind (2 x key 6 .. 8; 0 = that minimum); key 18: 0 = the BUTD engine's GRU recurrence as one GEMM + one gate kernel per
- * token from the host, 1 = one persistent launch per direction (default; bf16, hidden 1024, B <= 256). */
+ * token from the host, 1 = one persistent launch per direction, 4 waves (default; bf16, hidden 1024, B <= 256), 2 = the same with 8 waves. */
 int rgqa_debug_set(int key, int value);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over

@@ -8,6 +8,8 @@
 struct WnDesc {
     const float* v; const float* g; float* sumsq; void* eff; void* efft; float* eff_f32;
     const float* dw; int lddw; float* dv; float* dgp;
+    int nsplit; size_t split_stride;      // dW = sum of nsplit partial results (the long contractions are cut along the rows), split_stride floats apart
+    const float* bpart; float* db;        // nsplit > 1: the bias gradient's partial column sums [nsplit][out] and where their sum goes
     int out, in, kp, op;
     int blk0, nblk, tile0, tiles_x, tiles_y;
 };

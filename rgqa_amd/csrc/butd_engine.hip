@@ -25,7 +25,9 @@ __global__ void butd_sum_small_kernel(const float* __restrict__ src, int n, floa
 struct BLin {            // one linear layer: V (or W) [out, in], optional scalar g, bias [out]
     size_t v, g, b; int out, in, kp, op; bool wn;
     size_t eff, efft;    // byte offsets of the effective-weight copies in the workspace
-    size_t dwo;          // byte offset of its dW scratch [out, kp] f32 (the grouped weight-gradient launch)
+    size_t dwo;          // byte offset of its dW scratch [nsplit][out, kp] f32 (the grouped weight-gradient launch)
+    size_t bpo;          // byte offset of its bias-gradient partials [nsplit][out] (nsplit > 1)
+    int nsplit;          // row slices its weight-gradient contraction is cut into (1: whole)
     int norm;            // index of its ||V||^2 scalar
 };
 
@@ -136,7 +138,14 @@ public:
         for (BLin* l : lins) { size_t n = (size_t)l->out * l->kp; if (n > mw) mw = n; }
         dwscr = take<float>(mw); dw_part = take<float>((size_t)B * H); db_part = take<float>(B);
         gru_cnt = take<int>(gru_persist_counter_ints(B, L));
-        for (BLin* l : lins) { l->dwo = ws_used; take<float>((size_t)l->out * l->kp); }
+        // the three long contractions of the pass - W_hh and W_ih over L * B rows, image_proj over B * O rows - are cut into 4 row slices each: as whole
+        // problems their 108 output tiles walked 144-160 K-steps on an otherwise idle chip (one launch of 280 us: as long as its longest chain)
+        for (BLin* l : lins) {
+            const long rows = (l == &whh || l == &wih) ? (long)L * B : (l == &ip ? (long)B * O : (long)B);
+            l->nsplit = (LP && rows >= 4096) ? 4 : 1;
+            l->dwo = ws_used; take<float>((size_t)l->nsplit * l->out * l->kp);
+            l->bpo = ws_used; take<float>((size_t)l->nsplit * l->out);
+        }
         wn_dev = take<WnDesc>(16); wn_partial = take<float>(1024);
         gemm_ws_floats = LP ? (size_t)GEMM_NT_MAX_PROBLEMS * 256 * 2112 : 0;        // split-K scratch of the M = B GEMMs (csrc/gemm_mfma256.hip)
         gemm_ws = LP ? take<float>(gemm_ws_floats) : nullptr;
@@ -145,7 +154,8 @@ public:
     float* gemm_ws = nullptr; size_t gemm_ws_floats = 0;
     float* dwp(const BLin& l) const { return reinterpret_cast<float*>(ws + l.dwo); }
     // the whh weight gradient goes straight into the gradient arena (no weight norm, kp == in)
-    bool dw_direct(const BLin& l) const { return !l.wn && l.kp == l.in; }
+    bool dw_direct(const BLin& l) const { return !l.wn && l.kp == l.in && l.nsplit == 1; }
+    float* bpp(const BLin& l) const { return reinterpret_cast<float*>(ws + l.bpo); }
     void build_wn_table() {
         wn_host.clear(); wn_blocks = 0; wn_tiles = 0;
         for (BLin* l : lins) {
@@ -155,6 +165,8 @@ public:
             const bool direct = dw_direct(*l);
             d.dw = (G && direct) ? G + l->v : dwp(*l); d.lddw = direct ? l->in : l->kp; d.dv = G ? G + l->v : nullptr; d.dgp = (G && l->wn) ? G + l->g : nullptr;
             d.out = l->out; d.in = l->in; d.kp = l->kp; d.op = l->op;
+            d.nsplit = l->nsplit; d.split_stride = (size_t)l->out * l->kp;
+            d.bpart = (l->nsplit > 1) ? bpp(*l) : nullptr; d.db = (G && l->nsplit > 1) ? G + l->b : nullptr;
             const long n = (long)l->out * l->in;
             d.blk0 = wn_blocks; d.nblk = (int)((n + 8191) / 8192); if (d.nblk > 100) d.nblk = 100; if (d.nblk < 1) d.nblk = 1;
             wn_blocks += d.nblk;
@@ -320,12 +332,18 @@ public:
     GemmGroup wg; bool wg_collect = false;
     int wgrad(const void* dy, int lddy, const void* x, int ldx, int rows, const BLin& l, int accumulate, hipStream_t s) {
         if (!wg_collect) return gemm_wgrad(dy, lddy, x, ldx, rows, l, accumulate, s);
-        RGQA_REQUIRE(wg.count < GEMM_MAX_PROBLEMS, "butd backward: too many weight-gradient problems");
-        GemmProblem& p = wg.p[wg.count++];
-        memset(&p, 0, sizeof p);
+        RGQA_REQUIRE(wg.count + l.nsplit <= GEMM_MAX_PROBLEMS, "butd backward: too many weight-gradient problems");
         const bool direct = dw_direct(l);
-        p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.C = direct ? G + l.v : dwp(l); p.ldc = direct ? l.in : l.kp;
-        p.M = l.out; p.N = direct ? l.in : l.kp; p.K = rows; p.epi = EPI_BIAS; p.colsum_out = G + l.b;
+        const int S = l.nsplit, kc = S > 1 ? (rows / S) / 64 * 64 : rows;
+        for (int i = 0; i < S; ++i) {
+            GemmProblem& p = wg.p[wg.count++];
+            memset(&p, 0, sizeof p);
+            const int r0 = i * kc, n = (i == S - 1) ? rows - r0 : kc;
+            p.A = (const T*)dy + (size_t)r0 * lddy; p.lda = lddy; p.B = (const T*)x + (size_t)r0 * ldx; p.ldb = ldx;
+            p.C = direct ? G + l.v : dwp(l) + (size_t)i * l.out * l.kp; p.ldc = direct ? l.in : l.kp;
+            p.M = l.out; p.N = direct ? l.in : l.kp; p.K = n; p.epi = EPI_BIAS;
+            p.colsum_out = S > 1 ? bpp(l) + (size_t)i * l.out : G + l.b;
+        }
         return RGQA_OK;
     }
 

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256 * KSP) void gru_fwd_persist_kernel(const GruFwd
 
 template <int H, int KSP>
 __global__ __launch_bounds__(256 * KSP) void gru_bwd_persist_kernel(const GruBwdArgs a) {
-    // CH K-steps of operand fragments are requested together (4 registers each): with two waves per SIMD a wave may hold all 48 of its half
-    constexpr int K3 = 3 * H, KS3 = K3 / 32, KSW = KS3 / KSP, CH = KSP == 2 ? KSW : 32, NCH = KSW / CH, PITCH = 2 * K3 + 16, CS = H / 16, WBYTES = 16 * PITCH;
+    // CH = 48 K-steps of operand fragments are requested together (4 registers each: 192 of the 256 architectural VGPRs a wave can address; all 96 of
+    // a 4-wave block's share spilled 148 registers)
+    constexpr int K3 = 3 * H, KS3 = K3 / 32, KSW = KS3 / KSP, CH = 48, NCH = KSW / CH, PITCH = 2 * K3 + 16, CS = H / 16, WBYTES = 16 * PITCH;
     static_assert(KSW % CH == 0, "whole chunks");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mt = wave & 3, kh = wave >> 2;
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(256 * KSP) void gru_bwd_persist_kernel(const GruBwd
 }
 
 // ---------------------------------------------------------------------------------------------------------------- launchers
-int g_rgqa_butd_gru_persist = 1;      // rgqa_debug_set key 18: 0 = the host-driven recurrence (one GEMM + one gate kernel per token); 1 = persistent, 8 waves
-                                      // (the contraction split over wave pairs); 2 = persistent, 4 waves
+int g_rgqa_butd_gru_persist = 1;      // rgqa_debug_set key 18: 0 = the host-driven recurrence (one GEMM + one gate kernel per token); 1 = persistent, 4 waves
+                                      // (default: 1.82 ms per B = 256 step against 1.87 with 8); 2 = persistent, 8 waves (the contraction split over wave pairs)
 
 // the persistent launches apply: bf16, H = 1024, at most four row groups, and every workgroup resident at once (one per CU)
 bool gru_persist_ok(int B, int H) {
@@ -272,7 +273,7 @@ int k_gru_fwd_persist(const bf16_t* GI, long ldgi, const bf16_t* W, int ldw, con
     }
     RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RG * (2 * L + 1), s));
     GruFwdArgs a{GI, ldgi, W, ldw, bhh, Hall, Rg, Zg, Ng, GHN, B, L, counters, counters + (size_t)RG * (2 * L + 1)};
-    if (g_rgqa_butd_gru_persist == 2) hipLaunchKernelGGL((gru_fwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    if (g_rgqa_butd_gru_persist != 2) hipLaunchKernelGGL((gru_fwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
     else hipLaunchKernelGGL((gru_fwd_persist_kernel<HH, 2>), dim3(RG * (HH / 16)), dim3(512), LDS_BYTES, s, a);
     RGQA_LAUNCH_CHECK("gru_fwd_persist_kernel");
     return RGQA_OK;
@@ -290,7 +291,7 @@ int k_gru_bwd_persist(const bf16_t* dH, const bf16_t* Hall, const bf16_t* Rg, co
     }
     RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RG * (2 * L + 1), s));
     GruBwdArgs a{dH, Hall, Rg, Zg, Ng, GHN, dGI, lddgi, dGH, WT, ldwt, B, L, counters + (size_t)RG * (L + 1), counters + (size_t)RG * (2 * L + 1)};
-    if (g_rgqa_butd_gru_persist == 2) hipLaunchKernelGGL((gru_bwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    if (g_rgqa_butd_gru_persist != 2) hipLaunchKernelGGL((gru_bwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
     else hipLaunchKernelGGL((gru_bwd_persist_kernel<HH, 2>), dim3(RG * (HH / 16)), dim3(512), LDS_BYTES, s, a);
     RGQA_LAUNCH_CHECK("gru_bwd_persist_kernel");
     return RGQA_OK;

@@ -351,6 +351,19 @@ __device__ __forceinline__ int wn_find(const WnDesc* d, int n, int b, int WnDesc
     for (int i = 1; i < n; ++i) if (b >= d[i].*first) l = i;
     return l;
 }
+__device__ __forceinline__ float4 wn_dw4(const WnDesc& d, size_t off) {
+    float4 w = *reinterpret_cast<const float4*>(d.dw + off);
+    for (int s = 1; s < d.nsplit; ++s) {
+        const float4 x = *reinterpret_cast<const float4*>(d.dw + (size_t)s * d.split_stride + off);
+        w.x += x.x; w.y += x.y; w.z += x.z; w.w += x.w;
+    }
+    return w;
+}
+__device__ __forceinline__ float wn_dw1(const WnDesc& d, size_t off) {
+    float w = d.dw[off];
+    for (int s = 1; s < d.nsplit; ++s) w += d.dw[(size_t)s * d.split_stride + off];
+    return w;
+}
 // MODE 0: partial[b] = sum over the block's stripe of V^2;  MODE 1: of dW * V
 template <int MODE>
 __global__ __launch_bounds__(256) void wn_partials_group_kernel(const WnDesc* __restrict__ descs, int nd, float* __restrict__ partial) {
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(256) void wn_partials_group_kernel(const WnDesc* __
                 const float4 v = reinterpret_cast<const float4*>(d.v)[q];
                 if (MODE == 0) acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                 else {
-                    const float4 w = *reinterpret_cast<const float4*>(d.dw + (size_t)(q / inq) * d.lddw + (q % inq) * 4);
+                    const float4 w = wn_dw4(d, (size_t)(q / inq) * d.lddw + (q % inq) * 4);
                     acc += w.x * v.x + w.y * v.y + w.z * v.z + w.w * v.w;
                 }
             }
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(256) void wn_partials_group_kernel(const WnDesc* __
         for (size_t i = (size_t)(blockIdx.x - d.blk0) * 256 + threadIdx.x; i < n; i += (size_t)d.nblk * 256) {
             const float v = d.v[i];
             if (MODE == 0) acc = fmaf(v, v, acc);
-            else acc = fmaf(d.dw[(size_t)(i / d.in) * d.lddw + (i % d.in)], v, acc);
+            else acc = fmaf(wn_dw1(d, (size_t)(i / d.in) * d.lddw + (i % d.in)), v, acc);
         }
     }
     acc = wave_sum(acc);
@@ -425,10 +438,16 @@ __global__ __launch_bounds__(256) void wn_bwd_group_kernel(const WnDesc* __restr
     const int l = wn_find(descs, nd, blockIdx.x, &WnDesc::blk0);
     const WnDesc d = descs[l];
     const size_t n = (size_t)d.out * d.in;
+    if (d.bpart != nullptr && blockIdx.x == d.blk0)          // bias gradient: the partial column sums of the row slices, in slice order
+        for (int m = threadIdx.x; m < d.out; m += 256) {
+            float b = 0.f;
+            for (int s = 0; s < d.nsplit; ++s) b += d.bpart[(size_t)s * d.out + m];
+            d.db[m] = b;
+        }
     if (d.g == nullptr) {
         if (d.dv == d.dw) return;                // the wgrad GEMM wrote straight into the gradient arena
         for (size_t i = (size_t)(blockIdx.x - d.blk0) * 256 + threadIdx.x; i < n; i += (size_t)d.nblk * 256)
-            d.dv[i] = d.dw[(size_t)(i / d.in) * d.lddw + (i % d.in)];
+            d.dv[i] = wn_dw1(d, (size_t)(i / d.in) * d.lddw + (i % d.in));
         return;
     }
     const float dot = wn_fold(partial, d), ss = d.sumsq[0], nrm = sqrtf(ss), s = d.g[0] / nrm, c = dot / ss;
@@ -437,12 +456,12 @@ __global__ __launch_bounds__(256) void wn_bwd_group_kernel(const WnDesc* __restr
         const int inq = d.in >> 2;
         for (size_t q = (size_t)(blockIdx.x - d.blk0) * 256 + threadIdx.x; q < nq; q += (size_t)d.nblk * 256) {
             const float4 v = reinterpret_cast<const float4*>(d.v)[q];
-            const float4 w = *reinterpret_cast<const float4*>(d.dw + (size_t)(q / inq) * d.lddw + (q % inq) * 4);
+            const float4 w = wn_dw4(d, (size_t)(q / inq) * d.lddw + (q % inq) * 4);
             reinterpret_cast<float4*>(d.dv)[q] = make_float4(s * (w.x - c * v.x), s * (w.y - c * v.y), s * (w.z - c * v.z), s * (w.w - c * v.w));
         }
     } else
     for (size_t i = (size_t)(blockIdx.x - d.blk0) * 256 + threadIdx.x; i < n; i += (size_t)d.nblk * 256)
-        d.dv[i] = s * (d.dw[(size_t)(i / d.in) * d.lddw + (i % d.in)] - c * d.v[i]);
+        d.dv[i] = s * (wn_dw1(d, (size_t)(i / d.in) * d.lddw + (i % d.in)) - c * d.v[i]);
     if (blockIdx.x == d.blk0 && threadIdx.x == 0) d.dgp[0] = dot / nrm;
 }
 
