@@ -446,6 +446,13 @@ __global__ __launch_bounds__(256) void wn_bwd_group_kernel(const WnDesc* __restr
         }
     if (d.g == nullptr) {
         if (d.dv == d.dw) return;                // the wgrad GEMM wrote straight into the gradient arena
+        if ((d.in & 3) == 0 && (d.lddw & 3) == 0) {
+            const size_t nq = n >> 2;
+            const int inq = d.in >> 2;
+            for (size_t q = (size_t)(blockIdx.x - d.blk0) * 256 + threadIdx.x; q < nq; q += (size_t)d.nblk * 256)
+                reinterpret_cast<float4*>(d.dv)[q] = wn_dw4(d, (size_t)(q / inq) * d.lddw + (q % inq) * 4);
+            return;
+        }
         for (size_t i = (size_t)(blockIdx.x - d.blk0) * 256 + threadIdx.x; i < n; i += (size_t)d.nblk * 256)
             d.dv[i] = wn_dw1(d, (size_t)(i / d.in) * d.lddw + (i % d.in));
         return;
