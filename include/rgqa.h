@@ -59,6 +59,8 @@ int rgqa_version(void);
  * key 5 (measurement only): 1 skips the deferred weight-gradient launches; key 6: periods of backward whose weight-gradient problems go into
  * one launch (1..4; 0 = default); key 7: 0 = the [CLS]-row GEMMs (K >= 1536) run whole instead of split along K; key 9: NT tile numbering: 0 = row-major, -1 = panels of N-tiles sized to the L2 (default), n = panel width n; key 8: 0 computes
  * the last language FFN on every row (as the reference does), 1 on the [CLS] rows only (default), -1 = environment RGQA_CLS_TAIL;
+ * key 14: 1 (default) = the bf16 engine's dgrad GEMMs read the weights as they lie ([K, N] operand form; two transposed copies are kept),
+ * 0 = every dgrad on a transposed bf16 copy; takes effect at the next rgqa_engine_sync_weights / optimizer step;
  * key 16: 0 launches the two attention problems of a stage separately, 1 as one launch (default); key 17: gradient-buffer sets planned by
  * the NEXT rgqa_engine_bind (2 x key 6 .. 8; 0 = that minimum); key 18: 0 = the BUTD engine's GRU recurrence as one GEMM + one gate kernel per
  * token from the host, 1 = one persistent launch per direction, 4 waves (default; bf16, hidden 1024, B <= 256), 2 = the same with 8 waves. */
@@ -266,6 +268,11 @@ int rgqa_op_linear(const void* A, const void* W, const float* bias, void* C, int
  * NULL when the epilogue does not use them.  Kernel parity tests and tools/lab only. */
 int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const void* aux, void* C, void* C2, int M, int N,
                       int K, int lda, int ldw, int ldc, int ldaux, int epilogue, float drop_p, int dtype, void* stream);
+/* C[M,N] = A[M,K] B[K,N] (+ epilogue 0 bias-less plain, 4 x*aux, 5 x+aux, 7 x*(1-aux^2)) with the B operand stored [K, N] row-major: the form the bf16
+ * engine's dgrad GEMMs take on the weight as it lies ([out, in]: no transposed copy).  bf16, K % 64 == 0; out_f32 != 0: C is float (epilogue 0);
+ * ws (optional, >= 12 * min(M, 256) * N floats): split-K scratch as in rgqa_op_linear_splitk.  Kernel parity tests. */
+int rgqa_op_linear_kn(const void* A, const void* Bkn, const void* aux, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+                      int epilogue, int out_f32, float* ws, size_t ws_floats, void* stream);
 /* The same bf16 problem with split-K scratch: problems of K >= 1536 are cut into <= 12 slices along the contraction (the count depends on K
  * alone), run as one grouped launch into f32 partial tiles in ws (>= 12 * min(M, 256) * N floats) and folded in slice order with the epilogue
  * applied once; more than 256 rows run as row groups of 256, so a row's arithmetic does not depend on M.

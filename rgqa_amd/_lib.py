@@ -67,6 +67,7 @@ SIGNATURES = {
     "rgqa_scale_rows": [_vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rgqa_op_linear_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "rgqa_op_linear_kn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp],
     "rgqa_op_linear_splitk": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, C.c_size_t, _vp],
     "rgqa_op_matmul_tn": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rgqa_op_matmul_tn_group": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],

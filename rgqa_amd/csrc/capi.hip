@@ -25,6 +25,7 @@ extern int g_rgqa_wgrad_merge;
 extern int g_rgqa_nt_splitk;
 extern int g_rgqa_nt_panel;
 extern int g_rgqa_wgrad_sets;
+extern int g_rgqa_dgrad_nn;
 extern int g_rgqa_butd_gru_persist;
 // debug / test switches (include/rgqa.h)
 int rgqa_debug_set(int key, int value) {
@@ -37,6 +38,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 7) { g_rgqa_nt_splitk = value; return RGQA_OK; }
     if (key == 8) { g_rgqa_cls_tail = value; return RGQA_OK; }
     if (key == 9) { g_rgqa_nt_panel = value; return RGQA_OK; }
+    if (key == 14) { g_rgqa_dgrad_nn = value; return RGQA_OK; }
     if (key == 16) { g_rgqa_attn_pair = value; return RGQA_OK; }
     if (key == 17) { g_rgqa_wgrad_sets = value; return RGQA_OK; }
     if (key == 18) { g_rgqa_butd_gru_persist = value; return RGQA_OK; }
@@ -298,6 +300,17 @@ int rgqa_op_linear_ex(const void* A, const void* W, const float* bias, const voi
     p.A = A; p.B = W; p.C = C; p.C2 = C2; p.bias = bias; p.aux = aux; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.ldaux = ldaux;
     p.epi = epilogue; p.drop_site = 17u;
     return dtype == 2 ? launch_gemm_nt_x3(g, 0, S(stream)) : launch_gemm_nt_bf16(g, 0, S(stream));
+}
+// C[M,N] = A[M,K] B[K,N] (+ epilogue): the dgrad form on the weight as it lies (csrc/gemm_nt256.h NN); bf16, K % 64 == 0; ws: optional split-K scratch
+int rgqa_op_linear_kn(const void* A, const void* Bkn, const void* aux, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int epilogue,
+                      int out_f32, float* ws, size_t ws_floats, void* stream) {
+    RGQA_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_DGELU || epilogue == EPI_ADD || epilogue == EPI_DTANH, "op_linear_kn: epilogue %d has no [K, N]-operand kernel (0, 4, 5, 7)", epilogue);
+    RGQA_REQUIRE(K % 64 == 0 && K >= 64, "op_linear_kn: K must be a whole number of 64-row K-steps (got %d)", K);
+    GemmGroup g; memset(&g, 0, sizeof g);
+    g.count = 1; g.b_kn = 1; g.drop = make_drop(0.f, 0, 0); g.splitk_ws = ws; g.splitk_floats = ws_floats;
+    GemmProblem& p = g.p[0];
+    p.A = A; p.B = Bkn; p.C = C; p.aux = aux; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.epi = epilogue;
+    return launch_gemm_nt_bf16(g, out_f32, S(stream));
 }
 // the same bf16 problem with split-K scratch (ws_floats floats): problems of M <= 256 rows and K >= 1536 are cut along the contraction
 // (csrc/gemm_mfma256.hip); out_f32: C is float (plain-bias epilogue only)

@@ -156,6 +156,9 @@ int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad l
 int g_rgqa_skip_wgrad = 0;     // rgqa_debug_set(5, v): MEASUREMENT ONLY - the deferred weight-gradient launches are not issued (gradients are then wrong)
 int g_rgqa_wgrad_merge = 0;    // rgqa_debug_set(6, v): periods per weight-gradient launch (1 .. WGRAD_MERGE_MAX); 0 = default
 #define WGRAD_MERGE_DEFAULT 3
+int g_rgqa_dgrad_nn = 1;       // rgqa_debug_set(14, v): 1 = the bf16 engine's dgrad GEMMs read the weight as it lies ([K, N] operand form; only the visual projection's and the
+                               // answer layer's transposed copies are kept), 0 = every dgrad on the transposed bf16 copy (rounds 1-4).  Takes effect at the next
+                               // rgqa_engine_sync_weights / optimizer step (the copies are re-made by the table the switch selects)
 int g_rgqa_wgrad_sets = 0;     // rgqa_debug_set(17, v): gradient-buffer sets planned at the next bind (2 * periods-per-launch .. NPAR); 0 = default (the minimum)
 int g_rgqa_attn_pair = 1;      // rgqa_debug_set(16, v): 0 = the two attention problems of a stage as two launches (the bit-identity test's other arm)
 
@@ -406,12 +409,23 @@ public:
         return RGQA_OK;
     }
 
+    // dgrad in the [K, N] operand form (the weight as it lies, csrc/gemm_nt256.h NN): the pure bf16 engine, whole 64-row K-steps of weight rows
+    static bool dgrad_nn_on() { return std::is_same<T, bf16_t>::value && !MIXED && g_rgqa_dgrad_nn != 0; }
+    static bool dgrad_nn_shape(const Lin& l, int wrows) { return wrows % 64 == 0 && wrows >= 64 && l.in % 8 == 0 && l.in >= 64; }
+    std::vector<TransDesc> tdesc_min_host; int n_tdesc_min = 0, tdesc_min_tiles = 0; TransDesc* tdesc_min = nullptr;
     void build_transpose_table() {
-        // every [out,in] linear weight gets a transposed low-precision copy at the same arena offset
+        // every [out,in] linear weight gets a transposed low-precision copy at the same arena offset (full table); with the [K, N]-form dgrads only the
+        // weights that still need one: the visual projection (the f32 input-gradient GEMM of the ODIN scorer) and layers whose row count is not a
+        // whole number of K-steps (the answer layer: 1842 rows)
         auto add = [&](const Lin& l) {
             TransDesc d; d.src_off = (long)l.w; d.dst_off = (long)l.w; d.N = l.out; d.K = l.in; d.ld_dst = l.ldt; d.tile_start = tdesc_tiles;
             tdesc_tiles += cdiv(l.ldt, TRANSPOSE_TILE) * cdiv(l.in, TRANSPOSE_TILE);
             tdesc_host.push_back(d);
+            if (&l == &mp.visn_fc || !dgrad_nn_shape(l, l.out)) {
+                d.tile_start = tdesc_min_tiles;
+                tdesc_min_tiles += cdiv(l.ldt, TRANSPOSE_TILE) * cdiv(l.in, TRANSPOSE_TILE);
+                tdesc_min_host.push_back(d);
+            }
         };
         add(mp.visn_fc);
         auto addatt = [&](const AttP& a) { add(a.qkv); add(a.o); };
@@ -427,6 +441,7 @@ public:
         for (auto& f : mp.x_vffn) addffn(f);
         add(mp.pooler); add(mp.head0); add(mp.head3);
         n_tdesc = (int)tdesc_host.size();
+        n_tdesc_min = (int)tdesc_min_host.size();
     }
 
     // ------------------------------------------------------------------ workspace plan
@@ -558,6 +573,7 @@ public:
             u_st = take<float>(6 * ni);
         }
         tdesc = take<TransDesc>(n_tdesc + 1);
+        tdesc_min = take<TransDesc>(n_tdesc_min + 1);
         if (MIXED) {          // the bf16 images: a half-size mirror of the forward tensors planned above (img()); gradient buffers, f32 scratch and
             mirror_off = rup(ws_used, 256);      // index arrays have no image (the mirror used to cover the whole plan, +40 %)
             ws_used = mirror_off + rup(fwd_end / 2, 256);
@@ -600,6 +616,7 @@ public:
         return RGQA_OK;
     }
     bool tdesc_uploaded = false;
+    bool nn_synced = false;        // the transposed copies were last re-made by the minimal table: the other weights' copies are stale
 
     // gradients w.r.t. the inputs (f32 [B*O, feat_dim] / [B*O, pos_dim]) written by the following backward calls; null = not computed
     float* dfeats_out = nullptr; float* dboxes_out = nullptr;
@@ -647,8 +664,11 @@ public:
         if (!LP) return RGQA_OK;
         if (!tdesc_uploaded) {
             RGQA_HIP(hipMemcpyAsync(tdesc, tdesc_host.data(), sizeof(TransDesc) * n_tdesc, hipMemcpyHostToDevice, s));
+            if (n_tdesc_min) RGQA_HIP(hipMemcpyAsync(tdesc_min, tdesc_min_host.data(), sizeof(TransDesc) * n_tdesc_min, hipMemcpyHostToDevice, s));
             tdesc_uploaded = true;
         }
+        nn_synced = dgrad_nn_on();
+        if (nn_synced) return k_cast_transpose(Pb, 1, PbT, 0, tdesc_min, n_tdesc_min, tdesc_min_tiles, s);      // 2 of the 98 copies: 9 MB instead of 410
         if constexpr (MIXED) return k_cast_transpose(P, 0, PbT, 0, tdesc, n_tdesc, tdesc_tiles, s);      // bf16 transposed copy (the dgrad operand) from the f32 masters
         else if constexpr (X3) return k_cast_transpose(P, 0, PbT, 1, tdesc, n_tdesc, tdesc_tiles, s);
         else return k_cast_transpose(Pb, 1, PbT, 0, tdesc, n_tdesc, tdesc_tiles, s);     // from the bf16 copy (the optimizer kernel / sync_weights wrote it): half the read bytes
@@ -675,11 +695,22 @@ public:
         }
     }
     // dx[rows, in] = dy[rows, cols] @ W[wrow0 : wrow0+cols, :]      ; DGRAD
-    void add_dgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, void* dx, int lddx, int M, int epi, const void* aux, int ldaux) {
+    bool dgrad_mixed = false;      // a group mixing [K, N] and [N, K] weight operands was built (never for the encoder's layer shapes): run_dgrad refuses it
+    void add_dgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, void* dx, int lddx, int M, int epi, const void* aux, int ldaux, bool allow_nn = true) {
         GemmProblem& p = g.p[g.count++];
         memset(&p, 0, sizeof p);
         p.A = dy; p.lda = lddy; p.M = M; p.N = l.in; p.C = dx; p.ldc = lddx;
-        if (LP) { p.B = PbT + l.w + wrow0; p.ldb = l.ldt; p.K = (wrow0 + wrows == l.out) ? (int)rup(wrows, 64) : wrows; if (p.K > l.ldt - wrow0) p.K = l.ldt - wrow0; }   // the transposed copy and dy are zero-padded up to ldt = round_up(out, 64): a whole number of K-steps for the LDS-DMA kernel
+        const bool nn = allow_nn && nn_synced && dgrad_nn_shape(l, wrows) && &l != &mp.visn_fc;
+        if (LP && nn && (g.count == 1 || g.b_kn)) {
+            // the weight as stored, [out, in]: rows wrow0 .. wrow0 + wrows are the contraction - no transposed copy involved (gemm.h b_kn)
+            if constexpr (std::is_same<T, bf16_t>::value) { g.b_kn = 1; p.B = Pb + l.w + (size_t)wrow0 * l.in; p.ldb = l.in; p.K = wrows; }
+        } else if (LP) {
+            // the transposed copy ([in, ldt]; it and dy are zero-padded up to ldt = round_up(out, 64): a whole number of K-steps for the LDS-DMA kernel).
+            // Under the [K, N] regime only the minimal table's copies are current: anything else here is a bug of the caller
+            const bool has_copy = !nn_synced || &l == &mp.visn_fc || !dgrad_nn_shape(l, l.out);
+            if (g.b_kn || !has_copy) dgrad_mixed = true;
+            p.B = PbT + l.w + wrow0; p.ldb = l.ldt; p.K = (wrow0 + wrows == l.out) ? (int)rup(wrows, 64) : wrows; if (p.K > l.ldt - wrow0) p.K = l.ldt - wrow0;
+        }
         else { p.B = P + l.w + (size_t)wrow0 * l.in; p.ldb = l.in; p.K = wrows; }
         p.aux = aux; p.ldaux = ldaux; p.epi = epi;
     }
@@ -728,6 +759,7 @@ public:
     }
     int run_dgrad(GemmGroup& g, hipStream_t s, bool cls_rows = false) {
         if (g.count == 0) return RGQA_OK;
+        RGQA_REQUIRE(!dgrad_mixed, "dgrad: a launch mixes [K, N] and transposed weight operands, or names a transposed copy that is not kept");
         double f, b; gemm_work(g, f, b);
         char tg[48];
         prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "", last_obytes);

@@ -49,6 +49,8 @@ struct GemmGroupT {
     int count;
     int total_tiles;
     int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
+    int b_kn;           // bf16 NT LDS-DMA kernels only: EVERY problem's B operand is stored [K, N] row-major (ldb = row pitch) instead of [N, K]: C = A B.
+                        // The dgrad GEMMs on the weight as it lies ([out, in]: the contraction runs over its rows) - no transposed copy.  K % 64 == 0
     const void* zeros;  // TN LDS-DMA kernel: >= 16 zero bytes on the device (source of the contraction tail's A rows)
     unsigned long long* stamps;   // clock probe only (rgqa_probe_gemm: separately instantiated, stamped kernels): 8 words per block
     float* splitk_ws;   // bf16 NT launches: scratch for the split-K path of skinny problems (gemm_mfma256.hip), splitk_floats floats, or null

@@ -76,12 +76,21 @@ int launch_gemm_nt256_probe(GemmGroup& g, int mt, hipStream_t s) {
     return RGQA_ERR_ARG;
 }
 
-int launch_gemm_nt256_f32out(GemmGroup& g, hipStream_t s) { return launch256<float, EPI_BIAS, 2, false>(g, s); }
+int launch_gemm_nt256_f32out(GemmGroup& g, hipStream_t s) { return g.b_kn ? launch256<float, EPI_BIAS, 2, false, true>(g, s) : launch256<float, EPI_BIAS, 2, false>(g, s); }
 
 int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
     long tiles = 0;
     int mt = pick_mt(g, tiles);
     if (g_rgqa_force_mt) mt = g_rgqa_force_mt;
+    if (g.b_kn) {       // B operands stored [K, N] (dgrad on the weight as it lies): the epilogues a dgrad uses
+        switch (g.p[0].epi) {
+            case EPI_BIAS: return launch256_mt<bf16_t, EPI_BIAS, false, true>(g, mt, s);
+            case EPI_DGELU: return launch256_mt<bf16_t, EPI_DGELU, false, true>(g, mt, s);
+            case EPI_ADD: return launch256_mt<bf16_t, EPI_ADD, false, true>(g, mt, s);
+            case EPI_DTANH: return launch256_mt<bf16_t, EPI_DTANH, false, true>(g, mt, s);
+            default: rgqa_set_error("gemm: no [K, N]-operand kernel for epilogue %d", g.p[0].epi); return RGQA_ERR_ARG;
+        }
+    }
     switch (g.p[0].epi) {
         case EPI_BIAS: return launch256_mt<bf16_t, EPI_BIAS, false>(g, mt, s);
         case EPI_GELU: return launch256_mt<bf16_t, EPI_GELU, false>(g, mt, s);
@@ -141,12 +150,12 @@ static int launch_gemm_nt_splitk(GemmGroup& g, int S, int out_f32, hipStream_t s
         const int rows = P.M - m0 < SPLITK_ROWS ? P.M - m0 : SPLITK_ROWS;
         const size_t stride = (size_t)rows * ldp;
         GemmGroup g2; memset(&g2, 0, sizeof g2);
-        g2.count = S; g2.drop = g.drop;
+        g2.count = S; g2.drop = g.drop; g2.b_kn = g.b_kn;
         for (int i = 0, k0 = 0; i < S; ++i) {
             const int ks = (steps / S + (i < steps % S ? 1 : 0)) * TK;
             GemmProblem& q = g2.p[i];
             q.A = reinterpret_cast<const bf16_t*>(P.A) + (size_t)m0 * P.lda + k0; q.lda = P.lda;
-            q.B = reinterpret_cast<const bf16_t*>(P.B) + k0; q.ldb = P.ldb;
+            q.B = reinterpret_cast<const bf16_t*>(P.B) + (g.b_kn ? (size_t)k0 * P.ldb : (size_t)k0); q.ldb = P.ldb;
             q.C = g.splitk_ws + (size_t)i * stride; q.ldc = ldp;
             q.M = rows; q.N = P.N; q.K = ks; q.epi = EPI_BIAS;
             k0 += ks;

@@ -38,9 +38,16 @@ __device__ __forceinline__ void nt_tile_coords(const GemmProblem& P, int local, 
 }
 
 #define RGQA_NT_PIPE 3
-template <int MT, bool X3>
+// NN (bf16 only): the W stage is a [64 contraction rows][256 columns] image - the weight as it is stored, [out, in], serves the dgrad GEMMs without a
+// transposed copy (round 5: the copy cost 0.16 ms per train step to re-make and 410 MB) - and its fragments come through ds_read_b64_tr_b16 like the
+// weight-gradient kernel's operands (tr_frag_dma, 32-byte granule swizzle)
+template <int MT, bool X3, bool NN = false>
 __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsigned char* w, int wm, int wn, int fr, int fq, f32x4 (&acc)[MT][4]) {
-    auto ldw = [&](int half, int t) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, half * 4 + fq)); };
+    static_assert(!(X3 && NN), "the [K, N] operand form exists for bf16 only");
+    auto ldw = [&](int half, int t) -> bf16x8 {
+        if constexpr (NN) return tr_frag_dma<TN * 2>(w, half * 32, wn * 64 + t * 16, fq * 16 + fr);
+        else return *reinterpret_cast<const bf16x8*>(w + off256(wn * 64 + t * 16 + fr, half * 4 + fq));
+    };
     constexpr int PD = RGQA_NT_PIPE, NF = 2 * MT;
     if constexpr (X3) {
         // fragment order hi(0), lo(0), hi(1), lo(1), ...: half 0 of the stage = hi parts, half 1 = lo parts of the same 32 contraction elements
@@ -99,7 +106,7 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
 // 0/1 s_memtime / s_memrealtime at entry, 2/3 at exit (shader cycles per 100-MHz tick over the block's life = the clock the chip holds
 // under this loop), 4 s_memrealtime when the first tile's first operands have landed, 5 at the end of its K loop, 6 after its epilogue
 // (stores issued, not drained), 7 the number of tiles the block walked.
-template <typename OutT, int EPI, int MT, bool X3, bool STAMP = false>
+template <typename OutT, int EPI, int MT, bool X3, bool STAMP = false, bool NN = false>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroupNT g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned long long st_c0 = 0, st_r0 = 0, st_r1 = 0, st_r2 = 0, st_r3 = 0, st_nt = 0;
@@ -119,6 +126,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     const int lch_w[2] = {(lane & 7) ^ (lrow >> 1), (lane & 7) ^ (4 + (lrow >> 1))};
     const bf16_t* asrc[AG];
     const bf16_t* wsrc[4];
+    size_t wstep = TK;      // W source advance per K-step: TK elements along a row (NT) or TK rows (NN)
     int pi = 0, m0 = 0, n0 = 0, nkt = 0;
     // tile id -> problem, tile origin and this lane's DMA source rows
     auto locate = [&](int vt) {
@@ -137,10 +145,21 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             int am = m0 + (i * 8 + wave) * 8 + lrow; if (am > P.M - 1) am = P.M - 1;   // clamp: rows past the edge are never stored
             asrc[i] = A + (size_t)am * P.lda * KV + lch_a * 8;
         }
+        if constexpr (NN) {
+            wstep = (size_t)TK * P.ldb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {      // piece = 2 contraction rows x 256 columns; source columns un-swizzled per lane, clamped in-bounds (columns past N are never stored)
+                const int row = (wave * 4 + i) * 2 + (lane >> 5);
+                int col = n0 + (((lane & 31) ^ (tn_f(row) << 1)) << 3);
+                if (col > P.ldb - 8) col = P.ldb - 8;
+                wsrc[i] = W + (size_t)row * P.ldb + col;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > P.N - 1) wn_ = P.N - 1;
             wsrc[i] = W + (size_t)wn_ * P.ldb * KV + lch_w[i & 1] * 8;
+        }
         }
     };
     // LDS ring depth 2. Measured alternatives on these shapes (round 1): 3 stages for MT <= 4 lost 10..20 % (MT2 loses its
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
         for (int i = 0; i < AG; ++i)
             if ((MT & 1) == 0 || i * 8 + wave < NAG) dma16(asrc[i] + kt * TK, base + (i * 8 + wave) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * TK, base + A_BYTES + (wave * 4 + i) * 1024);
+        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * wstep, base + A_BYTES + (wave * 4 + i) * 1024);
     };
 
     const int fr = lane & 15, fq = lane >> 4;
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
             if (kt + 1 < nkt && !(pre1 && kt == 0)) issue(st ^ 1, kt + 1);
             const unsigned char* a = lds + st * STAGE_BYTES;
             const unsigned char* w = a + A_BYTES;
-            nt256_kstep<MT, X3>(a, w, wm, wn, fr, fq, acc);
+            nt256_kstep<MT, X3, NN>(a, w, wm, wn, fr, fq, acc);
         }
         __syncthreads();   // every wave is done with the operand stages: they may be refilled (PERSIST) or reused as scratch
         if (STAMP && threadIdx.x == 0 && st_nt == 0) st_r2 = __builtin_amdgcn_s_memrealtime();
@@ -211,7 +230,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
 // costs a full L2/MALL round trip (~1 us) whatever the MFMA work.  One tile per block, so the whole 160 KiB of LDS can hold
 // the ring: NS = 4 slots for MT = 2 (40 KiB each) - three K-steps in flight under counted vmcnt waits; the epilogue scratch
 // aliases the ring once the last step has been consumed.
-template <typename OutT, int EPI, int MT, int NS, bool X3, bool STAMP = false>
+template <typename OutT, int EPI, int MT, int NS, bool X3, bool STAMP = false, bool NN = false>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGroupNT g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned long long st_c0 = 0, st_r0 = 0, st_r1 = 0, st_r2 = 0;
@@ -245,10 +264,22 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
         int am = m0 + (i * 8 + wave) * 8 + lrow; if (am > P.M - 1) am = P.M - 1;
         asrc[i] = A + (size_t)am * P.lda * KV + lch_a * 8;
     }
+    size_t wstep = TK;
+    if constexpr (NN) {
+        wstep = (size_t)TK * P.ldb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 2 + (lane >> 5);
+            int col = n0 + (((lane & 31) ^ (tn_f(row) << 1)) << 3);
+            if (col > P.ldb - 8) col = P.ldb - 8;
+            wsrc[i] = W + (size_t)row * P.ldb + col;
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int wn_ = n0 + (wave * 4 + i) * 8 + lrow; if (wn_ > P.N - 1) wn_ = P.N - 1;
         wsrc[i] = W + (size_t)wn_ * P.ldb * KV + lch_w[i & 1] * 8;
+    }
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int kt) {
@@ -257,7 +288,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
         for (int i = 0; i < AG; ++i)
             if (i * 8 + wave < NAG) dma16(asrc[i] + kt * TK, base + (i * 8 + wave) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * TK, base + A_BYTES + (wave * 4 + i) * 1024);
+        for (int i = 0; i < 4; ++i) dma16(wsrc[i] + kt * wstep, base + A_BYTES + (wave * 4 + i) * 1024);
     };
     // wait until at most `slots` of my slots (my_a + 4 DMA instructions each) are still in flight
     auto wait_keep = [&](int slots) {
@@ -289,7 +320,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
         if (kt + NS - 1 < nkt) issue(kt + NS - 1);      // refills slot (kt-1) % NS
         const unsigned char* a = lds + (kt % NS) * STAGE_BYTES;
         const unsigned char* w = a + A_BYTES;
-        nt256_kstep<MT, X3>(a, w, wm, wn, fr, fq, acc);
+        nt256_kstep<MT, X3, NN>(a, w, wm, wn, fr, fq, acc);
     }
     __syncthreads();   // the ring is dead: reuse it as the epilogue's transpose scratch
     if (STAMP && threadIdx.x == 0) st_r2 = __builtin_amdgcn_s_memrealtime();
@@ -359,7 +390,7 @@ static inline void nt_set_panels(GemmGroup& g) {
 // Launch of one grouped problem set at tile height MT.  64-, 128- and 160-row tiles take the deep-ring kernel (4 / 3 LDS slots,
 // one tile per block): measured IN SITU (operands arriving from MALL/HBM) -4..-25 % on those launches against the two-slot loop;
 // forcing 160- or 128-row tiles on the big launches to get them onto the deep ring loses 5..30 %.
-template <typename OutT, int EPI, int MT, bool X3>
+template <typename OutT, int EPI, int MT, bool X3, bool NN = false>
 static int launch256(GemmGroup& g, hipStream_t s) {
     constexpr int LDS_BYTES = NT256_LDS(MT);
     gemm_group_finalize(g, 32 * MT, TN);
@@ -369,34 +400,34 @@ static int launch256(GemmGroup& g, hipStream_t s) {
         constexpr int LDS_D = NSD * (32 * MT * TK * 2 + TN * TK * 2);
         static bool attr_set_d = false;
         if (!attr_set_d) {
-            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
+            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3, false, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
             attr_set_d = true;
         }
-        hipLaunchKernelGGL((gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, nt_prefix(g));
+        hipLaunchKernelGGL((gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3, false, NN>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, nt_prefix(g));
         RGQA_LAUNCH_CHECK("gemm_nt256d_kernel");
         return RGQA_OK;
     } else {
         static bool attr_set = false;
         if (!attr_set) {
-            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<OutT, EPI, MT, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<OutT, EPI, MT, X3, false, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
             attr_set = true;
         }
         int grid = g.total_tiles;
         if (grid > rgqa_num_cus()) grid = rgqa_num_cus();     // one persistent block per CU
-        hipLaunchKernelGGL((gemm_nt256_kernel<OutT, EPI, MT, X3>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, nt_prefix(g));
+        hipLaunchKernelGGL((gemm_nt256_kernel<OutT, EPI, MT, X3, false, NN>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, nt_prefix(g));
         RGQA_LAUNCH_CHECK("gemm_nt256_kernel");
         return RGQA_OK;
     }
 }
 
-template <typename OutT, int EPI, bool X3>
+template <typename OutT, int EPI, bool X3, bool NN = false>
 static int launch256_mt(GemmGroup& g, int mt, hipStream_t s) {
     switch (mt) {
-        case 8: return launch256<OutT, EPI, 8, X3>(g, s);
-        case 7: return launch256<OutT, EPI, 7, X3>(g, s);
-        case 6: return launch256<OutT, EPI, 6, X3>(g, s);
-        case 5: return launch256<OutT, EPI, 5, X3>(g, s);
-        case 4: return launch256<OutT, EPI, 4, X3>(g, s);
-        default: return launch256<OutT, EPI, 2, X3>(g, s);
+        case 8: return launch256<OutT, EPI, 8, X3, NN>(g, s);
+        case 7: return launch256<OutT, EPI, 7, X3, NN>(g, s);
+        case 6: return launch256<OutT, EPI, 6, X3, NN>(g, s);
+        case 5: return launch256<OutT, EPI, 5, X3, NN>(g, s);
+        case 4: return launch256<OutT, EPI, 4, X3, NN>(g, s);
+        default: return launch256<OutT, EPI, 2, X3, NN>(g, s);
     }
 }

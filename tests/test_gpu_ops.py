@@ -181,6 +181,38 @@ def test_linear_splitk_matches_the_whole_problem(lib, M, N, K, epi):
         assert torch.equal(Cs.float(), c1[r0:r1])
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(12356, 768, 3072, 5), (12356, 3072, 768, 4), (12356, 768, 2304, 5), (3140, 768, 768, 0), (9216, 768, 1536, 0),
+                                       (256, 768, 1536, 7), (256, 768, 3072, 5), (77, 1536, 256, 0), (5000, 2048, 64, 0)])
+def test_linear_kn_is_the_transposed_weight_problem(lib, M, N, K, epi):
+    """The dgrad form on the weight as it lies (round 5; csrc/gemm_nt256.h NN): C = A B with B stored [K, N] gives, bit for bit, what the NT kernel
+    gives on the transposed copy B^T [N, K] - the same products summed in the same order, only the operand's LDS image and its fragment reads
+    (ds_read_b64_tr_b16) differ - for every epilogue a dgrad uses, at every tile height, and through the split-K path of the [CLS]-row GEMMs."""
+    A = rnd(M, K, seed=1).bfloat16()
+    Bkn = (rnd(K, N, seed=2) * 0.05).bfloat16()
+    Bt = Bkn.t().contiguous()
+    aux = rnd(M, N, seed=4).bfloat16() if epi else None
+    ws = torch.empty(12 * min(M, 256) * N, device="cuda")
+    outs = {}
+    try:
+        for mt in (0, 8, 5, 2):
+            assert lib.rgqa_debug_set(1, mt) == 0
+            C1 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); C0 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            ck(lib.rgqa_op_linear_kn(P(A), P(Bkn), P(aux), P(C1), M, N, K, K, N, N, N, epi, 0, None, 0, S()))
+            ck(lib.rgqa_op_linear_ex(P(A), P(Bt), None, P(aux), P(C0), None, M, N, K, K, K, N, N, epi, 0.0, 1, S()))
+            assert torch.equal(C1, C0), (mt, float((C1.float() - C0.float()).abs().max()))
+            outs[mt] = C1
+    finally:
+        lib.rgqa_debug_set(1, 0)
+    pre = A.float() @ Bkn.float()
+    ref = {0: pre, 4: pre * aux.float() if epi else pre, 5: pre + aux.float() if epi else pre, 7: pre * (1 - aux.float() ** 2) if epi else pre}[epi]
+    assert float((outs[0].float() - ref).norm() / ref.norm()) < 1e-2
+    if M <= 256 and K >= 1536:
+        Cs = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); Ct = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        ck(lib.rgqa_op_linear_kn(P(A), P(Bkn), P(aux), P(Cs), M, N, K, K, N, N, N, epi, 0, P(ws), ws.numel(), S()))
+        ck(lib.rgqa_op_linear_splitk(P(A), P(Bt), None, P(aux), P(Ct), None, M, N, K, K, K, N, N, epi, 0.0, 0, P(ws), ws.numel(), S()))
+        assert torch.equal(Cs, Ct)
+
+
 def test_linear_splitk_f32_result(lib):
     """the logits GEMM's shape: f32 result, plain bias"""
     M, N, K = 256, 1856, 1536
