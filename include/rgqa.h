@@ -59,8 +59,8 @@ int rgqa_version(void);
  * key 5 (measurement only): 1 skips the deferred weight-gradient launches; key 6: periods of backward whose weight-gradient problems go into
  * one launch (1..4; 0 = default); key 7: 0 = the [CLS]-row GEMMs (K >= 1536) run whole instead of split along K; key 9: NT tile numbering: 0 = row-major, -1 = panels of N-tiles sized to the L2 (default), n = panel width n; key 8: 0 computes
  * the last language FFN on every row (as the reference does), 1 on the [CLS] rows only (default), -1 = environment RGQA_CLS_TAIL;
- * key 14: 1 (default) = the bf16 engine's dgrad GEMMs read the weights as they lie ([K, N] operand form; two transposed copies are kept),
- * 0 = every dgrad on a transposed bf16 copy; takes effect at the next rgqa_engine_sync_weights / optimizer step;
+ * key 14: 1 = the bf16 engine's dgrad GEMMs read the weights as they lie ([K, N] operand form; two transposed copies are kept: -400 MB, same
+ * step time), 0 (default) = every dgrad on a transposed bf16 copy; takes effect at the next rgqa_engine_sync_weights / optimizer step;
  * key 16: 0 launches the two attention problems of a stage separately, 1 as one launch (default); key 17: gradient-buffer sets planned by
  * the NEXT rgqa_engine_bind (2 x key 6 .. 8; 0 = that minimum); key 18: 0 = the BUTD engine's GRU recurrence as one GEMM + one gate kernel per
  * token from the host, 1 = one persistent launch per direction, 4 waves (default; bf16, hidden 1024, B <= 256), 2 = the same with 8 waves. */

@@ -156,9 +156,12 @@ int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad l
 int g_rgqa_skip_wgrad = 0;     // rgqa_debug_set(5, v): MEASUREMENT ONLY - the deferred weight-gradient launches are not issued (gradients are then wrong)
 int g_rgqa_wgrad_merge = 0;    // rgqa_debug_set(6, v): periods per weight-gradient launch (1 .. WGRAD_MERGE_MAX); 0 = default
 #define WGRAD_MERGE_DEFAULT 3
-int g_rgqa_dgrad_nn = 1;       // rgqa_debug_set(14, v): 1 = the bf16 engine's dgrad GEMMs read the weight as it lies ([K, N] operand form; only the visual projection's and the
-                               // answer layer's transposed copies are kept), 0 = every dgrad on the transposed bf16 copy (rounds 1-4).  Takes effect at the next
-                               // rgqa_engine_sync_weights / optimizer step (the copies are re-made by the table the switch selects)
+int g_rgqa_dgrad_nn = 0;       // rgqa_debug_set(14, v): 1 = the bf16 engine's dgrad GEMMs read the weight as it lies ([K, N] operand form; only the visual projection's and the
+                               // answer layer's transposed copies are kept: 9 MB instead of 410, their re-cast 0.16 ms shorter), 0 = every dgrad on the transposed bf16
+                               // copy (default).  Takes effect at the next rgqa_engine_sync_weights / optimizer step (the copies are re-made by the table the switch
+                               // selects).  Bit-identical results (tests/test_gpu_ops.py::test_linear_kn_...); measured on the train step, four interleaved rounds on
+                               // one box: 11.176 ms with it, 11.161 without (profiles/r05_dgrad_nn_ab.txt) - the transposed fragment reads (two ds_read_b64_tr_b16
+                               // per fragment) cost the 70 dgrad launches what the re-cast saved, so the default stays; the switch is for memory, not for time
 int g_rgqa_wgrad_sets = 0;     // rgqa_debug_set(17, v): gradient-buffer sets planned at the next bind (2 * periods-per-launch .. NPAR); 0 = default (the minimum)
 int g_rgqa_attn_pair = 1;      // rgqa_debug_set(16, v): 0 = the two attention problems of a stage as two launches (the bit-identity test's other arm)
 

@@ -655,6 +655,43 @@ def test_side_stream_wgrad_matches_serial():
         assert torch.equal(grads(0), ref)
 
 
+def test_dgrad_on_the_weights_as_they_lie_gives_the_same_gradients():
+    """rgqa_debug_set key 14 = 1: the bf16 engine's dgrad GEMMs take the [K, N] operand form on the forward copy of the weights and only two
+    transposed copies are re-made at a weight sync (9 MB instead of 410).  Gradients after a whole backward pass - the [CLS]-row split-K
+    launches, the last cross layer's partial q / kv projections, the input gradient of the visual projection (which keeps its transposed
+    copy) included - must equal the default regime's bit for bit, over two optimizer steps (the copies are re-made in between)."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    B, T, O = 48, 20, 36
+    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=9, min_len=3)
+    b = dev(raw)
+    lens = np.ascontiguousarray(raw["lengths"], dtype=np.int32)
+    res = {}
+    try:
+        for nn in (0, 1):
+            assert L.rgqa_debug_set(14, nn) == 0
+            e = make_engine(FULL, "bf16", dropout=0.1)
+            e.ensure_shape(B, T, O)
+            e.sync_weights()
+            dfe = torch.zeros(B * O, FULL["feat_dim"], device="cuda")
+            e.set_input_grads(dfe, None)
+            out = []
+            for step in range(2):
+                e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=31 + step, lengths=lens)
+                e.loss_backward(b["target"])
+                out.append((e.grads.clone(), dfe.clone()))
+                e.adam_step(1e-3, max_norm=5.0)
+            torch.cuda.synchronize()
+            res[nn] = (out, e.params.clone())
+            e.set_input_grads(None, None)
+    finally:
+        L.rgqa_debug_set(14, 0)
+    for (g0, d0), (g1, d1) in zip(res[0][0], res[1][0]):
+        assert float(g0.abs().max()) > 0 and float(d0.abs().max()) > 0
+        assert torch.equal(g0, g1) and torch.equal(d0, d1)
+    assert torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3", "f32"])
 def test_merged_wgrad_launches_give_the_same_gradients(prec):
     """The weight-gradient problems of 1, 2, 3 or 4 backward periods in one launch (rgqa_debug_set key 6): the kernel per output tile is the
