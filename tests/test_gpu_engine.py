@@ -686,10 +686,13 @@ def test_dgrad_on_the_weights_as_they_lie_gives_the_same_gradients():
             e.set_input_grads(None, None)
     finally:
         L.rgqa_debug_set(14, 0)
+    # (the three embedding tables are scatter-added by float atomics in arrival order: compared to rounding, everything behind them exactly)
+    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)
     for (g0, d0), (g1, d1) in zip(res[0][0], res[1][0]):
         assert float(g0.abs().max()) > 0 and float(d0.abs().max()) > 0
-        assert torch.equal(g0, g1) and torch.equal(d0, d1)
-    assert torch.equal(res[0][1], res[1][1])
+        assert torch.equal(g0[first:], g1[first:]) and torch.equal(d0, d1)
+        assert torch.allclose(g0[:first], g1[:first], rtol=1e-4, atol=1e-7)
+    assert torch.equal(res[0][1][first:], res[1][1][first:])
 
 
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3", "f32"])
