@@ -27,6 +27,7 @@ extern int g_rgqa_nt_panel;
 extern int g_rgqa_wgrad_sets;
 extern int g_rgqa_dgrad_nn;
 extern int g_rgqa_butd_gru_persist;
+extern int g_rgqa_ln_fuse;
 // debug / test switches (include/rgqa.h)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }
@@ -42,6 +43,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 16) { g_rgqa_attn_pair = value; return RGQA_OK; }
     if (key == 17) { g_rgqa_wgrad_sets = value; return RGQA_OK; }
     if (key == 18) { g_rgqa_butd_gru_persist = value; return RGQA_OK; }
+    if (key == 19) { g_rgqa_ln_fuse = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }

@@ -156,6 +156,12 @@ int g_rgqa_wgrad_serial = 0;   // rgqa_debug_set(2, v): run the deferred wgrad l
 int g_rgqa_skip_wgrad = 0;     // rgqa_debug_set(5, v): MEASUREMENT ONLY - the deferred weight-gradient launches are not issued (gradients are then wrong)
 int g_rgqa_wgrad_merge = 0;    // rgqa_debug_set(6, v): periods per weight-gradient launch (1 .. WGRAD_MERGE_MAX); 0 = default
 #define WGRAD_MERGE_DEFAULT 3
+extern int g_rgqa_force_gemm128;
+int g_rgqa_ln_fuse = 0;        // rgqa_debug_set(19, v): 1 = the bf16 engine's LayerNorms behind the attention-output / FFN-output projections ride in the GEMM launch
+                               // (gemm256_dev.h nt256_ln_after_tile), bit-identical to the separate launches (tests/test_gpu_engine.py).  Default 0: measured, no gain -
+                               // the rows come back from the memory side of the L2s either way, so the launch grows by 7 us where the separate kernel took 10
+                               // (serial sums: gemm_nt +0.25 ms, layernorm -0.35 ms per step) and the step, whose LayerNorm launches already overlap the
+                               // side stream's weight-gradient GEMMs, does not move: 11.404 against 11.406 ms (profiles/r05_ln_fuse_ab.txt)
 int g_rgqa_dgrad_nn = 0;       // rgqa_debug_set(14, v): 1 = the bf16 engine's dgrad GEMMs read the weight as it lies ([K, N] operand form; only the visual projection's and the
                                // answer layer's transposed copies are kept: 9 MB instead of 410, their re-cast 0.16 ms shorter), 0 = every dgrad on the transposed bf16
                                // copy (default).  Takes effect at the next rgqa_engine_sync_weights / optimizer step (the copies are re-made by the table the switch
@@ -577,6 +583,7 @@ public:
         }
         tdesc = take<TransDesc>(n_tdesc + 1);
         tdesc_min = take<TransDesc>(n_tdesc_min + 1);
+        ln_tk = take<int>(2 * LN_TK_PER_PROBLEM);        // tickets of the LayerNorms fused into the projections' launches: per problem of a launch, one per row block
         if (MIXED) {          // the bf16 images: a half-size mirror of the forward tensors planned above (img()); gradient buffers, f32 scratch and
             mirror_off = rup(ws_used, 256);      // index arrays have no image (the mirror used to cover the whole plan, +40 %)
             ws_used = mirror_off + rup(fwd_end / 2, 256);
@@ -613,6 +620,7 @@ public:
         P = p; G = g; Pb = (T*)plp; PbT = (TB*)plpt; ws = (char*)w; ws_bytes_ = wb;
         plan(B_, T_, O_);
         RGQA_HIP(hipMemset(sumsq_ws, 0, sizeof(float) * (size_t)sumsq_ws_segs * SUMSQ_WS_STRIDE));       // the ticket words of k_sumsq_owned start at zero
+        RGQA_HIP(hipMemset(ln_tk, 0, sizeof(int) * 2 * LN_TK_PER_PROBLEM));                               // ... and so do the fused LayerNorms' (the last arriver of a row block re-zeroes its own)
         varlen = false; lens_dirty = false;
         have_fwd = false;
         tdesc_uploaded = false;
@@ -697,6 +705,17 @@ public:
             if (c2 != nullptr) { p.C2 = img(c2); p.c2_lp = 1; }
         }
     }
+    // The LayerNorm behind the projection just added to g (EPI_RESID_DROP, N = hidden = 768) rides in its launch: the workgroup that finishes the last
+    // of a row block's three tiles normalises it (gemm.h ln_*; gemm256_dev.h nt256_ln_after_tile).  bf16 engine only: the split-f32 rows of the
+    // bf16x3 precisions would need 3 x 512 B per row and lane-exact agreement with their own LayerNorm kernel - not built.
+    static constexpr int LN_TK_PER_PROBLEM = 512;      // row blocks of >= 64 rows: up to 32768 rows per problem
+    int* ln_tk = nullptr;
+    bool ln_fuse_on() const { return std::is_same<T, bf16_t>::value && !MIXED && g_rgqa_ln_fuse != 0 && !g_rgqa_force_gemm128 && cfg.hidden == 768 && R <= 64 * LN_TK_PER_PROBLEM; }
+    void fuse_ln(GemmGroup& g, const LNp& ln, void* y, float* mean, float* rstd) {
+        GemmProblem& p = g.p[g.count - 1];
+        p.ln_g = P + ln.w; p.ln_b = P + ln.b; p.ln_y = y; p.ln_mean = mean; p.ln_rstd = rstd; p.ln_eps = cfg.ln_eps;
+        p.ln_tk = ln_tk + (size_t)(g.count - 1) * LN_TK_PER_PROBLEM;
+    }
     // dx[rows, in] = dy[rows, cols] @ W[wrow0 : wrow0+cols, :]      ; DGRAD
     bool dgrad_mixed = false;      // a group mixing [K, N] and [N, K] weight operands was built (never for the encoder's layer shapes): run_dgrad refuses it
     void add_dgrad(GemmGroup& g, const void* dy, int lddy, const Lin& l, int wrow0, int wrows, void* dx, int lddx, int M, int epi, const void* aux, int ldaux, bool allow_nn = true) {
@@ -744,6 +763,7 @@ public:
             if (epi_needs_aux(p.epi) && p.aux != nullptr) bytes += sizeof(T) * (double)p.M * p.N;
             if (p.C2 != nullptr) bytes += (p.c2_lp ? 2.0 : (double)sizeof(T)) * (double)p.M * p.N;
             if (p.Cb != nullptr) bytes += 2.0 * (double)p.M * p.N;
+            if (p.ln_tk != nullptr) bytes += 2.0 * sizeof(T) * (double)p.M * p.N;      // the fused LayerNorm: the sum read back, the normalised rows written
         }
     }
     // cls_rows: the launch is one of those whose rows are the B [CLS] rows (tail of the last layer, pooler, answer head): skinny whatever the
@@ -830,9 +850,13 @@ public:
                 add_fwd(g, st.sb[m].x_in, H, st.ffn[m]->up, 0, I, st.sb[m].h, I, seg_rows(m), EPI_GELU, nullptr, 0, st.sb[m].hpre, 0);
             CK(run_fwd(g, s));
             gg_init(g); g.drop = drop_base(pd);
-            for (int m = 0; m < 2; ++m) if (st.active[m])
+            const bool lnf = ln_fuse_on();
+            for (int m = 0; m < 2; ++m) if (st.active[m]) {
                 add_fwd(g, st.sb[m].h, I, st.ffn[m]->down, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
+                if (lnf) fuse_ln(g, st.ffn[m]->ln, st.sb[m].y, st.sb[m].mean, st.sb[m].rstd);
+            }
             CK(run_fwd(g, s));
+            if (lnf) return RGQA_OK;
             if (ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && (T*)st.sb[1].y == (T*)st.sb[0].y + (size_t)Rl * H) {
                 // language | vision rows are adjacent in the stage buffers: one launch, per-segment module parameters
                 CKP(PC_LN, k_ln_fwd2<T>((T*)st.sb[0].z, H, P + st.ffn[0]->ln.w, P + st.ffn[0]->ln.b, P + st.ffn[1]->ln.w, P + st.ffn[1]->ln.b, Rl,
@@ -894,13 +918,18 @@ public:
         }
         {
             GemmGroup g; gg_init(g); g.drop = drop_base(pd);
+            const bool lnf = ln_fuse_on();
             if (cross && st.active[1]) {
                 add_fwd(g, st.sb[0].ctx, H, st.att[0]->o, 0, H, st.sb[0].z, H, R, EPI_RESID_DROP, st.sb[0].x_in, H, nullptr, st.site + 1);
+                if (lnf) fuse_ln(g, st.att[0]->ln, st.sb[0].y, st.sb[0].mean, st.sb[0].rstd);
             } else {
-                for (int m = 0; m < 2; ++m) if (st.active[m])
+                for (int m = 0; m < 2; ++m) if (st.active[m]) {
                     add_fwd(g, st.sb[m].ctx, H, st.att[m]->o, 0, H, st.sb[m].z, H, seg_rows(m), EPI_RESID_DROP, st.sb[m].x_in, H, nullptr, st.site + m * 4 + 1);
+                    if (lnf) fuse_ln(g, st.att[m]->ln, st.sb[m].y, st.sb[m].mean, st.sb[m].rstd);
+                }
             }
             CK(run_fwd(g, s));
+            if (lnf) return RGQA_OK;
         }
         if (cross && st.active[1]) {
             CKP(PC_LN, k_ln_fwd<T>((T*)st.sb[0].z, H, P + st.att[0]->ln.w, P + st.att[0]->ln.b, (T*)st.sb[0].y, H, st.sb[0].mean, st.sb[0].rstd, R, H, cfg.ln_eps, s, img(st.sb[0].y)));

@@ -36,6 +36,11 @@ struct GemmProblem {
     uint32_t drop_site; // mixed into the dropout stream for EPI_RESID_DROP
     float* colsum_out;  // TN kernels only: colsum_out[m] (+)= sum_k A[k][m]  (bias gradient riding the wgrad GEMM), or null
     int epi;            // GemmEpi
+    // bf16 LDS-DMA NT kernels, EPI_RESID_DROP, N == 768 (round 5): the LayerNorm that follows the dense layer (BertAttOutput / BertOutput,
+    // lxrt/modeling.py:350-361, 404-415), done by the workgroup that finishes the LAST of a row block's N / 256 tiles - ln_tk != null switches it on:
+    // ln_y[m, :] = (C[m, :] - mean) * rstd * ln_g + ln_b (ld = ldc), ln_mean / ln_rstd [M] for the backward pass; ln_tk: one zeroed int per row block
+    // of this problem (the last arriver resets it)
+    const float* ln_g; const float* ln_b; void* ln_y; float* ln_mean; float* ln_rstd; int* ln_tk; float ln_eps;
 };
 
 // 32 (3,888 bytes of kernel arguments): two or three layers' weight-gradient problems go into one launch (engine.hip, flush_wgrad)

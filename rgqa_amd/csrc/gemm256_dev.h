@@ -191,6 +191,104 @@ __device__ __forceinline__ void nt256_epilogue(const GemmGroupNT& g, const GemmP
     if (AUX && SF) after_loads();
 }
 
+// ---- LayerNorm of a finished row block, inside the GEMM launch that produced it (round 5).
+// The N = 768 projections that end an attention / FFN sub-block are followed by a LayerNorm over whole rows - three 256-column tiles that three
+// different workgroups compute.  Until round 5 a separate launch read the pre-LN sum back (34 launches of 8.5 us at the HBM floor + a kernel
+// boundary each).  Now every workgroup stores its tile write-through (sc1), every wave drains, the workgroup barrier, ONE lane draws a ticket of the
+// row block (agent-scope add) - and the workgroup whose ticket is the last (told by the value its add returned: MI355X_MICROARCH.md, Valid forms,
+// first table row) normalises the row block: sc1 loads of the rows, half a wave per row, 16 bytes per lane and access - the arithmetic of
+// ln_fwd16_kernel (csrc/norm.hip) in the same order: bit-identical to the separate launch.  Nobody ever waits: no residency assumption.
+__device__ __forceinline__ float nt256_half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// rows [m0, m0 + TM) of problem P (N == 768), by the 512 threads of the workgroup: 16 half-waves, one row each per trip, U trips' loads in flight
+// at once (the rows come from the memory side of the L2s - sc1 - at its latency: one trip at a time cost ~8 us per launch, measured)
+template <int TM>
+__device__ __forceinline__ void nt256_ln_rows(const GemmProblem& P, int m0) {
+    constexpr int NC = 3, N = 768, TRIPS = TM / 16;
+    constexpr int U = (TRIPS % 5 == 0) ? 5 : (TRIPS % 7 == 0) ? 7 : (TRIPS % 6 == 0) ? 6 : 4;
+    static_assert(TRIPS % U == 0, "row trips per batch");
+    const int hl = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, (int)((size_t)P.M * P.ldc * 2), 0x00020000);
+    bf16_t* y = reinterpret_cast<bf16_t*>(P.ln_y);
+    float g[NC][8], b[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = (hl + 32 * i) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 gv = *reinterpret_cast<const float4*>(P.ln_g + c + 4 * h), bv = *reinterpret_cast<const float4*>(P.ln_b + c + 4 * h);
+            g[i][4 * h] = gv.x; g[i][4 * h + 1] = gv.y; g[i][4 * h + 2] = gv.z; g[i][4 * h + 3] = gv.w;
+            b[i][4 * h] = bv.x; b[i][4 * h + 1] = bv.y; b[i][4 * h + 2] = bv.z; b[i][4 * h + 3] = bv.w;
+        }
+    }
+    using raw_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(rs_c, 0u, 0, 16));
+    for (int t0 = 0; t0 < TRIPS; t0 += U) {
+        if (m0 + t0 * 16 >= P.M) break;                     // block-uniform
+        raw_t raw[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int row = m0 + (t0 + u) * 16 + hw;
+            row = row < P.M ? row : P.M - 1;                // a valid address; the result is dropped below
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                raw[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (unsigned)(((size_t)row * P.ldc + (hl + 32 * i) * 8) * 2), 0, 16);      // aux 16 = sc1
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = m0 + (t0 + u) * 16 + hw;        // uniform over the half-wave: the shuffles below stay inside a half
+            float v[NC][8];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw[u][i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = (float)t[j];
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[i][j];
+            const float mu = nt256_half_sum(s) * (1.0f / (float)N);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
+            const float rs = rsqrtf(nt256_half_sum(q) * (1.0f / (float)N) + P.ln_eps);
+            if (row < P.M) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((v[i][j] - mu) * rs * g[i][j] + b[i][j]);
+                    *reinterpret_cast<bf16x8*>(y + (size_t)row * P.ldc + (hl + 32 * i) * 8) = o;
+                }
+                if (hl == 0) { P.ln_mean[row] = mu; P.ln_rstd[row] = rs; }
+            }
+        }
+    }
+}
+// called by EVERY thread of the workgroup after the tile's epilogue (its stores were issued write-through); `flag`: 4 bytes of LDS nobody else uses now
+template <int TM>
+__device__ __forceinline__ void nt256_ln_after_tile(const GemmProblem& P, int m0, int* flag) {
+    if (P.ln_tk == nullptr) return;                           // block-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int* tk = P.ln_tk + m0 / TM;
+        const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (P.tiles_n & 0xFFFF) - 1);
+        if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch that uses this ticket
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag) nt256_ln_rows<TM>(P, m0);
+    __syncthreads();                                          // `flag` may be overwritten (it lives in scratch the next tile reuses)
+}
+
 // ---- row-major-over-the-contraction LDS images (wgrad operands; the weight operand of the NN dgrad): 32-byte granule swizzle + transposed fragment reads
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 

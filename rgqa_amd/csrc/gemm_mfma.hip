@@ -302,6 +302,7 @@ int launch_gemm_nt_bf16(GemmGroup& g, int out_f32, hipStream_t s) {
     int r = check_group(g, false);
     if (r) return r;
     if (!g_rgqa_force_gemm128 && gemm_nt256_eligible(g, out_f32)) return launch_gemm_nt256_any(g, out_f32, s);
+    for (int i = 0; i < g.count; ++i) RGQA_REQUIRE(g.p[i].ln_tk == nullptr, "gemm: a fused LayerNorm runs on the LDS-DMA kernels only - group not eligible / 128 x 128 kernels forced");
     RGQA_REQUIRE(!g.b_kn, "gemm: a [K, N]-operand group (dgrad on the weight as it lies) runs on the LDS-DMA kernels only - not eligible / 128 x 128 kernels forced");
     static const bool log_fb = getenv("RGQA_GEMM_LOG_FALLBACK") != nullptr;       // which launches still take the 128x128 register-staged kernel
     if (log_fb && !g_rgqa_force_gemm128)

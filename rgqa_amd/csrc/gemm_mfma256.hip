@@ -94,7 +94,16 @@ int launch_gemm_nt256_bf16(GemmGroup& g, hipStream_t s) {
     switch (g.p[0].epi) {
         case EPI_BIAS: return launch256_mt<bf16_t, EPI_BIAS, false>(g, mt, s);
         case EPI_GELU: return launch256_mt<bf16_t, EPI_GELU, false>(g, mt, s);
-        case EPI_RESID_DROP: return launch256_mt<bf16_t, EPI_RESID_DROP, false>(g, mt, s);
+        case EPI_RESID_DROP: {
+            bool lnf = g.p[0].ln_tk != nullptr;            // the LayerNorm behind the dense layer rides in the launch: every problem or none
+            for (int i = 1; i < g.count; ++i) RGQA_REQUIRE((g.p[i].ln_tk != nullptr) == lnf, "gemm: the fused LayerNorm must be set on every problem of a group or on none");
+            if (lnf) {
+                for (int i = 0; i < g.count; ++i)
+                    RGQA_REQUIRE(g.p[i].N == 768 && g.p[i].ln_g && g.p[i].ln_b && g.p[i].ln_y && g.p[i].ln_mean && g.p[i].ln_rstd, "gemm: the fused LayerNorm needs N == 768 and all of its operands");
+                return launch256_mt<bf16_t, EPI_RESID_DROP, false, false, true>(g, mt, s);
+            }
+            return launch256_mt<bf16_t, EPI_RESID_DROP, false>(g, mt, s);
+        }
         case EPI_DGELU: return launch256_mt<bf16_t, EPI_DGELU, false>(g, mt, s);
         case EPI_TANH: return launch256_mt<bf16_t, EPI_TANH, false>(g, mt, s);
         case EPI_DTANH: return launch256_mt<bf16_t, EPI_DTANH, false>(g, mt, s);
@@ -172,7 +181,10 @@ static int launch_gemm_nt_splitk(GemmGroup& g, int S, int out_f32, hipStream_t s
 }
 // the bf16 NT entry of the LDS-DMA kernels: skinny single problems take the split-K path when the caller provides scratch
 int launch_gemm_nt256_any(GemmGroup& g, int out_f32, hipStream_t s) {
-    if (const int S = splitk_slices(g, out_f32)) return launch_gemm_nt_splitk(g, S, out_f32, s);
+    if (const int S = splitk_slices(g, out_f32)) {
+        RGQA_REQUIRE(g.p[0].ln_tk == nullptr, "gemm: the split-K path has no fused LayerNorm");
+        return launch_gemm_nt_splitk(g, S, out_f32, s);
+    }
     return out_f32 ? launch_gemm_nt256_f32out(g, s) : launch_gemm_nt256_bf16(g, s);
 }
 

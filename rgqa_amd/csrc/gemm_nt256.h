@@ -106,7 +106,8 @@ __device__ __forceinline__ void nt256_kstep(const unsigned char* a, const unsign
 // 0/1 s_memtime / s_memrealtime at entry, 2/3 at exit (shader cycles per 100-MHz tick over the block's life = the clock the chip holds
 // under this loop), 4 s_memrealtime when the first tile's first operands have landed, 5 at the end of its K loop, 6 after its epilogue
 // (stores issued, not drained), 7 the number of tiles the block walked.
-template <typename OutT, int EPI, int MT, bool X3, bool STAMP = false, bool NN = false>
+// LNF (bf16, EPI_RESID_DROP): result tiles stored write-through and the row block's LayerNorm done by the last arriver (gemm256_dev.h nt256_ln_after_tile)
+template <typename OutT, int EPI, int MT, bool X3, bool STAMP = false, bool NN = false, bool LNF = false>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGroupNT g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned long long st_c0 = 0, st_r0 = 0, st_r1 = 0, st_r2 = 0, st_r3 = 0, st_nt = 0;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
         const int nvt = vt + (int)gridDim.x;
         const bool more = PERSIST && nvt < g.total_tiles;
         pre1 = false;
-        nt256_epilogue<OutT, EPI, MT>(g, g.p[cpi], lds + EPI_OFF, wave, lane, cm0, cn0, wm, wn, acc, [&]() {
+        nt256_epilogue<OutT, EPI, MT, LNF>(g, g.p[cpi], lds + EPI_OFF, wave, lane, cm0, cn0, wm, wn, acc, [&]() {
             if (more) {
                 locate(nvt);
                 issue(0, 0);
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
                 if (pre1) issue(1, 1);
             }
         });
+        if constexpr (LNF) nt256_ln_after_tile<TM>(g.p[cpi], cm0, reinterpret_cast<int*>(lds + EPI_OFF));
         if (STAMP && threadIdx.x == 0) { if (st_nt == 0) st_r3 = __builtin_amdgcn_s_memrealtime(); ++st_nt; }
         if (!more) break;
         vt = nvt;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
 // costs a full L2/MALL round trip (~1 us) whatever the MFMA work.  One tile per block, so the whole 160 KiB of LDS can hold
 // the ring: NS = 4 slots for MT = 2 (40 KiB each) - three K-steps in flight under counted vmcnt waits; the epilogue scratch
 // aliases the ring once the last step has been consumed.
-template <typename OutT, int EPI, int MT, int NS, bool X3, bool STAMP = false, bool NN = false>
+template <typename OutT, int EPI, int MT, int NS, bool X3, bool STAMP = false, bool NN = false, bool LNF = false>
 __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGroupNT g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned long long st_c0 = 0, st_r0 = 0, st_r1 = 0, st_r2 = 0;
@@ -324,7 +326,8 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256d_kernel(const GemmGro
     }
     __syncthreads();   // the ring is dead: reuse it as the epilogue's transpose scratch
     if (STAMP && threadIdx.x == 0) st_r2 = __builtin_amdgcn_s_memrealtime();
-    nt256_epilogue<OutT, EPI, MT>(g, P, lds, wave, lane, m0, n0, wm, wn, acc, []() {});
+    nt256_epilogue<OutT, EPI, MT, LNF>(g, P, lds, wave, lane, m0, n0, wm, wn, acc, []() {});
+    if constexpr (LNF) { __syncthreads(); nt256_ln_after_tile<TM>(P, m0, reinterpret_cast<int*>(lds)); }
     if (STAMP && threadIdx.x == 0) {
         unsigned long long* o = g.stamps + (size_t)blockIdx.x * 8;
         const unsigned long long r3 = __builtin_amdgcn_s_memrealtime();
@@ -390,7 +393,7 @@ static inline void nt_set_panels(GemmGroup& g) {
 // Launch of one grouped problem set at tile height MT.  64-, 128- and 160-row tiles take the deep-ring kernel (4 / 3 LDS slots,
 // one tile per block): measured IN SITU (operands arriving from MALL/HBM) -4..-25 % on those launches against the two-slot loop;
 // forcing 160- or 128-row tiles on the big launches to get them onto the deep ring loses 5..30 %.
-template <typename OutT, int EPI, int MT, bool X3, bool NN = false>
+template <typename OutT, int EPI, int MT, bool X3, bool NN = false, bool LNF = false>
 static int launch256(GemmGroup& g, hipStream_t s) {
     constexpr int LDS_BYTES = NT256_LDS(MT);
     gemm_group_finalize(g, 32 * MT, TN);
@@ -400,34 +403,34 @@ static int launch256(GemmGroup& g, hipStream_t s) {
         constexpr int LDS_D = NSD * (32 * MT * TK * 2 + TN * TK * 2);
         static bool attr_set_d = false;
         if (!attr_set_d) {
-            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3, false, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
+            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3, false, NN, LNF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
             attr_set_d = true;
         }
-        hipLaunchKernelGGL((gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3, false, NN>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, nt_prefix(g));
+        hipLaunchKernelGGL((gemm_nt256d_kernel<OutT, EPI, MT, NSD, X3, false, NN, LNF>), dim3(g.total_tiles), dim3(T256_THREADS), LDS_D, s, nt_prefix(g));
         RGQA_LAUNCH_CHECK("gemm_nt256d_kernel");
         return RGQA_OK;
     } else {
         static bool attr_set = false;
         if (!attr_set) {
-            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<OutT, EPI, MT, X3, false, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+            RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<OutT, EPI, MT, X3, false, NN, LNF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
             attr_set = true;
         }
         int grid = g.total_tiles;
         if (grid > rgqa_num_cus()) grid = rgqa_num_cus();     // one persistent block per CU
-        hipLaunchKernelGGL((gemm_nt256_kernel<OutT, EPI, MT, X3, false, NN>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, nt_prefix(g));
+        hipLaunchKernelGGL((gemm_nt256_kernel<OutT, EPI, MT, X3, false, NN, LNF>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, nt_prefix(g));
         RGQA_LAUNCH_CHECK("gemm_nt256_kernel");
         return RGQA_OK;
     }
 }
 
-template <typename OutT, int EPI, bool X3, bool NN = false>
+template <typename OutT, int EPI, bool X3, bool NN = false, bool LNF = false>
 static int launch256_mt(GemmGroup& g, int mt, hipStream_t s) {
     switch (mt) {
-        case 8: return launch256<OutT, EPI, 8, X3, NN>(g, s);
-        case 7: return launch256<OutT, EPI, 7, X3, NN>(g, s);
-        case 6: return launch256<OutT, EPI, 6, X3, NN>(g, s);
-        case 5: return launch256<OutT, EPI, 5, X3, NN>(g, s);
-        case 4: return launch256<OutT, EPI, 4, X3, NN>(g, s);
-        default: return launch256<OutT, EPI, 2, X3, NN>(g, s);
+        case 8: return launch256<OutT, EPI, 8, X3, NN, LNF>(g, s);
+        case 7: return launch256<OutT, EPI, 7, X3, NN, LNF>(g, s);
+        case 6: return launch256<OutT, EPI, 6, X3, NN, LNF>(g, s);
+        case 5: return launch256<OutT, EPI, 5, X3, NN, LNF>(g, s);
+        case 4: return launch256<OutT, EPI, 4, X3, NN, LNF>(g, s);
+        default: return launch256<OutT, EPI, 2, X3, NN, LNF>(g, s);
     }
 }

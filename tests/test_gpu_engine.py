@@ -695,6 +695,42 @@ def test_dgrad_on_the_weights_as_they_lie_gives_the_same_gradients():
     assert torch.equal(res[0][1][first:], res[1][1][first:])
 
 
+@pytest.mark.parametrize("B,varlen", [(48, True), (48, False), (256, True), (3, True)])
+def test_layernorm_inside_the_projection_launch_is_the_separate_kernel(B, varlen):
+    """Round 5: the LayerNorm behind every attention-output / FFN-output projection of the bf16 engine is done inside the projection's launch by the
+    workgroup that finishes a row block's last tile (rgqa_debug_set key 19 = 1, opt-in; gemm256_dev.h nt256_ln_after_tile).  Same arithmetic in the
+    same order as ln_fwd16_kernel: logits and every gradient equal the separate launches' bit for bit - three passes, so that a ticket left
+    behind by a pass (the last arriver re-zeroes it) would show; row counts that end inside a row block and inside a half-wave trip included."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    T, O = 20, 36
+    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=17, min_len=3)
+    b = dev(raw)
+    lens = np.ascontiguousarray(raw["lengths"], dtype=np.int32) if varlen else None
+    res = {}
+    try:
+        for fuse in (0, 1):
+            assert L.rgqa_debug_set(19, fuse) == 0
+            e = make_engine(FULL, "bf16", dropout=0.1)
+            e.ensure_shape(B, T, O)
+            e.sync_weights()
+            out = []
+            for step in range(3):
+                lg = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=5 + step, lengths=lens)[0].clone()
+                e.loss_backward(b["target"])
+                out.append((lg, e.grads.clone()))
+            torch.cuda.synchronize()
+            res[fuse] = out
+    finally:
+        L.rgqa_debug_set(19, 0)
+    first = min(sp.offset for sp in e.specs if "embeddings.LayerNorm" in sp.name)      # the embedding tables are scatter-added with f32 atomics
+    for (l0, g0), (l1, g1) in zip(res[0], res[1]):
+        assert float(g0.abs().max()) > 0
+        assert torch.equal(l0, l1)
+        assert torch.equal(g0[first:], g1[first:])
+        assert torch.allclose(g0[:first], g1[:first], rtol=1e-4, atol=1e-7)
+
+
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3", "f32"])
 def test_merged_wgrad_launches_give_the_same_gradients(prec):
     """The weight-gradient problems of 1, 2, 3 or 4 backward periods in one launch (rgqa_debug_set key 6): the kernel per output tile is the
