@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 FWD_BWD_GFLOP = {20: 30.3388, 30: 37.0403}   # per QA pair, SURVEY.md §8 D3
 FWD_GFLOP = {20: 10.5827, 30: 12.8330}
 PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16, MI355X_MICROARCH.md (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
-PMC_PROFILE = "r04_pmc_gemm_nt.json"
+PMC_PROFILE = "r05_pmc_gemm_nt.json"
 FULL = dict(vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9, x_layers=5,
             r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842)
 
