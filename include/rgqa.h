@@ -63,7 +63,8 @@ int rgqa_version(void);
  * step time), 0 (default) = every dgrad on a transposed bf16 copy; takes effect at the next rgqa_engine_sync_weights / optimizer step;
  * key 16: 0 launches the two attention problems of a stage separately, 1 as one launch (default); key 17: gradient-buffer sets planned by
  * the NEXT rgqa_engine_bind (2 x key 6 .. 8; 0 = that minimum); key 18: 0 = the BUTD engine's GRU recurrence as one GEMM + one gate kernel per
- * token from the host, 1 = one persistent launch per direction, 4 waves (default; bf16, hidden 1024, B <= 256), 2 = the same with 8 waves;
+ * token from the host, 1 = one persistent launch per direction (bf16, hidden 1024, B <= 256): 64-sample row groups x 16-unit slices, W_hh slice
+ * in LDS, 4 waves, 2 = the same with 8 waves, 3 (default) = 32-sample row groups x 32-unit slices, weights in registers, 8 waves;
  * key 19: 1 = the bf16 engine's LayerNorms behind the attention-output / FFN-output projections are done inside the projection's launch by the
  * workgroup that finishes a row block last, 0 (default: same step time) = separate LayerNorm launches; bit-identical results either way. */
 int rgqa_debug_set(int key, int value);

@@ -47,12 +47,14 @@ struct GruBwdArgs {
 __device__ __forceinline__ float sigm_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // one lane polls until *p >= want (sc1 loads; the caller joins a workgroup barrier afterwards)
-__device__ __forceinline__ void gru_wait(const int* p, int want, int* err) {
+// returns false when it gave up (the error word is raised; the caller poisons its outputs with NaNs so that the loss / the gradient norm shows it)
+__device__ __forceinline__ bool gru_wait(const int* p, int want, int* err) {
     unsigned spins = 0;
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24)) { __hip_atomic_fetch_add(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (++spins > (1u << 24)) { __hip_atomic_fetch_add(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
     }
+    return true;
 }
 
 // KSP = 1: 4 waves, each 16 samples x the whole contraction; KSP = 2: 8 waves, waves w and w + 4 share 16 samples and take one half of the contraction
@@ -249,31 +251,279 @@ __global__ __launch_bounds__(256 * KSP) void gru_bwd_persist_kernel(const GruBwd
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------- launchers
-int g_rgqa_butd_gru_persist = 1;      // rgqa_debug_set key 18: 0 = the host-driven recurrence (one GEMM + one gate kernel per token); 1 = persistent, 4 waves
-                                      // (default: 1.82 ms per B = 256 step against 1.87 with 8); 2 = persistent, 8 waves (the contraction split over wave pairs)
-
-// the persistent launches apply: bf16, H = 1024, at most four row groups, and every workgroup resident at once (one per CU)
-bool gru_persist_ok(int B, int H) {
-    return g_rgqa_butd_gru_persist != 0 && H == 1024 && B >= 1 && B <= 256 && ((B + 63) / 64) * (H / 16) <= rgqa_num_cus();
+// ---------------------------------------------------------------------------------------------------------------- 32-unit slices (round 5, second form)
+// What a token costs above is the operand every workgroup pulls from the memory side of the L2s (sc1 loads are never L2 hits): 64 workgroups per row
+// group each read the group's whole h_{t-1} (128 KB) / dgh_t (384 KB) - 32 / 96 MB per token over the fabric, at 36 GB/s per CU (7 -> 14 us per token
+// for 128 -> 384 KB: 3.5 us + 27 ns per KB).  Here a workgroup owns 32 hidden units and 32 samples: 32 slices x 8 row groups, half the bytes per
+// workgroup and per token.  The slice's weights (192 KB) do not fit the LDS; they live in REGISTERS: 8 waves split the contraction 8 ways, each wave
+// keeps its 96 fragments (16 rows x 32 k each) for the whole sequence - 96 VGPRs -, loads the operand of both 16-sample tiles for its K range only
+// (every byte of the operand is requested once per workgroup), and the partial sums meet in LDS (summed in wave order: deterministic).  Waves 0-3 then
+// finish the gates for one (sample tile, unit tile) pair each, a lane owning the same (sample, 4 units) at every step as above.  Hand-off: as above.
+template <int H>
+__global__ __launch_bounds__(512) void gru_fwd_persist32_kernel(const GruFwdArgs a) {
+    constexpr int KSW = H / 32 / 8, CS = H / 32;                  // K-steps of 32 per wave; slices per row group
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    f32x4* xch = reinterpret_cast<f32x4*>(lds);                   // [8 waves][12 tiles: (m, gate, u)][64 lanes]
+    int* s_bad = reinterpret_cast<int*>(lds + 8 * 12 * 64 * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int cs = blockIdx.x % CS, rg = blockIdx.x / CS;
+    const int B = a.B, L = a.L;
+    const int kw0 = wave * KSW;
+    if (tid == 0) *s_bad = 0;
+    // this wave's weight fragments: rows {r, z, n} x 2 unit tiles of W_hh, its K range
+    bf16x8 wreg[3][2][KSW];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks)
+                wreg[g][u][ks] = *reinterpret_cast<const bf16x8*>(a.W + (size_t)(g * H + cs * 32 + u * 16 + fr) * a.ldw + (kw0 + ks) * 32 + fq * 8);
+    // gate phase (waves 0-3): sample tile gm, unit tile gu
+    const int gm = wave & 1, gu = (wave >> 1) & 1;
+    const int row = rg * 32 + gm * 16 + fr;
+    const bool gate = wave < 4, live = gate && row < B;
+    const int rowc = row < B ? row : B - 1;
+    const int u0 = cs * 32 + gu * 16 + fq * 4;
+    float bh[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bh[g][j] = a.bhh[g * H + u0 + j];
+    float hown[4] = {0.f, 0.f, 0.f, 0.f};
+    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(a.Hall, 0, (int)((size_t)(L + 1) * B * H * 2), 0x00020000);
+    int* cnt = a.cnt + rg * (L + 1);
+    int lrow[2];                                                   // the operand rows of this lane (clamped: the result of a row >= B is dropped)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const int r = rg * 32 + m * 16 + fr; lrow[m] = r < B ? r : B - 1; }
+    bf16x4 rr, zz, nn, gg;
+    __syncthreads();
+    for (int t = 0; t < L; ++t) {
+        bf16x4 gir, giz, gin;
+        if (gate) {
+            const bf16_t* gi = a.GI + (size_t)rowc * a.ldgi + (size_t)t * 3 * H + u0;
+            gir = *reinterpret_cast<const bf16x4*>(gi); giz = *reinterpret_cast<const bf16x4*>(gi + H); gin = *reinterpret_cast<const bf16x4*>(gi + 2 * H);
+        }
+        if (t > 0) {
+            if (live) {          // what the backward pass needs of step t - 1: behind that step's signal
+                const size_t o = ((size_t)(t - 1) * B + row) * H + u0;
+                *reinterpret_cast<bf16x4*>(a.Rg + o) = rr; *reinterpret_cast<bf16x4*>(a.Zg + o) = zz;
+                *reinterpret_cast<bf16x4*>(a.Ng + o) = nn; *reinterpret_cast<bf16x4*>(a.GHN + o) = gg;
+            }
+            if (tid == 0 && !gru_wait(cnt + t, CS, a.err)) *s_bad = 1;
+            __syncthreads();
+        }
+        bf16x8 af[2][KSW];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_h, (unsigned)((((size_t)t * B + lrow[m]) * H + (kw0 + ks) * 32 + fq * 8) * 2), 0, 16);      // aux 16 = sc1
+                af[m][ks] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+        __builtin_amdgcn_sched_barrier(0);       // every operand load of the step is in flight before the first MFMA waits for one
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KSW; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[g][u][ks], af[m][ks], acc, 0, 0, 0);
+                    xch[(wave * 12 + (m * 3 + g) * 2 + u) * 64 + lane] = acc;
+                }
+        __syncthreads();
+        bf16x4 hn;
+        if (gate) {
+            float gh[3][4];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                f32x4 sum = xch[((gm * 3 + g) * 2 + gu) * 64 + lane];
+#pragma unroll
+                for (int p = 1; p < 8; ++p) sum += xch[(p * 12 + (gm * 3 + g) * 2 + gu) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gh[g][j] = sum[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float r = sigm_f((float)gir[j] + gh[0][j] + bh[0][j]);
+                const float z = sigm_f((float)giz[j] + gh[1][j] + bh[1][j]);
+                const float gn = gh[2][j] + bh[2][j];
+                const float n = tanhf((float)gin[j] + r * gn);
+                const float h = (1.f - z) * n + z * hown[j];
+                hn[j] = (bf16_t)h; rr[j] = (bf16_t)r; zz[j] = (bf16_t)z; nn[j] = (bf16_t)n; gg[j] = (bf16_t)gn;
+                hown[j] = (float)hn[j];
+            }
+            if (live)
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned*>(&hn), rs_h,
+                                                      (unsigned)((((size_t)(t + 1) * B + row) * H + u0) * 2), 0, 16);       // write-through
+        }
+        if (t + 1 < L) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt + t + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const size_t o = ((size_t)(L - 1) * B + row) * H + u0;
+        *reinterpret_cast<bf16x4*>(a.Rg + o) = rr; *reinterpret_cast<bf16x4*>(a.Zg + o) = zz;
+        *reinterpret_cast<bf16x4*>(a.Ng + o) = nn; *reinterpret_cast<bf16x4*>(a.GHN + o) = gg;
+        if (*s_bad) {            // a poll gave up: the final state of this slice says so
+            const unsigned long long q = 0x7FC07FC07FC07FC0ull;      // four bf16 NaNs
+            *reinterpret_cast<unsigned long long*>(a.Hall + ((size_t)L * B + row) * H + u0) = q;
+        }
+    }
 }
-// [forward counters: row groups x (L + 1)] [backward counters: row groups x L] [error word, zeroed once by the owner] ...
-size_t gru_persist_counter_ints(int B, int L) { return (size_t)((B + 63) / 64) * (2 * L + 1) + 16; }
+
+template <int H>
+__global__ __launch_bounds__(512) void gru_bwd_persist32_kernel(const GruBwdArgs a) {
+    constexpr int K3 = 3 * H, KSW = K3 / 32 / 8, CS = H / 32;   // 12 K-steps of 32 per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    f32x4* xch = reinterpret_cast<f32x4*>(lds);                   // [8 waves][4 tiles: (m, u)][64 lanes]
+    int* s_bad = reinterpret_cast<int*>(lds + 8 * 4 * 64 * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int cs = blockIdx.x % CS, rg = blockIdx.x / CS;
+    const int B = a.B, L = a.L;
+    const int kw0 = wave * KSW;
+    if (tid == 0) *s_bad = 0;
+    // W_hh^T rows cs * 32 + u * 16 + fr (hidden units), this wave's range of the 3H gate outputs
+    bf16x8 wreg[2][KSW];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks)
+            wreg[u][ks] = *reinterpret_cast<const bf16x8*>(a.WT + (size_t)(cs * 32 + u * 16 + fr) * a.ldwt + (kw0 + ks) * 32 + fq * 8);
+    const int gm = wave & 1, gu = (wave >> 1) & 1;
+    const int row = rg * 32 + gm * 16 + fr;
+    const bool gate = wave < 4, live = gate && row < B;
+    const int rowc = row < B ? row : B - 1;
+    const int u0 = cs * 32 + gu * 16 + fq * 4;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gate) {
+        const bf16x4 d0 = *reinterpret_cast<const bf16x4*>(a.dH + (size_t)rowc * H + u0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (float)d0[j];
+    }
+    const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(a.dGH, 0, (int)((size_t)L * B * K3 * 2), 0x00020000);
+    int* cnt = a.cnt + rg * L;
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    int lrow[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const int r = rg * 32 + m * 16 + fr; lrow[m] = r < B ? r : B - 1; }
+    size_t o = ((size_t)(L - 1) * B + rowc) * H + u0;
+    bf16x4 r4, z4, n4, g4, h4;
+    if (gate) {
+        r4 = *reinterpret_cast<const bf16x4*>(a.Rg + o); z4 = *reinterpret_cast<const bf16x4*>(a.Zg + o); n4 = *reinterpret_cast<const bf16x4*>(a.Ng + o);
+        g4 = *reinterpret_cast<const bf16x4*>(a.GHN + o); h4 = *reinterpret_cast<const bf16x4*>(a.Hall + o);
+    }
+    __syncthreads();
+    for (int t = L - 1; t >= 0; --t) {
+        bf16x4 qr, qz, qn, qnr;
+        float carry[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gate) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float r = (float)r4[j], z = (float)z4[j], n = (float)n4[j], gn = (float)g4[j], hp = (float)h4[j];
+                const float dn = d[j] * (1.f - z) * (1.f - n * n);
+                const float dz = d[j] * (hp - n) * z * (1.f - z);
+                const float dr = dn * gn * r * (1.f - r);
+                qr[j] = (bf16_t)dr; qz[j] = (bf16_t)dz; qn[j] = (bf16_t)dn; qnr[j] = (bf16_t)(dn * r);
+                carry[j] = d[j] * z;
+            }
+            if (live) {
+                const unsigned go = (unsigned)((((size_t)t * B + row) * K3 + u0) * 2);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2*>(&qr), rs_g, go, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2*>(&qz), rs_g, go + 2 * H, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2*>(&qnr), rs_g, go + 4 * H, 0, 16);
+            }
+        }
+        if (t > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (live) {
+            bf16_t* gi = a.dGI + (size_t)row * a.lddgi + (size_t)t * K3 + u0;
+            *reinterpret_cast<bf16x4*>(gi) = qr; *reinterpret_cast<bf16x4*>(gi + H) = qz; *reinterpret_cast<bf16x4*>(gi + 2 * H) = qn;
+        }
+        if (t == 0) break;
+        if (gate) {
+            o = ((size_t)(t - 1) * B + rowc) * H + u0;
+            r4 = *reinterpret_cast<const bf16x4*>(a.Rg + o); z4 = *reinterpret_cast<const bf16x4*>(a.Zg + o); n4 = *reinterpret_cast<const bf16x4*>(a.Ng + o);
+            g4 = *reinterpret_cast<const bf16x4*>(a.GHN + o); h4 = *reinterpret_cast<const bf16x4*>(a.Hall + o);
+        }
+        if (tid == 0 && !gru_wait(cnt + t, CS, a.err)) *s_bad = 1;
+        __syncthreads();
+        bf16x8 af[2][KSW];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (unsigned)((((size_t)t * B + lrow[m]) * K3 + (kw0 + ks) * 32 + fq * 8) * 2), 0, 16);
+                af[m][ks] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KSW; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[u][ks], af[m][ks], acc, 0, 0, 0);
+                xch[(wave * 4 + m * 2 + u) * 64 + lane] = acc;
+            }
+        __syncthreads();
+        if (gate) {
+            f32x4 sum = xch[(gm * 2 + gu) * 64 + lane];
+#pragma unroll
+            for (int p = 1; p < 8; ++p) sum += xch[(p * 4 + gm * 2 + gu) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = sum[j] + carry[j];
+        }
+    }
+    __syncthreads();
+    if (live && *s_bad) {        // a poll gave up: the first token's input gradient of this slice says so
+        const unsigned long long q = 0x7FC07FC07FC07FC0ull;
+        *reinterpret_cast<unsigned long long*>(a.dGI + (size_t)row * a.lddgi + u0) = q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- launchers
+int g_rgqa_butd_gru_persist = 3;      // rgqa_debug_set key 18: 0 = the host-driven recurrence (one GEMM + one gate kernel per token); 1 = persistent, 64-sample row groups x
+                                      // 16-unit slices, W_hh slice in LDS, 4 waves; 2 = the same with 8 waves (the contraction split over wave pairs); 3 (default) = persistent,
+                                      // 32-sample row groups x 32-unit slices, weights in registers, 8 waves (half the operand bytes per workgroup and token)
+
+// the persistent launches apply: bf16, H = 1024, B <= 256 (at most 256 workgroups, every one resident at once: one per CU)
+static int gru_row_groups(int B) { return g_rgqa_butd_gru_persist == 3 ? (B + 31) / 32 : (B + 63) / 64; }
+static int gru_slices(int H) { return g_rgqa_butd_gru_persist == 3 ? H / 32 : H / 16; }
+bool gru_persist_ok(int B, int H) {
+    return g_rgqa_butd_gru_persist != 0 && H == 1024 && B >= 1 && B <= 256 && gru_row_groups(B) * gru_slices(H) <= rgqa_num_cus();
+}
+// [forward counters: row groups x (L + 1)] [backward counters: row groups x L] [error word, zeroed once by the owner] ... - laid out for the finer
+// row groups (32 samples) whatever the form in use: the debug key may change between bind and launch
+static int gru_rgm(int B) { return (B + 31) / 32; }
+size_t gru_persist_counter_ints(int B, int L) { return (size_t)gru_rgm(B) * (2 * L + 1) + 16; }
 
 int k_gru_fwd_persist(const bf16_t* GI, long ldgi, const bf16_t* W, int ldw, const float* bhh, bf16_t* Hall, bf16_t* Rg, bf16_t* Zg, bf16_t* Ng, bf16_t* GHN,
                       int B, int L, int H, int* counters, hipStream_t s) {
     RGQA_REQUIRE(gru_persist_ok(B, H), "gru_fwd_persist: B=%d H=%d not covered", B, H);
-    constexpr int HH = 1024, LDS_BYTES = 48 * (2 * HH + 16) + 4 * 3 * 64 * 16;
-    const int RG = (B + 63) / 64;
+    constexpr int HH = 1024, LDS_BYTES = 48 * (2 * HH + 16) + 4 * 3 * 64 * 16, LDS32 = 8 * 12 * 64 * 16 + 16;
+    const int RG = gru_row_groups(B), RGM = gru_rgm(B);
     static bool attr = false;
     if (!attr) {
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persist_kernel<HH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persist_kernel<HH, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persist32_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS32));
         attr = true;
     }
-    RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RG * (2 * L + 1), s));
-    GruFwdArgs a{GI, ldgi, W, ldw, bhh, Hall, Rg, Zg, Ng, GHN, B, L, counters, counters + (size_t)RG * (2 * L + 1)};
-    if (g_rgqa_butd_gru_persist != 2) hipLaunchKernelGGL((gru_fwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RGM * (2 * L + 1), s));
+    GruFwdArgs a{GI, ldgi, W, ldw, bhh, Hall, Rg, Zg, Ng, GHN, B, L, counters, counters + (size_t)RGM * (2 * L + 1)};
+    if (g_rgqa_butd_gru_persist == 3) hipLaunchKernelGGL((gru_fwd_persist32_kernel<HH>), dim3(RG * (HH / 32)), dim3(512), LDS32, s, a);
+    else if (g_rgqa_butd_gru_persist != 2) hipLaunchKernelGGL((gru_fwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
     else hipLaunchKernelGGL((gru_fwd_persist_kernel<HH, 2>), dim3(RG * (HH / 16)), dim3(512), LDS_BYTES, s, a);
     RGQA_LAUNCH_CHECK("gru_fwd_persist_kernel");
     return RGQA_OK;
@@ -281,17 +531,19 @@ int k_gru_fwd_persist(const bf16_t* GI, long ldgi, const bf16_t* W, int ldw, con
 int k_gru_bwd_persist(const bf16_t* dH, const bf16_t* Hall, const bf16_t* Rg, const bf16_t* Zg, const bf16_t* Ng, const bf16_t* GHN, bf16_t* dGI, long lddgi, bf16_t* dGH,
                       const bf16_t* WT, int ldwt, int B, int L, int H, int* counters, hipStream_t s) {
     RGQA_REQUIRE(gru_persist_ok(B, H) && ldwt >= 3 * H, "gru_bwd_persist: B=%d H=%d ldwt=%d not covered", B, H, ldwt);
-    constexpr int HH = 1024, LDS_BYTES = 16 * (2 * 3 * HH + 16) + 4 * 64 * 16;
-    const int RG = (B + 63) / 64;
+    constexpr int HH = 1024, LDS_BYTES = 16 * (2 * 3 * HH + 16) + 4 * 64 * 16, LDS32 = 8 * 4 * 64 * 16 + 16;
+    const int RG = gru_row_groups(B), RGM = gru_rgm(B);
     static bool attr = false;
     if (!attr) {
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persist_kernel<HH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persist_kernel<HH, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persist32_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS32));
         attr = true;
     }
-    RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RG * (2 * L + 1), s));
-    GruBwdArgs a{dH, Hall, Rg, Zg, Ng, GHN, dGI, lddgi, dGH, WT, ldwt, B, L, counters + (size_t)RG * (L + 1), counters + (size_t)RG * (2 * L + 1)};
-    if (g_rgqa_butd_gru_persist != 2) hipLaunchKernelGGL((gru_bwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
+    RGQA_HIP(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)RGM * (2 * L + 1), s));
+    GruBwdArgs a{dH, Hall, Rg, Zg, Ng, GHN, dGI, lddgi, dGH, WT, ldwt, B, L, counters + (size_t)RGM * (L + 1), counters + (size_t)RGM * (2 * L + 1)};
+    if (g_rgqa_butd_gru_persist == 3) hipLaunchKernelGGL((gru_bwd_persist32_kernel<HH>), dim3(RG * (HH / 32)), dim3(512), LDS32, s, a);
+    else if (g_rgqa_butd_gru_persist != 2) hipLaunchKernelGGL((gru_bwd_persist_kernel<HH, 1>), dim3(RG * (HH / 16)), dim3(256), LDS_BYTES, s, a);
     else hipLaunchKernelGGL((gru_bwd_persist_kernel<HH, 2>), dim3(RG * (HH / 16)), dim3(512), LDS_BYTES, s, a);
     RGQA_LAUNCH_CHECK("gru_bwd_persist_kernel");
     return RGQA_OK;

@@ -152,6 +152,61 @@ def test_butd_step_at_config5_size_vs_oracle(precision, ltol, lrel, gtol):
     assert float(e.view(e.grads, [sp for sp in e.specs if sp.name == "w_emb.emb.weight"][0])[NT].abs().max()) == 0.0       # the padding row gets no gradient
 
 
+@pytest.mark.parametrize("B", [70, 256, 5])
+def test_butd_gru_forms_agree(B):
+    """The question encoder's GRU (butd/butd.py:48-73) in its four forms - rgqa_debug_set key 18: 0 = one GEMM + one gate kernel per token from the
+    host, 1 / 2 = persistent with 64-sample row groups x 16-unit slices (4 / 8 waves), 3 = persistent with 32-sample row groups x 32-unit
+    slices and the weights in registers (default) - on batch sizes that end inside a row group: same logits and gradients to bf16 rounding (the
+    persistent forms keep h W_hh^T in f32 between the MFMAs and the gates; they differ from each other only in summation order), two passes each
+    so that a counter left behind by a launch would show."""
+    from rgqa_amd import _lib
+    from rgqa_amd.engine import Engine
+    from oracle import butd_ref as BR
+    from tests.test_oracle_golden import butd_fill
+    L_ = _lib.load()
+    L, O, NA, NT = 40, 36, 1842, 3000
+    c = BR.ButdConfig(ntoken=NT, num_answers=NA)
+    filled = butd_fill(c)
+    b = synth.synth_batch(B, L, seed=99, uq_frac=0.25, vocab=NT)
+    rng = np.random.RandomState(4)
+    toks = np.full((B, L), NT, dtype=np.int64)
+    for r in range(B):
+        n = int(rng.randint(1, L + 1)) if r else L
+        toks[r, L - n:] = rng.randint(0, NT, size=n)
+    fg, pg, tg, kg = (torch.from_numpy(x).cuda() for x in (b["feats"], b["boxes"], b["target"], toks))
+    res = {}
+    try:
+        for form in (0, 1, 2, 3):
+            assert L_.rgqa_debug_set(18, form) == 0
+            e = Engine(arch=1, vocab_size=NT + 1, hidden=1024, emb_dim=300, feat_dim=2048, pos_dim=4, num_answers=NA, precision="bf16",
+                       hidden_dropout=0.0, attn_dropout=0.0, heads=1, inter=8, l_layers=0, x_layers=0, r_layers=0).allocate("cuda")
+            for sp in e.specs:
+                e.view(e.params, sp).copy_(torch.from_numpy(np.asarray(filled[sp.name]).reshape(sp.shape)))
+            e.ensure_shape(B, L, O)
+            e.sync_weights()
+            out = []
+            for _ in range(2):
+                lg = e.forward(fg, pg, kg, kg, None, train=False)[0].clone()
+                e.loss_backward(tg)
+                out.append((lg, e.grads.clone()))
+            torch.cuda.synchronize()
+            # every form is deterministic (the word-embedding gradient is scatter-added with float atomics: to rounding)
+            assert torch.equal(out[0][0], out[1][0]) and float((out[0][1] - out[1][1]).norm()) < 1e-5 * float(out[0][1].norm()), form
+            res[form] = out[0]
+    finally:
+        L_.rgqa_debug_set(18, 3)
+    l0, g0 = res[0]
+    assert torch.isfinite(l0).all() and torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    for form in (1, 2, 3):
+        lf, gf = res[form]
+        assert torch.isfinite(lf).all() and torch.isfinite(gf).all()
+        assert float((lf - l0).abs().max()) < 2e-3 * max(1.0, float(l0.abs().max())), form
+        assert float((gf - g0).norm()) < 3e-2 * float(g0.norm()), form
+    # the two persistent families differ only in the order of the f32 sums
+    assert float((res[3][0] - res[1][0]).abs().max()) < 5e-4 * max(1.0, float(l0.abs().max()))
+    assert float((res[3][1] - res[1][1]).norm()) < 1e-2 * float(g0.norm())
+
+
 def test_butd_train_step_runs_with_dropout():
     from rgqa_amd.lxrt.optimization import BertAdam
     m, c, _ = build("bf16", dropout=True)
