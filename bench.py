@@ -403,10 +403,16 @@ def dropin_step_leg(B, T, n_steps, precision):
         batcher = DeviceBatcher(FeatureStore(prefix), ans2label, NA, B)
         state = dict(i=0)
 
+        reuse = os.environ.get("RGQA_DROPIN_REUSE_BATCH") == "1"          # tools/dropin_profile.py only: what the fresh batch costs the step
+        held = batcher.batch([data[k % len(data)] for k in range(B)]) if reuse else None
+
         def step():
             i = state["i"]
-            batch = [data[(i * B + k) % len(data)] for k in range(B)]
-            ques_id, feats, boxes, sent, target = batcher.batch(batch)
+            if reuse:
+                ques_id, feats, boxes, sent, target = held
+            else:
+                batch = [data[(i * B + k) % len(data)] for k in range(B)]
+                ques_id, feats, boxes, sent, target = batcher.batch(batch)
             optim.zero_grad()
             logit = model(feats, boxes, sent)
             loss = bce(logit, target) * logit.size(1)
