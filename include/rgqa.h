@@ -165,6 +165,9 @@ int rgqa_engine_wait_grad_event(rgqa_engine* e, int event, void* stream);
  * event must stay alive until that pass has been enqueued. */
 int rgqa_engine_set_weight_event(rgqa_engine* e, int segment_event, void* hip_event);
 int rgqa_engine_set_backward_event(rgqa_engine* e, void* hip_event);
+/* how many segment events the engine's forward pass honours (0: this engine waits for none - the BUTD engine re-derives every effective weight from
+ * the f32 masters at the start of each pass -, so its caller must have the weights in place on the pass's stream before it calls forward) */
+int rgqa_engine_num_weight_segments(const rgqa_engine* e, int* out);
 
 /* measurement: time every GEMM / attention launch with HIP events on the launch stream. profile_read synchronises
  * on the recorded events; categories: 0 gemm NT (fwd + dgrad), 1 gemm TN (wgrad), 2 attention fwd, 3 attention bwd,

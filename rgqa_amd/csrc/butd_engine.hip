@@ -404,6 +404,13 @@ public:
             CKB(kb_wn_backward_group(wn_dev, (int)wn_host.size(), wn_blocks, wn_partial, s));
             wg_collect = false;
         }
+        // the one gradient segment of this engine (the whole arena: every weight gradient lands in the last launches of the pass) is final: the
+        // data-parallel exchange waits for this event on its side stream (rgqa_engine_wait_grad_event)
+        if (seg_events.empty()) {
+            seg_events.resize(1);
+            RGQA_HIP(hipEventCreateWithFlags(&seg_events[0], hipEventDisableTiming));
+        }
+        RGQA_HIP(hipEventRecord(seg_events[0], s));
         return RGQA_OK;
     }
 

@@ -180,6 +180,12 @@ int rgqa_engine_set_weight_event(rgqa_engine* e, int segment_event, void* hip_ev
     e->impl->wready[segment_event] = reinterpret_cast<hipEvent_t>(hip_event);
     return RGQA_OK;
 }
+int rgqa_engine_num_weight_segments(const rgqa_engine* e, int* out) {
+    NEED(e);
+    RGQA_REQUIRE(out != nullptr, "num_weight_segments: null argument");
+    *out = e->impl->num_weight_segments();
+    return RGQA_OK;
+}
 int rgqa_engine_set_backward_event(rgqa_engine* e, void* hip_event) {
     NEED(e);
     RGQA_REQUIRE(e->impl->num_weight_segments() > 0, "set_backward_event: not supported by this engine");

@@ -289,6 +289,12 @@ class Engine:
         the first launch that reads those weights (rgqa_engine_set_weight_event; one-shot).  The caller keeps `event` alive until then."""
         check(self.lib.rgqa_engine_set_weight_event(self.h, int(segment_event), C.c_void_p(event.cuda_event) if event is not None else None))
 
+    def num_weight_segments(self):
+        """segment events the engine's forward pass waits for (set_weight_event); 0: none - the weights must be in place before forward is called"""
+        n = C.c_int(0)
+        check(self.lib.rgqa_engine_num_weight_segments(self.h, C.byref(n)))
+        return n.value
+
     def set_backward_event(self, event):
         """the next backward pass waits for `event` before its first launch (the transposed operand copies are refreshed behind it); one-shot"""
         check(self.lib.rgqa_engine_set_backward_event(self.h, C.c_void_p(event.cuda_event) if event is not None else None))

@@ -226,7 +226,10 @@ class ShardedExchange:
         # head last), one event per chunk; the engine's forward waits, per layer, for the event of the chunk that holds the layer's weights, its
         # backward for the transposed copies refreshed behind the last chunk.  bf16 engines on a real device only (a split-f32 operand copy is
         # re-made from the gathered masters as a whole); RGQA_DP_GATHER_OVERLAP=0 keeps the gather on the step's stream.
+        # ... and only around an engine whose forward waits per segment (the BUTD engine re-derives its effective weights from the masters at the
+        # start of every pass: it waits for nothing, its gather stays on the step's stream)
         self.gather_overlap = (self.overlap and self.lp and dev.type == "cuda" and hasattr(engine, "set_weight_event")
+                               and hasattr(engine, "num_weight_segments") and engine.num_weight_segments() > 0
                                and os.environ.get("RGQA_DP_GATHER_OVERLAP", "1") != "0")
         self._wevents = []
         # bf16 engines: the forward reads biases, LayerNorm parameters, the embedding tables and the K = 4 box projection from the F32 masters

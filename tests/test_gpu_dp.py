@@ -175,3 +175,102 @@ def test_exchange_on_rccl_single_rank_group(mode, precision):
         assert diff.max() < 1e-4 and diff.mean() < 1e-7, (diff.max(), diff.mean())
     else:
         assert diff.max() < 1.3e-2 and diff.mean() < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE config 5 under the exchange
+BUTD = dict(arch=1, vocab_size=201, hidden=1024, emb_dim=300, feat_dim=2048, pos_dim=4, num_answers=70, heads=1, inter=8, l_layers=0, x_layers=0, r_layers=0)
+BB, BL, BO = 6, 14, 36
+
+
+def _butd_batch():
+    from rgqa_amd import synth
+    b = synth.synth_batch(2 * BB, BL, O=BO, F=BUTD["feat_dim"], NA=BUTD["num_answers"], vocab=200, seed=77, min_len=2)
+    rng = np.random.RandomState(8)
+    toks = np.full((2 * BB, BL), 200, dtype=np.int64)            # dictionary indices, front-padded with the padding index (butd.py:180-193)
+    for r in range(2 * BB):
+        n = int(rng.randint(1, BL + 1))
+        toks[r, BL - n:] = rng.randint(0, 200, size=n)
+    return dict(feats=b["feats"], boxes=b["boxes"], target=b["target"], toks=toks)
+
+
+def _make_butd(batch, precision):
+    from rgqa_amd.engine import Engine
+    from rgqa_amd import synth
+    e = Engine(precision=precision, hidden_dropout=0.0, attn_dropout=0.0, **BUTD).allocate("cuda")
+    for sp in e.specs:
+        e.view(e.params, sp).copy_(torch.from_numpy(synth.fill_value(sp.name, sp.shape)))
+    d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in batch.items()}
+    e.ensure_shape(d["feats"].shape[0], BL, BO)
+    e.sync_weights()
+    return e, d
+
+
+def _butd_step(e, d, comm, world):
+    e.forward(d["feats"], d["boxes"], d["toks"], d["toks"], None, train=False)
+    e.loss_backward(d["target"])
+    if comm is not None:
+        comm.exchange()
+        comm.step(1e-3, max_norm=5.0)
+    else:
+        e.adam_step(1e-3, max_norm=5.0, grad_prescale=1.0 / world)
+
+
+def _butd_worker(rank, world, port, backend, mode, precision, q):
+    import torch.distributed as dist
+    from rgqa_amd.parallel import make_exchange
+    torch.cuda.set_device(0)
+    kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, **kw)
+    full = _butd_batch()
+    n = 2 * BB // world
+    e, d = _make_butd({k: v[rank * n:(rank + 1) * n] for k, v in full.items()}, precision)
+    comm = make_exchange(e, dist, mode, overlap=True, **(dict(chunk_mb=8, bucket_mb=8) if mode.startswith("sharded") else dict(bucket_mb=8)))
+    assert not getattr(comm, "gather_overlap", False)        # this engine's forward waits for no weight event: the gather stays on the step's stream
+    for _ in range(2):
+        _butd_step(e, d, comm, world)
+    comm.gather_master()
+    torch.cuda.synchronize()
+    q.put((rank, e.params.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,world,mode,precision", [("nccl", 1, "sharded", "bf16"), ("nccl", 1, "allreduce", "bf16"), ("gloo", 2, "sharded", "bf16"),
+                                                           ("gloo", 2, "sharded", "f32"), ("gloo", 2, "allreduce", "bf16x3")])
+def test_butd_engine_under_the_exchange(backend, world, mode, precision):
+    """BASELINE config 5 is a data-parallel run (8 GPUs): the gradient exchange around the BUTD engine (rgqa_config.arch = 1) - ONE gradient
+    segment, its event recorded by the last launch of backward; no per-segment weight events (the engine re-derives its effective weights from
+    the masters at the start of every pass), so the sharded mode's weight gather stays on the step's stream.  One rank on RCCL, two ranks on
+    gloo: two optimizer steps == the plain step on the whole batch (round 5: until now the exchange raised at the first step - the event had
+    never been recorded)."""
+    import torch.multiprocessing as mp
+    e, d = _make_butd(_butd_batch(), precision)
+    for _ in range(2):
+        _butd_step(e, d, None, 1)
+    ref = e.params.cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 500) + 13 * (["sharded", "allreduce"].index(mode) * 8 + _PRECS.index(precision) * 2 + (world - 1))
+    procs = [ctx.Process(target=_butd_worker, args=(r, world, port, backend, mode, precision, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r, params = q.get(timeout=240)
+            res[r] = params
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    if world == 2:
+        assert np.array_equal(res[0], res[1])
+    diff = np.abs(res[0] - ref)
+    print("butd dp %s x%d %s/%s: |params - plain step| max %.3e mean %.3e" % (backend, world, mode, precision, diff.max(), diff.mean()))
+    from rgqa_amd.parallel import exchange_payload
+    if exchange_payload(mode, precision) == torch.float32 and precision == "f32":
+        np.testing.assert_allclose(res[0], ref, rtol=2e-4, atol=2e-6)
+    else:
+        assert diff.max() < 1.3e-2 and diff.mean() < 1e-5, (diff.max(), diff.mean())
