@@ -213,6 +213,9 @@ class ShardedExchange:
         dev = engine.grads.device
         self._send = torch.zeros(self.world * self.smax, dtype=self.payload, device=dev)
         self._recv = torch.zeros(self.world * self.smax, dtype=self.payload, device=dev)
+        self._stage = [(self._send, self._recv)]       # one staging set per exchange stream (the second is made on first use)
+        self.nstreams = 2 if os.environ.get("RGQA_DP_EXCHANGE_STREAMS", "2") != "1" else 1
+        self.side2 = self._sumsq2 = self._sqws2 = None
         self._sumsq = self._sqws = None
         self._sumsq_from_exchange = False
         self._norm_read = None
@@ -297,9 +300,9 @@ class ShardedExchange:
             self._sumsq = torch.zeros(1, dtype=torch.float32, device=g.device)
             self._sqws = torch.zeros(2048, dtype=torch.float32, device=g.device)
 
-        def one(a, b, s):
+        def one(a, b, s, k=0):
             n = b - a
-            send, recv = self._send[:W * s], self._recv[:W * s]
+            send, recv = self._stage[k][0][:W * s], self._stage[k][1][:W * s]
             if self.payload == torch.bfloat16:
                 self.ops.cast_bf16(send[:n], g[a:b])        # part r of the chunk at send[r*s : (r+1)*s]; the ragged tail is never read
             elif n == W * s:
@@ -309,7 +312,7 @@ class ShardedExchange:
             self._a2a(recv, send)
             lo, hi = owned((a, b, s), self.rank)
             if hi > lo:
-                self.ops.sum_parts(g[lo:hi], recv, s, W, self._sqws, self._sumsq)    # f32 accumulation in rank order + this range's sum(g^2)
+                self.ops.sum_parts(g[lo:hi], recv, s, W, self._sqws if k == 0 else self._sqws2, self._sumsq if k == 0 else self._sumsq2)    # f32 accumulation in rank order + this range's sum(g^2)
 
         self._sumsq_from_exchange = True
         if not (self.overlap and g.is_cuda):
@@ -317,19 +320,35 @@ class ShardedExchange:
             for c in self.chunks:
                 one(*c)
             return
-        # every chunk on ONE side stream (they share the staging buffers), each behind the event of the gradient segment it holds:
-        # the exchange of the layers backward has finished runs beside the layers it is still computing
+        # Chunks alternate between TWO side streams, each with a staging set and a norm accumulator of its own, each chunk behind the event of the
+        # gradient segment it holds: the exchange of the layers backward has finished runs beside the layers it is still computing, and a chunk's
+        # cast and shard sum run beside the neighbouring chunk's all-to-all (the weight gradients of a step come from six grouped launches, so
+        # segments become final in bursts of several chunks - the last bursts are what backward cannot hide; round 5: one stream walked them
+        # cast -> wire -> sum, chunk after chunk).  RGQA_DP_EXCHANGE_STREAMS=1 restores the single stream.
         if self.side is None:
             self.side = torch.cuda.Stream(device=g.device)
+        two = self.nstreams > 1 and len(self.chunks) > 1
+        if two and self.side2 is None:
+            self.side2 = torch.cuda.Stream(device=g.device)
+            self._stage.append((torch.zeros_like(self._send), torch.zeros_like(self._recv)))
+            self._sumsq2 = torch.zeros(1, dtype=torch.float32, device=g.device)
+            self._sqws2 = torch.zeros(2048, dtype=torch.float32, device=g.device)
         cur = torch.cuda.current_stream()
-        if self._norm_read is not None:
-            self.side.wait_event(self._norm_read)       # the previous step's optimizer has read the norm before it is cleared
-        with torch.cuda.stream(self.side):
-            self._sumsq.zero_()
-            for c, ev in zip(self.chunks, self.events):
-                self.e.wait_grad_event(ev, self.side)
-                one(*c)
-        cur.wait_stream(self.side)
+        streams = [self.side, self.side2] if two else [self.side]
+        for k, st in enumerate(streams):
+            if self._norm_read is not None:
+                st.wait_event(self._norm_read)          # the previous step's optimizer has read the norm before it is cleared
+            with torch.cuda.stream(st):
+                (self._sumsq if k == 0 else self._sumsq2).zero_()
+        for i, (c, ev) in enumerate(zip(self.chunks, self.events)):
+            k = i % len(streams)
+            with torch.cuda.stream(streams[k]):
+                self.e.wait_grad_event(ev, streams[k])
+                one(*c, k=k)
+        for st in streams:
+            cur.wait_stream(st)
+        if two:
+            self._sumsq += self._sumsq2                 # (fixed chunk -> stream assignment: the norm is the same number every run)
 
     all_reduce = exchange
 
