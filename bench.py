@@ -723,9 +723,14 @@ def main():
     blocks = None
     if rank == 0:
         note("live per-launch timing (%d steps)" % args.profile_steps)
+        if hasattr(e, "join_update"):
+            e.join_update()
+        torch.cuda.synchronize()
         e.profile(True)
-        for _ in range(args.profile_steps):
+        ov, e.adam_overlap = getattr(e, "adam_overlap", False), False      # per-kernel timing with every other stream folded into the launch stream (as the
+        for _ in range(args.profile_steps):                                # weight-gradient side stream is under profiling): a kernel's own duration, not its neighbours'
             step(exchange=False)      # rank-0-only kernel timing AFTER the timed region: no collective (the other ranks are at the barrier below)
+        e.adam_overlap = ov
         prof = e.profile_read()
         blocks = e.profile_blocks() if hasattr(e, "profile_blocks") and not (args.butd or args.uniter) else None
         e.profile(False)

@@ -82,7 +82,7 @@ class GQABUTD(nn.Module):
     # engine plumbing shared with the LXMERT modules (lxrt/modeling.py)
     def _engine_forward(self, feats, boxes, toks, mask, seg, train):
         b = self._binding
-        if b.engine.params is None or b.engine.device != feats.device or not b.packed():
+        if b.engine._params is None or b.engine.device != feats.device or not b.packed():
             b.materialize(feats.device)
         e = b.engine
         e.ensure_shape(feats.shape[0], toks.shape[1], feats.shape[1])

@@ -4,6 +4,7 @@ torch is plumbing only here: it owns device memory (arenas, workspace, I/O tenso
 Every tensor operation of the hot path happens inside librgqa_hip.so.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -33,7 +34,7 @@ ARENAS = weakref.WeakValueDictionary()
 def engine_of(ptr_bytes):
     """the engine whose parameter arena contains the device address, or None"""
     for base, e in list(ARENAS.items()):
-        if e.params is not None and base <= ptr_bytes < base + 4 * e.arena_elems:
+        if e._params is not None and base <= ptr_bytes < base + 4 * e.arena_elems:
             return e
     return None
 
@@ -88,10 +89,12 @@ class Engine:
         check(self.lib.rgqa_engine_dead_range(self.h, C.byref(b), C.byref(e)))
         self.dead_range = (b.value, e.value)
         self.device = None
-        self.params = self.grads = self.params_lp = self.params_lp_t = self.workspace = None
-        self.adam_m = self.adam_v = None
+        self._params = self._grads = self._params_lp = self._params_lp_t = self.workspace = None
+        self._adam_m = self._adam_v = None
         self._seg_sumsq = None
         self._seg_sumsq_valid = False
+        self._upd_stream = self._upd_done = None
+        self.adam_overlap = os.environ.get("RGQA_ADAM_OVERLAP", "1") != "0"      # adam_step's default for `overlap` (see _update_beside_forward)
         self._pending_clip = None        # max_norm of a deferred clip_grads_ (lxrt.optimization.clip_grad_norm_ -> BertAdam.step), else None
         self._sharded_owner = None       # set by parallel.ShardedExchange while the f32 masters / Adam moments are valid on their owner rank only
         self.shape = None
@@ -105,6 +108,28 @@ class Engine:
         except Exception:
             pass
 
+    # The arenas as the world outside this class sees them: reading (or replacing) one first makes the caller's stream wait for an optimizer pass
+    # that may still be running beside the forward pass (adam_step, _update_beside_forward); the class itself works on the underscore fields.
+    def _arena_property(name):
+        raw = "_" + name
+
+        def get(self):
+            self.join_update()
+            return getattr(self, raw)
+
+        def put(self, value):
+            self.join_update()
+            setattr(self, raw, value)
+        return property(get, put)
+
+    params = _arena_property("params")
+    grads = _arena_property("grads")
+    params_lp = _arena_property("params_lp")
+    params_lp_t = _arena_property("params_lp_t")
+    adam_m = _arena_property("adam_m")
+    adam_v = _arena_property("adam_v")
+    del _arena_property
+
     # ------------------------------------------------------------------ memory
     def allocate(self, device):
         """Allocates the parameter / gradient arenas on `device` (a CUDA==HIP device)."""
@@ -117,18 +142,18 @@ class Engine:
         n = self.arena_elems
         for k in [k for k, v in list(ARENAS.items()) if v is self]:
             del ARENAS[k]
-        self.params = torch.zeros(n, dtype=torch.float32, device=device)
-        self.grads = torch.zeros(n, dtype=torch.float32, device=device)
-        ARENAS[self.params.data_ptr()] = self
+        self._params = torch.zeros(n, dtype=torch.float32, device=device)
+        self._grads = torch.zeros(n, dtype=torch.float32, device=device)
+        ARENAS[self._params.data_ptr()] = self
         if self.precision == "bf16":
-            self.params_lp = torch.zeros(n, dtype=torch.bfloat16, device=device)
-            self.params_lp_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
+            self._params_lp = torch.zeros(n, dtype=torch.bfloat16, device=device)
+            self._params_lp_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
         elif self.precision == "bf16x3":     # split-f32 operand copies: 4 bytes per element slot (csrc/common.h sf32), opaque to torch
-            self.params_lp = torch.zeros(n, dtype=torch.int32, device=device)
-            self.params_lp_t = torch.zeros(n, dtype=torch.int32, device=device)
+            self._params_lp = torch.zeros(n, dtype=torch.int32, device=device)
+            self._params_lp_t = torch.zeros(n, dtype=torch.int32, device=device)
         elif self.precision == "bf16x3_fwd":     # forward operand copy split f32, the backward's (transposed) copy bf16
-            self.params_lp = torch.zeros(n, dtype=torch.int32, device=device)
-            self.params_lp_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
+            self._params_lp = torch.zeros(n, dtype=torch.int32, device=device)
+            self._params_lp_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
         self.shape = None
         return self
 
@@ -143,7 +168,7 @@ class Engine:
         if self.workspace is None or self.workspace.numel() < need.value:
             self.workspace = None
             self.workspace = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-        check(self.lib.rgqa_engine_bind(self.h, ptr(self.params), ptr(self.grads), ptr(self.params_lp), ptr(self.params_lp_t),
+        check(self.lib.rgqa_engine_bind(self.h, ptr(self._params), ptr(self._grads), ptr(self._params_lp), ptr(self._params_lp_t),
                                         ptr(self.workspace), self.workspace.numel(), B, T, O))
         self.shape = (B, T, O)
         na, H = self.cfg.num_answers, self.cfg.hidden
@@ -191,6 +216,7 @@ class Engine:
         lg, pl = self._io["logits"], self._io["pooled"]
         check(self.lib.rgqa_engine_forward(self.h, ptr(feats), ptr(boxes), ptr(input_ids), ptr(segment_ids), ptr(input_mask),
                                            ptr(pl), ptr(lg), lg.stride(0), 1 if train else 0, C.c_uint64(seed), _stream()))
+        self.join_update()      # an optimizer pass beside this forward (it finished long ago: 1.3 ms against 3.6): whatever follows on this stream sees its results
         return lg, pl
 
     def loss_backward(self, target, grad_scale=1.0, accumulate=False):
@@ -322,7 +348,7 @@ class Engine:
         n = self.arena_elems
         return [(0, b), (e, n)] if e > b else [(0, n)]
 
-    def adam_step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, grad_prescale=1.0, clip=True):
+    def adam_step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, grad_prescale=1.0, clip=True, overlap=None):
         """clip_grad_norm_(params, max_norm) + BertAdam.step over every parameter that receives a gradient
         (gqa_conf.py:201-202), on the caller's stream; the same kernel re-writes the operand copy of the weights (bf16 / split f32)
         and the transposed copies follow."""
@@ -331,9 +357,9 @@ class Engine:
         if self._sharded_owner is not None:
             raise RuntimeError("adam_step: the optimizer state of this engine is sharded over the data-parallel ranks "
                                "(ShardedExchange); step through the exchange, or call its gather_master() / release() first")
-        if self.adam_m is None:
-            self.adam_m = torch.zeros_like(self.params)
-            self.adam_v = torch.zeros_like(self.params)
+        if self._adam_m is None:
+            self._adam_m = torch.zeros_like(self._params)
+            self._adam_v = torch.zeros_like(self._params)
         if getattr(self, "_sumsq", None) is None:
             self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._sq_ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
@@ -343,16 +369,76 @@ class Engine:
             torch.sum(self._seg_sumsq, dim=0, keepdim=True, out=self._sumsq)      # the segments' shares, taken during backward
         elif clip:
             for i, (a, b) in enumerate(rngs):
-                check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
+                check(self.lib.rgqa_grad_sumsq(ptr(self._grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
         self._seg_sumsq_valid = False
         lp_split = 1 if self.precision in ("bf16x3", "bf16x3_fwd") else 0
-        for a, b in rngs:
-            lp = ptr(self.params_lp[a:b]) if self.params_lp is not None else None
-            check(self.lib.rgqa_bertadam_step(ptr(self.params[a:b]), ptr(self.grads[a:b]), ptr(self.adam_m[a:b]), ptr(self.adam_v[a:b]),
+
+        def update(a, b, stream):
+            lp = ptr(self._params_lp[a:b]) if self._params_lp is not None else None
+            check(self.lib.rgqa_bertadam_step(ptr(self._params[a:b]), ptr(self._grads[a:b]), ptr(self._adam_m[a:b]), ptr(self._adam_v[a:b]),
                                               lp, lp_split, b - a, lr_t, b1, b2, eps, weight_decay, ptr(self._sumsq) if clip else None,
-                                              max_norm, grad_prescale, s))
-        if self.params_lp is not None:
+                                              max_norm, grad_prescale, stream))
+
+        if overlap is None:
+            overlap = self.adam_overlap
+        if overlap and self.device.type == "cuda" and self.num_weight_segments() > 0:
+            return self._update_beside_forward(update)
+        for a, b in rngs:
+            update(a, b, s)
+        if self._params_lp is not None:
             check(self.lib.rgqa_engine_sync_transposed(self.h, s))
+
+    def _update_beside_forward(self, update):
+        """The optimizer pass beside the NEXT forward pass (round 5): BertAdam is a pure HBM stream (30 bytes per parameter: 1.1 ms at B = 256), the
+        forward pass that follows it is bound by its GEMMs.  The update runs on a stream of its own, gradient segment by gradient segment in
+        FORWARD order (embeddings first, the answer head last), one event per segment; the engine's forward waits, per layer, for the event of the
+        segment that holds the layer's weights (rgqa_engine_set_weight_event - the mechanism the sharded exchange's weight all-gather uses), the
+        next backward for the transposed operand copies re-made behind the last segment (rgqa_engine_set_backward_event).  The caller's stream
+        goes straight on to the next forward.  Whoever reads the parameters OUTSIDE the engine (state_dict, a checkpoint, a test) first calls
+        join_update() - or synchronises the device."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._upd_stream is None:
+            self._upd_stream = torch.cuda.Stream(device=self.device)      # (stream priorities make no difference: measured)
+            by_ev = {}
+            for a, b, ev in self.grad_segments():
+                by_ev.setdefault(ev, []).append((a, b))
+            self._upd_order = [(ev, by_ev[ev]) for ev in sorted(by_ev, reverse=True)]
+            cov = sorted(r for _, rs in self._upd_order for r in rs)
+            merged = []
+            for a, b in cov:
+                if merged and a <= merged[-1][1]:
+                    merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+                else:
+                    merged.append((a, b))
+            if merged != [tuple(r) for r in self.live_ranges()]:
+                raise RuntimeError("adam_step(overlap): the gradient segments do not cover the live parameter ranges")
+        side = self._upd_stream
+        ready = torch.cuda.Event()
+        ready.record(cur)                              # the gradients and the norm are final on the caller's stream
+        evs = []
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            ss = C.c_void_p(side.cuda_stream)
+            for ev, ranges in self._upd_order:
+                for a, b in ranges:
+                    update(a, b, ss)
+                t = torch.cuda.Event()
+                t.record(side)
+                evs.append(t)
+                self.set_weight_event(ev, t)
+            if self._params_lp is not None:
+                check(self.lib.rgqa_engine_sync_transposed(self.h, ss))
+            t = torch.cuda.Event()
+            t.record(side)
+            evs.append(t)
+            self.set_backward_event(t)
+        self._upd_events, self._upd_done = evs, t      # alive until the passes that wait for them have been enqueued (the next step replaces them)
+
+    def join_update(self):
+        """the caller's stream waits for an optimizer pass still running beside the forward (adam_step(overlap=True)); no-op otherwise"""
+        t, self._upd_done = getattr(self, "_upd_done", None), None
+        if t is not None:
+            torch.cuda.current_stream(self.device).wait_event(t)
 
     def flush_deferred_clip(self):
         """Materialises a deferred clip_grads_(..., defer=True): the gradient arena is scaled in place now (one kernel; no traffic when the
@@ -361,7 +447,7 @@ class Engine:
         if mn is not None:
             s = _stream()
             for a, b in self.live_ranges():
-                check(self.lib.rgqa_clip_scale(ptr(self.grads[a:b]), b - a, ptr(self._sumsq), float(mn), s))
+                check(self.lib.rgqa_clip_scale(ptr(self._grads[a:b]), b - a, ptr(self._sumsq), float(mn), s))
 
     def drop_deferred_clip(self):
         self._pending_clip = None
@@ -385,13 +471,13 @@ class Engine:
             torch.sum(self._seg_sumsq, dim=0, keepdim=True, out=self._sumsq)
         else:
             for i, (a, b) in enumerate(rngs):
-                check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
+                check(self.lib.rgqa_grad_sumsq(ptr(self._grads[a:b]), b - a, ptr(self._sq_ws), ptr(self._sumsq), 1 if i else 0, s))
         self._seg_sumsq_valid = False            # the gradients change below (or may have: the caller owns them from here on)
         if defer:
             self._pending_clip = float(max_norm)
             return self._sumsq.sqrt().reshape(())
         for a, b in rngs:
-            check(self.lib.rgqa_clip_scale(ptr(self.grads[a:b]), b - a, ptr(self._sumsq), float(max_norm), s))
+            check(self.lib.rgqa_clip_scale(ptr(self._grads[a:b]), b - a, ptr(self._sumsq), float(max_norm), s))
         return self._sumsq.sqrt().reshape(())
 
     def grad_norm(self):
@@ -399,5 +485,5 @@ class Engine:
         tot = torch.zeros(1, dtype=torch.float32, device=self.device)
         ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
         for i, (a, b) in enumerate(self.live_ranges()):
-            check(self.lib.rgqa_grad_sumsq(ptr(self.grads[a:b]), b - a, ptr(ws), ptr(tot), 1 if i else 0, _stream()))
+            check(self.lib.rgqa_grad_sumsq(ptr(self._grads[a:b]), b - a, ptr(ws), ptr(tot), 1 if i else 0, _stream()))
         return tot.sqrt()

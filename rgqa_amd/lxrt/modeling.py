@@ -208,16 +208,16 @@ class ArenaBinding(object):
 
     def packed(self):
         e = self.engine
-        if e is None or e.params is None:
+        if e is None or e._params is None:          # (the raw field: an address check must not wait for an optimizer pass in flight)
             return False
-        base = e.params.data_ptr()
+        base = e._params.data_ptr()
         for sp, p in (self.params[0], self.params[-1], self.params[len(self.params) // 2]):
             if p.data_ptr() != base + 4 * sp.offset:
                 return False
         return True
 
     def ensure(self, device):
-        if not self.packed() or any(p.data_ptr() != self.engine.params.data_ptr() + 4 * sp.offset for sp, p in self.params):
+        if not self.packed() or any(p.data_ptr() != self.engine._params.data_ptr() + 4 * sp.offset for sp, p in self.params):
             self.materialize(device)
 
     def versions(self):
@@ -246,7 +246,7 @@ class ArenaBinding(object):
         zero_grad() (which sets every .grad to None) is then 439 attribute stores instead of 439 x (slice + view) tensor constructions
         per step (~3 ms of host time at the full model: the drop-in step was host-bound on it)"""
         e = self.engine
-        key = (e.grads.data_ptr(), len(self.params))
+        key = (e._grads.data_ptr(), len(self.params))
         if getattr(self, "_gv_key", None) != key:
             self._gv = [None if sp.dead else e.view(e.grads, sp) for sp, p in self.params]
             self._gv_key = key
@@ -255,7 +255,7 @@ class ArenaBinding(object):
     def grads_state(self):
         """'none' if every live parameter has grad None, 'views' if they are the arena views, else 'foreign'."""
         e = self.engine
-        base = e.grads.data_ptr()
+        base = e._grads.data_ptr()
         gv = self._views()
         none = views = 0
         live = 0
@@ -419,6 +419,10 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         _build_tree(self, self._binding.engine.specs, self.TREE_PREFIX)
         self._rebind()
         self.apply(self.init_bert_weights)      # as LXRTModel / LXRTFeatureExtraction do (modeling.py:843, 1018)
+        # an optimizer pass may still be running beside the forward pass on a stream of its own (Engine._update_beside_forward): whoever reads or
+        # overwrites the parameters through nn.Module's own paths joins it first (a stream-side wait, no host synchronisation)
+        self._register_state_dict_hook(lambda module, *_: module._binding.engine.join_update())
+        self._register_load_state_dict_pre_hook(lambda *_: self._binding.engine.join_update())
 
     # -- engine / arena -------------------------------------------------------------------------------------------
     def _make_engine(self, num_answers):
@@ -462,7 +466,7 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
     def _ready(self, device):
         # parameters moved by .cuda()/.to() (or freshly built on the host) are packed into the flat arenas here
         b = self._binding
-        if b.engine.params is None or b.engine.device != device or not b.packed():
+        if b.engine._params is None or b.engine.device != device or not b.packed():
             b.materialize(device)
         else:
             b.ensure(device)

@@ -41,7 +41,7 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
             # revalidation on EVERY call: each gradient is still the arena view it was when the engine was recognised (a foreign
             # tensor bound to .grad - a clone, an unscaled copy, None for a frozen parameter - sends the call to torch's implementation),
             # and the arenas themselves have not moved (a re-materialised module re-packs).  One data_ptr() per parameter.
-            if eng.params is None or eng.grads is None or eng.grads.data_ptr() != cached[3]:
+            if eng._params is None or eng._grads is None or eng._grads.data_ptr() != cached[3]:
                 eng = None
             else:
                 for p, want in zip(params, cached[2]):
@@ -56,7 +56,7 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
             if eng is not None:
                 import weakref
                 _CLIP_CACHE.clear()
-                _CLIP_CACHE[sig[0]] = (sig, weakref.ref(eng), [None if raw_grad(p) is None else raw_grad(p).data_ptr() for p in params], eng.grads.data_ptr())
+                _CLIP_CACHE[sig[0]] = (sig, weakref.ref(eng), [None if raw_grad(p) is None else raw_grad(p).data_ptr() for p in params], eng._grads.data_ptr())
     if eng is None:
         return _torch_clip_grad_norm_(params, max_norm, norm_type=norm_type, error_if_nonfinite=error_if_nonfinite, foreach=foreach)
     binding = getattr(eng, "_binding_ref", None)
@@ -76,11 +76,11 @@ _CLIP_CACHE = {}
 
 def engine_view_offset(eng, p):
     """element offset of parameter p in the engine's arena if p AND p.grad are the arena views, else None"""
-    off = p.data_ptr() - eng.params.data_ptr()
+    off = p.data_ptr() - eng._params.data_ptr()
     if off < 0 or off % 4 or off // 4 + p.numel() > eng.arena_elems or p.dtype != torch.float32:
         return None
     g = raw_grad(p)
-    if g is not None and g.data_ptr() != eng.grads.data_ptr() + off:
+    if g is not None and g.data_ptr() != eng._grads.data_ptr() + off:
         return None
     return off // 4
 
@@ -91,7 +91,7 @@ def _arena_engine_of(params):
     if not live or not live[0].is_cuda:
         return None
     eng = _engine.engine_of(live[0].data_ptr())
-    if eng is None or eng.grads is None:
+    if eng is None or eng._grads is None:
         return None
     covered = 0
     for p in live:
@@ -201,6 +201,12 @@ class BertAdam(Optimizer):
                 r["m"] = r["v"] = None
         return runs
 
+    def zero_grad(self, set_to_none=True):
+        if not set_to_none:      # zeroing in place writes the gradient arena: an update still running beside the forward pass reads it
+            for eng in list(_engine.ARENAS.values()):
+                eng.join_update()
+        return super().zero_grad(set_to_none=set_to_none)
+
     def step(self, closure=None):
         loss = None
         if closure is not None:
@@ -238,6 +244,17 @@ class BertAdam(Optimizer):
                 fold[key] = (_lib.ptr(eng._sumsq), float(eng._pending_clip))
             else:
                 eng.flush_deferred_clip()
+        # ---- an engine whose EVERY live parameter this call updates through the fused path, with its operand copies current, takes the update
+        # beside its next forward pass (Engine._update_beside_forward: gradient segment by gradient segment in forward order on a stream of its
+        # own, the forward waiting per layer) - what the engine-direct adam_step does; RGQA_ADAM_OVERLAP=0 keeps it on this stream
+        beside = {}
+        for key, (eng, n_cov) in cover.items():
+            if n_cov != self._live_numel(eng) or not getattr(eng, "adam_overlap", False) or eng._params_lp is None or eng.num_weight_segments() <= 0:
+                continue
+            b = getattr(eng, "_binding_ref", None)
+            b = b() if b is not None else None
+            if b is not None and b.in_sync():
+                beside[key] = (eng, b, [])
         # ---- pass 2: the update launches
         for group, runs in work:
             if stream is None:
@@ -262,19 +279,24 @@ class BertAdam(Optimizer):
                     eng = self._run_engine(r)
                     if eng is not None:
                         sumsq, max_norm = fold.get(id(eng), (None, 0.0))
-                    if eng is not None and eng.params_lp is not None:
-                        off = (r["p0"] - eng.params.data_ptr()) // 4
-                        lp_split = 1 if eng.precision in ("bf16x3", "bf16x3_fwd") else 0
-                        lp = C.c_void_p(eng.params_lp.data_ptr() + off * eng.params_lp.element_size())
-                        ent = touched.setdefault(id(eng), [eng, 0, None])
-                        ent[1] += r["numel"]
-                        if ent[2] is None:
-                            b = getattr(eng, "_binding_ref", None)
-                            b = b() if b is not None else None
-                            ent[2] = b if (b is not None and b.in_sync()) else False
-                    _lib.check(lib.rgqa_bertadam_step(C.c_void_p(r["p0"]), C.c_void_p(r["g0"]), _lib.ptr(r["m"]), _lib.ptr(r["v"]), lp, lp_split,
-                                                      r["n"], lr_scheduled, group['b1'], group['b2'], group['e'], group['weight_decay'],
-                                                      sumsq, max_norm, 1.0, stream))
+                    if eng is not None and id(eng) in beside:
+                        # launched below, cut at the gradient segments' boundaries: (arena offset, elements, this run's arguments)
+                        off = (r["p0"] - eng._params.data_ptr()) // 4
+                        beside[id(eng)][2].append((off, r["n"], r, (lr_scheduled, group['b1'], group['b2'], group['e'], group['weight_decay'], sumsq, max_norm)))
+                    else:
+                        if eng is not None and eng._params_lp is not None:
+                            off = (r["p0"] - eng._params.data_ptr()) // 4
+                            lp_split = 1 if eng.precision in ("bf16x3", "bf16x3_fwd") else 0
+                            lp = C.c_void_p(eng._params_lp.data_ptr() + off * eng._params_lp.element_size())
+                            ent = touched.setdefault(id(eng), [eng, 0, None])
+                            ent[1] += r["numel"]
+                            if ent[2] is None:
+                                b = getattr(eng, "_binding_ref", None)
+                                b = b() if b is not None else None
+                                ent[2] = b if (b is not None and b.in_sync()) else False
+                        _lib.check(lib.rgqa_bertadam_step(C.c_void_p(r["p0"]), C.c_void_p(r["g0"]), _lib.ptr(r["m"]), _lib.ptr(r["v"]), lp, lp_split,
+                                                          r["n"], lr_scheduled, group['b1'], group['b2'], group['e'], group['weight_decay'],
+                                                          sumsq, max_norm, 1.0, stream))
                 else:
                     for p in r["params"]:
                         st = self.state[p]
@@ -293,6 +315,21 @@ class BertAdam(Optimizer):
                 if binding and n_upd == self._live_numel(eng):
                     eng.sync_transposed()
                     binding.mark_synced()
+        for eng, binding, pieces in beside.values():
+            lp_split = 1 if eng.precision in ("bf16x3", "bf16x3_fwd") else 0
+            lp_base, lp_es = eng._params_lp.data_ptr(), eng._params_lp.element_size()
+
+            def update(a, b, st, pieces=pieces, lp_split=lp_split, lp_base=lp_base, lp_es=lp_es):
+                # the part of every run that lies in arena elements [a, b)
+                for off, n, r, (lr_s, b1, b2, e_, wd, sumsq, max_norm) in pieces:
+                    lo, hi = max(a, off), min(b, off + n)
+                    if hi > lo:
+                        d = lo - off
+                        _lib.check(lib.rgqa_bertadam_step(C.c_void_p(r["p0"] + 4 * d), C.c_void_p(r["g0"] + 4 * d), C.c_void_p(r["m"].data_ptr() + 4 * d),
+                                                          C.c_void_p(r["v"].data_ptr() + 4 * d), C.c_void_p(lp_base + lo * lp_es), lp_split, hi - lo,
+                                                          lr_s, b1, b2, e_, wd, sumsq, max_norm, 1.0, st))
+            eng._update_beside_forward(update)          # ... and the transposed copies behind the last segment
+            binding.mark_synced()
         for key in fold:
             cover[key][0].drop_deferred_clip()          # consumed: the update used g * coef; the .grad views keep the unclipped gradients
         return loss
@@ -309,8 +346,8 @@ class BertAdam(Optimizer):
         """the engine whose arenas the run lies in - parameters in its parameter arena, gradients at the same offsets of its gradient arena - or None"""
         ref = r.get("eng")
         eng = ref() if ref is not None else None
-        if eng is None or eng.params is None or eng.grads is None:
+        if eng is None or eng._params is None or eng._grads is None:
             return None
-        if r["g0"] - eng.grads.data_ptr() != r["p0"] - eng.params.data_ptr():
+        if r["g0"] - eng._grads.data_ptr() != r["p0"] - eng._params.data_ptr():
             return None
         return eng

@@ -177,6 +177,46 @@ def test_encoder_alone_under_a_foreign_head(env):
     os.remove(path + "_LXRT.pth")
 
 
+def test_trainer_step_with_the_update_beside_the_next_forward(env, monkeypatch):
+    """The drop-in BertAdam.step hands the update to the engine's pass beside the next forward (round 5; RGQA_ADAM_OVERLAP=0 keeps it on the
+    step's stream) when it covers every live parameter: the unchanged trainer loop then ends in the same parameters bit for bit, a
+    state_dict() taken right after optimizer.step() - no synchronisation, no forward in between - holds the finished update (the module's
+    state_dict hook joins the update stream), and zero_grad(set_to_none=False) cannot overtake the update that still reads the gradients."""
+    import lxrt.entry  # noqa: F401
+    from lxrt.optimization import BertAdam
+    feats, boxes, target = batch(20)
+    res = {}
+    for ov in ("0", "1"):
+        monkeypatch.setenv("RGQA_ADAM_OVERLAP", ov)
+        m, _ = build("bf16", 20)
+        m.train()
+        eng = m.lxrt_encoder.model._binding.engine
+        assert eng.adam_overlap == (ov == "1")
+        optim = BertAdam(list(m.parameters()), lr=1e-3, warmup=0.1, t_total=20)
+        snaps = []
+        for step in range(4):
+            optim.zero_grad(set_to_none=(step % 2 == 0))
+            logit = m(feats.cuda(), boxes.cuda(), SENTS)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, target.cuda()) * logit.size(1)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 5.)
+            optim.step()
+            assert (eng._upd_done is not None) == (ov == "1")          # the pass really runs beside what follows
+            if step == 2:
+                snaps.append({k: v.clone() for k, v in m.state_dict().items()})
+                torch.cuda.synchronize()
+                snaps.append({k: v.clone() for k, v in m.state_dict().items()})
+        assert all(torch.equal(snaps[0][k], snaps[1][k]) for k in snaps[0])
+        torch.cuda.synchronize()
+        res[ov] = {k: v.detach().clone() for k, v in m.named_parameters()}
+    emb = ("embeddings.word_embeddings", "embeddings.position_embeddings", "embeddings.token_type_embeddings")
+    for k in res["0"]:
+        if any(t in k for t in emb):
+            assert torch.allclose(res["0"][k], res["1"][k], rtol=1e-4, atol=1e-6), k      # float-atomic scatter-add: to rounding
+        else:
+            assert torch.equal(res["0"][k], res["1"][k]), k
+
+
 @pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
 def test_trainer_step_fused_clip_and_operand_copies(env, precision, monkeypatch):
     """The unchanged trainer's `nn.utils.clip_grad_norm_` + `BertAdam.step` (tasks/gqa_conf.py:201-202) through the drop-in's fast paths:

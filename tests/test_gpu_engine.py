@@ -695,6 +695,51 @@ def test_dgrad_on_the_weights_as_they_lie_gives_the_same_gradients():
     assert torch.equal(res[0][1][first:], res[1][1][first:])
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f32", "bf16x3_fwd"])
+def test_optimizer_pass_beside_the_next_forward_is_the_serial_step(prec):
+    """Engine.adam_step(overlap=True) (round 5, the default): BertAdam runs on a stream of its own, gradient segment by gradient segment in forward
+    order, while the caller's stream goes straight on to the next forward pass, whose layers wait for the event of their segment; the
+    transposed copies follow behind the last segment and the next backward waits for them.  Same kernels on the same ranges: parameters, Adam
+    moments and both operand copies equal the serial step's bit for bit after four steps (compared behind the embedding tables, whose
+    gradients are scatter-added by float atomics: those to rounding), and an arena read through the engine's attributes right after adam_step -
+    no synchronisation - already sees the finished update (the properties join the update stream)."""
+    cfg = FULL if prec != "f32" else MED
+    B, T, O = (24, 20, 36) if prec != "f32" else (6, 12, 10)
+    raw = synth.synth_batch(B, T, O=O, F=cfg["feat_dim"], NA=cfg["num_answers"], vocab=cfg["vocab_size"], seed=12, min_len=3)
+    b = dev(raw)
+    lens = np.ascontiguousarray(raw["lengths"], dtype=np.int32)
+    res = {}
+    for ov in (False, True):
+        e = make_engine(cfg, prec, dropout=0.1)
+        e.ensure_shape(B, T, O)
+        e.sync_weights()
+        e.enable_segment_sumsq(True)
+        assert e.num_weight_segments() > 0
+        early = None
+        for step in range(4):
+            e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=3 + step, lengths=lens)
+            e.loss_backward(b["target"])
+            e.adam_step(1e-3, max_norm=5.0, overlap=ov)
+            assert (e._upd_done is not None) == ov
+            if step == 1:
+                early = e.params.clone()            # read through the property: joins the update stream first
+                torch.cuda.synchronize()
+                assert torch.equal(early, e.params)
+        torch.cuda.synchronize()
+        res[ov] = [t.clone() for t in (e.params, e.adam_m, e.adam_v)] + ([e.params_lp.clone(), e.params_lp_t.clone()] if prec == "bf16" else [])
+    first = max(sp.offset + sp.numel for sp in e.specs if "embeddings" in sp.name and "LayerNorm" not in sp.name and "visn" not in sp.name)
+    for a, c in zip(res[False], res[True]):
+        if prec == "bf16":
+            assert torch.equal(a[first:], c[first:])
+            assert torch.allclose(a[:first].float(), c[:first].float(), rtol=1e-4, atol=1e-6)
+        else:
+            # f32-precise gradients: the tables' float-atomic scatter-add rounds differently from run to run, the clip coefficient with it, and
+            # BertAdam moves an element whose tiny gradient changes sign by up to 3.2 lr per step whatever its size (tests/test_gpu_dp.py): the
+            # mean is the meaningful bound between two RUNS of this engine, whichever stream the update took
+            d = (a - c).abs()
+            assert float(d.max()) < 1.3e-2 and float(d.mean()) < 1e-6, (float(d.max()), float(d.mean()))
+
+
 @pytest.mark.parametrize("B,varlen", [(48, True), (48, False), (256, True), (3, True)])
 def test_layernorm_inside_the_projection_launch_is_the_separate_kernel(B, varlen):
     """Round 5: the LayerNorm behind every attention-output / FFN-output projection of the bf16 engine is done inside the projection's launch by the
