@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline view of a rocprofv3 --kernel-trace CSV: for the steady-state steps (delimited by the big bertadam launch) print
+"""Timeline view of a rocprofv3 --kernel-trace CSV: for two steady-state steps (delimited by the first kernel of a forward pass) print
 per-queue busy time, time with NO kernel resident on any queue, and the largest idle gaps of the main queue with the
 kernels either side. usage: tools/timeline.py <kernel_trace.csv> [n_gaps]"""
 import csv, sys
@@ -12,11 +12,12 @@ with open(sys.argv[1]) as f:
 rows.sort()
 ngaps = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # optimizer launches per step (the drop-in BertAdam: one per contiguous run = 3)
-adam = [i for i, r in enumerate(rows) if "bertadam" in r[3] and r[1] - r[0] > (300000 if per_step == 1 else 20000)]
-if len(adam) < 2 * per_step + 1:
-    sys.exit("need >= %d optimizer launches" % (2 * per_step + 1))
-lo, hi = adam[-1 - 2 * per_step], adam[-1]          # two full steps: end of the last optimizer launch of step n-2 .. end of step n's
-t0, t1 = rows[lo][1], rows[hi][1]
+# steps are delimited by the first kernel of a forward pass (round 5: the optimizer no longer runs as one long launch - it is cut at the gradient
+# segments and runs beside the next forward)
+fw = [i for i, r in enumerate(rows) if "embed_fwd" in r[3]]
+if len(fw) < 3:
+    sys.exit("need >= 3 forward passes in the trace")
+t0, t1 = rows[fw[-3]][0], rows[fw[-1]][0]          # two full steps: forward start of step n-2 .. forward start of step n
 span = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 nsteps = 2
 print("window: %.3f ms over %d steps = %.3f ms/step, %d launches/step" % ((t1 - t0) / 1e6, nsteps, (t1 - t0) / 1e6 / nsteps, len(span) / nsteps))
