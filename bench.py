@@ -682,7 +682,7 @@ def main():
     # the step without any exchange -> what the exchange costs beyond what backward hides; the reference's padded layout
     dp_legs = None
     if dist is not None and not args.lean:
-        n2 = max(3, min(args.steps, 10))
+        n2 = max(3, min(args.steps, 40))       # (10 until round 5: a leg that short carries its own start-up and drain, +0.3..0.6 ms per step)
         dp_legs = {"mode": comm.describe(), "ms_per_step": round(ms, 3)}
         comm.release()                               # every rank holds the full optimizer state again
         if hasattr(comm, "overlap"):
@@ -706,7 +706,7 @@ def main():
     state["comm"] = None          # everything below runs on rank-local state (replicas may diverge from here on: nothing is exchanged again)
     padded_leg = None
     if lengths is not None and not (args.butd or args.uniter or args.mixup or args.lean):
-        n2 = max(3, min(args.steps, 10))
+        n2 = max(3, min(args.steps, 40))       # (10 until round 5: a leg that short carries its own start-up and drain, +0.3..0.6 ms per step)
         state["lengths"] = None
         for _ in range(2):
             step(exchange=False)

@@ -68,6 +68,11 @@ int rgqa_version(void);
  * key 19: 1 = the bf16 engine's LayerNorms behind the attention-output / FFN-output projections are done inside the projection's launch by the
  * workgroup that finishes a row block last, 0 (default: same step time) = separate LayerNorm launches; bit-identical results either way. */
 int rgqa_debug_set(int key, int value);
+/* The library runs the deferred weight-gradient GEMMs on ONE side stream per device, shared by every engine of the process.  By default it makes
+ * that stream itself when the first engine is bound; a caller that knows better hands one in BEFORE that (the Python binding does: HIP maps streams
+ * onto a handful of hardware queues, and a side stream that shares a queue with the launch stream serialises with it - rgqa_amd/streams.py picks
+ * streams that demonstrably run beside the caller's).  The stream must outlive every engine. */
+int rgqa_set_side_stream(int device, void* stream);
 
 /* ---- host text path: replaces the per-batch Python loop convert_sents_to_features (lxrt/entry.py:36-71) over
  * BertTokenizer.tokenize (lxrt/tokenization.py:174-348) for pure-ASCII sentences. vocab_path: one wordpiece per line

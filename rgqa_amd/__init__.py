@@ -1,0 +1,1 @@
+"""rgqa_amd: the LXMERT-GQA train-step hot path on MI355X."""

@@ -49,6 +49,7 @@ SIGNATURES = {
     "rgqa_engine_set_weight_event": [_vp, _i, _vp],
     "rgqa_engine_set_backward_event": [_vp, _vp],
     "rgqa_engine_num_weight_segments": [_vp, C.POINTER(_i)],
+    "rgqa_set_side_stream": [_i, _vp],
     "rgqa_engine_profile": [_vp, _i],
     "rgqa_engine_profile_read": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _i],
     "rgqa_engine_profile_blocks": [_vp, _vp, _vp, _i],

@@ -28,6 +28,14 @@ extern int g_rgqa_wgrad_sets;
 extern int g_rgqa_dgrad_nn;
 extern int g_rgqa_butd_gru_persist;
 extern int g_rgqa_ln_fuse;
+int rgqa_set_side_stream(int device, void* stream) {
+    RGQA_REQUIRE(device >= 0 && stream != nullptr, "set_side_stream: bad argument");
+    std::lock_guard<std::mutex> lk(rgqa_side_stream_mutex());
+    auto& m = rgqa_side_streams();
+    RGQA_REQUIRE(m.find(device) == m.end() || m[device] == reinterpret_cast<hipStream_t>(stream), "set_side_stream: device %d already has a side stream (set it before the first engine is bound)", device);
+    m[device] = reinterpret_cast<hipStream_t>(stream);
+    return RGQA_OK;
+}
 // debug / test switches (include/rgqa.h)
 int rgqa_debug_set(int key, int value) {
     if (key == 0) { g_rgqa_force_gemm128 = value; return RGQA_OK; }

@@ -145,3 +145,8 @@ public:
 };
 
 EngineBase* make_engine(const rgqa_config& cfg);
+// the weight-gradient side stream, one per device for all engines of the process (engine.hip make_side_stream; rgqa_set_side_stream)
+#include <map>
+#include <mutex>
+std::mutex& rgqa_side_stream_mutex();
+std::map<int, hipStream_t>& rgqa_side_streams();

@@ -1,5 +1,7 @@
 // Engine implementation: parameter table, workspace plan, forward and backward launch sequences.
 #include "engine.h"
+#include <map>
+#include <mutex>
 
 int g_rgqa_cls_tail = -1;   // rgqa_debug_set key 8: 1 / 0 = last language FFN on the [CLS] rows only / on every row; -1 = env RGQA_CLS_TAIL (default on)
 #include <string.h>
@@ -157,6 +159,8 @@ int g_rgqa_skip_wgrad = 0;     // rgqa_debug_set(5, v): MEASUREMENT ONLY - the d
 int g_rgqa_wgrad_merge = 0;    // rgqa_debug_set(6, v): periods per weight-gradient launch (1 .. WGRAD_MERGE_MAX); 0 = default
 #define WGRAD_MERGE_DEFAULT 3
 extern int g_rgqa_force_gemm128;
+std::mutex& rgqa_side_stream_mutex() { static std::mutex m; return m; }
+std::map<int, hipStream_t>& rgqa_side_streams() { static std::map<int, hipStream_t> m; return m; }
 int g_rgqa_ln_fuse = 0;        // rgqa_debug_set(19, v): 1 = the bf16 engine's LayerNorms behind the attention-output / FFN-output projections ride in the GEMM launch
                                // (gemm256_dev.h nt256_ln_after_tile), bit-identical to the separate launches (tests/test_gpu_engine.py).  Default 0: measured, no gain -
                                // the rows come back from the memory side of the L2s either way, so the launch grows by 7 us where the separate kernel took 10
@@ -259,6 +263,33 @@ public:
     TB *gA = nullptr, *gB = nullptr, *gctx = nullptr;
     TB *gz_s[NPAR][3] = {}, *gzd_s[NPAR][3] = {}, *gqkv_s[NPAR][3] = {}, *gh_s[NPAR][3] = {};   // [ring position of the launch period][stage slot]
     hipStream_t s_w = nullptr;                 // side stream: the deferred weight-gradient GEMMs of a layer run beside the next layer's chain
+    // Made at bind(), not at the first backward: HIP hands streams to its hardware queues in creation order, and which queue a stream shares with
+    // which other decides whether two streams really run side by side (round 5: with a RCCL communicator in the process and two to four other
+    // streams made first, this stream - or the update stream - landed on a queue where it serialised with the launch stream: 18-20 ms per
+    // step instead of 11; tools/rccl_presence3.py).  Engine streams first, in a fixed order, whatever the caller makes later.
+    // ONE side stream per device for all engines of the process (a process makes several: bench.py's legs, a trainer's train / eval models): they
+    // run one after the other anyway, and every further stream is one more chance to share a hardware queue with the launch stream.
+    int make_side_stream() {
+        if (s_w != nullptr) return RGQA_OK;
+        int dev = 0;
+        RGQA_HIP(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(rgqa_side_stream_mutex());
+            auto& shared = rgqa_side_streams();
+            auto it = shared.find(dev);
+            if (it == shared.end()) {       // nobody handed one in (rgqa_set_side_stream): make one
+                hipStream_t st = nullptr;
+                RGQA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                it = shared.emplace(dev, st).first;
+            }
+            s_w = it->second;
+        }
+        for (int i = 0; i < NPAR; ++i) {
+            RGQA_HIP(hipEventCreateWithFlags(&ev_chain[i], hipEventDisableTiming));
+            RGQA_HIP(hipEventCreateWithFlags(&ev_wdone[i], hipEventDisableTiming));
+        }
+        return RGQA_OK;
+    }
     hipEvent_t ev_chain[NPAR] = {}, ev_wdone[NPAR] = {};
     bool wdone_valid[NPAR] = {};
     TB* gemb = nullptr;
@@ -356,13 +387,7 @@ public:
         const bool on_main = serial || g_rgqa_wgrad_serial || profiling;
         hipStream_t st = s;
         if (!on_main) {
-            if (s_w == nullptr) {
-                RGQA_HIP(hipStreamCreateWithFlags(&s_w, hipStreamNonBlocking));
-                for (int i = 0; i < NPAR; ++i) {
-                    RGQA_HIP(hipEventCreateWithFlags(&ev_chain[i], hipEventDisableTiming));
-                    RGQA_HIP(hipEventCreateWithFlags(&ev_wdone[i], hipEventDisableTiming));
-                }
-            }
+            if (int r = make_side_stream()) return r;
             const int par = pend_par[pend_n - 1];
             RGQA_HIP(hipEventRecord(ev_chain[par], s));
             RGQA_HIP(hipStreamWaitEvent(s_w, ev_chain[par], 0));
@@ -618,6 +643,7 @@ public:
         size_t need = workspace_bytes(B_, T_, O_);
         if (wb < need) { rgqa_set_error("bind: workspace too small (%zu < %zu bytes)", wb, need); return RGQA_ERR_WORKSPACE; }
         P = p; G = g; Pb = (T*)plp; PbT = (TB*)plpt; ws = (char*)w; ws_bytes_ = wb;
+        if (int r = make_side_stream()) return r;
         plan(B_, T_, O_);
         RGQA_HIP(hipMemset(sumsq_ws, 0, sizeof(float) * (size_t)sumsq_ws_segs * SUMSQ_WS_STRIDE));       // the ticket words of k_sumsq_owned start at zero
         RGQA_HIP(hipMemset(ln_tk, 0, sizeof(int) * 2 * LN_TK_PER_PROBLEM));                               // ... and so do the fused LayerNorms' (the last arriver of a row block re-zeroes its own)

@@ -17,6 +17,23 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_UPD_STREAMS = {}
+_SIDE_SET = {}
+
+
+def _update_stream(device):
+    """ONE update stream per device for every engine of the process (like the library's weight-gradient side stream, csrc/engine.hip
+    make_side_stream): engines run one after the other, and streams are a scarce resource - HIP maps them onto a handful of hardware queues
+    in creation order, and a stream that ends up sharing a queue with the launch stream serialises with it (bench.py's legs make six
+    engines: with a stream each, a later leg ran at 33 ms per step instead of 23)."""
+    key = (device.type, device.index)
+    st = _UPD_STREAMS.get(key)
+    if st is None:
+        from . import streams
+        st = _UPD_STREAMS[key] = streams.pick(device, 3)[1]      # [0] is the library's weight-gradient side stream, [2] the second exchange stream
+    return st
+
+
 _RAW_GRAD = torch.Tensor.grad          # the C-level .grad descriptor
 
 
@@ -93,7 +110,7 @@ class Engine:
         self._adam_m = self._adam_v = None
         self._seg_sumsq = None
         self._seg_sumsq_valid = False
-        self._upd_stream = self._upd_done = None
+        self._upd_stream = self._upd_done = self._upd_order = None
         self.adam_overlap = os.environ.get("RGQA_ADAM_OVERLAP", "1") != "0"      # adam_step's default for `overlap` (see _update_beside_forward)
         self._pending_clip = None        # max_norm of a deferred clip_grads_ (lxrt.optimization.clip_grad_norm_ -> BertAdam.step), else None
         self._sharded_owner = None       # set by parallel.ShardedExchange while the f32 masters / Adam moments are valid on their owner rank only
@@ -168,8 +185,17 @@ class Engine:
         if self.workspace is None or self.workspace.numel() < need.value:
             self.workspace = None
             self.workspace = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        if self.device.type == "cuda" and (self.device.type, self.device.index) not in _SIDE_SET:
+            # the library's weight-gradient side stream: one per device, picked so that it runs beside the caller's stream (streams.py)
+            from . import streams
+            _SIDE_SET[(self.device.type, self.device.index)] = sw = streams.pick(self.device, 3)[0]
+            check(self.lib.rgqa_set_side_stream(self.device.index, C.c_void_p(sw.cuda_stream)))
         check(self.lib.rgqa_engine_bind(self.h, ptr(self._params), ptr(self._grads), ptr(self._params_lp), ptr(self._params_lp_t),
                                         ptr(self.workspace), self.workspace.numel(), B, T, O))
+        if self._upd_stream is None and self.device.type == "cuda":
+            # right behind the engine's own side stream (made by bind), before anything the caller makes: which hardware queue a stream lands
+            # on - and with whom it shares it - follows the creation order (csrc/engine.hip make_side_stream)
+            self._upd_stream = _update_stream(self.device)
         self.shape = (B, T, O)
         na, H = self.cfg.num_answers, self.cfg.hidden
         self._io = dict(logits=torch.empty(B, na, dtype=torch.float32, device=self.device),
@@ -397,8 +423,9 @@ class Engine:
         goes straight on to the next forward.  Whoever reads the parameters OUTSIDE the engine (state_dict, a checkpoint, a test) first calls
         join_update() - or synchronises the device."""
         cur = torch.cuda.current_stream(self.device)
-        if self._upd_stream is None:
-            self._upd_stream = torch.cuda.Stream(device=self.device)      # (stream priorities make no difference: measured)
+        if self._upd_order is None:
+            if self._upd_stream is None:
+                self._upd_stream = _update_stream(self.device)      # (stream priorities make no difference: measured)
             by_ev = {}
             for a, b, ev in self.grad_segments():
                 by_ev.setdefault(ev, []).append((a, b))

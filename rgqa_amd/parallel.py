@@ -121,6 +121,25 @@ class _HipOps:
                                       ptr(sq_ws) if sq_out is not None else None, ptr(sq_out), self._s()))
 
 
+_DP_STREAMS = {}
+
+
+def _engine_stream(engine, k, device):
+    """the k-th exchange stream of an engine: ONE set per engine, shared by every exchange object made for it (bench.py makes three in a run:
+    the mode under test, its counterpart, the fallback) - streams are mapped onto a handful of hardware queues in creation order, and every
+    further stream is one more chance to share a queue with the launch stream (csrc/engine.hip make_side_stream)"""
+    pool = _DP_STREAMS.setdefault((device.type, device.index), {})
+    if k not in pool:
+        # stream 0 IS the engine's update stream (the optimizer pass beside the forward; made when the engine was bound): the exchange uses it
+        # during backward and for the weight gather, the update runs between the two - one stream fewer to place
+        upd = getattr(engine, "_upd_stream", None) if k == 0 else None
+        if upd is None and device.type == "cuda":
+            from . import streams
+            upd = streams.pick(device, 3)[1 if k == 0 else 2]      # picked to run beside the caller's stream and beside each other
+        pool[k] = upd if upd is not None else torch.cuda.Stream(device=device)
+    return pool[k]
+
+
 class GradAllReduce:
     """modes 'allreduce' / 'allreduce_bf16'"""
 
@@ -165,7 +184,7 @@ class GradAllReduce:
             hs = [self._reduce_bucket(g, a, b) for a, b, _ in self.buckets]
         else:
             if self.side is None:
-                self.side = torch.cuda.Stream(device=g.device)
+                self.side = _engine_stream(self.e, 0, g.device)
             for a, b, ev in self.buckets:
                 with torch.cuda.stream(self.side):
                     self.e.wait_grad_event(ev, self.side)
@@ -326,10 +345,10 @@ class ShardedExchange:
         # segments become final in bursts of several chunks - the last bursts are what backward cannot hide; round 5: one stream walked them
         # cast -> wire -> sum, chunk after chunk).  RGQA_DP_EXCHANGE_STREAMS=1 restores the single stream.
         if self.side is None:
-            self.side = torch.cuda.Stream(device=g.device)
+            self.side = _engine_stream(self.e, 0, g.device)
         two = self.nstreams > 1 and len(self.chunks) > 1
         if two and self.side2 is None:
-            self.side2 = torch.cuda.Stream(device=g.device)
+            self.side2 = _engine_stream(self.e, 1, g.device)
             self._stage.append((torch.zeros_like(self._send), torch.zeros_like(self._recv)))
             self._sumsq2 = torch.zeros(1, dtype=torch.float32, device=g.device)
             self._sqws2 = torch.zeros(2048, dtype=torch.float32, device=g.device)
@@ -440,7 +459,7 @@ class ShardedExchange:
                 self.dist.all_reduce(pack)
             e.params[self._small_idx] = pack
         if self.side is None:
-            self.side = torch.cuda.Stream(device=e.grads.device)
+            self.side = _engine_stream(e, 0, e.grads.device)
         updated = torch.cuda.Event()
         updated.record(cur)
         evs = []
