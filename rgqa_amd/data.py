@@ -112,7 +112,10 @@ class DeviceBatcher(object):
         self.lib = _lib.load()
         O, F = store.O, store.F
         tdt = torch.float16 if store.dtype == "f16" else torch.float32
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        from . import streams
+        # a stream shown to run beside the caller's (streams.py): the third of the device's set - the sharded exchange's second stream, which
+        # the trainer loop that feeds from a DeviceBatcher (all-reduce exchange) does not use
+        self.copy_stream = streams.pick(self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device()), 3)[2]
         self.sets = []
         for _ in range(2):
             s = {"feats_h": torch.empty(self.maxB, O, F, dtype=tdt).pin_memory(), "boxes_h": torch.empty(self.maxB, O, 4).pin_memory(),
