@@ -183,11 +183,13 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const AdamArgs a) {
     adam_tail(a, coef, nv);
 }
 
+int g_rgqa_adam_blocks = 2048;      // rgqa_debug_set key 20: cap on the update kernel's (grid-stride) grid
 int k_bertadam(const AdamArgs& a, hipStream_t s) {
     if (a.n == 0) return RGQA_OK;
     RGQA_REQUIRE(((uintptr_t)a.p % 16) == 0 && ((uintptr_t)a.g % 16) == 0 && ((uintptr_t)a.m % 16) == 0 && ((uintptr_t)a.v % 16) == 0, "bertadam: 16-byte alignment required");
     size_t nb = (a.n / 4 + 255) / 256;
-    int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
+    const size_t cap = g_rgqa_adam_blocks > 0 ? (size_t)g_rgqa_adam_blocks : 2048;
+    int nblk = nb > cap ? (int)cap : (nb < 1 ? 1 : (int)nb);
     hipLaunchKernelGGL(bertadam_kernel<true>, dim3(nblk), dim3(256), 0, s, a);
     RGQA_LAUNCH_CHECK("bertadam_kernel");
     return RGQA_OK;
