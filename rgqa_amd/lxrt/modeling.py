@@ -142,6 +142,9 @@ def _build_tree(root, specs, prefix):
     return leaves
 
 
+_RAW_DATA = torch.Tensor.data          # the C-level .data descriptor
+
+
 class ArenaParameter(nn.Parameter):
     """nn.Parameter whose data / .grad are views of an engine's arenas.  The ONLY behavioural difference to nn.Parameter: reading `.grad` first
     materialises a deferred `clip_grad_norm_` (lxrt.optimization.clip_grad_norm_ leaves the clip coefficient with the engine so that
@@ -166,6 +169,26 @@ class ArenaParameter(nn.Parameter):
     @grad.deleter
     def grad(self):
         _RAW_GRAD.__delete__(self)
+
+    # `.data` - how loggers, initialisers and checkpoint code usually reach a parameter's values - first puts the caller's stream behind an
+    # optimizer pass that may still be running beside the forward pass (Engine._update_beside_forward; a stream-side wait, free when none is)
+    @property
+    def data(self):
+        ref = self.__dict__.get("_rgqa_binding")
+        if ref is not None:
+            b = ref()
+            if b is not None and b.engine is not None:
+                b.engine.join_update()
+        return _RAW_DATA.__get__(self, type(self))
+
+    @data.setter
+    def data(self, value):
+        ref = self.__dict__.get("_rgqa_binding")
+        if ref is not None:
+            b = ref()
+            if b is not None and b.engine is not None:
+                b.engine.join_update()
+        _RAW_DATA.__set__(self, value)
 
 
 class ArenaBinding(object):

@@ -206,6 +206,10 @@ def test_trainer_step_with_the_update_beside_the_next_forward(env, monkeypatch):
                 snaps.append({k: v.clone() for k, v in m.state_dict().items()})
                 torch.cuda.synchronize()
                 snaps.append({k: v.clone() for k, v in m.state_dict().items()})
+            if step == 3:       # ... and so does `.data`, the way loggers and checkpoint code usually reach a parameter (ArenaParameter.data joins too)
+                early = {k: p.data.clone() for k, p in m.named_parameters()}
+                torch.cuda.synchronize()
+                assert all(torch.equal(early[k], p.detach()) for k, p in m.named_parameters())
         assert all(torch.equal(snaps[0][k], snaps[1][k]) for k in snaps[0])
         torch.cuda.synchronize()
         res[ov] = {k: v.detach().clone() for k, v in m.named_parameters()}
