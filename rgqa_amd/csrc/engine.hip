@@ -1406,8 +1406,8 @@ public:
         prof_block = PB_EMBED;
         if (joint) {
             CK(backward_joint_embeddings(dyp[0], accumulate, s));
-            CK(join_wgrad(par, s));
             CK(mark_segment(s));
+            CK(join_wgrad(par, s));
             return RGQA_OK;
         }
         TB* gz = gemb;
@@ -1460,8 +1460,11 @@ public:
                 CK(r);
             }
         }
-        CK(join_wgrad(par, s));      // everything on the side stream has joined the caller's stream before backward returns
-        CK(mark_segment(s));     // embeddings + visual embedding
+        // embeddings + visual embedding: every gradient of this segment was computed on the caller's stream, so its event and its share of the clip
+        // norm (23 us for the tables) need not wait for the side stream - they run while the side stream finishes the first layer's shares;
+        // only then is everything on the side stream joined to the caller's stream (round 5: the other order left 50 us of the step idle)
+        CK(mark_segment(s));
+        CK(join_wgrad(par, s));
         return RGQA_OK;
     }
 
