@@ -396,7 +396,10 @@ public:
         for (int k = 0; k < pend_n; ++k) if (int r = fin_flush(pend_fin[k], pend_acc[k], st)) return r;
         if (int r = run_wgrad(wgm, st)) return r;
         gg_init(wgm);
-        for (int k = 0; k < pend_marks; ++k) if (int r = mark_segment(st)) return r;
+        sq_defer = true;
+        for (int k = 0; k < pend_marks; ++k) if (int r = mark_segment(st)) { sq_defer = false; return r; }
+        sq_defer = false;
+        if (int r = k_sumsq_owned_group(sq_batch, st)) return r;
         if (!on_main)
             for (int k = 0; k < pend_n; ++k) {
                 RGQA_HIP(hipEventRecord(ev_wdone[pend_par[k]], s_w));
@@ -436,12 +439,15 @@ public:
             if (sumsq_slots != nullptr && sumsq_ws != nullptr)
                 for (int k = 0; k < (int)grad_segs.size() && k < sumsq_ws_segs; ++k)
                     if (grad_segs[k].event == ev) {
-                        int r = k_sumsq_owned(G + grad_segs[k].begin, grad_segs[k].end - grad_segs[k].begin, sumsq_ws + (size_t)k * SUMSQ_WS_STRIDE, sumsq_slots + k, 0, s);
-                        if (r) return r;
+                        if (sq_batch.count == SUMSQ_GROUP_MAX) { int r = k_sumsq_owned_group(sq_batch, s); if (r) return r; }
+                        sq_batch.r[sq_batch.count++] = SumsqRange{G + grad_segs[k].begin, grad_segs[k].end - grad_segs[k].begin, sumsq_ws + (size_t)k * SUMSQ_WS_STRIDE, sumsq_slots + k, 0};
                     }
+            if (!sq_defer) return k_sumsq_owned_group(sq_batch, s);
         }
         return RGQA_OK;
     }
+    // the shares of every segment one weight-gradient launch finalises go out as ONE launch (launch_pending brackets its marks with sq_defer)
+    SumsqGroup sq_batch{}; bool sq_defer = false;
 
     // dgrad in the [K, N] operand form (the weight as it lies, csrc/gemm_nt256.h NN): the pure bf16 engine, whole 64-row K-steps of weight rows
     static bool dgrad_nn_on() { return std::is_same<T, bf16_t>::value && !MIXED && g_rgqa_dgrad_nn != 0; }

@@ -119,6 +119,11 @@ int k_bce_fwd_bwd(const float* logits, int ldl, const float* target, int ldt, fl
 
 // ---- optim.hip
 int k_sumsq(const float* g, size_t n, float* partial /* >= 1025 floats, any content ([1024] = ticket word, zeroed on the stream by the call) */, float* out_sumsq, int accumulate_into_out, hipStream_t s);
+// several owned ranges in one launch (each with partials / ticket / output slot of its own, as k_sumsq_owned; never accumulating)
+#define SUMSQ_GROUP_MAX 8
+struct SumsqRange { const float* g; size_t n; float* partial; float* out; int nblk; };
+struct SumsqGroup { int count; SumsqRange r[SUMSQ_GROUP_MAX]; };
+int k_sumsq_owned_group(SumsqGroup& gr, hipStream_t s);
 int k_sumsq_owned(const float* g, size_t n, float* partial /* >= 1025 floats touched by nothing else, [1024] zeroed once by the owner */, float* out_sumsq, int accumulate_into_out, hipStream_t s);
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;

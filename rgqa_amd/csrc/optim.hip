@@ -82,6 +82,74 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     }
 }
 
+// Up to SUMSQ_GROUP_MAX ranges in ONE launch (blockIdx.y = range), each with its own partials / ticket / output slot: the shares of the gradient
+// segments one weight-gradient launch finalises (round 5: six launches of 14 us in a row at the end of backward, in front of the optimizer).  The
+// arithmetic per range is sumsq_kernel's with the same grid: the same bits.
+__global__ __launch_bounds__(256) void sumsq_group_kernel(const SumsqGroup gr) {
+    const SumsqRange& r = gr.r[blockIdx.y];
+    if ((int)blockIdx.x >= r.nblk) return;                      // block-uniform
+    const float* __restrict__ g = r.g;
+    const size_t n = r.n;
+    float* partial = r.partial;
+    __shared__ float red[4];
+    __shared__ int last;
+    const size_t nv = n >> 2;
+    const size_t stride = (size_t)r.nblk * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (; i + 3 * stride < nv; i += 4 * stride) {
+        const float4 v0 = reinterpret_cast<const float4*>(g)[i], v1 = reinterpret_cast<const float4*>(g)[i + stride];
+        const float4 v2 = reinterpret_cast<const float4*>(g)[i + 2 * stride], v3 = reinterpret_cast<const float4*>(g)[i + 3 * stride];
+        a0 += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+        a1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+        a2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
+        a3 += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
+    }
+    for (; i < nv; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        a0 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    float acc = (a0 + a1) + (a2 + a3);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[(nv << 2) + threadIdx.x]; acc += v * v; }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    int* ticket = reinterpret_cast<int*>(partial + 1024);
+    if (threadIdx.x == 0)
+        last = publish_partial_draw_ticket(reinterpret_cast<unsigned*>(partial) + blockIdx.x, __float_as_uint(red[0] + red[1] + red[2] + red[3]), ticket, r.nblk);
+    __syncthreads();
+    if (!last) return;                                          // block-uniform
+    double t = 0.0;
+    for (int j = threadIdx.x; j < r.nblk; j += 256)
+        t += (double)__uint_as_float(__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(partial) + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    __shared__ double redd[4];
+    if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *r.out = (float)(redd[0] + redd[1] + redd[2] + redd[3]);
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+int k_sumsq_owned_group(SumsqGroup& gr, hipStream_t s) {
+    if (gr.count <= 0) return RGQA_OK;
+    RGQA_REQUIRE(gr.count <= SUMSQ_GROUP_MAX, "sumsq group: %d ranges", gr.count);
+    int mx = 1;
+    for (int k = 0; k < gr.count; ++k) {
+        RGQA_REQUIRE(((uintptr_t)gr.r[k].g % 16) == 0, "sumsq: 16-byte alignment required");
+        int nblk = (int)((gr.r[k].n / 4 + 255) / 256);
+        if (nblk > 512) nblk = 512;
+        if (nblk < 1) nblk = 1;
+        gr.r[k].nblk = nblk;
+        if (nblk > mx) mx = nblk;
+    }
+    hipLaunchKernelGGL(sumsq_group_kernel, dim3(mx, gr.count), dim3(256), 0, s, gr);
+    RGQA_LAUNCH_CHECK("sumsq_group_kernel");
+    gr.count = 0;
+    return RGQA_OK;
+}
+
 int k_sumsq(const float* g, size_t n, float* partial, float* out_sumsq, int accumulate_into_out, hipStream_t s) {
     RGQA_HIP(hipMemsetAsync(partial + 1024, 0, sizeof(int), s));
     return k_sumsq_owned(g, n, partial, out_sumsq, accumulate_into_out, s);

@@ -268,8 +268,10 @@ def test_trainer_step_fused_clip_and_operand_copies(env, precision, monkeypatch)
     if precision == "bf16":
         assert nf == ni and all(torch.equal(pf[k], pi_[k]) for k in pf)
     else:
+        # (tools/x3_repro.py, eight pairs of runs, update beside the forward or not: the tables differ by 2e-9 every time, and in three pairs of
+        # eight ~1000 elements of the head's first layer by 3.8e-7 - BertAdam's normalised update amplifies a last-bit difference where |g| ~ eps)
         np.testing.assert_allclose(nf, ni, rtol=1e-6)
-        assert all(torch.allclose(pf[k], pi_[k], rtol=2e-6, atol=1e-8) for k in pf)
+        assert all(torch.allclose(pf[k], pi_[k], rtol=1e-4, atol=2e-6) for k in pf)
     assert sync_f                                   # the fused optimizer path left the copies current: no re-cast happened at the forward
     assert torch.equal(la, lb)                      # ... and they are exactly what a full re-cast produces
     np.testing.assert_allclose(nf, nt, rtol=2e-5)
