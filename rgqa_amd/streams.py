@@ -40,7 +40,7 @@ def _beside(a, b, device, spin_cycles):
 _TINY = {}
 
 
-def pick(device, n=3, candidates=24, spin_ms=1.0):
+def pick(device, n=3, candidates=24, spin_ms=0.4):
     """n streams on `device`, each shown to run beside the current stream and beside each other (fewer if the device's queues do not allow it:
     the rest are taken as they come).  Cached per device."""
     key = (device.type, device.index)
@@ -51,7 +51,7 @@ def pick(device, n=3, candidates=24, spin_ms=1.0):
         main = torch.cuda.current_stream(device)
         _TINY.setdefault(key, torch.zeros(16, device=device))
         torch.cuda.synchronize(device)
-        cycles = int(spin_ms * 1e-3 * 1.5e9)        # ~1 ms at the spin kernel's clock (generous: only "still running" matters)
+        cycles = int(spin_ms * 1e-3 * 1.5e9)        # the tiny kernel needs ~10 us: only "the spin is still running" matters
         good, rest = list(got or []), []
         for _ in range(candidates):
             if len(good) >= n:
