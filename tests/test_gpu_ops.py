@@ -703,3 +703,45 @@ def test_roi_mixup_entry_vs_golden(golden_dir, mode):
     f3, b3, t3 = RoIMixup(mode, 1.0, 5.0)(feats, boxes, target, ["A", "B", "A", "C", "D", "B"])
     assert f3.shape == (2 * B, O, Fd) and b3.shape == (2 * B, O, 4) and t3.shape == (2 * B, NA)
     assert torch.equal(f3[:B], feats) and torch.equal(t3[:B], target)
+
+
+def test_picked_streams_run_beside_the_callers_stream():
+    """rgqa_amd/streams.py: HIP maps streams onto a handful of hardware queues in creation order, and a side stream that shares the launch stream's
+    queue serialises with it (round 5: 18-33 ms train steps).  The device's set - the library's weight-gradient side stream, the update / first
+    exchange stream, the second exchange stream - is picked by test: while a spin kernel occupies one stream, a tiny kernel on the other must
+    complete.  Checked here again from outside, pairwise, and that an engine bound afterwards uses exactly this set."""
+    import time
+    from rgqa_amd import streams
+    from rgqa_amd.engine import Engine, _SIDE_SET, _UPD_STREAMS
+    dev = torch.device("cuda", torch.cuda.current_device())
+    picked = streams.pick(dev, 3)
+    assert len(picked) == 3 and len({s.cuda_stream for s in picked}) == 3
+    assert streams.pick(dev, 3)[0] is picked[0]                       # one set per device
+    main = torch.cuda.current_stream(dev)
+    x = torch.zeros(16, device=dev)
+
+    def beside(a, b):
+        ea, eb = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(3_000_000)                              # ~1.5 ms
+            ea.record(a)
+        with torch.cuda.stream(b):
+            x.add_(1)
+            eb.record(b)
+        t0 = time.perf_counter()
+        while not eb.query() and not ea.query() and time.perf_counter() - t0 < 0.5:
+            pass
+        ok = eb.query() and not ea.query()
+        torch.cuda.synchronize()
+        return ok
+
+    for s in picked:
+        assert beside(main, s) and beside(s, main)
+    for i in range(3):
+        for j in range(3):
+            if i != j:
+                assert beside(picked[i], picked[j])
+    e = Engine(precision="bf16", vocab_size=512, hidden=128, heads=2, inter=256, max_pos=64, type_vocab=2, l_layers=1, x_layers=1, r_layers=1,
+               feat_dim=64, pos_dim=4, num_answers=70).allocate("cuda")
+    e.ensure_shape(4, 12, 10)
+    assert _SIDE_SET[(dev.type, dev.index)] is picked[0] and _UPD_STREAMS[(dev.type, dev.index)] is picked[1] and e._upd_stream is picked[1]
