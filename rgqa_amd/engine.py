@@ -206,10 +206,12 @@ class Engine:
         """Refreshes the operand copies of the weights (direct + transposed; bf16 or split f32) from the f32 master arena."""
         if self.shape is None:
             raise RuntimeError("sync_weights before the first ensure_shape/bind")
+        self.join_update()      # (reads the masters on the caller's stream: behind an optimizer pass that may still be running beside the forward)
         check(self.lib.rgqa_engine_sync_weights(self.h, _stream()))
 
     def sync_transposed(self):
         """only the transposed operand copies (after rgqa_bertadam_step wrote the direct copy itself)"""
+        self.join_update()
         check(self.lib.rgqa_engine_sync_transposed(self.h, _stream()))
 
     # ------------------------------------------------------------------ compute
@@ -472,6 +474,7 @@ class Engine:
         norm was below max_norm)."""
         mn, self._pending_clip = getattr(self, "_pending_clip", None), None
         if mn is not None:
+            self.join_update()      # (writes the gradient arena)
             s = _stream()
             for a, b in self.live_ranges():
                 check(self.lib.rgqa_clip_scale(ptr(self._grads[a:b]), b - a, ptr(self._sumsq), float(mn), s))
