@@ -778,7 +778,7 @@ def main():
     engines = {"bf16": e}
     if extra_legs:
         # ---- the tolerance-compliant mode on the same workload: second engine, same weights, same batch
-        n2 = max(5, min(args.steps, 20))
+        n2 = max(5, min(args.steps, 40))        # (20 until round 5: a leg's start-up and drain are 1-2 % of twenty 11-ms steps)
         note("leg: bf16x3 train step")
         ex = Engine(precision="bf16x3", **FULL).allocate("cuda")
         ex.params.copy_(e.params)
