@@ -8,12 +8,15 @@ synthetic inputs already resident in HBM.
 
 A "step" = forward (train mode, dropout 0.1) + BCE x NA loss + backward + [RCCL gradient exchange] +
 clip_grad_norm_(5.) + BertAdam + re-cast of the weight operand copies: everything tasks/gqa_conf.py:174-202 does per batch.
-Rank 0 prints ONE JSON line.  The headline (`value`, `dtype` "bf16") is BASELINE config 3's mode; its logits are outside the north
-star's 1e-3 bound, so the same line carries `tolerance_compliant` - the bf16x3 mode (split-f32 operands, three bf16 MFMA products
-per f32 product) timed on the same workload, with its measured logits error against the CPU oracle - plus `forward_only_b256`
-(BASELINE config 2), `dropin_step` (the reference trainer's own statements through GQAModel / BertAdam on fresh batches from the
-device batcher) and the roofline of the dominant kernel against the datasheet peak and against the peak at the clock the chip
-actually holds under that kernel.
+Rank 0 prints ONE JSON line.  The headline (`value`, `dtype` "bf16x3_fwd") is the mode whose logits stay inside the north star's
+1e-3 bound - the forward pass on split-f32 operands (three bf16 MFMA products per f32 product), the backward pass in bf16 as
+BASELINE config 3 prescribes - with its logits error re-measured in-run against the CPU oracle (`parity_in_run`).  The same line
+carries `config3_bf16` (bf16 forward too: faster, logits OUTSIDE the bound, its error next to it), `tolerance_compliant` (bf16x3
+throughout), `seq30` (T = 30, what tasks/gqa_model.py:11 pads to), `forward_only_b256` (BASELINE config 2), `dropin_step` (the
+reference trainer's own statements through GQAModel / BertAdam on fresh batches from the device batcher), BASELINE configs 4 and 5
+(`other_workloads`, each with a leg inside the bound) and the roofline of the headline's dominant kernel - the split-f32 NT GEMM
+launches of the forward pass - against the datasheet peak, counting one product per f32 product (and, beside it, the 3x figure of
+MFMA work actually issued).
 
 Multi-GPU runs are supervised: the process that the launcher (or the user) started never touches the GPU; it runs the ranks as
 child processes and, when the default gradient exchange ("sharded": all-to-all + all-gather) fails or hangs, starts a FRESH set
@@ -35,7 +38,7 @@ sys.path.insert(0, ROOT)
 FWD_BWD_GFLOP = {20: 30.3388, 30: 37.0403}   # per QA pair, SURVEY.md §8 D3
 FWD_GFLOP = {20: 10.5827, 30: 12.8330}
 PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16, MI355X_MICROARCH.md (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
-PMC_PROFILE = "r05_pmc_gemm_nt.json"
+PMC_PROFILES = {"bf16x3_fwd": "r06_pmc_gemm_nt_x3fwd.json", "bf16": "r06_pmc_gemm_nt_bf16.json"}      # tools/pmc_summary.py, per headline precision
 FULL = dict(vocab_size=30522, hidden=768, heads=12, inter=3072, max_pos=512, type_vocab=2, l_layers=9, x_layers=5,
             r_layers=5, feat_dim=2048, pos_dim=4, num_answers=1842)
 
@@ -287,6 +290,61 @@ def dp_selfcheck(dist, mode, device, precision="bf16"):
         raise SystemExit("bench.py: collective self-check failed under RGQA_DP_MODE=%s" % mode)
 
 
+XGMI_LINKS, XGMI_GBS_PER_LINK_DIR = 7, 76.8      # MI355X: 7 Infinity Fabric links per GPU, 153.6 GB/s each bidirectional = 76.8 GB/s per direction (MI355X_MICROARCH.md)
+
+
+def dp_wire_probe(dist, comm, device, iters=10):
+    """OUTSIDE the timed region, before the warm-up steps: the collectives of the gradient exchange on the REAL chunk sizes, timed with device events,
+    as achieved GB/s per GPU and direction - so that the first record of a multi-GPU run tells whether RCCL's all-to-all / all-gather drive all seven
+    xGMI links of a GPU at once (the assumption behind DESIGN.md §5's prediction; a ring-shaped schedule would show 1/7 of it).  Bytes on the wire per
+    GPU and direction: (W - 1) / W of the buffer for all-to-all and all-gather, 2 (W - 1) / W for an all-reduce (its bus bandwidth).  At W = 1 (the
+    one-rank rehearsal) nothing is on a wire: the figures are then the library's local copy rate, reported as such."""
+    W = dist.get_world_size()
+    out = {"world": W, "links_per_gpu": XGMI_LINKS, "link_peak_gbs_per_direction": XGMI_GBS_PER_LINK_DIR,
+           "all_links_peak_gbs_per_direction": XGMI_LINKS * XGMI_GBS_PER_LINK_DIR}
+    if W == 1:
+        out["note"] = "one rank: nothing on a wire - local copy rates of the library, not link rates"
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([a.elapsed_time(b) / iters], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e-3
+
+    wire = (W - 1) / W if W > 1 else 1.0
+    peak = XGMI_LINKS * XGMI_GBS_PER_LINK_DIR
+    try:
+        if hasattr(comm, "chunks"):          # sharded exchange: all-to-all of the largest chunk in the payload type, all-gather of the same chunk of weights
+            s_ = comm.smax
+            send, recv = comm._send[:W * s_], comm._recv[:W * s_]
+            nbytes = W * s_ * send.element_size()
+            t = timed(lambda: dist.all_to_all_single(recv, send))
+            out["all_to_all"] = dict(buffer_mb=round(nbytes / 2**20, 1), dtype=str(send.dtype).replace("torch.", ""), ms=round(t * 1e3, 3), gbs_per_gpu_per_direction=round(nbytes * wire / t / 1e9, 1),
+                                     frac_of_all_links=round(nbytes * wire / t / 1e9 / peak, 3))
+            part = recv[:s_].clone()
+            t = timed(lambda: dist.all_gather_into_tensor(recv, part))
+            out["all_gather"] = dict(buffer_mb=round(nbytes / 2**20, 1), dtype=str(recv.dtype).replace("torch.", ""), ms=round(t * 1e3, 3), gbs_per_gpu_per_direction=round(nbytes * wire / t / 1e9, 1),
+                                     frac_of_all_links=round(nbytes * wire / t / 1e9 / peak, 3))
+        buf = torch.zeros(64 * (1 << 20) // 4, device=device)       # the all-reduce mode's bucket: 64 MB f32
+        t = timed(lambda: dist.all_reduce(buf))
+        bus = buf.numel() * 4 * (2 * wire if W > 1 else 1.0) / t / 1e9
+        out["all_reduce_f32_64mb"] = dict(ms=round(t * 1e3, 3), bus_gbs_per_gpu=round(bus, 1), frac_of_all_links=round(bus / peak, 3))
+        if W > 1 and "all_to_all" in out:
+            out["all_links_in_use"] = bool(out["all_to_all"]["frac_of_all_links"] >= 0.35)      # a one-link-at-a-time schedule cannot exceed 1/7 = 0.14
+    except Exception as ex:          # a diagnostic: never lose the run over it
+        out["error"] = repr(ex)
+    return out
+
+
 def launch_check(world, rank, fail_rank, fail_mode):
     """rehearsal of the launch path without a GPU (tests/test_host.py): rendezvous over gloo, the exchange's self-check, one JSON line"""
     import torch.distributed as dist
@@ -501,7 +559,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="QA pairs per GPU per step")
     ap.add_argument("--seq", type=int, default=20)
-    ap.add_argument("--precision", default="bf16", help="bf16 (BASELINE config 3, the headline) | bf16x3 (inside the 1e-3 logits bound) | bf16x3_fwd (that forward pass with the bf16 backward pass) | f32 (exact, vector ALU)")
+    ap.add_argument("--precision", default="bf16x3_fwd", help="bf16x3_fwd (the headline: split-f32 forward pass inside the 1e-3 logits bound, bf16 backward pass as BASELINE config 3 prescribes) | bf16 (bf16 forward too: outside the bound) | bf16x3 (split f32 throughout) | f32 (exact, vector ALU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -617,6 +675,10 @@ def main():
     e.ensure_shape(MB, T, O)
     e.sync_weights()
     comm = make_exchange(e, dist, mode=dp_mode) if dist is not None else None      # RGQA_DP_MODE: sharded (default, payload by precision) | allreduce (f32; _bf16 opts in) (rgqa_amd/parallel.py)
+    dp_wire = None
+    if dist is not None and dist.get_backend() == "nccl" and not args.lean:
+        note("dp_wire: collectives of the exchange on the real chunk sizes")
+        dp_wire = dp_wire_probe(dist, comm, torch.device("cuda", local))
     if dist is None and not args.butd:
         e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
     # (under an exchange the norm belongs to the REDUCED gradients: the sharded exchange takes each owner's share while it sums the shards,
@@ -734,22 +796,32 @@ def main():
         prof = e.profile_read()
         blocks = e.profile_blocks() if hasattr(e, "profile_blocks") and not (args.butd or args.uniter) else None
         e.profile(False)
-        nt = prof["gemm_nt"]
+        x3f = args.precision in ("bf16x3_fwd", "bf16x3")      # the forward launches of the NT family are split-f32 kernels (3 MFMA products per f32 product)
+        fw, dg = prof["gemm_nt"], prof.get("gemm_nt_dgrad", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        obs = e.profile_operand_bytes() if hasattr(e, "profile_operand_bytes") else {}
+        # the dominant kernel: under bf16 ONE kernel family computes forward and dgrad launches alike; under bf16x3_fwd the forward launches
+        # (gemm_nt256*_kernel<sf32, ...>) are a family of their own - 60 % of the NT time - and the dgrad launches are the bf16 kernels
+        if args.precision == "bf16x3_fwd":
+            nt, ob_tot, kname = fw, obs.get("gemm_nt", 0.0), "gemm_nt256_kernel / gemm_nt256d_kernel<sf32, EPI, MT, X3 = true>: every forward GEMM launch (split-f32 operands)"
+        else:
+            nt = {k: fw[k] + dg[k] for k in ("ms", "flops", "bytes", "launches")}
+            ob_tot = obs.get("gemm_nt", 0.0) + obs.get("gemm_nt_dgrad", 0.0)
+            kname = "gemm_nt (gemm_nt256_kernel / gemm_nt256d_kernel<OutT,EPI,MT,X3> + gemm_nt_kernel: every forward/dgrad GEMM launch)"
         if nt["launches"]:
             per_launch_flops = nt["flops"] / nt["launches"]
             avg_ms = nt["ms"] / nt["launches"]
             ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
             traffic, traffic_note = None, "no PMC profile for this workload"
-            pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)    # separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), tools/pmc_summary.py
-            if os.path.exists(pmc) and B == 256 and T == 20 and args.precision == "bf16" and not (args.mixup or args.uniter or args.butd or args.padded):
+            pmc_name = PMC_PROFILES.get(args.precision)
+            pmc = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else ""    # separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), tools/pmc_summary.py
+            if pmc and os.path.exists(pmc) and B == 256 and T == 20 and not (args.mixup or args.uniter or args.butd or args.padded):
                 from rgqa_amd.build import source_digest
                 pj = json.load(open(pmc))
                 if pj.get("kernel_source_digest") == source_digest():
-                    traffic, traffic_note = round(pj["traffic_bytes_per_launch"]), "profiles/%s (same kernel sources)" % PMC_PROFILE
+                    traffic, traffic_note = round(pj["traffic_bytes_per_launch"]), "profiles/%s (same kernel sources)" % pmc_name
                 else:       # the kernels changed since the counters were collected: a stale figure is worse than none
-                    traffic_note = "profiles/%s was collected on other kernel sources (digest mismatch): not reported" % PMC_PROFILE
-            ob = e.profile_operand_bytes()["gemm_nt"] if hasattr(e, "profile_operand_bytes") else 0.0
-            alg_b, op_b = nt["bytes"] / nt["launches"], (ob / nt["launches"] if ob else None)
+                    traffic_note = "profiles/%s was collected on other kernel sources (digest mismatch): not reported" % pmc_name
+            alg_b, op_b = nt["bytes"] / nt["launches"], (ob_tot / nt["launches"] if ob_tot else None)
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_note, algorithmic_bytes_per_launch=round(alg_b),
                         # the two denominators: since round 4 `algorithmic_bytes_per_launch` counts the fused epilogues' operands
@@ -757,10 +829,19 @@ def main():
                         gemm_operand_bytes_per_launch=None if op_b is None else round(op_b),
                         traffic_over_algorithmic=None if traffic is None else round(traffic / alg_b, 3),
                         traffic_over_gemm_operands=None if (traffic is None or not op_b) else round(traffic / op_b, 3),
-                        kernel="gemm_nt (gemm_nt256_kernel / gemm_nt256d_kernel<OutT,EPI,MT,X3> + gemm_nt_kernel: every forward/dgrad GEMM launch)", launches_per_step=nt["launches"] // args.profile_steps,
+                        kernel=kname, launches_per_step=nt["launches"] // args.profile_steps,
                         avg_launch_us=round(avg_ms * 1e3, 2), gflop_per_launch=round(per_launch_flops / 1e9, 3))
-            if args.precision == "bf16x3":
-                roof["note"] = "bf16x3: 3 MFMA products per counted FLOP - the matrix pipe does 3x the work `achieved` credits"
+            if x3f:
+                # `achieved` counts ONE product per f32 product (2 M N K): what the reference's f32 GEMM computes.  The matrix pipe issues three bf16
+                # products for each (hi*hi + hi*lo + lo*hi): the MFMA work the kernel really does is 3x, priced against the same dense-bf16 peak
+                roof["mfma_issued"] = dict(achieved=round(3 * ach, 2), unit="TFLOP/s", frac=round(3 * ach / PEAK_BF16_TFLOPS, 4),
+                                           note="3 bf16 MFMA products per counted f32 product")
+            if args.precision == "bf16x3_fwd" and dg["launches"]:
+                dms = dg["ms"] / dg["launches"]
+                dach = dg["flops"] / dg["launches"] / (dms * 1e-3) / 1e12
+                roof["dgrad_family"] = dict(kernel="gemm_nt256*_kernel<bf16, ...>: the dgrad launches (bf16 operands)", launches_per_step=dg["launches"] // args.profile_steps,
+                                            avg_launch_us=round(dms * 1e3, 2), gflop_per_launch=round(dg["flops"] / dg["launches"] / 1e9, 3), achieved=round(dach, 2),
+                                            unit="TFLOP/s", frac=round(dach / PEAK_BF16_TFLOPS, 4), algorithmic_bytes_per_launch=round(dg["bytes"] / dg["launches"]))
             if not (args.butd or args.lean):
                 try:
                     mhz, nl = probe_sustained_clock(e)
@@ -773,35 +854,35 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    extra_legs = rank == 0 and world == 1 and not (args.no_extra_legs or args.lean or args.butd or args.uniter or args.mixup or args.padded) and args.precision == "bf16"
-    tol = tol_fwd = fwd_only = dropin = other = None
-    engines = {"bf16": e}
+    HEAD = "bf16x3_fwd"
+    extra_legs = rank == 0 and world == 1 and not (args.no_extra_legs or args.lean or args.butd or args.uniter or args.mixup or args.padded) and args.precision == HEAD
+    cfg3 = tol = seq30 = fwd_only = dropin = other = parity = None
+    engines = {args.precision: e}
     if extra_legs:
-        # ---- the tolerance-compliant mode on the same workload: second engine, same weights, same batch
         n2 = max(5, min(args.steps, 40))        # (20 until round 5: a leg's start-up and drain are 1-2 % of twenty 11-ms steps)
+
+        def second_engine(prec):
+            en = Engine(precision=prec, **FULL).allocate("cuda")
+            en.params.copy_(e.params)
+            en.ensure_shape(B, T, O)
+            en.sync_weights()
+            en.enable_segment_sumsq(True)
+            engines[prec] = en
+            return en
+        # ---- BASELINE config 3 with a bf16 FORWARD pass as well (rounds 1-5's headline): faster, but its logits are outside the north star's bound
+        note("leg: bf16 train step (config3_bf16)")
+        eb = second_engine("bf16")
+        bms = time_steps(engine_step_fn(eb, dev, lengths), n2, 3)
+        cfg3 = dict(precision="bf16", ms_per_step=round(bms, 3), value=round(B / bms * 1e3, 1), unit="QA-pairs/s", steps=n2,
+                    note="same workload, weights and batch as the headline with bf16 operands in the forward pass too (rgqa.h RGQA_PRECISION_BF16): NOT inside the 1e-3 logits "
+                         "bound (logits_max_err below, re-measured in-run) - reported for what the bound costs, never as `value`")
+        # ---- split-f32 operands throughout (forward and backward)
         note("leg: bf16x3 train step")
-        ex = Engine(precision="bf16x3", **FULL).allocate("cuda")
-        ex.params.copy_(e.params)
-        ex.ensure_shape(B, T, O)
-        ex.sync_weights()
-        ex.enable_segment_sumsq(True)
-        engines["bf16x3"] = ex
+        ex = second_engine("bf16x3")
         xms = time_steps(engine_step_fn(ex, dev, lengths), n2, 3)
         tol = dict(precision="bf16x3", ms_per_step=round(xms, 3), value=round(B / xms * 1e3, 1), unit="QA-pairs/s", steps=n2,
-                   note="same workload, weights and batch as the headline; split-f32 operands, 3 bf16 MFMA products per f32 product (rgqa.h RGQA_PRECISION_BF16X3)")
-        # ---- the same forward pass with the bf16 backward pass (BASELINE config 3 prescribes a bf16 backward): logits identical to bf16x3's
-        note("leg: bf16x3_fwd train step")
-        exf = Engine(precision="bf16x3_fwd", **FULL).allocate("cuda")
-        exf.params.copy_(e.params)
-        exf.ensure_shape(B, T, O)
-        exf.sync_weights()
-        exf.enable_segment_sumsq(True)
-        engines["bf16x3_fwd"] = exf
-        fms_ = time_steps(engine_step_fn(exf, dev, lengths), n2, 3)
-        tol_fwd = dict(precision="bf16x3_fwd", ms_per_step=round(fms_, 3), value=round(B / fms_ * 1e3, 1), unit="QA-pairs/s", steps=n2,
-                       note="same workload, weights and batch as the headline; forward pass = the bf16x3 kernels (logits inside the bound, re-measured below), backward pass = "
-                            "the bf16 kernels on bf16 images of the saved activations (rgqa.h RGQA_PRECISION_BF16X3_FWD); gradients carry bf16 rounding and are held to "
-                            "the bf16 mode's loss / gradient-norm / sampled-gradient gates (tests/test_gpu_engine.py::test_mixed_*)")
+                   note="same workload, weights and batch as the headline; split-f32 operands and 3 bf16 MFMA products per f32 product in the backward pass as well "
+                        "(rgqa.h RGQA_PRECISION_BF16X3): gradients at f32-class accuracy")
         # ---- BASELINE config 2: forward-only inference at B=256
         fwd_only = {}
         note("leg: forward-only B=256, three precisions")
@@ -809,44 +890,69 @@ def main():
             fms = time_steps(lambda en=en: en.forward(dev["feats"], dev["boxes"], dev["input_ids"], dev["input_mask"], dev["segment_ids"], train=False, lengths=lengths), n2, 3)
             fwd_only[name] = dict(ms=round(fms, 3), value=round(B / fms * 1e3, 1), unit="QA-pairs/s",
                                   reference_equivalent_tflops=round(B / fms * 1e3 * FWD_GFLOP.get(T, FWD_GFLOP[20]) / 1e3, 1))
-        # ---- the reference trainer's statements through the drop-in modules
+        # ---- T = 30: what the GQA wrapper pads every question to (tasks/gqa_model.py:11 MAX_GQA_LENGTH; SURVEY §8 D1 asks for it alongside T = 20)
+        try:
+            note("leg: T=30 train step (seq30)")
+            b30 = synth.synth_batch(B, 30, seed=1234 + rank)
+            d30 = {k: torch.from_numpy(v).cuda() for k, v in b30.items() if k != "lengths"}
+            l30 = np.ascontiguousarray(b30["lengths"], dtype=np.int32)
+            e.ensure_shape(B, 30, O)
+            e.sync_weights()
+            e.enable_segment_sumsq(True)
+            s30 = time_steps(engine_step_fn(e, d30, l30), n2, 3)
+            p30 = time_steps(engine_step_fn(e, d30, None), max(5, n2 // 2), 2)
+            seq30 = dict(precision=args.precision, seq_len=30, ms_per_step=round(s30, 3), value=round(B / s30 * 1e3, 1), unit="QA-pairs/s", steps=n2,
+                         language_rows="packed: %d real tokens of %d positions (question length ~ U{5..30})" % (int(l30.sum()), B * 30),
+                         padded_ms_per_step=round(p30, 3), padded_value=round(B / p30 * 1e3, 1),
+                         reference_equivalent_tflops=round(B / s30 * 1e3 * FWD_BWD_GFLOP[30] / 1e3, 1),
+                         note="same engine and weights re-bound to T = 30 (tasks/gqa_model.py:11); padded_* computes all 30 positions of every question as the reference does")
+            del d30
+            e.ensure_shape(B, T, O)
+            e.sync_weights()
+            e.enable_segment_sumsq(True)
+        except Exception as exn:
+            seq30 = dict(error=repr(exn))
+        # ---- the reference trainer's statements through the drop-in modules, in the headline's precision
         try:
             note("leg: drop-in trainer step")
-            dms = dropin_step_leg(B, T, n2, "bf16")
-            dropin = dict(ms_per_step=round(dms, 3), value=round(B / dms * 1e3, 1), unit="QA-pairs/s", steps=n2, vs_headline=round(dms / ms, 3),
+            dms = dropin_step_leg(B, T, n2, args.precision)
+            dropin = dict(ms_per_step=round(dms, 3), value=round(B / dms * 1e3, 1), unit="QA-pairs/s", steps=n2, vs_headline=round(dms / ms, 3), precision=args.precision,
                           what="GQAModel(feats, boxes, list_of_str) + BCE x NA + backward + nn.utils.clip_grad_norm_ + BertAdam.step (tasks/gqa_conf.py:174-202) on a fresh "
-                               "batch per step from the f16 feature store (pinned gather + H2D + device preparation); bf16")
+                               "batch per step from the f16 feature store (pinned gather + H2D + device preparation); the headline's precision")
         except Exception as exn:
             dropin = dict(error=repr(exn))
-        # ---- BASELINE configs 4 and 5 under the same clock: the RoI-mixup step (2B model rows per B loader pairs) on the headline's
-        # engine re-bound to 2B rows (LAST user of that engine: nothing below needs its B-row binding again except the oracle check, which re-binds),
-        # and the BUTD backbone's step
+        # ---- BASELINE configs 4 and 5 under the same clock, each in a mode inside the bound and in bf16: the RoI-mixup step (2B model rows per B loader
+        # pairs) on the engines above re-bound to 2B rows, and the BUTD backbone's step
         other = {}
-        try:
-            n3 = 10
-            note("leg: RoI-mixup step (config 4), 2 x %d rows" % B)
-            mms = mixup_leg(e, dev, lengths, B, T, O, n3, rank)
-            other["roi_mixup_b256"] = dict(ms_per_step=round(mms, 3), loader_qa_per_s=round(B / mms * 1e3, 1), model_rows_per_s=round(2 * B / mms * 1e3, 1), steps=n3, dtype="bf16",
-                                           what="BASELINE config 4 on one GPU: RoI-mixup finetune step (tasks/gqa_mixup_vis.py:134-181, 250-259; mixup_v1, Beta(1,5)): host draws + one "
-                                                "device gather, 2 x %d model rows per %d loader QA pairs, fwd+BCE+bwd+clip+BertAdam; packed language rows" % (B, B))
-            e.ensure_shape(B, T, O)              # back to the headline's binding
-            e.sync_weights()
-        except Exception as exn:
-            other["roi_mixup_b256"] = dict(error=repr(exn))
-        try:
-            note("leg: BUTD step (config 5)")
-            bms = butd_leg(B, 10, "bf16", rank)
-            other["butd_b256"] = dict(ms_per_step=round(bms, 3), value=round(B / bms * 1e3, 1), unit="QA-pairs/s", steps=10, dtype="bf16",
-                                      what="BASELINE config 5 on one GPU: BUTD backbone train step (butd/butd.py:195-221): GRU over 40 tokens x 1024, region attention over 36 RoIs, "
-                                           "classifier; dictionary 3000 words; fwd+BCE+bwd+clip+BertAdam")
-        except Exception as exn:
-            other["butd_b256"] = dict(error=repr(exn))
+        n3 = 10
+        for key, en, inb in (("roi_mixup_b256", e, True), ("roi_mixup_b256_bf16", eb, False)):
+            try:
+                note("leg: RoI-mixup step (config 4), 2 x %d rows, %s" % (B, en.precision))
+                mms = mixup_leg(en, dev, lengths, B, T, O, n3, rank)
+                other[key] = dict(ms_per_step=round(mms, 3), loader_qa_per_s=round(B / mms * 1e3, 1), model_rows_per_s=round(2 * B / mms * 1e3, 1), steps=n3, dtype=en.precision,
+                                  within_logits_bound=inb,
+                                  what="BASELINE config 4 on one GPU: RoI-mixup finetune step (tasks/gqa_mixup_vis.py:134-181, 250-259; mixup_v1, Beta(1,5)): host draws + one "
+                                       "device gather, 2 x %d model rows per %d loader QA pairs, fwd+BCE+bwd+clip+BertAdam; packed language rows" % (B, B))
+                en.ensure_shape(B, T, O)              # back to the B-row binding (the oracle check below runs on it)
+                en.sync_weights()
+            except Exception as exn:
+                other[key] = dict(error=repr(exn))
+        for key, prec, inb in (("butd_b256", "bf16x3", True), ("butd_b256_bf16", "bf16", False)):
+            try:
+                note("leg: BUTD step (config 5), %s" % prec)
+                bms_ = butd_leg(B, 10, prec, rank)
+                other[key] = dict(ms_per_step=round(bms_, 3), value=round(B / bms_ * 1e3, 1), unit="QA-pairs/s", steps=10, dtype=prec, within_logits_bound=inb,
+                                  what="BASELINE config 5 on one GPU: BUTD backbone train step (butd/butd.py:195-221): GRU over 40 tokens x 1024, region attention over 36 RoIs, "
+                                       "classifier; dictionary 3000 words; fwd+BCE+bwd+clip+BertAdam" + ("; split-f32 operands (logits within 1e-3 of the reference: tests/test_gpu_butd.py)" if inb else
+                                       "; bf16 operands (logits gated at 1e-2: outside the bound)"))
+            except Exception as exn:
+                other[key] = dict(error=repr(exn))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.uniter:
         def check(P, cb, ref_logits):
             """the GPU engines on the oracle's weights and eval batch: max / mean |logit - oracle logit| over all 256 x 1842 entries"""
-            if not extra_legs:
+            if args.butd or args.mixup or args.padded or T != 20 or B != 256:
                 return None
             d2 = {k: torch.from_numpy(v).cuda() for k, v in cb.items() if k != "lengths"}
             res = {}
@@ -865,17 +971,19 @@ def main():
         note("leg: CPU baseline (the oracle on the host cores) + logits check of the GPU engines")
         cpu, checked = cpu_baseline(T, args.cpu_sample, 5, extra=not args.butd, check=check)
         note("CPU baseline done")
-        if checked and tol is not None:
-            tol.update(logits_max_err=checked["bf16x3"]["logits_max_err"], logits_mean_err=checked["bf16x3"]["logits_mean_err"], bound=1e-3,
-                       within_bound=bool(checked["bf16x3"]["logits_max_err"] <= 1e-3),
-                       checked_on="B=256 eval forward, golden-fixture filler weights, all 256 x 1842 logits against the CPU oracle (f32)",
-                       headline_mode_logits_max_err=checked["bf16"]["logits_max_err"], headline_mode_logits_mean_err=checked["bf16"]["logits_mean_err"])
-            if tol_fwd is not None:
-                tol_fwd.update(logits_max_err=checked["bf16x3_fwd"]["logits_max_err"], logits_mean_err=checked["bf16x3_fwd"]["logits_mean_err"], bound=1e-3,
-                               within_bound=bool(checked["bf16x3_fwd"]["logits_max_err"] <= 1e-3), checked_on=tol["checked_on"])
+        if checked:
+            on = "B=256 eval forward, golden-fixture filler weights, all 256 x 1842 logits against the CPU oracle (f32)"
+            hd = checked[args.precision]
+            parity = dict(precision=args.precision, logits_max_err=hd["logits_max_err"], logits_mean_err=hd["logits_mean_err"], bound=1e-3,
+                          within_bound=bool(hd["logits_max_err"] <= 1e-3), checked_on=on)
+            for leg, name in ((cfg3, "bf16"), (tol, "bf16x3")):
+                if leg is not None and name in checked:
+                    leg.update(logits_max_err=checked[name]["logits_max_err"], logits_mean_err=checked[name]["logits_mean_err"], bound=1e-3,
+                               within_bound=bool(checked[name]["logits_max_err"] <= 1e-3), checked_on=on)
             if fwd_only is not None:
                 for name in fwd_only:
-                    fwd_only[name]["logits_max_err"] = checked[name]["logits_max_err"]
+                    if name in checked:
+                        fwd_only[name]["logits_max_err"] = checked[name]["logits_max_err"]
 
     if rank == 0:
         # UNITER, padded: 12 layers x (56 x 7,077,888 + 2 x 56^2 x 768) MAC + 36 x 2048 x 768 + head = 4.880 GMAC fwd per QA pair; x2 FLOP, x3 fwd+bwd
@@ -889,8 +997,10 @@ def main():
                                     "LXMERT-GQA RP finetune train step (fwd+BCE+bwd+clip+BertAdam), 9/5/5 layers, H=768"), "model_rows_per_gpu": MB,
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "rois": O, "feat_dim": 2048,
                        "num_answers": 1842, "parallelism": "dp%d" % world, "dropout": 0.1,
-                       "precision_note": {"bf16": "BASELINE config 3's mode; logits outside the north star's 1e-3 bound (see tolerance_compliant)",
-                                          "bf16x3": "split-f32 operands: inside the 1e-3 logits bound", "bf16x3_fwd": "bf16x3 forward pass (logits inside the 1e-3 bound), bf16 backward pass",
+                       "precision_note": {"bf16": "bf16 operands in the forward pass too; logits outside the north star's 1e-3 bound",
+                                          "bf16x3": "split-f32 operands throughout: inside the 1e-3 logits bound",
+                                          "bf16x3_fwd": "forward pass on split-f32 operands, 3 bf16 MFMA products per f32 product: logits inside the 1e-3 bound (parity_in_run); "
+                                                        "backward pass in bf16 as BASELINE config 3 prescribes (gradients carry bf16 rounding; weights, moments, optimizer f32)",
                                           "f32": "exact f32 on the vector ALU"}.get(args.precision, ""),
                        "language_rows": ("padded: all %d token positions computed" % (MB * T)) if lengths is None else
                                         ("packed: %d real tokens of %d positions (question length ~ U{5..%d}); padding rows are not computed, results identical" % (int(lengths.sum()), MB * T, T))},
@@ -900,10 +1010,14 @@ def main():
             # (30.339 GFLOP per QA pair); with packed language rows part of them is never executed here
             "reference_equivalent_tflops_per_gpu": round(step_tflops / world, 1),
         }
+        if parity is not None:
+            out["parity_in_run"] = parity
+        if cfg3 is not None:
+            out["config3_bf16"] = cfg3
         if tol is not None:
             out["tolerance_compliant"] = tol
-        if tol_fwd is not None:
-            out["tolerance_compliant_fwd"] = tol_fwd
+        if seq30 is not None:
+            out["seq30"] = seq30
         if fwd_only is not None:
             out["forward_only_b256"] = fwd_only
         if dropin is not None:
@@ -915,6 +1029,8 @@ def main():
             out["dp_fallback"] = os.environ.get("RGQA_BENCH_DP_FALLBACK")
             if world == 1:
                 out["rccl_rehearsal"] = "one rank on RCCL: every collective of the exchange runs through the library; the exchange's local arithmetic is timed at full size"
+        if dp_wire is not None:
+            out["dp_wire"] = dp_wire
         if dp_legs is not None:
             out["exposed_comm_ms"] = dp_legs["exposed_comm_ms"]      # step time minus the time of the same step with no exchange and a local whole-arena optimizer
             out["dp_exchange"] = dp_legs
@@ -922,13 +1038,15 @@ def main():
             out["padded_layout"] = padded_leg
         if prof is not None and args.profile_steps > 0:
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.profile_steps, 3) for k, v in prof.items() if v["launches"]}
+            if "gemm_nt_dgrad" in out["kernel_ms_per_step"]:       # (rounds 1-5 reported the forward and dgrad launches of the NT family as one figure)
+                out["kernel_ms_per_step"]["gemm_nt_fwd_plus_dgrad"] = round(out["kernel_ms_per_step"].get("gemm_nt", 0.0) + out["kernel_ms_per_step"]["gemm_nt_dgrad"], 3)
             # the utilisation figure: FLOPs the engine actually executed (GEMMs + attention, packed rows) over the measured step time
             ex_fl = sum(v["flops"] for v in prof.values()) / max(1, args.profile_steps)
             out["step_executed_tflops_per_gpu"] = round(ex_fl / (ms * 1e-3) / 1e12, 1)
             out["step_executed_frac_of_bf16_peak"] = round(ex_fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
             # the same figure for the legs that satisfy the 1e-3 logits bound (same workload: the same FLOPs are credited; the bf16x3 kernels issue
             # three MFMA products per credited product, which `executed` does not count)
-            for leg in (tol, tol_fwd):
+            for leg in (cfg3, tol):
                 if leg is not None and leg.get("ms_per_step"):
                     leg["executed_tflops_per_gpu"] = round(ex_fl / (leg["ms_per_step"] * 1e-3) / 1e12, 1)
                     leg["executed_frac"] = round(ex_fl / (leg["ms_per_step"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)

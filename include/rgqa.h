@@ -177,8 +177,9 @@ int rgqa_engine_set_backward_event(rgqa_engine* e, void* hip_event);
 int rgqa_engine_num_weight_segments(const rgqa_engine* e, int* out);
 
 /* measurement: time every GEMM / attention launch with HIP events on the launch stream. profile_read synchronises
- * on the recorded events; categories: 0 gemm NT (fwd + dgrad), 1 gemm TN (wgrad), 2 attention fwd, 3 attention bwd,
- * 4 layernorm, 5 other. flops / bytes are algorithmic (2*M*N*K; operand + result bytes). */
+ * on the recorded events; categories: 0 gemm NT forward, 1 gemm TN (wgrad), 2 attention fwd, 3 attention bwd,
+ * 4 layernorm, 5 other, 6 gemm NT dgrad (with 0 until round 5). flops / bytes are algorithmic (2*M*N*K - one per f32 product whatever
+ * the number of bf16 MFMA products behind it; operand + result bytes in the launch's own element type). ncat >= 7. */
 int rgqa_engine_profile(rgqa_engine* e, int enable);
 int rgqa_engine_profile_read(rgqa_engine* e, double* ms, double* flops, double* bytes, int64_t* launches, int ncat);
 /* the same records of the last profile_read, split by model block: 0 input embeddings (text + visual), 1 language / vision

@@ -137,7 +137,7 @@ public:
         size_t mw = 0;
         for (BLin* l : lins) { size_t n = (size_t)l->out * l->kp; if (n > mw) mw = n; }
         dwscr = take<float>(mw); dw_part = take<float>((size_t)B * H); db_part = take<float>(B);
-        gru_cnt = take<int>(gru_persist_counter_ints(B, L));
+        gru_cnt = take<int>(gru_persist_counter_ints(B, L)); emb_keys = take<int>((size_t)B * L);
         // the three long contractions of the pass - W_hh and W_ih over L * B rows, image_proj over B * O rows - are cut into 4 row slices each: as whole
         // problems their 108 output tiles walked 144-160 K-steps on an otherwise idle chip (one launch of 280 us: as long as its longest chain)
         for (BLin* l : lins) {
@@ -177,7 +177,7 @@ public:
         }
         wn_uploaded = false;
     }
-    int* gru_cnt = nullptr;
+    int* gru_cnt = nullptr; int* emb_keys = nullptr;
     bool gru_persist() const { if constexpr (LP && !X3) return gru_persist_ok(B, H); else return false; }
     size_t workspace_bytes(int B_, int L_, int O_) override { dry = true; plan(B_, L_, O_); dry = false; return ws_used + 256; }
     int bind(float* p, float* g, void*, void*, void* w, size_t wb, int B_, int L_, int O_) override {
@@ -313,7 +313,7 @@ public:
     int loss_backward(const float* target, int ldt, float* loss_out, float grad_scale, int accumulate, hipStream_t s) override {
         RGQA_REQUIRE(have_fwd && G != nullptr, "loss_backward: no forward pass recorded / no gradient arena");
         float* dl32 = dwscr;
-        CKB(k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, NA, NAp, grad_scale, s));
+        CKB(k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, NA, NAp, grad_scale, s, db_part));      // (db_part: B floats, free until the backward pass below)
         if (loss_out) CKB(rgqa_check_hip(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s), "loss copy"));
         CKB(k_cast_pad<T>(dl32, NAp, dlogits, NAp, B, NAp, 1.0f, s));
         return backward_impl(accumulate, s);
@@ -398,7 +398,10 @@ public:
         CKB(wgrad(dGH, 3 * H, Hall, H, L * B, whh, accumulate, s));
         CKB(wgrad(dGI, 3 * H, X, Ep, B * L, wih, accumulate, s));
         CKB(gemm_dgrad(dGI, 3 * H, B * L, wih, dX, Ep, EPI_BIAS, nullptr, 0, nd, s));
-        CKB(kb_embed_bwd<T>(in_toks, dX, G + emb, B * L, E, Ep, cfg.vocab_size - 1, s));
+        // dense gradient of the word table (nn.Embedding(padding_idx = ntoken): that row gets none, butd.py:36), every table row summed by one workgroup
+        // in a fixed order (csrc/embed.hip; until round 6 a float-atomic scatter-add: the last bits changed from run to run)
+        CKB(k_embed_keys(in_toks, B * L, emb_keys, s));
+        CKB(k_embed_word_grad<T>(dX, Ep, emb_keys, B * L, G + emb, E, cfg.vocab_size - 1, accumulate, s));
         if (wg_collect) {
             CKB(tn_gemm(wg, s));
             CKB(kb_wn_backward_group(wn_dev, (int)wn_host.size(), wn_blocks, wn_partial, s));

@@ -64,10 +64,12 @@ template <int H, int KSP>
 __global__ __launch_bounds__(256 * KSP) void gru_fwd_persist_kernel(const GruFwdArgs a) {
     constexpr int KS = H / 32, KSW = KS / KSP, PITCH = 2 * H + 16, CS = H / 16, WBYTES = 48 * PITCH;     // K-steps of 32; LDS row pitch: +16 bytes, conflict-free b128 reads
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int s_bad;                                            // a poll gave up (as in the 32-unit form below: the slice's output is poisoned)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mt = wave & 3, kh = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
     const int cs = blockIdx.x % CS, rg = blockIdx.x / CS;
     const int B = a.B, L = a.L;
+    if (tid == 0) s_bad = 0;
     // the slice's weight rows: LDS row g * 16 + u = W_hh row g * H + cs * 16 + u
     for (int i = tid; i < 48 * (H / 8); i += 256 * KSP) {
         const int r = i / (H / 8), c = i % (H / 8);
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256 * KSP) void gru_fwd_persist_kernel(const GruFwd
                 *reinterpret_cast<bf16x4*>(a.Rg + o) = rr; *reinterpret_cast<bf16x4*>(a.Zg + o) = zz;
                 *reinterpret_cast<bf16x4*>(a.Ng + o) = nn; *reinterpret_cast<bf16x4*>(a.GHN + o) = gg;
             }
-            if (tid == 0) gru_wait(cnt + t, CS, a.err);              // h_t of every slice of this row group is in place (Hall[0] is the caller's zero block)
+            if (tid == 0 && !gru_wait(cnt + t, CS, a.err)) s_bad = 1;   // h_t of every slice of this row group is in place (Hall[0] is the caller's zero block)
             __syncthreads();
         }
         bf16x8 af[KSW];
@@ -149,10 +151,15 @@ __global__ __launch_bounds__(256 * KSP) void gru_fwd_persist_kernel(const GruFwd
             if (tid == 0) __hip_atomic_fetch_add(cnt + t + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    __syncthreads();
     if (live) {
         const size_t o = ((size_t)(L - 1) * B + row) * H + u0;
         *reinterpret_cast<bf16x4*>(a.Rg + o) = rr; *reinterpret_cast<bf16x4*>(a.Zg + o) = zz;
         *reinterpret_cast<bf16x4*>(a.Ng + o) = nn; *reinterpret_cast<bf16x4*>(a.GHN + o) = gg;
+        if (s_bad) {             // a poll gave up: the final state of this slice says so (NaNs reach the loss)
+            const unsigned long long q = 0x7FC07FC07FC07FC0ull;
+            *reinterpret_cast<unsigned long long*>(a.Hall + ((size_t)L * B + row) * H + u0) = q;
+        }
     }
 }
 
@@ -163,10 +170,12 @@ __global__ __launch_bounds__(256 * KSP) void gru_bwd_persist_kernel(const GruBwd
     constexpr int K3 = 3 * H, KS3 = K3 / 32, KSW = KS3 / KSP, CH = 48, NCH = KSW / CH, PITCH = 2 * K3 + 16, CS = H / 16, WBYTES = 16 * PITCH;
     static_assert(KSW % CH == 0, "whole chunks");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mt = wave & 3, kh = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
     const int cs = blockIdx.x % CS, rg = blockIdx.x / CS;
     const int B = a.B, L = a.L;
+    if (tid == 0) s_bad = 0;
     // LDS row u = W_hh^T row cs * 16 + u: the 3H gate-output weights that feed hidden unit u of h_{t-1}
     for (int i = tid; i < 16 * (K3 / 8); i += 256 * KSP) {
         const int r = i / (K3 / 8), c = i % (K3 / 8);
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(256 * KSP) void gru_bwd_persist_kernel(const GruBwd
         o = ((size_t)(t - 1) * B + rowc) * H + u0;
         r4 = *reinterpret_cast<const bf16x4*>(a.Rg + o); z4 = *reinterpret_cast<const bf16x4*>(a.Zg + o); n4 = *reinterpret_cast<const bf16x4*>(a.Ng + o);
         g4 = *reinterpret_cast<const bf16x4*>(a.GHN + o); h4 = *reinterpret_cast<const bf16x4*>(a.Hall + o);
-        if (tid == 0) gru_wait(cnt + t, CS, a.err);                  // dgh_t of every slice of this row group
+        if (tid == 0 && !gru_wait(cnt + t, CS, a.err)) s_bad = 1;    // dgh_t of every slice of this row group
         __syncthreads();
         // dh_{t-1}[sample][u0 + j] = carry + sum over the 3H gate outputs of dgh_t[sample][.] W_hh[., u0 + j]
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -248,6 +257,11 @@ __global__ __launch_bounds__(256 * KSP) void gru_bwd_persist_kernel(const GruBwd
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = acc[j] + carry[j];
+    }
+    __syncthreads();
+    if (live && s_bad) {         // a poll gave up: the first token's input gradient of this slice says so
+        const unsigned long long q = 0x7FC07FC07FC07FC0ull;
+        *reinterpret_cast<unsigned long long*>(a.dGI + (size_t)row * a.lddgi + u0) = q;
     }
 }
 
@@ -513,7 +527,10 @@ int k_gru_fwd_persist(const bf16_t* GI, long ldgi, const bf16_t* W, int ldw, con
     RGQA_REQUIRE(gru_persist_ok(B, H), "gru_fwd_persist: B=%d H=%d not covered", B, H);
     constexpr int HH = 1024, LDS_BYTES = 48 * (2 * HH + 16) + 4 * 3 * 64 * 16, LDS32 = 8 * 12 * 64 * 16 + 16;
     const int RG = gru_row_groups(B), RGM = gru_rgm(B);
-    static bool attr = false;
+    static bool attr_dev[64] = {};     // hipFuncSetAttribute is per device
+    int dev = 0;
+    RGQA_HIP(hipGetDevice(&dev));
+    bool& attr = attr_dev[dev & 63];
     if (!attr) {
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persist_kernel<HH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persist_kernel<HH, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -533,7 +550,10 @@ int k_gru_bwd_persist(const bf16_t* dH, const bf16_t* Hall, const bf16_t* Rg, co
     RGQA_REQUIRE(gru_persist_ok(B, H) && ldwt >= 3 * H, "gru_bwd_persist: B=%d H=%d ldwt=%d not covered", B, H, ldwt);
     constexpr int HH = 1024, LDS_BYTES = 16 * (2 * 3 * HH + 16) + 4 * 64 * 16, LDS32 = 8 * 4 * 64 * 16 + 16;
     const int RG = gru_row_groups(B), RGM = gru_rgm(B);
-    static bool attr = false;
+    static bool attr_dev[64] = {};
+    int dev = 0;
+    RGQA_HIP(hipGetDevice(&dev));
+    bool& attr = attr_dev[dev & 63];
     if (!attr) {
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persist_kernel<HH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persist_kernel<HH, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));

@@ -62,22 +62,165 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
     }
 }
 
-// de [rows, H] f32 -> atomic scatter-add into the tables (dense f32 gradients, as the reference's
-// nn.Embedding produces; rows with index 0 are skipped: padding_idx=0 on all three tables in LXMERT (pad0_all), on the word
-// table only in UNITER (uniter/modeling.py:563-568)).
-template <typename T>
-__global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict__ de, const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const int* __restrict__ row_src,
-                                                            float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype, int rows, int Tn, int H, int pad0_all) {
-    const int row = blockIdx.x;
-    if (row >= rows) return;
-    const int src = row_src ? row_src[row] : row;
-    const int t = src % Tn;
-    const int64_t id = ids[src], sg = seg ? seg[src] : 0;
+// ---------------------------------------------------------------------------------------------------------------- embedding gradients
+// de [rows, H] -> the dense f32 gradients of the three tables (what the reference's nn.Embedding produces, lxrt/modeling.py:264-292; rows with index 0 are
+// skipped: padding_idx = 0 on all three tables in LXMERT (pad0_all), on the word table only in UNITER, uniter/modeling.py:563-568).
+// Round 6: DETERMINISTIC - no float atomics.  Until round 5 every row was scatter-added with atomicAdd; the order in which the 256 [CLS] rows of a batch
+// met in table row 101 changed from run to run, the last bits of the sums with it, and BertAdam's normalised update amplified that over a few steps
+// (every "equal to one rank" / "equal to the serial step" test inherited the noise).  Now every table row is summed by ONE workgroup in an order that depends on
+// the batch alone:
+//   word table   one workgroup per packed row r; it goes on only if no earlier row holds the same word id (the id's FIRST occurrence).  Its four waves
+//                scan one contiguous quarter each of the rows r .. rows-1 for the same id (ballot; the matches of a wave are in row order), sum their
+//                de rows in that order (loads of eight rows in flight), and the four partial rows are folded in wave order: dword[id] (+)= sum.
+//   pos / type   few keys with many rows each (position t: one row per sample; token type: up to every row): partial sums per (key, chunk of 256 rows) - a wave per 64
+//                rows, folded in wave order - then one workgroup per key folds the chunks in chunk order.
+// 5,120 rows at B = 256: 33 us for the three launches where the atomic kernel took 24 (and 129 when many rows shared one id).
+__global__ void embed_keys_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const int* __restrict__ row_src, int rows, int Tn,
+                                  int* __restrict__ kw, int* __restrict__ kp, int* __restrict__ kt) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int src = row_src ? row_src[r] : r;
+    kw[r] = (int)ids[src];
+    kp[r] = src % Tn;
+    kt[r] = seg ? (int)seg[src] : 0;
+}
+
+// the de rows lst[0 .. cnt) (offsets from row0) added in list order to acc, eight rows' loads in flight; one wave, lane = 4-column groups lane + 64 i
+template <typename T, int NV>
+__device__ __forceinline__ void embed_sum_rows(const T* __restrict__ de, int ldde, int H, int row0, const unsigned short* lst, int cnt, int lane, float (&acc)[NV][4]) {
+    const int nv = H >> 2;
+    for (int i0 = 0; i0 < cnt; i0 += 8) {
+        float v[8][NV][4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool on = i0 + k < cnt;
+            const size_t row = (size_t)(row0 + (on ? (int)lst[i0 + k] : (int)lst[i0]));
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) load4(de + row * ldde + c * 4, v[k][i]);
+                else { v[k][i][0] = v[k][i][1] = v[k][i][2] = v[k][i][3] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k < cnt) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += v[k][i][j];
+            }
+    }
+}
+
+// four waves' partial rows -> wave 0's acc, in wave order (fold: [3][H] floats of LDS)
+template <int NV>
+__device__ __forceinline__ void embed_fold_waves(float* fold, int H, int wave, int lane, float (&acc)[NV][4]) {
+    const int nv = H >> 2;
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int c = lane + 64 * i; if (c < nv) store4(fold + (size_t)(wave - 1) * H + c * 4, acc[i]); }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) { float t[4]; load4(fold + (size_t)w * H + c * 4, t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += t[j]; }
+            }
+    }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void embed_word_grad_kernel(const T* __restrict__ de, int ldde, const int* __restrict__ kw, float* __restrict__ dword, int rows, int H, int q_cap, int pad_key, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
+    float* fold = reinterpret_cast<float*>(emb_lds);                                      // [3][H]
+    unsigned short* lists = reinterpret_cast<unsigned short*>(emb_lds + (size_t)3 * H * 4);   // [4][q_cap]
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int key = kw[r];
+    if (key == pad_key) return;                                 // padding_idx
+    int found = 0;
+    for (int j = tid; j < r; j += 256) found |= (kw[j] == key);
+    if (__syncthreads_or(found)) return;                        // an earlier row owns this id
+    const int span = rows - r, q = (span + 3) >> 2;
+    const int lo = r + wave * q, hi = (lo + q < rows) ? lo + q : rows;
+    unsigned short* lst = lists + (size_t)wave * q_cap;
+    int cnt = 0;
+    for (int base = lo; base < hi; base += 64) {
+        const int j = base + lane;
+        const bool m = j < hi && kw[j] == key;
+        const unsigned long long mask = __ballot(m);
+        if (m) lst[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(j - lo);
+        cnt += __popcll(mask);
+    }
+    __syncthreads();
+    float acc[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+    if (lo < hi) embed_sum_rows<T, NV>(de, ldde, H, lo, lst, cnt, lane, acc);
+    embed_fold_waves<NV>(fold, H, wave, lane, acc);
+    if (wave == 0) {
+        const int nv = H >> 2;
+        float* dst = dword + (size_t)key * H;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                if (accumulate) { float t[4]; load4(dst + c * 4, t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += t[j]; }
+                store4(dst + c * 4, acc[i]);
+            }
+        }
+    }
+}
+
+// partial[(ky * nchunk + chunk)][H] = sum of the de rows of this 256-row chunk whose key is ky (ky < Tn: position ky; else token type ky - Tn)
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void embed_small_partial_kernel(const T* __restrict__ de, const int* __restrict__ kp, const int* __restrict__ kt, float* __restrict__ partial,
+                                                                  int rows, int Tn, int H, int pad0_all) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
+    float* fold = reinterpret_cast<float*>(emb_lds);
+    unsigned short* lists = reinterpret_cast<unsigned short*>(emb_lds + (size_t)3 * H * 4);   // [4][64]
+    const int chunk = blockIdx.x, ky = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool is_pos = ky < Tn;
+    const int k = is_pos ? ky : ky - Tn;
+    if (k == 0 && pad0_all) return;                             // never folded either
+    const int* keys = is_pos ? kp : kt;
+    const int lo = chunk * 256 + wave * 64, j = lo + lane;
+    const bool m = j < rows && keys[j] == k;
+    const unsigned long long mask = __ballot(m);
+    unsigned short* lst = lists + wave * 64;
+    if (m) lst[__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)lane;
+    const int cnt = __popcll(mask);
+    __syncthreads();
+    float acc[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+    if (cnt) embed_sum_rows<T, NV>(de, H, H, lo, lst, cnt, lane, acc);
+    embed_fold_waves<NV>(fold, H, wave, lane, acc);
+    if (wave == 0) {
+        const int nv = H >> 2;
+        float* dst = partial + ((size_t)ky * gridDim.x + chunk) * H;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int c = lane + 64 * i; if (c < nv) store4(dst + c * 4, acc[i]); }
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_small_fold_kernel(const float* __restrict__ partial, int nchunk, float* __restrict__ dpos, float* __restrict__ dtype, int Tn, int H,
+                                                               int pad0_all, int accumulate) {
+    const int ky = blockIdx.x;
+    const bool is_pos = ky < Tn;
+    const int k = is_pos ? ky : ky - Tn;
+    if (k == 0 && pad0_all) return;
+    float* dst = (is_pos ? dpos : dtype) + (size_t)k * H;
     for (int n = threadIdx.x; n < H; n += 256) {
-        const float g = ld_elem(de + (size_t)row * H + n);
-        if (id != 0) atomicAdd(dword + (size_t)id * H + n, g);
-        if (t != 0 || !pad0_all) atomicAdd(dpos + (size_t)t * H + n, g);
-        if (sg != 0 || !pad0_all) atomicAdd(dtype + (size_t)sg * H + n, g);
+        float s = 0.f;
+        for (int c = 0; c < nchunk; ++c) s += partial[((size_t)ky * nchunk + c) * H + n];
+        dst[n] = accumulate ? dst[n] + s : s;
     }
 }
 
@@ -100,12 +243,59 @@ int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, cons
     return RGQA_OK;
 }
 
+// One table: dtable[key[r]] (+)= sum of the de rows that name it (rows of key pad_key: none).  keys: rows ints (device).  de row pitch ldde, table rows of H floats.
 template <typename T>
-int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, int pad0_all, hipStream_t s) {
+int k_embed_word_grad(const T* de, int ldde, const int* keys, int rows, float* dtable, int H, int pad_key, int accumulate, hipStream_t s) {
+    if (rows <= 0) return RGQA_OK;
+    RGQA_REQUIRE(H % 4 == 0 && H <= 2048 && ldde % 4 == 0 && ldde >= H, "embed word grad: hidden %d / pitch %d unsupported", H, ldde);
+    const int q_cap = (rows + 3) / 4 + 1;
+    RGQA_REQUIRE(q_cap <= 65536, "embed word grad: %d rows exceed the 16-bit row lists", rows);
+    const size_t lds_w = (size_t)3 * H * 4 + (size_t)4 * q_cap * 2;
+    RGQA_REQUIRE(lds_w <= 160 * 1024, "embed word grad: %d rows need %zu bytes of LDS", rows, lds_w);
+    const int nvl = cdiv(H / 4, 64);
+#define EMBW(NVV) do { \
+        if (lds_w > 64 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_word_grad_kernel<T, NVV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); \
+        hipLaunchKernelGGL((embed_word_grad_kernel<T, NVV>), dim3(rows), dim3(256), lds_w, s, de, ldde, keys, dtable, rows, H, q_cap, pad_key, accumulate); } while (0)
+    if (nvl <= 1) EMBW(1); else if (nvl == 2) EMBW(2); else if (nvl == 3) EMBW(3); else if (nvl == 4) EMBW(4); else EMBW(8);
+#undef EMBW
+    RGQA_LAUNCH_CHECK("embed_word_grad_kernel");
+    return RGQA_OK;
+}
+
+__global__ void embed_keys_i64_kernel(const int64_t* __restrict__ ids, int rows, int* __restrict__ keys) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) keys[r] = (int)ids[r];
+}
+int k_embed_keys(const int64_t* ids, int rows, int* keys, hipStream_t s) {
+    if (rows <= 0) return RGQA_OK;
+    hipLaunchKernelGGL(embed_keys_i64_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, ids, rows, keys);
+    RGQA_LAUNCH_CHECK("embed_keys_i64_kernel");
+    return RGQA_OK;
+}
+
+// keys: 3 * rows ints of scratch; scratch: f32 scratch for the position / token-type partial sums ((Tn + type_vocab) * ceil(rows / 256) * H floats).
+// accumulate = 0: the tables were zeroed by the caller (rows no token names keep the zeros); 1: the sums are added to what the tables hold.
+template <typename T>
+int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, int type_vocab,
+                    int pad0_all, int accumulate, int* keys, float* scratch, size_t scratch_floats, hipStream_t s) {
     RGQA_REQUIRE(rows <= B * Tn, "embed scatter: %d rows exceed B*T = %d", rows, B * Tn);
     if (rows <= 0) return RGQA_OK;
-    hipLaunchKernelGGL(embed_scatter_kernel<T>, dim3(rows), dim3(256), 0, s, de, ids, seg, row_src, dword, dpos, dtype, rows, Tn, H, pad0_all);
-    RGQA_LAUNCH_CHECK("embed_scatter_kernel");
+    const int nchunk = cdiv(rows, 256), nkeys = Tn + type_vocab;
+    RGQA_REQUIRE(H % 4 == 0 && H <= 2048, "embed scatter: hidden %d unsupported", H);
+    RGQA_REQUIRE(keys != nullptr && scratch != nullptr && (size_t)nkeys * nchunk * H <= scratch_floats, "embed scatter: scratch too small (%zu floats for %d keys x %d chunks x %d)",
+                 scratch_floats, nkeys, nchunk, H);
+    const size_t lds_p = (size_t)3 * H * 4 + 4 * 64 * 2;
+    int *kw = keys, *kp = keys + rows, *kt = keys + 2 * (size_t)rows;
+    hipLaunchKernelGGL(embed_keys_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, ids, seg, row_src, rows, Tn, kw, kp, kt);
+    RGQA_LAUNCH_CHECK("embed_keys_kernel");
+    if (int r = k_embed_word_grad<T>(de, H, kw, rows, dword, H, 0, accumulate, s)) return r;
+    const int nvl = cdiv(H / 4, 64);
+#define EMBP(NVV) hipLaunchKernelGGL((embed_small_partial_kernel<T, NVV>), dim3(nchunk, nkeys), dim3(256), lds_p, s, de, kp, kt, scratch, rows, Tn, H, pad0_all)
+    if (nvl <= 1) EMBP(1); else if (nvl == 2) EMBP(2); else if (nvl == 3) EMBP(3); else if (nvl == 4) EMBP(4); else EMBP(8);
+#undef EMBP
+    RGQA_LAUNCH_CHECK("embed_small_partial_kernel");
+    hipLaunchKernelGGL(embed_small_fold_kernel, dim3(nkeys), dim3(256), 0, s, scratch, nchunk, dpos, dtype, Tn, H, pad0_all, accumulate);
+    RGQA_LAUNCH_CHECK("embed_small_fold_kernel");
     return RGQA_OK;
 }
 
@@ -119,6 +309,9 @@ int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s) {
 template int k_embed_fwd<float>(const int64_t*, const int64_t*, const int*, const int*, int, const float*, const float*, const float*, const float*, const float*, float*, int, float*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
 template int k_embed_fwd<bf16_t>(const int64_t*, const int64_t*, const int*, const int*, int, const float*, const float*, const float*, const float*, const float*, bf16_t*, int, bf16_t*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
 template int k_embed_fwd<sf32>(const int64_t*, const int64_t*, const int*, const int*, int, const float*, const float*, const float*, const float*, const float*, sf32*, int, sf32*, float*, float*, int, int, int, int, int, float, DropCfg, hipStream_t);
-template int k_embed_scatter<sf32>(const sf32*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, hipStream_t);
-template int k_embed_scatter<float>(const float*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, hipStream_t);
-template int k_embed_scatter<bf16_t>(const bf16_t*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, hipStream_t);
+template int k_embed_scatter<sf32>(const sf32*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
+template int k_embed_scatter<float>(const float*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
+template int k_embed_scatter<bf16_t>(const bf16_t*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
+template int k_embed_word_grad<sf32>(const sf32*, int, const int*, int, float*, int, int, int, hipStream_t);
+template int k_embed_word_grad<float>(const float*, int, const int*, int, float*, int, int, int, hipStream_t);
+template int k_embed_word_grad<bf16_t>(const bf16_t*, int, const int*, int, float*, int, int, int, hipStream_t);

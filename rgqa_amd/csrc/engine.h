@@ -47,7 +47,7 @@ struct Stage {
 };
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's live roofline figures).
-enum ProfCat { PC_GEMM_NT = 0, PC_GEMM_TN = 1, PC_ATTN_FWD = 2, PC_ATTN_BWD = 3, PC_LN = 4, PC_OTHER = 5, PC_COUNT = 6 };
+enum ProfCat { PC_GEMM_NT = 0, PC_GEMM_TN = 1, PC_ATTN_FWD = 2, PC_ATTN_BWD = 3, PC_LN = 4, PC_OTHER = 5, PC_GEMM_NT_D = 6 /* the dgrad launches of the NT family (round 6: under bf16x3_fwd they are bf16 kernels, the forward's split f32) */, PC_COUNT = 7 };
 enum ProfBlock { PB_EMBED = 0, PB_LR = 1, PB_X = 2, PB_HEAD = 3, PB_COUNT = 4 };   // input embeddings | l/r layers | cross-modality layers | pooler + head + loss
 struct ProfRec { hipEvent_t a, b; int cat; int block; double flops, bytes, obytes; char tag[48]; };
 struct ProfSummary { double ms[PC_COUNT]; double flops[PC_COUNT]; double bytes[PC_COUNT]; long launches[PC_COUNT]; };

@@ -506,7 +506,7 @@ public:
         ws_used = 0;
         stages.clear();
         maskf = take<float>(RlC);
-        lens_dev = take<int>(B); cu_dev = take<int>(B + 1); row_src_dev = take<int>(RlC); cls_rows = take<T>((size_t)B * H); tail_x = take<T>((size_t)B * H); tail_dx = take<TB>((size_t)B * H);
+        lens_dev = take<int>(B); cu_dev = take<int>(B + 1); row_src_dev = take<int>(RlC); emb_keys = take<int>(3 * (size_t)RlC); cls_rows = take<T>((size_t)B * H); tail_x = take<T>((size_t)B * H); tail_dx = take<TB>((size_t)B * H);
         emb_out = take<T>((size_t)RC * H); emb_z = take<T>((size_t)RlC * H); emb_mean = take<float>(RlC); emb_rstd = take<float>(RlC);
         zf = take<T>((size_t)Rv * H); visn_stats = take<float>((size_t)Rv * 4);
         feats_lp = LP ? take<T>((size_t)Rv * cfg.feat_dim) : nullptr;   // bf16 copy of the RoI features: read by visn_fc forward AND its wgrad
@@ -620,6 +620,7 @@ public:
             ws_used = mirror_off + rup(fwd_end / 2, 256);
         }
     }
+    int* emb_keys = nullptr;      // word / position / token-type key of every packed row (embedding backward)
     int *lens_dev = nullptr, *cu_dev = nullptr, *row_src_dev = nullptr; T* cls_rows = nullptr; T* tail_x = nullptr; TB* tail_dx = nullptr; T* pool_in = nullptr;
     // UNITER (arch 2): ONE sequence per sample, [text tokens ; image regions], laid out as the engine's language modality with
     // Tn = Tt + Oi rows per sample (packed: real text tokens + Oi) and no vision modality; only the embedding front-end differs.
@@ -783,19 +784,21 @@ public:
         return buf;
     }
     double last_obytes = 0;        // gemm_work: the operands alone (A + B + C) of the group it was last called for
-    void gemm_work(const GemmGroup& g, double& flops, double& bytes) {
+    void gemm_work(const GemmGroup& g, double& flops, double& bytes) { gemm_work_t<T>(g, flops, bytes); }
+    // U = element type of the launch's operands (T forward; TB dgrad / wgrad: bf16 under MIXED, where round 5 priced them at 4 bytes)
+    template <typename U> void gemm_work_t(const GemmGroup& g, double& flops, double& bytes) {
         flops = 0; bytes = 0;
         for (int i = 0; i < g.count; ++i) {
             const GemmProblem& p = g.p[i];
             flops += 2.0 * p.M * p.N * p.K;
-            bytes += sizeof(T) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
-            last_obytes = (i == 0 ? 0.0 : last_obytes) + sizeof(T) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+            bytes += sizeof(U) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+            last_obytes = (i == 0 ? 0.0 : last_obytes) + sizeof(U) * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
             // the operands of the fused epilogue are algorithmic bytes of the launch too: the residual / gelu' / activation it reads and
             // the second output it writes would be moved by a separate element-wise kernel otherwise (twice: that kernel would re-read C)
-            if (epi_needs_aux(p.epi) && p.aux != nullptr) bytes += sizeof(T) * (double)p.M * p.N;
-            if (p.C2 != nullptr) bytes += (p.c2_lp ? 2.0 : (double)sizeof(T)) * (double)p.M * p.N;
+            if (epi_needs_aux(p.epi) && p.aux != nullptr) bytes += sizeof(U) * (double)p.M * p.N;
+            if (p.C2 != nullptr) bytes += (p.c2_lp ? 2.0 : (double)sizeof(U)) * (double)p.M * p.N;
             if (p.Cb != nullptr) bytes += 2.0 * (double)p.M * p.N;
-            if (p.ln_tk != nullptr) bytes += 2.0 * sizeof(T) * (double)p.M * p.N;      // the fused LayerNorm: the sum read back, the normalised rows written
+            if (p.ln_tk != nullptr) bytes += 2.0 * sizeof(U) * (double)p.M * p.N;      // the fused LayerNorm: the sum read back, the normalised rows written
         }
     }
     // cls_rows: the launch is one of those whose rows are the B [CLS] rows (tail of the last layer, pooler, answer head): skinny whatever the
@@ -815,9 +818,9 @@ public:
     int run_dgrad(GemmGroup& g, hipStream_t s, bool cls_rows = false) {
         if (g.count == 0) return RGQA_OK;
         RGQA_REQUIRE(!dgrad_mixed, "dgrad: a launch mixes [K, N] and transposed weight operands, or names a transposed copy that is not kept");
-        double f, b; gemm_work(g, f, b);
+        double f, b; gemm_work_t<TB>(g, f, b);
         char tg[48];
-        prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "", last_obytes);
+        prof_begin(PC_GEMM_NT_D, f, b, s, profiling ? gemm_tag(g, tg) : "", last_obytes);
         if constexpr (std::is_same<TB, bf16_t>::value) { if (cls_rows) { g.splitk_ws = part; g.splitk_floats = part_floats; } }
         int r = nt_gemm_b(g, 0, 1, s);
         prof_end(s);
@@ -826,7 +829,7 @@ public:
     int run_wgrad(GemmGroup& g, hipStream_t s, int b_f32 = 0) {
         if (g.count == 0 || g_rgqa_skip_wgrad) return RGQA_OK;
         g.a_f32 = b_f32;
-        double f, b; gemm_work(g, f, b);
+        double f, b; gemm_work_t<TB>(g, f, b);
         char tg[48];
         prof_begin(PC_GEMM_TN, f, b, s, profiling ? gemm_tag(g, tg) : "");
         int r = tn_gemm(g, s);
@@ -1009,7 +1012,7 @@ public:
         CKP(PC_OTHER, k_gather_rows<TB>(dy, H, text_dst_dev, 0, u_gt, H, n_text, H, s));
         CKP(PC_LN, k_ln_bwd<TB>(u_gt, H, sv(emb_z), H, P + mp.emb_ln.w, emb_mean, emb_rstd, u_de, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, n_text, H,
                                nodrop, drop_site(pd, 1), 1.0f, s));
-        CKP(PC_OTHER, k_embed_scatter<TB>(u_de, in_ids, in_seg, trow_src_dev, n_text, G + mp.word, G + mp.pos, G + mp.type, B, Tt, H, 0, s));
+        CKP(PC_OTHER, k_embed_scatter<TB>(u_de, in_ids, in_seg, trow_src_dev, n_text, G + mp.word, G + mp.pos, G + mp.type, B, Tt, H, cfg.type_vocab, 0, accumulate, emb_keys, part, part_floats, s));
         // image rows: final LayerNorm, then the same gradient enters both branch LayerNorms and the type-1 embedding row
         CKP(PC_OTHER, k_gather_rows<TB>(dy, H, img_dst_dev, 0, u_g, H, ni, H, s));
         CKP(PC_LN, k_ln_bwd<TB>(u_g, H, sv(u_x3), H, P + mp.img_ln.w, u_st + 4 * ni, u_st + 5 * ni, u_dx3, nullptr, H, part, G + mp.img_ln.w, G + mp.img_ln.b, nullptr, accumulate, ni, H,
@@ -1119,7 +1122,8 @@ public:
         // BCE on the f32 logits; dlogits written as f32 into `logits`' sibling then cast+padded to T
         prof_block = PB_HEAD;
         float* dl32 = part;   // scratch [B, NAp] f32
-        CKP(PC_OTHER, k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, cfg.num_answers, NAp, grad_scale, s));
+        RGQA_REQUIRE((size_t)B * NAp + B <= part_floats, "loss_backward: batch %d exceeds the scratch", B);
+        CKP(PC_OTHER, k_bce_fwd_bwd(logits, NAp, target, ldt, loss_dev, dl32, NAp, B, cfg.num_answers, NAp, grad_scale, s, part + (size_t)B * NAp));
         if (loss_out) CK(rgqa_check_hip(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s), "loss copy"));
         CKP(PC_OTHER, k_cast_pad<TB>(dl32, NAp, dlogits, NAp, B, NAp, 1.0f, s));
         return backward_impl(accumulate, s);
@@ -1142,7 +1146,7 @@ public:
         const float pd = cfg.hidden_dropout, pa = cfg.attn_dropout;
         const DropCfg nodrop = make_drop(0.f, 0, 0);
         if (!accumulate) {
-            // tables written by atomics and parameters that receive no gradient must start from zero
+            // table rows no token of the batch names and parameters that receive no gradient must be zero
             CK(rgqa_check_hip(hipMemsetAsync(G + mp.word, 0, sizeof(float) * (mp.emb_ln.w - mp.word), s), "zero embedding grads"));
             if (dead_end > dead_begin) CK(rgqa_check_hip(hipMemsetAsync(G + dead_begin, 0, sizeof(float) * (dead_end - dead_begin), s), "zero dead grads"));
         }
@@ -1422,7 +1426,7 @@ public:
             DropCfg din = drop_site(pd, 1);
             CKP(PC_LN, k_ln_bwd<TB>(dyp[0], H, sv(emb_z), H, P + mp.emb_ln.w, emb_mean, emb_rstd, gz, nullptr, H, part, G + mp.emb_ln.w, G + mp.emb_ln.b, nullptr, accumulate, Rl, H,
                            nodrop, din, 1.0f, s));
-            CKP(PC_OTHER, k_embed_scatter<TB>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, 1, s));
+            CKP(PC_OTHER, k_embed_scatter<TB>(gz, in_ids, in_seg, fwd_varlen ? row_src_dev : nullptr, Rl, G + mp.word, G + mp.pos, G + mp.type, B, Tn, H, cfg.type_vocab, 1, accumulate, emb_keys, part, part_floats, s));
         }
         // ---- visual embedding
         {
@@ -1459,8 +1463,8 @@ public:
             if (dfeats_out) {       // input gradient dL/dfeats [B*O, feat_dim] f32 = dzf . W_visn_fc   (ODIN, tasks/gqa_odin.py:97-121)
                 gg_init(g);
                 add_dgrad(g, dzf, H, mp.visn_fc, 0, H, dfeats_out, cfg.feat_dim, Rv, EPI_BIAS, nullptr, 0);
-                double f, b; gemm_work(g, f, b);
-                prof_begin(PC_GEMM_NT, f, b, s);
+                double f, b; gemm_work_t<TB>(g, f, b);
+                prof_begin(PC_GEMM_NT_D, f, b, s);
                 int r = nt_gemm_b(g, 1, 1, s);
                 prof_end(s);
                 CK(r);

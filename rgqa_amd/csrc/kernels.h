@@ -89,7 +89,12 @@ int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, cons
 // de [B*T, H] f32 (gradient w.r.t. the pre-LN embedding sum) scattered into the three tables; row 0 of each
 // table gets no gradient (padding_idx=0, modeling.py:269-271)
 template <typename T>
-int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, int pad0_all, hipStream_t s);
+int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, int type_vocab,
+                    int pad0_all, int accumulate, int* keys, float* scratch, size_t scratch_floats, hipStream_t s);
+// one embedding table's dense gradient without float atomics: dtable[keys[r]] (+)= sum over the rows r that name the key, in a fixed order (embed.hip)
+template <typename T>
+int k_embed_word_grad(const T* de, int ldde, const int* keys, int rows, float* dtable, int H, int pad_key, int accumulate, hipStream_t s);
+int k_embed_keys(const int64_t* ids, int rows, int* keys, hipStream_t s);
 // additive key mask (1 - m) * -10000 from the 0/1 int64 attention mask (modeling.py:857-865)
 int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s);
 
@@ -115,7 +120,8 @@ int k_visn_combine_bwd(const T* dout, int lddo, const T* zf, int ldz, const floa
 
 // ---- loss.hip
 // loss = mean_b sum_n BCEWithLogits(z, t)  (= BCEWithLogitsLoss() * NA, gqa_conf.py:197-198); dz = (sigmoid(z)-t)/B * grad_scale
-int k_bce_fwd_bwd(const float* logits, int ldl, const float* target, int ldt, float* loss_out, float* dlogits, int lddl, int B, int NA, int NAp, float grad_scale, hipStream_t s);
+int k_bce_fwd_bwd(const float* logits, int ldl, const float* target, int ldt, float* loss_out, float* dlogits, int lddl, int B, int NA, int NAp, float grad_scale, hipStream_t s,
+                  float* row_scratch = nullptr /* B floats: the loss is then folded in a fixed order (no float atomics) */);
 
 // ---- optim.hip
 int k_sumsq(const float* g, size_t n, float* partial /* >= 1025 floats, any content ([1024] = ticket word, zeroed on the stream by the call) */, float* out_sumsq, int accumulate_into_out, hipStream_t s);

@@ -116,6 +116,7 @@ class Engine:
         self._sharded_owner = None       # set by parallel.ShardedExchange while the f32 masters / Adam moments are valid on their owner rank only
         self.shape = None
         self._io = {}
+        self._wev_refs = {}              # events handed to the C++ engine by raw handle (set_weight_event / set_backward_event), alive until the pass that waits is enqueued
 
     def __del__(self):
         try:
@@ -180,6 +181,13 @@ class Engine:
     def ensure_shape(self, B, T, O):
         if self.shape == (B, T, O):
             return
+        # An optimizer pass may still be running beside the forward (adam_step(overlap), the sharded exchange's gather): its last kernel reads the
+        # transpose descriptor table out of the workspace, which the re-plan below moves or frees: the caller's stream - on which the
+        # re-bind's uploads and the next pass run - first joins it, and a sharded exchange joins its gather
+        self.join_update()
+        owner = self._sharded_owner
+        if owner is not None and hasattr(owner, "_join_gather"):
+            owner._join_gather()
         need = C.c_size_t()
         check(self.lib.rgqa_engine_workspace_bytes(self.h, B, T, O, C.byref(need)))
         if self.workspace is None or self.workspace.numel() < need.value:
@@ -244,6 +252,8 @@ class Engine:
         lg, pl = self._io["logits"], self._io["pooled"]
         check(self.lib.rgqa_engine_forward(self.h, ptr(feats), ptr(boxes), ptr(input_ids), ptr(segment_ids), ptr(input_mask),
                                            ptr(pl), ptr(lg), lg.stride(0), 1 if train else 0, C.c_uint64(seed), _stream()))
+        for k in [k for k in self._wev_refs if k != "bwd"]:      # the waits are enqueued: the one-shot weight events may go
+            del self._wev_refs[k]
         self.join_update()      # an optimizer pass beside this forward (it finished long ago: 1.3 ms against 3.6): whatever follows on this stream sees its results
         return lg, pl
 
@@ -255,17 +265,20 @@ class Engine:
             self.flush_deferred_clip() if accumulate else self.drop_deferred_clip()
         check(self.lib.rgqa_engine_loss_backward(self.h, ptr(target), target.stride(0), ptr(self._io["loss"]), grad_scale,
                                                  1 if accumulate else 0, _stream()))
+        self._wev_refs.pop("bwd", None)
         self._seg_sumsq_valid = self._seg_sumsq is not None
         return self._io["loss"]
 
     def backward(self, dlogits, accumulate=False):
         dlogits = dlogits.contiguous().float()
         check(self.lib.rgqa_engine_backward(self.h, ptr(dlogits), dlogits.stride(0), 1 if accumulate else 0, _stream()))
+        self._wev_refs.pop("bwd", None)
         self._seg_sumsq_valid = self._seg_sumsq is not None
 
     def backward_pooled(self, dpooled, accumulate=False):
         dpooled = dpooled.contiguous().float()
         check(self.lib.rgqa_engine_backward_pooled(self.h, ptr(dpooled), dpooled.stride(0), 1 if accumulate else 0, _stream()))
+        self._wev_refs.pop("bwd", None)
 
     def set_input_grads(self, dfeats=None, dboxes=None):
         """f32 device tensors [B*O, feat_dim] / [B*O, pos_dim] (or None) that the following backward calls fill with dL/dfeats and
@@ -293,7 +306,9 @@ class Engine:
         check(self.lib.rgqa_engine_get_cross_attention(self.h, int(layer), d, ptr(out), out.numel(), _stream()))
         return out
 
-    PROFILE_CATS = ("gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "layernorm", "other")
+    # "gemm_nt": the forward launches of the NT GEMM family, "gemm_nt_dgrad": its dgrad launches (one category until round 5; under bf16x3_fwd the
+    # forward launches are split-f32 kernels and the dgrad launches bf16 kernels)
+    PROFILE_CATS = ("gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "layernorm", "other", "gemm_nt_dgrad")
 
     def profile(self, enable):
         check(self.lib.rgqa_engine_profile(self.h, 1 if enable else 0))
@@ -340,7 +355,12 @@ class Engine:
 
     def set_weight_event(self, segment_event, event):
         """The next forward pass waits for torch event `event` (recorded once the weights of gradient segment `segment_event` are in place) before
-        the first launch that reads those weights (rgqa_engine_set_weight_event; one-shot).  The caller keeps `event` alive until then."""
+        the first launch that reads those weights (rgqa_engine_set_weight_event; one-shot).  The engine handle keeps `event` alive until that
+        pass has been enqueued (the C++ side holds the raw hipEvent_t only: ADVICE r5)."""
+        if event is None:
+            self._wev_refs.pop(int(segment_event), None)
+        else:
+            self._wev_refs[int(segment_event)] = event
         check(self.lib.rgqa_engine_set_weight_event(self.h, int(segment_event), C.c_void_p(event.cuda_event) if event is not None else None))
 
     def num_weight_segments(self):
@@ -351,6 +371,10 @@ class Engine:
 
     def set_backward_event(self, event):
         """the next backward pass waits for `event` before its first launch (the transposed operand copies are refreshed behind it); one-shot"""
+        if event is None:
+            self._wev_refs.pop("bwd", None)
+        else:
+            self._wev_refs["bwd"] = event
         check(self.lib.rgqa_engine_set_backward_event(self.h, C.c_void_p(event.cuda_event) if event is not None else None))
 
     def enable_segment_sumsq(self, on=True):

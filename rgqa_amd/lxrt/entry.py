@@ -10,15 +10,11 @@ from .tokenization import BertTokenizer
 from .modeling import LXRTFeatureExtraction as VisualBertForLXRFeature, VISUAL_CONFIG
 from . import optimization as _optimization
 
-# The unchanged trainers call `nn.utils.clip_grad_norm_(self.model.parameters(), 5.)` (tasks/gqa_conf.py:201, gqa_mixup_vis.py:258).  Importing the
-# drop-in entry module routes that name through rgqa_amd.lxrt.optimization.clip_grad_norm_: identical results, a fused fast path when the
-# parameters are the views of one engine's arena, torch's own implementation for everything else.  RGQA_PATCH_CLIP=0 leaves torch untouched.
-if os.environ.get("RGQA_PATCH_CLIP", "1") != "0" and torch.nn.utils.clip_grad_norm_ is not _optimization.clip_grad_norm_:
-    torch.nn.utils.clip_grad_norm_ = _optimization.clip_grad_norm_
-    import logging as _logging
-    _logging.getLogger(__name__).info("rgqa_amd: torch.nn.utils.clip_grad_norm_ is routed through rgqa_amd.lxrt.optimization.clip_grad_norm_ for this process "
-                                      "(engine arenas take a fused path, everything else torch's own implementation; RGQA_PATCH_CLIP=0 disables; names bound "
-                                      "with `from torch.nn.utils import clip_grad_norm_` BEFORE this import keep torch's function)")
+# The unchanged trainers call `nn.utils.clip_grad_norm_(self.model.parameters(), 5.)` (tasks/gqa_conf.py:201, gqa_mixup_vis.py:258).  While an
+# engine-backed LXRTEncoder is ALIVE that name is routed through rgqa_amd.lxrt.optimization.clip_grad_norm_ (identical results, a fused fast path
+# when the parameters are the views of one engine's arena, torch's own implementation for everything else): LXRTEncoder.__init__ installs the
+# routing, the encoder's finaliser removes it when the last one is collected (optimization.install_clip_routing).  Importing this module changes
+# nothing (until round 5 the import itself rebound the name for the whole process); RGQA_PATCH_CLIP=0 leaves torch untouched altogether.
 
 
 class InputFeatures(object):

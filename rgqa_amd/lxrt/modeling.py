@@ -158,8 +158,12 @@ class ArenaParameter(nn.Parameter):
         ref = self.__dict__.get("_rgqa_binding")
         if ref is not None:
             b = ref()
-            if b is not None and b.engine is not None and getattr(b.engine, "_pending_clip", None) is not None:
-                b.engine.flush_deferred_clip()
+            if b is not None and b.engine is not None:
+                if getattr(b.engine, "_pending_clip", None) is not None:
+                    b.engine.flush_deferred_clip()
+                # whoever takes the gradient view may write it in place (nn.Module.zero_grad(set_to_none=False), a foreign optimizer): the caller's
+                # stream first joins an optimizer pass still reading the arena beside the forward pass (a stream-side wait; free when none is)
+                b.engine.join_update()
         return _RAW_GRAD.__get__(self, type(self))
 
     @grad.setter
@@ -189,6 +193,12 @@ class ArenaParameter(nn.Parameter):
             if b is not None and b.engine is not None:
                 b.engine.join_update()
         _RAW_DATA.__set__(self, value)
+
+    def __reduce_ex__(self, proto):
+        # pickled (torch.save(model), copy.deepcopy of a container) as a plain nn.Parameter holding the current values: the arena binding is a
+        # property of the live engine, not of the tensor (and its weak reference is not picklable: ADVICE r5)
+        from collections import OrderedDict
+        return (torch._utils._rebuild_parameter, (self.data, self.requires_grad, OrderedDict()))
 
 
 class ArenaBinding(object):
@@ -446,6 +456,9 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         # overwrites the parameters through nn.Module's own paths joins it first (a stream-side wait, no host synchronisation)
         self._register_state_dict_hook(lambda module, *_: module._binding.engine.join_update())
         self._register_load_state_dict_pre_hook(lambda *_: self._binding.engine.join_update())
+        # the unchanged trainers' `nn.utils.clip_grad_norm_(model.parameters(), 5.)` takes the arena-aware implementation while this module is alive
+        from . import optimization as _optimization
+        _optimization.install_clip_routing(self)
 
     # -- engine / arena -------------------------------------------------------------------------------------------
     def _make_engine(self, num_answers):
@@ -485,6 +498,10 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         # the encoder tree's parameters keep their identity; only the binding (offsets) is rebuilt
         self._rebind()
         self.__dict__.pop("_hidden_head", None)
+
+    def __getstate__(self):
+        raise TypeError("rgqa_amd: an engine-backed module holds device arenas and a native handle and cannot be pickled whole; "
+                        "save model.state_dict() (what the reference's trainers do, tasks/gqa.py save()) and load it into a new model")
 
     def _ready(self, device):
         # parameters moved by .cuda()/.to() (or freshly built on the host) are packed into the flat arenas here

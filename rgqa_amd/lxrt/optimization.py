@@ -72,6 +72,32 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
 
 
 _CLIP_CACHE = {}
+_CLIP_OWNERS = 0
+
+
+def install_clip_routing(owner):
+    """Routes `torch.nn.utils.clip_grad_norm_` through clip_grad_norm_ above for as long as `owner` - an engine-backed module - is alive: a scope the
+    drop-in objects install and remove (a finaliser on the owner; the last one restores torch's own function), not a side effect of an import.
+    Names bound with `from torch.nn.utils import clip_grad_norm_` before the owner existed keep torch's function.  RGQA_PATCH_CLIP=0: no routing."""
+    global _CLIP_OWNERS
+    if os.environ.get("RGQA_PATCH_CLIP", "1") == "0":
+        return False
+    import weakref
+    if _CLIP_OWNERS == 0 and torch.nn.utils.clip_grad_norm_ is not clip_grad_norm_:
+        torch.nn.utils.clip_grad_norm_ = clip_grad_norm_
+        logger.info("rgqa_amd: torch.nn.utils.clip_grad_norm_ is routed through rgqa_amd.lxrt.optimization.clip_grad_norm_ while an engine-backed model is alive "
+                    "(engine arenas take a fused path, everything else torch's own implementation; RGQA_PATCH_CLIP=0 disables)")
+    _CLIP_OWNERS += 1
+    weakref.finalize(owner, _release_clip_routing)
+    return True
+
+
+def _release_clip_routing():
+    global _CLIP_OWNERS
+    _CLIP_OWNERS = max(0, _CLIP_OWNERS - 1)
+    if _CLIP_OWNERS == 0 and torch.nn.utils.clip_grad_norm_ is clip_grad_norm_:
+        torch.nn.utils.clip_grad_norm_ = _torch_clip_grad_norm_
+        _CLIP_CACHE.clear()
 
 
 def engine_view_offset(eng, p):

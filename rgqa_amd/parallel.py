@@ -116,6 +116,9 @@ class _HipOps:
     def cast_bf16(self, dst, src):
         check(self.lib.rgqa_cast_bf16(ptr(src), ptr(dst), src.numel(), self._s()))
 
+    def split_f32(self, dst, src):
+        check(self.lib.rgqa_split_f32(ptr(src), ptr(dst), src.numel(), self._s()))
+
     def sum_parts(self, dst, parts, stride, nparts, sq_ws=None, sq_out=None):
         check(self.lib.rgqa_sum_parts(ptr(parts), 1 if parts.dtype == torch.float32 else 0, stride, nparts, ptr(dst), dst.numel(),
                                       ptr(sq_ws) if sq_out is not None else None, ptr(sq_out), self._s()))
@@ -232,10 +235,23 @@ class ShardedExchange:
         dev = engine.grads.device
         self._send = torch.zeros(self.world * self.smax, dtype=self.payload, device=dev)
         self._recv = torch.zeros(self.world * self.smax, dtype=self.payload, device=dev)
-        self._stage = [(self._send, self._recv)]       # one staging set per exchange stream (the second is made on first use)
+        self._stage = [(self._send, self._recv)]       # one staging set per exchange stream
         self.nstreams = 2 if os.environ.get("RGQA_DP_EXCHANGE_STREAMS", "2") != "1" else 1
         self.side2 = self._sumsq2 = self._sqws2 = None
-        self._sumsq = self._sqws = None
+        # Everything the exchange streams touch is made HERE, not on first use inside exchange(): a torch.zeros() there put its fill kernel on
+        # the caller's stream BEHIND the whole backward pass while a side stream - which waits for a gradient-segment event in the middle of
+        # backward only - was already casting into / summing from the buffer: the fill could land between the cast and the shard sum of a chunk in
+        # flight.  `_alloc_ready` orders the side streams' first use behind these fills.
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._sqws = torch.zeros(2048, dtype=torch.float32, device=dev)
+        if self.overlap and self.nstreams > 1 and len(self.chunks) > 1:
+            self._stage.append((torch.zeros_like(self._send), torch.zeros_like(self._recv)))
+            self._sumsq2 = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._sqws2 = torch.zeros(2048, dtype=torch.float32, device=dev)
+        self._alloc_ready = None
+        if dev.type == "cuda":
+            self._alloc_ready = torch.cuda.Event()
+            self._alloc_ready.record(torch.cuda.current_stream(dev))
         self._sumsq_from_exchange = False
         self._norm_read = None
         self.side = None
@@ -250,7 +266,11 @@ class ShardedExchange:
         # re-made from the gathered masters as a whole); RGQA_DP_GATHER_OVERLAP=0 keeps the gather on the step's stream.
         # ... and only around an engine whose forward waits per segment (the BUTD engine re-derives its effective weights from the masters at the
         # start of every pass: it waits for nothing, its gather stays on the step's stream)
-        self.gather_overlap = (self.overlap and self.lp and dev.type == "cuda" and hasattr(engine, "set_weight_event")
+        # round 6: the split-f32 engines too (bf16x3_fwd is bench.py's headline) - their chunks gather the f32 masters and re-make the split operand copy of
+        # the chunk's own range behind it (chunks begin and end on tensor boundaries: 64-element aligned, whole 128-byte lines of the split layout)
+        self.x3 = engine.precision in ("bf16x3", "bf16x3_fwd") and getattr(engine, "_params_lp", None) is not None
+        split_ok = self.x3 and all(a % 32 == 0 and b % 32 == 0 for a, b, _ in self.chunks)
+        self.gather_overlap = (self.overlap and (self.lp or split_ok) and dev.type == "cuda" and hasattr(engine, "set_weight_event")
                                and hasattr(engine, "num_weight_segments") and engine.num_weight_segments() > 0
                                and os.environ.get("RGQA_DP_GATHER_OVERLAP", "1") != "0")
         self._wevents = []
@@ -315,10 +335,6 @@ class ShardedExchange:
         if hasattr(self.e, "invalidate_segment_sumsq"):
             self.e.invalidate_segment_sumsq()
 
-        if self._sumsq is None:
-            self._sumsq = torch.zeros(1, dtype=torch.float32, device=g.device)
-            self._sqws = torch.zeros(2048, dtype=torch.float32, device=g.device)
-
         def one(a, b, s, k=0):
             n = b - a
             send, recv = self._stage[k][0][:W * s], self._stage[k][1][:W * s]
@@ -346,15 +362,14 @@ class ShardedExchange:
         # cast -> wire -> sum, chunk after chunk).  RGQA_DP_EXCHANGE_STREAMS=1 restores the single stream.
         if self.side is None:
             self.side = _engine_stream(self.e, 0, g.device)
-        two = self.nstreams > 1 and len(self.chunks) > 1
+        two = len(self._stage) > 1
         if two and self.side2 is None:
             self.side2 = _engine_stream(self.e, 1, g.device)
-            self._stage.append((torch.zeros_like(self._send), torch.zeros_like(self._recv)))
-            self._sumsq2 = torch.zeros(1, dtype=torch.float32, device=g.device)
-            self._sqws2 = torch.zeros(2048, dtype=torch.float32, device=g.device)
         cur = torch.cuda.current_stream()
         streams = [self.side, self.side2] if two else [self.side]
         for k, st in enumerate(streams):
+            if self._alloc_ready is not None:
+                st.wait_event(self._alloc_ready)        # the staging buffers' and accumulators' fills (made on the constructor's stream)
             if self._norm_read is not None:
                 st.wait_event(self._norm_read)          # the previous step's optimizer has read the norm before it is cleared
             with torch.cuda.stream(st):
@@ -381,9 +396,6 @@ class ShardedExchange:
         if e.adam_m is None:
             e.adam_m = torch.zeros_like(e.params)        # only the owned ranges are ever touched (288 GB HBM: no need to compact)
             e.adam_v = torch.zeros_like(e.params)
-        if self._sumsq is None:
-            self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-            self._sqws = torch.zeros(2048, dtype=torch.float32, device=dev)
         mine = [owned(c, self.rank) for c in self.chunks]
         mine = [(lo, hi) for lo, hi in mine if hi > lo]
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev.type == "cuda" else None
@@ -441,6 +453,8 @@ class ShardedExchange:
             wts[a:b].copy_(buf[:n])
         if f32c:
             self.ops.cast_bf16(e.params_lp[a:b], e.params[a:b])
+        elif self.x3 and self.gather_overlap:      # the chunk's split-f32 operand copy from the gathered masters (the non-overlapped path re-makes the whole copy at the end)
+            self.ops.split_f32(e.params_lp[a:b], e.params[a:b])
 
     def _gather_beside_forward(self, s):
         """step()'s tail with the gather off the critical path.  On the caller's stream only what EVERY layer of the next forward reads from the

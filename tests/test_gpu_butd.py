@@ -190,8 +190,8 @@ def test_butd_gru_forms_agree(B):
                 e.loss_backward(tg)
                 out.append((lg, e.grads.clone()))
             torch.cuda.synchronize()
-            # every form is deterministic (the word-embedding gradient is scatter-added with float atomics: to rounding)
-            assert torch.equal(out[0][0], out[1][0]) and float((out[0][1] - out[1][1]).norm()) < 1e-5 * float(out[0][1].norm()), form
+            # every form is deterministic, the word-embedding gradient included (summed per table row in a fixed order since round 6)
+            assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), form
             res[form] = out[0]
     finally:
         L_.rgqa_debug_set(18, 3)
