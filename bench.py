@@ -679,6 +679,53 @@ def main():
     if dist is not None and dist.get_backend() == "nccl" and not args.lean:
         note("dp_wire: collectives of the exchange on the real chunk sizes")
         dp_wire = dp_wire_probe(dist, comm, torch.device("cuda", local))
+    if (dp_wire is not None and world > 1 and dp_mode.partition("_")[0] == "sharded" and "all_to_all" in dp_wire and os.environ.get("RGQA_DP_PEER_PROBE", "1") != "0"
+            and dp_wire["all_to_all"]["frac_of_all_links"] < float(os.environ.get("RGQA_DP_PEER_THRESHOLD", "0.7"))):
+        # RCCL's all-to-all runs below 70 % of what seven links carry (a ring-shaped schedule shows 1/7): measure the hand-written peer-to-peer exchange
+        # (hipIpc buffers, every rank pulling from all of its peers at once: rgqa_amd.parallel.PeerShardedExchange) on the same chunk and take it if it
+        # is clearly faster.  Every rank takes the same decision: times are maxima over the ranks, a rank that cannot set the buffers up vetoes.
+        note("dp_wire: all-to-all at %.2f of seven links - probing the peer-to-peer exchange" % dp_wire["all_to_all"]["frac_of_all_links"])
+        peer, ok = None, torch.ones(1, device="cuda")
+        try:
+            from rgqa_amd.parallel import PeerShardedExchange
+            peer = PeerShardedExchange(e, dist, payload=(dp_mode.partition("_")[2] or None))
+        except Exception as exn:
+            ok.zero_()
+            dp_wire["peer_error"] = repr(exn)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            W_, s_ = world, peer.smax
+            send, recv = peer._stage[0][0][:W_ * s_], peer._stage[0][1][:W_ * s_]
+
+            def timed_peer(fn, iters=10):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                dist.barrier()
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record()
+                for _ in range(iters):
+                    fn()
+                b_.record()
+                torch.cuda.synchronize()
+                t_ = torch.tensor([a_.elapsed_time(b_) / iters], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                return float(t_.item()) * 1e-3
+            tp = timed_peer(lambda: peer._a2a(recv, send))
+            nbytes = W_ * s_ * send.element_size()
+            wire = (W_ - 1) / W_
+            dp_wire["peer_all_to_all"] = dict(ms=round(tp * 1e3, 3), gbs_per_gpu_per_direction=round(nbytes * wire / tp / 1e9, 1),
+                                              frac_of_all_links=round(nbytes * wire / tp / 1e9 / (XGMI_LINKS * XGMI_GBS_PER_LINK_DIR), 3),
+                                              note="stage + barrier + pull from every peer + barrier (two barriers are part of every chunk's exchange)")
+            take = tp * 1.1 < dp_wire["all_to_all"]["ms"] * 1e-3
+            dp_wire["peer_selected"] = bool(take)
+            if take:
+                comm, dp_mode = peer, "peer" + dp_mode[len("sharded"):]
+                note("dp_wire: the peer-to-peer exchange is faster (%.3f ms vs %.3f): selected" % (tp * 1e3, dp_wire["all_to_all"]["ms"]))
+            else:
+                peer.close()
+        elif peer is not None:
+            peer.close()
     if dist is None and not args.butd:
         e.enable_segment_sumsq(True)        # the clip norm's sum(g^2) is taken segment by segment beside backward
     # (under an exchange the norm belongs to the REDUCED gradients: the sharded exchange takes each owner's share while it sums the shards,
@@ -921,6 +968,25 @@ def main():
                                "batch per step from the f16 feature store (pinned gather + H2D + device preparation); the headline's precision")
         except Exception as exn:
             dropin = dict(error=repr(exn))
+        if dist is not None:
+            # one-rank RCCL rehearsal of the drop-in trainer's data-parallel step (RGQA_BENCH_RCCL_REHEARSAL=1): the unchanged loop with the exchange inside
+            # backward() - `allreduce` (every rank steps every parameter) and `sharded` (round 6: BertAdam.step owns 1/N of the arena) - through the library
+            dropin["rccl_rehearsal"] = {}
+            for dmode in ("allreduce", "sharded"):
+                keep = {k: os.environ.get(k) for k in ("RGQA_DP_MODE", "RGQA_DP_REHEARSAL")}
+                try:
+                    os.environ["RGQA_DP_MODE"], os.environ["RGQA_DP_REHEARSAL"] = dmode, "1"
+                    note("leg: drop-in trainer step under a one-rank RCCL group, %s" % dmode)
+                    rms = dropin_step_leg(B, T, n2, args.precision)
+                    dropin["rccl_rehearsal"][dmode] = dict(ms_per_step=round(rms, 3), vs_headline=round(rms / ms, 3))
+                except Exception as exn:
+                    dropin["rccl_rehearsal"][dmode] = dict(error=repr(exn))
+                finally:
+                    for k, v in keep.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
         # ---- BASELINE configs 4 and 5 under the same clock, each in a mode inside the bound and in bf16: the RoI-mixup step (2B model rows per B loader
         # pairs) on the engines above re-bound to 2B rows, and the BUTD backbone's step
         other = {}

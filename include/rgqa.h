@@ -228,6 +228,27 @@ int rgqa_sum_bf16_parts(const void* parts_bf16, size_t part_stride, int nparts, 
 int rgqa_sum_parts(const void* parts, int parts_f32, size_t part_stride, int nparts, float* dst, size_t n, float* sq_ws, float* sumsq_accum,
                    void* stream);
 
+/* ---- peer-to-peer exchange over hipIpc buffers (rgqa_amd/csrc/peer.hip): the hand-written fallback for RCCL's all-to-all / all-gather in the gradient
+ * exchange that replaces nn.DataParallel's reduce / broadcast (lxrt/entry.py:102-103), for a node whose library collectives do not drive all seven
+ * xGMI links of a GPU (bench.py's `dp_wire` probe).  One process per GPU; every rank owns ONE staging buffer - library-owned fine-grained device
+ * memory, the only allocation this library makes besides its streams - exported as an IPC handle and mapped by every other rank.  Data moves by PULL:
+ *   rgqa_peer_pull   dst + r * dst_stride_bytes <- rank r's staging buffer [src_off_bytes, src_off_bytes + bytes), for every rank r (own buffer
+ *                    included), ONE launch whose workgroups are dealt over the peers: a rank reads from all of its peers at once.
+ * A reduce-scatter is: stage the payload, barrier, pull part `rank` of every rank, rgqa_sum_parts; an all-gather: stage the owned range, barrier,
+ * pull.  The barrier between a rank's staging kernel and its peers' pulls (and between the pulls and the next overwrite) is the CALLER's and is
+ * stream-ordered (a tiny collective on the exchange's stream; rgqa_amd/parallel.py PeerShardedExchange): nothing here spins on the device.
+ * create: world <= 16, stage_bytes of staging memory on the current device; export writes RGQA_PEER_HANDLE_BYTES bytes; connect takes the world
+ * handles in rank order (the own slot is ignored) and maps the peers' buffers; offsets / sizes of a pull are multiples of 16 bytes. */
+#define RGQA_PEER_HANDLE_BYTES 64
+typedef struct rgqa_peer_comm rgqa_peer_comm;
+int rgqa_peer_comm_create(int rank, int world, size_t stage_bytes, rgqa_peer_comm** out);
+int rgqa_peer_comm_stage(const rgqa_peer_comm* c, void** ptr, size_t* bytes);
+int rgqa_peer_comm_export(rgqa_peer_comm* c, void* handle);
+int rgqa_peer_comm_connect(rgqa_peer_comm* c, const void* handles);
+int rgqa_peer_comm_is_fine_grained(const rgqa_peer_comm* c);
+void rgqa_peer_comm_destroy(rgqa_peer_comm* c);
+int rgqa_peer_pull(rgqa_peer_comm* c, size_t src_off_bytes, size_t bytes, void* dst, size_t dst_stride_bytes, void* stream);
+
 /* ---- batch construction: replaces the host loop of RoI-mixup (tasks/gqa_mixup_vis.py:134-181).
  * feats [2B,O,F] / boxes [2B,O,4] with rows [0,B) filled; partner [B] i32; take_pos [B,O] u8 (1 = RoI taken from
  * the positive sample). Writes rows [B,2B). */

@@ -63,6 +63,13 @@ SIGNATURES = {
     "rgqa_unsplit_f32": [_vp, _vp, _sz, _vp],
     "rgqa_sum_bf16_parts": [_vp, _sz, _i, _vp, _sz, _vp],
     "rgqa_sum_parts": [_vp, _i, _sz, _i, _vp, _sz, _vp, _vp, _vp],
+    "rgqa_peer_comm_create": [_i, _i, _sz, C.POINTER(_vp)],
+    "rgqa_peer_comm_stage": [_vp, C.POINTER(_vp), C.POINTER(_sz)],
+    "rgqa_peer_comm_export": [_vp, _vp],
+    "rgqa_peer_comm_connect": [_vp, _vp],
+    "rgqa_peer_comm_is_fine_grained": [_vp],
+    "rgqa_peer_comm_destroy": [_vp],
+    "rgqa_peer_pull": [_vp, _sz, _sz, _vp, _sz, _vp],
     "rgqa_mixup_gather": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "rgqa_mixup_perturb": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "rgqa_mixup_weighted_sum": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -83,7 +90,7 @@ SIGNATURES = {
     "rgqa_score_rows": [_vp, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rgqa_last_error_string": [],
 }
-_RESTYPES = {"rgqa_last_error_string": C.c_char_p, "rgqa_engine_destroy": None, "rgqa_tokenizer_destroy": None}
+_RESTYPES = {"rgqa_last_error_string": C.c_char_p, "rgqa_engine_destroy": None, "rgqa_tokenizer_destroy": None, "rgqa_peer_comm_destroy": None}
 
 _lib = None
 

@@ -113,6 +113,7 @@ class Engine:
         self._upd_stream = self._upd_done = self._upd_order = None
         self.adam_overlap = os.environ.get("RGQA_ADAM_OVERLAP", "1") != "0"      # adam_step's default for `overlap` (see _update_beside_forward)
         self._pending_clip = None        # max_norm of a deferred clip_grads_ (lxrt.optimization.clip_grad_norm_ -> BertAdam.step), else None
+        self._dp_sharded = None          # the drop-in module's sharded exchange (lxrt.modeling._dp_exchange under RGQA_DP_MODE=sharded): clip / BertAdam go through it
         self._sharded_owner = None       # set by parallel.ShardedExchange while the f32 masters / Adam moments are valid on their owner rank only
         self.shape = None
         self._io = {}

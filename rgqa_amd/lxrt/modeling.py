@@ -328,6 +328,16 @@ def _dp_rank_world():
     return 0, 1
 
 
+def _dp_exchanging(world=None):
+    """does a training backward exchange gradients?  More than one rank - or a process group of ONE rank under RGQA_DP_REHEARSAL=1 (bench.py's one-GPU
+    rehearsal of the drop-in step on RCCL: every collective and the exchange's local arithmetic run at full size)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    w = dist.get_world_size() if world is None else world
+    return w > 1 or os.environ.get("RGQA_DP_REHEARSAL") == "1"
+
+
 class _EngineFunction(torch.autograd.Function):
     """Autograd boundary: forward and backward of the whole encoder (+ optional fused answer head) are single engine
     calls; parameter gradients are written straight into the gradient arena that the parameters' .grad view."""
@@ -377,9 +387,10 @@ class _EngineFunction(torch.autograd.Function):
         # The exchange belongs to TRAINING steps only: a backward in eval() mode (the test-time scorers that differentiate w.r.t. the
         # inputs, tasks/gqa_odin.py:97-121, run under model.eval()) exchanges nothing - ranks may then run different numbers of passes
         # without deadlocking, and no 819-MB collective rides on a scoring pass.
-        if world > 1 and not owner.training:
+        dp = _dp_exchanging(world) and owner.training
+        if not dp:
             world = 1
-        if world > 1:
+        if dp:
             if not ctx.want_logits and not owner.__dict__.get("_dp_warned"):
                 import warnings
                 warnings.warn("rgqa: data parallelism exchanges the engine's gradient arena only. This backward came through the pooled "
@@ -406,7 +417,7 @@ class _EngineFunction(torch.autograd.Function):
         finally:
             if want_f or want_b:
                 e.set_input_grads(None, None)
-        if world > 1:
+        if dp:
             owner._dp_exchange().all_reduce()
         b.attach_grads()
         return (None, None, dfeats.view(ctx.in_shapes[0]) if want_f else None, dboxes.view(ctx.in_shapes[1]) if want_b else None, None, None, None, None)
@@ -454,8 +465,8 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         self.apply(self.init_bert_weights)      # as LXRTModel / LXRTFeatureExtraction do (modeling.py:843, 1018)
         # an optimizer pass may still be running beside the forward pass on a stream of its own (Engine._update_beside_forward): whoever reads or
         # overwrites the parameters through nn.Module's own paths joins it first (a stream-side wait, no host synchronisation)
-        self._register_state_dict_hook(lambda module, *_: module._binding.engine.join_update())
-        self._register_load_state_dict_pre_hook(lambda *_: self._binding.engine.join_update())
+        self._register_state_dict_hook(lambda module, *_: module._before_state_read())
+        self._register_load_state_dict_pre_hook(lambda *_: self._before_state_read())
         # the unchanged trainers' `nn.utils.clip_grad_norm_(model.parameters(), 5.)` takes the arena-aware implementation while this module is alive
         from . import optimization as _optimization
         _optimization.install_clip_routing(self)
@@ -512,20 +523,31 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
             b.ensure(device)
 
     def _dp_exchange(self):
-        """The gradient exchange of this module's engine (rgqa_amd.parallel): an all-reduce - the unchanged trainer owns the optimizer object,
-        which steps every parameter, so the sharded-optimizer exchange of bench.py does not apply here - with an f32 payload whatever the engine's
-        precision (what the reference's nn.DataParallel reduces; RCCL keeps the running sum in the payload type); RGQA_DP_MODE=allreduce_bf16 opts in
-        to the 410-MB payload."""
+        """The gradient exchange of this module's engine (rgqa_amd.parallel), made on first use under an initialised process group.
+        RGQA_DP_MODE = `allreduce` (the drop-in default: f32 SUM all-reduce beside backward - what the reference's nn.DataParallel reduces - and the
+        trainer's optimizer steps every parameter on every rank; `allreduce_bf16` opts in to the 410-MB payload) or `sharded` (round 6: the
+        reduce-scatter / sharded BertAdam / weight all-gather of bench.py behind the UNCHANGED trainer: backward() leaves every rank the summed
+        gradients of the 1/N of the arena it owns, `clip_grad_norm_` returns the global norm from the owners' shares, `BertAdam.step()` - this
+        package's class - updates the owned 1/N and gathers the weights beside the next forward pass; `state_dict()` gathers the f32 masters and is
+        then a COLLECTIVE call: every rank must make it)."""
         ex = self.__dict__.get("_dp_ex")
         if ex is None or ex.e is not self._binding.engine:
             import torch.distributed as dist
-            from ..parallel import make_exchange
+            from ..parallel import make_exchange, ShardedExchange
             mode = os.environ.get("RGQA_DP_MODE", "allreduce")
-            if mode.startswith("sharded"):
-                mode = "allreduce" + mode[len("sharded"):]
             ex = make_exchange(self._binding.engine, dist, mode=mode)
             self.__dict__["_dp_ex"] = ex
+            self._binding.engine._dp_sharded = ex if isinstance(ex, ShardedExchange) else None
         return ex
+
+    def _before_state_read(self):
+        """state_dict() / load_state_dict(): behind an optimizer pass still running beside the forward pass; under the sharded exchange the f32 masters
+        are current on their owner rank only and are gathered first (a collective: every rank calls state_dict())"""
+        e = self._binding.engine
+        e.join_update()
+        ex = getattr(e, "_dp_sharded", None)
+        if ex is not None and e._sharded_owner is ex:
+            ex.gather_master()
 
     def _engine_forward(self, feats, boxes, ids, mask, seg, train):
         b = self._binding
@@ -533,7 +555,7 @@ class LXRTFeatureExtraction(BertPreTrainedModel):
         e = b.engine
         B, O = feats.shape[0], feats.shape[1]
         e.ensure_shape(B, ids.shape[1], O)
-        if train and e._seg_sumsq is None and _dp_rank_world()[1] == 1:
+        if train and e._seg_sumsq is None and not _dp_exchanging():
             e.enable_segment_sumsq(True)        # clip_grad_norm_ (lxrt.optimization.clip_grad_norm_) then adds ~20 numbers instead of re-reading 0.8 GB
         b.sync_if_stale()
         if self._seed_base is None:

@@ -59,6 +59,14 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
                 _CLIP_CACHE[sig[0]] = (sig, weakref.ref(eng), [None if raw_grad(p) is None else raw_grad(p).data_ptr() for p in params], eng._grads.data_ptr())
     if eng is None:
         return _torch_clip_grad_norm_(params, max_norm, norm_type=norm_type, error_if_nonfinite=error_if_nonfinite, foreach=foreach)
+    ex = _sharded_exchange_of(eng)
+    if ex is not None:
+        # data parallel, sharded optimizer (RGQA_DP_MODE=sharded): backward() left this rank the reduced gradients of the ranges it owns and the owners'
+        # shares of sum(g^2); the global norm is their sum over the ranks (one scalar all-reduce, reused by BertAdam.step); the rescale is always deferred -
+        # the gradient views outside the owned ranges hold local values nobody reads
+        ss = ex.global_sumsq()
+        eng._sumsq, eng._pending_clip, eng._seg_sumsq_valid = ss, float(max_norm), False
+        return ss.sqrt().reshape(())
     binding = getattr(eng, "_binding_ref", None)
     binding = binding() if binding is not None else None
     if binding is None or not binding.grads_untouched():
@@ -69,6 +77,16 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
     # from torch: AFTER BertAdam.step the .grad views hold the unclipped gradients (the reference's loops call zero_grad() next).
     # RGQA_DEFER_CLIP=0: scale in place here, as torch does (0.3 ms per step at the full model while clipping is active).
     return eng.clip_grads_(max_norm, defer=os.environ.get("RGQA_DEFER_CLIP", "1") != "0")
+
+
+def _sharded_exchange_of(eng):
+    """the engine's sharded data-parallel exchange (lxrt.modeling._dp_exchange under RGQA_DP_MODE=sharded) while a process group of more than one rank
+    is up and the module is training, else None"""
+    ex = getattr(eng, "_dp_sharded", None)
+    if ex is None:
+        return None
+    from .modeling import _dp_exchanging
+    return ex if _dp_exchanging() else None
 
 
 _CLIP_CACHE = {}
@@ -215,8 +233,15 @@ class BertAdam(Optimizer):
             eng = _engine.engine_of(r["p0"])
             r["eng"] = weakref.ref(eng) if eng is not None else None
             if not r["has_state"]:
-                r["m"] = torch.zeros(n, dtype=torch.float32, device=r["dev"])
-                r["v"] = torch.zeros(n, dtype=torch.float32, device=r["dev"])
+                if eng is not None and _sharded_exchange_of(eng) is not None and eng._grads is not None and r["g0"] - eng._grads.data_ptr() == r["p0"] - eng._params.data_ptr():
+                    # sharded data-parallel optimizer: the moments live in the ENGINE's arenas (each rank only ever touches the ranges it owns)
+                    if eng._adam_m is None:
+                        eng._adam_m, eng._adam_v = torch.zeros_like(eng._params), torch.zeros_like(eng._params)
+                    off = (r["p0"] - eng._params.data_ptr()) // 4
+                    r["m"], r["v"] = eng._adam_m[off:off + n], eng._adam_v[off:off + n]
+                else:
+                    r["m"] = torch.zeros(n, dtype=torch.float32, device=r["dev"])
+                    r["v"] = torch.zeros(n, dtype=torch.float32, device=r["dev"])
                 for p in r["params"]:
                     off = (p.data_ptr() - r["p0"]) // 4
                     st = self.state[p]
@@ -260,11 +285,14 @@ class BertAdam(Optimizer):
                 if eng is not None:
                     ent = cover.setdefault(id(eng), [eng, 0])
                     ent[1] += r["numel"]
+        # ---- data parallel with a sharded optimizer (RGQA_DP_MODE=sharded, round 6): this rank owns 1/N of the arena - the exchange clips and updates the
+        # owned ranges and gathers the weights beside the next forward pass; replaces the every-rank update below for that engine's runs
+        sharded = self._step_sharded(work, cover)
         # ---- a clip_grad_norm_ that was deferred to this step (clip_grad_norm_ above): folded into the update kernel when this call updates
         # EVERY gradient-carrying parameter of the engine (then no gradient is left behind unscaled), materialised in place otherwise
         fold = {}
         for key, (eng, n_cov) in cover.items():
-            if getattr(eng, "_pending_clip", None) is None:
+            if key in sharded or getattr(eng, "_pending_clip", None) is None:
                 continue
             if n_cov == self._live_numel(eng):
                 fold[key] = (_lib.ptr(eng._sumsq), float(eng._pending_clip))
@@ -275,7 +303,7 @@ class BertAdam(Optimizer):
         # own, the forward waiting per layer) - what the engine-direct adam_step does; RGQA_ADAM_OVERLAP=0 keeps it on this stream
         beside = {}
         for key, (eng, n_cov) in cover.items():
-            if n_cov != self._live_numel(eng) or not getattr(eng, "adam_overlap", False) or eng._params_lp is None or eng.num_weight_segments() <= 0:
+            if key in sharded or n_cov != self._live_numel(eng) or not getattr(eng, "adam_overlap", False) or eng._params_lp is None or eng.num_weight_segments() <= 0:
                 continue
             b = getattr(eng, "_binding_ref", None)
             b = b() if b is not None else None
@@ -287,6 +315,8 @@ class BertAdam(Optimizer):
                 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             touched = {}
             for r in runs:
+                if r["m"] is not None and sharded and id(self._run_engine(r)) in sharded:
+                    continue                                    # updated by the exchange above
                 step = self.state[r["params"][0]]["step"]
                 if group['t_total'] != -1:
                     progress = step / group['t_total']
@@ -359,6 +389,46 @@ class BertAdam(Optimizer):
         for key in fold:
             cover[key][0].drop_deferred_clip()          # consumed: the update used g * coef; the .grad views keep the unclipped gradients
         return loss
+
+    def _step_sharded(self, work, cover):
+        """-> {id(engine)} of the engines whose update went through their sharded exchange"""
+        done = set()
+        for key, (eng, n_cov) in cover.items():
+            ex = _sharded_exchange_of(eng)
+            if ex is None:
+                continue
+            if n_cov != self._live_numel(eng):
+                raise RuntimeError("BertAdam (rgqa_amd, RGQA_DP_MODE=sharded): the sharded data-parallel optimizer needs EVERY gradient-carrying parameter of the "
+                                   "model in this optimizer with freshly created state (the ranks own ranges of the flat arena, not tensors); use RGQA_DP_MODE=allreduce")
+            hyper = set()
+            runs_e = []
+            for group, runs in work:
+                for r in runs:
+                    if r["m"] is None or self._run_engine(r) is not eng:
+                        continue
+                    step = self.state[r["params"][0]]["step"]
+                    lr_s = group['lr'] * SCHEDULES[group['schedule']](step / group['t_total'], group['warmup']) if group['t_total'] != -1 else group['lr']
+                    hyper.add((lr_s, group['b1'], group['b2'], group['e'], group['weight_decay']))
+                    runs_e.append(r)
+            if len(hyper) != 1:
+                raise RuntimeError("BertAdam (rgqa_amd, RGQA_DP_MODE=sharded): one learning rate / beta / weight-decay setting for all parameters is required "
+                                   "(got %d); use RGQA_DP_MODE=allreduce" % len(hyper))
+            lr_s, b1, b2, e_, wd = next(iter(hyper))
+            pend = getattr(eng, "_pending_clip", None)
+            # dL/dlogits was scaled by 1 / world in backward(): the exchanged sums are the mean gradient already
+            ex.step(lr_s, max_norm=float(pend) if pend is not None else 0.0, b1=b1, b2=b2, eps=e_, weight_decay=wd, clip=pend is not None, grad_prescale=1.0)
+            eng.drop_deferred_clip()
+            for r in runs_e:
+                for p in r["params"]:
+                    self.state[p]["step"] += 1
+                p0 = r["params"][0]
+                torch._C._autograd._unsafe_set_version_counter((p0,), (p0._version + 1,))
+            b = getattr(eng, "_binding_ref", None)
+            b = b() if b is not None else None
+            if b is not None:
+                b.mark_synced()          # the exchange re-made (or gathers beside the next forward) every operand copy
+            done.add(key)
+        return done
 
     @staticmethod
     def _live_numel(eng):

@@ -50,7 +50,7 @@ def exchange_payload(mode, precision):
     """dtype on the wire for a full RGQA_DP_MODE string: the sharded exchange follows the engine's precision, an all-reduce is f32 unless the
     mode says _bf16 (its running sum lives in the payload type); a suffix forces either"""
     kind, _, forced = mode.partition("_")
-    if kind == "sharded":
+    if kind in ("sharded", "peer"):
         return payload_dtype(precision, forced or None)
     return torch.bfloat16 if forced == "bf16" else torch.float32
 
@@ -253,6 +253,7 @@ class ShardedExchange:
             self._alloc_ready = torch.cuda.Event()
             self._alloc_ready.record(torch.cuda.current_stream(dev))
         self._sumsq_from_exchange = False
+        self._norm_reduced = False       # _sumsq already holds the sum over ranks (global_sumsq(): the drop-in clip_grad_norm_ asks before step())
         self._norm_read = None
         self.side = None
         backend = dist.get_backend()
@@ -350,6 +351,7 @@ class ShardedExchange:
                 self.ops.sum_parts(g[lo:hi], recv, s, W, self._sqws if k == 0 else self._sqws2, self._sumsq if k == 0 else self._sumsq2)    # f32 accumulation in rank order + this range's sum(g^2)
 
         self._sumsq_from_exchange = True
+        self._norm_reduced = False
         if not (self.overlap and g.is_cuda):
             self._sumsq.zero_()
             for c in self.chunks:
@@ -386,7 +388,33 @@ class ShardedExchange:
 
     all_reduce = exchange
 
-    def step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, clip=True):
+    def global_sumsq(self):
+        """The squared norm of the REDUCED gradients on every rank (device scalar): the owners' shares of sum(g^2) - left behind by exchange(), or taken
+        now over the owned ranges - summed over the ranks by one scalar all-reduce.  What the unchanged trainer's `clip_grad_norm_` returns between
+        backward() and BertAdam.step() (tasks/gqa_conf.py:201); step(clip=True) then reuses it instead of reducing again."""
+        if self._norm_reduced:
+            return self._sumsq
+        dev = self.e.grads.device
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev.type == "cuda" else None
+        if not self._sumsq_from_exchange:
+            self._sumsq.zero_()
+            for c in self.chunks:
+                lo, hi = owned(c, self.rank)
+                if hi > lo:
+                    self._local_sumsq(lo, hi, s)
+            self._sumsq_from_exchange = True
+        if self._host_staged and self._sumsq.is_cuda:
+            t = self._sumsq.cpu()
+            self.dist.all_reduce(t)
+            self._sumsq.copy_(t)
+        else:
+            self.dist.all_reduce(self._sumsq)
+        self._norm_reduced = True
+        return self._sumsq
+
+    def step(self, lr_t, max_norm=5.0, b1=0.9, b2=0.999, eps=1e-6, weight_decay=0.01, clip=True, grad_prescale=None):
+        """grad_prescale: factor on the exchanged gradient SUMS inside the update kernel; default 1 / world (the engine-direct loop backpropagates the
+        local mean loss); the drop-in autograd path has already scaled dL/dlogits by 1 / world and passes 1."""
         e, W = self.e, self.world
         dev = e.grads.device
         if hasattr(e, "_sharded_owner"):
@@ -399,20 +427,12 @@ class ShardedExchange:
         mine = [owned(c, self.rank) for c in self.chunks]
         mine = [(lo, hi) for lo, hi in mine if hi > lo]
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev.type == "cuda" else None
-        from_exchange, self._sumsq_from_exchange = self._sumsq_from_exchange, False      # consumed by THIS step whatever `clip` says (a stale flag
-        if clip:                                                                           # would make a later step reuse an old norm: ADVICE r4)
-            if not from_exchange:                    # gradients that did not come through exchange() (tests, a caller's own reduction)
-                self._sumsq.zero_()
-                for lo, hi in mine:
-                    self._local_sumsq(lo, hi, s)
-            if self._host_staged and self._sumsq.is_cuda:
-                t = self._sumsq.cpu()
-                self.dist.all_reduce(t)
-                self._sumsq.copy_(t)
-            else:
-                self.dist.all_reduce(self._sumsq)        # sum over ranks of the shards' sum(g^2) = the global norm^2
+        if clip:
+            self.global_sumsq()                      # sum over ranks of the shards' sum(g^2) = the global norm^2 (already there if clip_grad_norm_ asked)
+        self._sumsq_from_exchange = self._norm_reduced = False      # consumed by THIS step whatever `clip` says (a stale flag would make a later step
+        pre = 1.0 / W if grad_prescale is None else float(grad_prescale)                   # reuse an old norm: ADVICE r4)
         for lo, hi in mine:
-            self._local_adam(lo, hi, lr_t, b1, b2, eps, weight_decay, clip, max_norm, 1.0 / W, s)
+            self._local_adam(lo, hi, lr_t, b1, b2, eps, weight_decay, clip, max_norm, pre, s)
         if dev.type == "cuda":
             if self._norm_read is None:
                 self._norm_read = torch.cuda.Event()
@@ -547,7 +567,112 @@ class ShardedExchange:
                 p[a:b].copy_(buf[:n])
 
 
-MODES = ("sharded", "sharded_bf16", "sharded_f32", "allreduce", "allreduce_bf16", "allreduce_f32")
+class _RawDeviceBytes:
+    """library-owned device memory as seen by torch (the __cuda_array_interface__ protocol): torch.as_tensor(...) aliases it, nothing is copied"""
+
+    def __init__(self, ptr_, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr_), False), "version": 2}
+
+
+class PeerShardedExchange(ShardedExchange):
+    """mode 'peer': the sharded exchange with its two collectives hand-written over hipIpc peer buffers (include/rgqa.h rgqa_peer_*, csrc/peer.hip) -
+    the fallback SURVEY §5 / §8 B6 planned for a node where RCCL's all-to-all / all-gather do not drive all seven xGMI links of a GPU (bench.py's
+    `dp_wire` probe measures both and picks).  Every rank stages what the others need in ONE library-owned, IPC-exported buffer and PULLS its share out of
+    every peer's buffer with one launch whose workgroups are dealt over the peers (all links at once); everything else - chunks beside backward on two
+    streams, f32 accumulation of the parts in rank order with the norm share, sharded BertAdam, the weight gather beside the next forward - is the
+    parent's, so the results are bit-identical to mode 'sharded'.  Ranks are ordered by a stream-ordered barrier (one tiny collective of the process
+    group on the exchange's stream) between a rank's staging kernel and its peers' pulls, and again before the staging area is overwritten: no kernel
+    ever spins on a flag."""
+
+    def __init__(self, engine, dist, **kw):
+        super().__init__(engine, dist, **kw)
+        lib = engine.lib
+        W, es = self.world, self._send.element_size()
+        self._send_bytes = -(-W * self.smax * es // 256) * 256
+        self._ag_bytes = -(-self.smax * 4 // 256) * 256                  # one owned part, f32 at worst
+        self._set_bytes = self._send_bytes + self._ag_bytes
+        nsets = 2
+        h = C.c_void_p()
+        check(lib.rgqa_peer_comm_create(self.rank, W, nsets * self._set_bytes, C.byref(h)))
+        self._comm = h
+        p, nb = C.c_void_p(), C.c_size_t()
+        check(lib.rgqa_peer_comm_stage(self._comm, C.byref(p), C.byref(nb)))
+        dev = engine.grads.device
+        self._stage_raw = torch.as_tensor(_RawDeviceBytes(p.value, nb.value), device=dev)
+        self._stage_raw.zero_()
+        hb = C.create_string_buffer(64)
+        check(lib.rgqa_peer_comm_export(self._comm, hb))
+        handles = [None] * W
+        dist.all_gather_object(handles, bytes(hb.raw))
+        check(lib.rgqa_peer_comm_connect(self._comm, C.create_string_buffer(b"".join(handles), 64 * W)))
+        # the parent's staging sets, their send halves now inside the exported buffer
+        sets = []
+        for k in range(nsets):
+            send = self._stage_raw[k * self._set_bytes:k * self._set_bytes + W * self.smax * es].view(self.payload)
+            recv = self._stage[k][1] if k < len(self._stage) else torch.zeros_like(self._recv)
+            sets.append((send, recv))
+        self._stage = sets[:max(1, len(self._stage))] if len(self._stage) < 2 else sets
+        self._send = self._stage[0][0]
+        self._tick = torch.zeros(1, dtype=torch.float32, device=dev)
+        if dev.type == "cuda":
+            self._alloc_ready = torch.cuda.Event()
+            self._alloc_ready.record(torch.cuda.current_stream(dev))
+        self._barrier()            # every rank has mapped every buffer before anyone pulls
+
+    def describe(self):
+        return "peer: " + super().describe()[len("sharded: "):].replace("all-to-all reduce-scatter", "reduce-scatter by hipIpc peer pulls").replace("weight all-gather", "weight all-gather by peer pulls")
+
+    def _k(self):
+        """which staging set the calling stream uses (the second exchange stream has its own)"""
+        return 1 if (self.side2 is not None and len(self._stage) > 1 and torch.cuda.current_stream() == self.side2) else 0
+
+    def _barrier(self):
+        if self._host_staged:          # rehearsal over gloo (two processes on one device): the collective is a host call
+            if self._tick.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            self.dist.barrier()
+        else:
+            self.dist.all_reduce(self._tick)      # on the current stream: completes only when every rank's stream has reached it
+
+    def _pull(self, src_off, nbytes, dst, stride):
+        check(self.e.lib.rgqa_peer_pull(self._comm, src_off, nbytes, ptr(dst), stride, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def _a2a(self, recv, send):
+        k = self._k()
+        W = self.world
+        s = send.numel() // W
+        mine = self._stage[k][0]
+        if send.data_ptr() != mine.data_ptr():      # an f32 payload straight from the gradient arena: into the exported buffer first
+            mine[:send.numel()].copy_(send)
+        es = mine.element_size()
+        self._barrier()                             # every rank's payload is staged
+        self._pull(k * self._set_bytes + self.rank * s * es, s * es, recv, s * es)
+        self._barrier()                             # every rank has pulled: the staging area may be overwritten
+
+    def _ag(self, out, inp):
+        k = self._k()
+        nbytes = inp.numel() * inp.element_size()
+        off = k * self._set_bytes + self._send_bytes
+        area = self._stage_raw[off:off + nbytes].view(inp.dtype)
+        area.copy_(inp)
+        self._barrier()
+        self._pull(off, nbytes, out, nbytes)
+        self._barrier()
+
+    def close(self):
+        c, self._comm = getattr(self, "_comm", None), None
+        if c is not None:
+            self._stage_raw = None
+            self.e.lib.rgqa_peer_comm_destroy(c)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+MODES = ("sharded", "sharded_bf16", "sharded_f32", "allreduce", "allreduce_bf16", "allreduce_f32", "peer", "peer_bf16", "peer_f32")
 
 
 def make_exchange(engine, dist, mode=None, default="sharded", **kw):
@@ -559,6 +684,8 @@ def make_exchange(engine, dist, mode=None, default="sharded", **kw):
     kind, _, forced = mode.partition("_")
     if kind == "sharded":
         return ShardedExchange(engine, dist, payload=forced or None, **kw)
+    if kind == "peer":
+        return PeerShardedExchange(engine, dist, payload=forced or None, **kw)
     # all-reduce: RCCL would keep a bf16 RUNNING sum across the ranks (error grows with the world size and depends on the reduction order), where
     # the sharded mode adds the N bf16 shards in f32 in rank order.  So the plain 'allreduce' is f32 whatever the engine's precision; the bf16
     # payload is opt-in by name.

@@ -67,7 +67,7 @@ def _worker(rank, world, port, mode, overlap, precision, q):
     dist.destroy_process_group()
 
 
-_MODES = ["allreduce", "allreduce_bf16", "sharded", "sharded_bf16", "allreduce_f32"]
+_MODES = ["allreduce", "allreduce_bf16", "sharded", "sharded_bf16", "allreduce_f32", "peer"]
 _PRECS = ["f32", "bf16", "bf16x3", "bf16x3_fwd"]
 
 
@@ -175,6 +175,70 @@ def test_exchange_on_rccl_single_rank_group(mode, precision):
         assert diff.max() < 1e-4 and diff.mean() < 1e-7, (diff.max(), diff.mean())
     else:
         assert diff.max() < 1.3e-2 and diff.mean() < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- the hand-written peer-to-peer exchange (hipIpc)
+def _peer_worker(rank, world, port, backend, precision, overlap, q):
+    """the SAME two steps under mode 'sharded' and under mode 'peer' (fresh engines): identical arithmetic - only the two collectives differ -
+    so parameters, Adam moments and the forward's operand copy must agree bit for bit"""
+    import torch.distributed as dist
+    from rgqa_amd.parallel import make_exchange
+    torch.cuda.set_device(0)
+    kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, **kw)
+    full = _full_batch()
+    n = 2 * B // world
+    shard = {k: v[rank * n:(rank + 1) * n] for k, v in full.items()}
+    out = {}
+    for mode in ("sharded", "peer"):
+        e, d = _make(shard, precision)
+        comm = make_exchange(e, dist, mode, chunk_mb=1, bucket_mb=1, overlap=overlap, f32_chunk_elems=1 << 14)
+        if mode == "peer":
+            assert type(comm).__name__ == "PeerShardedExchange" and len(comm.chunks) >= 3
+        for _ in range(3):
+            _step(e, d, comm, world)
+        lp = None if e.params_lp is None else e.params_lp.clone()
+        comm.gather_master()
+        comm.gather_master(e.adam_m)
+        torch.cuda.synchronize()
+        out[mode] = (e.params.clone(), e.adam_m.clone(), lp)
+        if hasattr(comm, "close"):
+            dist.barrier()
+            comm.close()
+    same = all((a is None and c is None) or torch.equal(a, c) for a, c in zip(out["sharded"], out["peer"]))
+    q.put((rank, same, out["peer"][0].cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,world,precision,overlap", [("gloo", 2, "bf16", True), ("gloo", 2, "f32", False), ("gloo", 2, "bf16x3_fwd", True), ("nccl", 1, "bf16", True)])
+def test_peer_exchange_equals_the_collective_exchange(backend, world, precision, overlap):
+    """VERDICT r5 #6 / SURVEY §8 B6: the sharded exchange with its all-to-all and all-gather hand-written over hipIpc peer buffers (rgqa_peer_*:
+    every rank stages into ONE exported buffer and pulls its share out of every peer's buffer, workgroups dealt over the peers).  Two PROCESSES
+    sharing this GPU map each other's staging buffer (IPC handles work intra-device; their barrier runs over gloo) - bf16 and f32 payloads, chunks
+    beside backward on two streams and after it, the weight gather beside the next forward - and one rank on RCCL (the stream-ordered barrier is a
+    tiny all-reduce there): three optimizer steps end bit-identical to mode 'sharded', replicas identical."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 400) + 5 * (_PRECS.index(precision) * 2 + (world - 1))
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, backend, precision, overlap, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r, same, params = q.get(timeout=300)
+            res[r] = (same, params)
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    assert all(v[0] for v in res.values()), "mode 'peer' differs from mode 'sharded'"
+    if world == 2:
+        assert np.array_equal(res[0][1], res[1][1])
 
 
 # ---------------------------------------------------------------------------------------------- BASELINE config 5 under the exchange

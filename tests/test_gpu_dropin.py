@@ -636,12 +636,13 @@ def _trainer_loop(m, feats, boxes, sents, target, steps):
     return {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
 
 
-def _dropin_dp_worker(rank, world, port, golden_dir, q):
+def _dropin_dp_worker(rank, world, port, golden_dir, q, mode="allreduce", precision="f32"):
     import torch.distributed as dist
     _patch_small_config(golden_dir)
+    os.environ["RGQA_DP_MODE"] = mode
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    m, _ = build("f32", 20)
+    m, _ = build(precision, 20)
     m.lxrt_encoder.multi_gpu()
     feats, boxes, target = batch(20)
     n = len(SENTS) // world
@@ -652,17 +653,21 @@ def _dropin_dp_worker(rank, world, port, golden_dir, q):
     dist.destroy_process_group()
 
 
-def test_unchanged_trainer_is_data_parallel_under_torch_distributed(env, golden_dir):
-    """VERDICT r1 #7 / ADVICE: the reference's train loop, untouched, launched as two processes (gloo here, RCCL with one GPU per
-    rank): gradients are averaged inside backward(), so two ranks on half the batch each == one rank on the whole batch."""
+@pytest.mark.parametrize("mode,precision", [("allreduce", "f32"), ("sharded", "f32"), ("sharded", "bf16"), ("sharded", "bf16x3_fwd")])
+def test_unchanged_trainer_is_data_parallel_under_torch_distributed(env, golden_dir, mode, precision):
+    """the reference's train loop, untouched, launched as two processes (gloo here, RCCL with one GPU per rank): two ranks on
+    half the batch each == one rank on the whole batch.  `allreduce`: gradients are averaged inside backward(), every rank steps every parameter.
+    `sharded` (RGQA_DP_MODE=sharded, round 6): backward() reduce-scatters, `clip_grad_norm_` returns the global norm from the owners' shares,
+    this package's `BertAdam.step()` updates the 1/N of the arena the rank owns and gathers the weights (bf16 / bf16x3_fwd engines: beside the next
+    forward pass), `state_dict()` gathers the f32 masters."""
     import torch.multiprocessing as mp
-    m, _ = build("f32", 20)
+    m, _ = build(precision, 20)
     feats, boxes, target = batch(20)
     ref = _trainer_loop(m, feats, boxes, SENTS, target, 2)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29300 + (os.getpid() % 500)
-    procs = [ctx.Process(target=_dropin_dp_worker, args=(r, 2, port, golden_dir, q), daemon=True) for r in range(2)]
+    port = 29300 + (os.getpid() % 500) + 3 * (["allreduce", "sharded"].index(mode) * 4 + ["f32", "bf16", "bf16x3_fwd"].index(precision))
+    procs = [ctx.Process(target=_dropin_dp_worker, args=(r, 2, port, golden_dir, q, mode, precision), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -677,13 +682,19 @@ def test_unchanged_trainer_is_data_parallel_under_torch_distributed(env, golden_
             if p.is_alive():
                 p.terminate()
     assert all(p.exitcode == 0 for p in procs)
-    worst = 0.0
+    worst, tot, cnt = 0.0, 0.0, 0
     for k in ref:
-        assert np.array_equal(res[0][k], res[1][k]), k              # replicas identical
-        worst = max(worst, float(np.abs(res[0][k] - ref[k]).max()))
-        # BCEWithLogitsLoss takes the mean over the LOCAL batch: the average of the two half-batch means == the full-batch mean
-        np.testing.assert_allclose(res[0][k], ref[k], rtol=2e-4, atol=2e-5, err_msg=k)
-    print("drop-in DP, 2 ranks vs 1: max |param diff| = %.3e" % worst)
+        assert np.array_equal(res[0][k], res[1][k]), k              # replicas identical (sharded: after state_dict()'s gather)
+        d = np.abs(res[0][k] - ref[k])
+        worst, tot, cnt = max(worst, float(d.max())), tot + float(d.sum()), cnt + d.size
+        if precision == "f32":
+            # BCEWithLogitsLoss takes the mean over the LOCAL batch: the average of the two half-batch means == the full-batch mean
+            np.testing.assert_allclose(res[0][k], ref[k], rtol=2e-4, atol=2e-5, err_msg=k)
+    print("drop-in DP %s / %s, 2 ranks vs 1: |param diff| max %.3e mean %.3e" % (mode, precision, worst, tot / cnt))
+    if precision != "f32":
+        # bf16 operands / a bf16 payload round differently under the other batch split; BertAdam moves an element whose tiny gradient changes sign by up to
+        # 3.2 lr per step whatever its size (tests/test_gpu_dp.py): the MEAN is the meaningful bound
+        assert worst < 1.3e-2 and tot / cnt < 2e-5, (worst, tot / cnt)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16", "bf16x3"])
