@@ -68,7 +68,9 @@ int rgqa_version(void);
  * key 19: 1 = the bf16 engine's LayerNorms behind the attention-output / FFN-output projections are done inside the projection's launch by the
  * workgroup that finishes a row block last, 0 (default: same step time) = separate LayerNorm launches; bit-identical results either way;
  * key 20: cap on the grid of the (grid-stride) BertAdam kernel, default 2048 workgroups (with the update beside the forward pass a smaller grid
- * only delays the weights the forward waits for: 2048 10.98, 512 11.15, 128 11.61 ms per step). */
+ * only delays the weights the forward waits for: 2048 10.98, 512 11.15, 128 11.61 ms per step);
+ * key 21: bf16x3_fwd precision, 1 (default) = the LayerNorm backward reads the hi parts of the split-f32 pre-LayerNorm sums in place, 0 = a bf16 image of them is
+ * stored by the projections' epilogues (round 5); bit-identical gradients. */
 int rgqa_debug_set(int key, int value);
 /* The library runs the deferred weight-gradient GEMMs on ONE side stream per device, shared by every engine of the process.  By default it makes
  * that stream itself when the first engine is bound; a caller that knows better hands one in BEFORE that (the Python binding does: HIP maps streams

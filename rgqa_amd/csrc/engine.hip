@@ -173,6 +173,8 @@ int g_rgqa_dgrad_nn = 0;       // rgqa_debug_set(14, v): 1 = the bf16 engine's d
                                // one box: 11.176 ms with it, 11.161 without (profiles/r05_dgrad_nn_ab.txt) - the transposed fragment reads (two ds_read_b64_tr_b16
                                // per fragment) cost the 70 dgrad launches what the re-cast saved, so the default stays; the switch is for memory, not for time
 int g_rgqa_wgrad_sets = 0;     // rgqa_debug_set(17, v): gradient-buffer sets planned at the next bind (2 * periods-per-launch .. NPAR); 0 = default (the minimum)
+int g_rgqa_z_in_place = 1;   // rgqa_debug_set(21, v): bf16x3_fwd precision: 1 (default) = the LayerNorm backward reads the pre-LayerNorm sums' hi parts out of the split-f32 tensor, 0 = out of a bf16
+                               // image the projections' epilogues store beside it (round 5); the same bits either way; read at the next forward pass
 int g_rgqa_attn_pair = 1;      // rgqa_debug_set(16, v): 0 = the two attention problems of a stage as two launches (the bit-identity test's other arm)
 
 // RGQA_ATTN_REF (test switch: the plain attention kernels instead of the MFMA ones), read once
@@ -235,6 +237,11 @@ public:
         else return reinterpret_cast<const TB*>(p);
     }
     size_t mirror_off = 0, fwd_end = 0;
+    // MIXED, hidden = 768 (round 6): the pre-LayerNorm sums have no bf16 image - the LayerNorm backward kernel reads the hi parts of the split-f32 tensor in
+    // place (norm.hip ln_bwd16_kernel<.., ZSF>), and the projections' epilogues write 8 instead of 10 bytes per element
+    bool z_in_place() const { return MIXED && cfg.hidden == 768 && fwd_z_in_place; }
+    bool fwd_z_in_place = true;      // latched by forward(): backward follows the recorded pass
+    const TB* svz(const void* z) const { return z_in_place() ? reinterpret_cast<const TB*>(z) : sv(z); }
     int image_of(const void* p, int ld, int rows, int cols, hipStream_t s) {        // one-off tensors: the image by a copy kernel
         if constexpr (MIXED) return k_sf_image(reinterpret_cast<const sf32*>(p), ld, img(p), ld, rows, cols, s);
         else return RGQA_OK;
@@ -734,7 +741,7 @@ public:
         p.bias = bias ? P + l.b + wrow0 : nullptr;
         p.aux = aux; p.ldaux = ldaux; p.epi = epi; p.drop_site = site;
         if (MIXED) {      // the bf16 image of the result beside it; gelu' (read by the backward alone) only as its image
-            p.Cb = img(y);
+            p.Cb = (epi == EPI_RESID_DROP && z_in_place()) ? nullptr : img(y);      // (a pre-LayerNorm sum: read in place by the LayerNorm backward)
             if (c2 != nullptr) { p.C2 = img(c2); p.c2_lp = 1; }
         }
     }
@@ -1054,6 +1061,7 @@ public:
             if (varlen && lens_dirty) { CK(k_set_lengths(lens_host.data(), B, Tn, lens_dev, cu_dev, row_src_dev, s)); lens_dirty = false; }
             fwd_varlen = varlen;
             fwd_cls_tail = cls_tail_wanted();
+            fwd_z_in_place = g_rgqa_z_in_place != 0;
         }
         const int* cu = fwd_varlen ? cu_dev : nullptr;
         CK(wait_wready(n_seg_events - 1, s));         // embedding tables, visual projection (the segment backward finishes last)
@@ -1252,8 +1260,8 @@ public:
                 // B compact [CLS] rows: LayerNorm / FFN backward on them, then the input gradient goes back to the [CLS] rows of a zeroed buffer
                 const FfnP& f = *st.ffn[0];
                 DropCfg d = drop_site(pd, st.site + 1);
-                CKP(PC_LN, k_ln_bwd<TB>(gp2, H, sv(st.sb[0].z), H, P + f.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b,
-                               accumulate, B, H, d, nodrop, 1.0f, s, &fin));
+                CKP(PC_LN, k_ln_bwd<TB>(gp2, H, svz(st.sb[0].z), H, P + f.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b,
+                               accumulate, B, H, d, nodrop, 1.0f, s, &fin, z_in_place()));
                 TB* gzm = d.thresh ? gzd : gz;
                 gg_init(g); add_dgrad(g, gzm, H, f.down, 0, H, gh, I, B, EPI_DGELU, sv(st.sb[0].hpre), I); CK(run_dgrad(g, s, true));
                 add_wgrad(wg, gzm, H, f.down, 0, H, sv(st.sb[0].h), I, B, accumulate);
@@ -1269,15 +1277,15 @@ public:
                 const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && dyp[1] == dyp[0] + (size_t)Rl * H;
                 if (both) {
                     const FfnP &f0 = *st.ffn[0], &f1 = *st.ffn[1];
-                    CKP(PC_LN, k_ln_bwd2<TB>(dyp[0], H, sv(st.sb[0].z), H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
+                    CKP(PC_LN, k_ln_bwd2<TB>(dyp[0], H, svz(st.sb[0].z), H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
                                             Rl, P + f0.ln.w, G + f0.ln.w, G + f0.ln.b, G + f0.down.b, drop_site(pd, st.site + 1),
-                                            Rv, P + f1.ln.w, G + f1.ln.w, G + f1.ln.b, G + f1.down.b, drop_site(pd, st.site + 5), s, &fin));
+                                            Rv, P + f1.ln.w, G + f1.ln.w, G + f1.ln.b, G + f1.down.b, drop_site(pd, st.site + 5), s, &fin, z_in_place()));
                 }
                 for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const FfnP& f = *st.ffn[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
-                    CKP(PC_LN, k_ln_bwd<TB>(dyp[m], H, sv(st.sb[m].z), H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
-                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s, &fin));
+                    CKP(PC_LN, k_ln_bwd<TB>(dyp[m], H, svz(st.sb[m].z), H, P + f.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + f.ln.w, G + f.ln.b, G + f.down.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s, &fin, z_in_place()));
                 }
                 TB* gzm = drop_base(pd).thresh ? gzd : gz;
                 gg_init(g);
@@ -1303,22 +1311,22 @@ public:
                 const AttP& ap = *st.att[0];
                 DropCfg d = drop_site(pd, st.site + 1);
                 CK(adjacent());
-                CKP(PC_LN, k_ln_bwd<TB>(dyp[0], H, sv(st.sb[0].z), H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
-                               G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, R, H, d, nodrop, 1.0f, s, &fin));
+                CKP(PC_LN, k_ln_bwd<TB>(dyp[0], H, svz(st.sb[0].z), H, P + ap.ln.w, st.sb[0].mean, st.sb[0].rstd, gz, d.thresh ? gzd : nullptr, H, part,
+                               G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, R, H, d, nodrop, 1.0f, s, &fin, z_in_place()));
                 gg_init(g); add_dgrad(g, gzm, H, ap.o, 0, H, gctx, H, R, EPI_BIAS, nullptr, 0); CK(run_dgrad(g, s));
             } else {
                 const bool both = ln_merge && st.active[0] && st.active[1] && Rl > 0 && Rv > 0 && dyp[1] == dyp[0] + (size_t)Rl * H;
                 if (both) {
                     const AttP &a0 = *st.att[0], &a1 = *st.att[1];
-                    CKP(PC_LN, k_ln_bwd2<TB>(dyp[0], H, sv(st.sb[0].z), H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
+                    CKP(PC_LN, k_ln_bwd2<TB>(dyp[0], H, svz(st.sb[0].z), H, st.sb[0].mean, st.sb[0].rstd, gz, gzd, H, part, H, accumulate,
                                             Rl, P + a0.ln.w, G + a0.ln.w, G + a0.ln.b, G + a0.o.b, drop_site(pd, st.site + 1),
-                                            Rv, P + a1.ln.w, G + a1.ln.w, G + a1.ln.b, G + a1.o.b, drop_site(pd, st.site + 5), s, &fin));
+                                            Rv, P + a1.ln.w, G + a1.ln.w, G + a1.ln.b, G + a1.o.b, drop_site(pd, st.site + 5), s, &fin, z_in_place()));
                 }
                 for (int m = 0; m < 2; ++m) if (st.active[m] && !both) {
                     const AttP& ap = *st.att[m];
                     DropCfg d = drop_site(pd, st.site + m * 4 + 1);
-                    CKP(PC_LN, k_ln_bwd<TB>(dyp[m], H, sv(st.sb[m].z), H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
-                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s, &fin));
+                    CKP(PC_LN, k_ln_bwd<TB>(dyp[m], H, svz(st.sb[m].z), H, P + ap.ln.w, st.sb[m].mean, st.sb[m].rstd, rowp(gz, m, H),
+                                   d.thresh ? rowp(gzd, m, H) : nullptr, H, part, G + ap.ln.w, G + ap.ln.b, G + ap.o.b, accumulate, seg_rows(m), H, d, nodrop, 1.0f, s, &fin, z_in_place()));
                 }
                 gg_init(g);
                 for (int m = 0; m < 2; ++m) if (st.active[m])

@@ -33,12 +33,12 @@ int ln_bwd_blocks(int M, int N);
 template <typename T>
 int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, const float* mean, const float* rstd, T* dz, T* dzd, int lddz,
              float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s,
-             FinDefer* defer = nullptr);
+             FinDefer* defer = nullptr, int z_split = 0 /* T = bf16_t, N = 768: z points at a split-f32 tensor (ldz in its elements) whose hi parts are read in place */);
 // two adjacent row segments of the same buffers (language | vision), each with its own module parameters, gradients and dropout site
 template <typename T>
 int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, const float* rstd, T* dz, T* dzd, int lddz, float* part, int N, int accumulate,
               int M0, const float* gamma0, float* dgamma0, float* dbeta0, float* dbias0, DropCfg drop0,
-              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s, FinDefer* defer = nullptr);
+              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s, FinDefer* defer = nullptr, int z_split = 0);
 // out[n] (+)= sum_m x[m][n]; part: workspace of 256*N floats
 template <typename T>
 int k_colsum(const T* x, int ldx, float* part, float* out, int accumulate, int M, int N, hipStream_t s);

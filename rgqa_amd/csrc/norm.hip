@@ -130,6 +130,7 @@ template <typename T>
 struct LnBwdSeg {
     const T* dy; const T* z; const float* gamma; const float* mean; const float* rstd; T* dz; T* dzd;
     int M; DropCfg drop, drop_in;
+    int z_split = 0;      // (T = bf16_t, ln_bwd16 only) z points at a SPLIT-f32 tensor (common.h sf32, ldz in its elements): its hi parts are read in place
 };
 template <typename T, int NV, int LN_BWD_THREADS>
 __global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const LnBwdSeg<T> sg0, const LnBwdSeg<T> sg1, int nblk0, int lddy, int ldz, int lddz,
@@ -263,7 +264,10 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const LnBwdSeg<T
 // a 16-wave block at 128 VGPRs spilled: 52 us against 24 us per launch, round 1).  Two rows per wave per trip, the next pair's loads issued
 // before the current pair's reductions; the two halves of a wave own the same columns, so their column sums meet in registers (one
 // shuffle) before the 8 waves fold through LDS in a fixed order.  Same partials layout as ln_bwd_kernel.
-template <int NC>
+// ZSF (round 6, bf16x3_fwd precision): the pre-LayerNorm sums are read straight out of the forward pass's split-f32 tensor - the hi parts ARE the bf16
+// image the forward pass used to store beside it (16 bytes of a 64-byte hi run per lane: the same accesses, at twice the row pitch) - so the projections'
+// epilogues no longer write that image: 2 of their 10 bytes per element.
+template <int NC, bool ZSF>
 __global__ __launch_bounds__(512) void ln_bwd16_kernel(const LnBwdSeg<bf16_t> sg0, const LnBwdSeg<bf16_t> sg1, int nblk0, int lddy, int ldz, int lddz,
                                                        float* __restrict__ part, float dy_scale) {
     constexpr int N = 256 * NC, NHW = 16, NW = 8;
@@ -286,6 +290,10 @@ __global__ __launch_bounds__(512) void ln_bwd16_kernel(const LnBwdSeg<bf16_t> sg
     }
     const int stride = lgrid * NHW;
     int row = lblk * NHW + hw;
+    auto ldz8 = [&](size_t r, int e0) -> bf16x8 {
+        if constexpr (ZSF) return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(z) + r * (size_t)ldz * 4 + (size_t)(e0 >> 5) * 128 + (e0 & 31) * 2);
+        else return *reinterpret_cast<const bf16x8*>(z + r * (size_t)ldz + e0);
+    };
     bf16x8 rd[NC], rz[NC];
     float mu = 0.f, rs = 0.f;
     if (row < M) {
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(512) void ln_bwd16_kernel(const LnBwdSeg<bf16_t> sg
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             rd[i] = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * lddy + (hl + 32 * i) * 8);
-            rz[i] = *reinterpret_cast<const bf16x8*>(z + (size_t)row * ldz + (hl + 32 * i) * 8);
+            rz[i] = ldz8((size_t)row, (hl + 32 * i) * 8);
         }
     }
     // (a half-wave whose rows have run out keeps taking part in the shuffles below with zeros: the loop is uniform over the WAVE)
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(512) void ln_bwd16_kernel(const LnBwdSeg<bf16_t> sg
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 rd[i] = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * lddy + (hl + 32 * i) * 8);
-                rz[i] = *reinterpret_cast<const bf16x8*>(z + (size_t)row * ldz + (hl + 32 * i) * 8);
+                rz[i] = ldz8((size_t)row, (hl + 32 * i) * 8);
             }
         }
         s1 = half_sum(s1) * (1.0f / (float)N);
@@ -485,12 +493,15 @@ static int ln_bwd_launch(const LnBwdSeg<T>& a, const LnBwdSeg<T>& b, int nblk0, 
         const bool al = lddy % 8 == 0 && ldz % 8 == 0 && lddz % 8 == 0 && ((uintptr_t)a.dy % 16) == 0 && ((uintptr_t)a.z % 16) == 0 && ((uintptr_t)a.dz % 16) == 0 &&
                         (a.dzd == nullptr || ((uintptr_t)a.dzd % 16) == 0) && ((uintptr_t)b.dy % 16) == 0 && ((uintptr_t)b.z % 16) == 0 && ((uintptr_t)b.dz % 16) == 0 &&
                         (b.dzd == nullptr || ((uintptr_t)b.dzd % 16) == 0) && ((uintptr_t)a.gamma % 16) == 0 && ((uintptr_t)b.gamma % 16) == 0;
+        RGQA_REQUIRE(a.z_split == b.z_split && (!a.z_split || (al && N == 768 && ldz % 32 == 0 && ((uintptr_t)a.z % 128) == 0 && ((uintptr_t)b.z % 128) == 0)),
+                     "layernorm bwd: split-f32 z needs N = 768 and 128-byte aligned rows (N=%d ldz=%d)", N, ldz);
         if (al && N == 768) {            // (N = 1536, the answer head's LayerNorm over 256 rows, stays on the generic kernel: 144 column accumulators per lane would spill)
-            hipLaunchKernelGGL(ln_bwd16_kernel<3>, dim3(nblk), dim3(512), 0, s, a, b, nblk0, lddy, ldz, lddz, part, dy_scale);
+            if (a.z_split) hipLaunchKernelGGL((ln_bwd16_kernel<3, true>), dim3(nblk), dim3(512), 0, s, a, b, nblk0, lddy, ldz, lddz, part, dy_scale);
+            else hipLaunchKernelGGL((ln_bwd16_kernel<3, false>), dim3(nblk), dim3(512), 0, s, a, b, nblk0, lddy, ldz, lddz, part, dy_scale);
             RGQA_LAUNCH_CHECK("ln_bwd16_kernel");
             return RGQA_OK;
         }
-    }
+    } else RGQA_REQUIRE(!a.z_split, "layernorm bwd: split-f32 z is read by the bf16 kernel only");
 #define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, (NVV <= 3 ? (sizeof(T) == 2 ? 1024 : 512) : 256)>), dim3(nblk), dim3(NVV <= 3 ? (sizeof(T) == 2 ? 1024 : 512) : 256), 0, s, a, b, nblk0, lddy, ldz, lddz, part, N, dy_scale)
     const int nvl = cdiv(N / 4, 64);
     if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4);
@@ -503,14 +514,14 @@ static int ln_bwd_launch(const LnBwdSeg<T>& a, const LnBwdSeg<T>& b, int nblk0, 
 template <typename T>
 int k_ln_bwd(const T* dy, int lddy, const T* z, int ldz, const float* gamma, const float* mean, const float* rstd, T* dz, T* dzd, int lddz,
              float* part, float* dgamma, float* dbeta, float* dbias, int accumulate, int M, int N, DropCfg drop, DropCfg drop_in, float dy_scale, hipStream_t s,
-             FinDefer* defer) {
+             FinDefer* defer, int z_split) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256, "layernorm bwd: N=%d unsupported", N);
     if (M <= 0) return RGQA_OK;
     const int nblk = ln_bwd_blocks_t<T>(M, N);
     if (part && defer && !defer->room(nblk, 3, N)) defer = nullptr;
     const int blk0 = defer ? defer->blk : 0;
     if (part && defer) part = defer->take(nblk);
-    LnBwdSeg<T> a; a.dy = dy; a.z = z; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.dz = dz; a.dzd = dzd; a.M = M; a.drop = drop; a.drop_in = drop_in;
+    LnBwdSeg<T> a; a.dy = dy; a.z = z; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.dz = dz; a.dzd = dzd; a.M = M; a.drop = drop; a.drop_in = drop_in; a.z_split = z_split;
     int r = ln_bwd_launch<T>(a, a, nblk, nblk, lddy, ldz, lddz, part, N, dy_scale, s);
     if (r) return r;
     if (part && defer) {
@@ -536,7 +547,7 @@ int fin_flush(FinDefer& d, int accumulate, hipStream_t s) {
 template <typename T>
 int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, const float* rstd, T* dz, T* dzd, int lddz, float* part, int N, int accumulate,
               int M0, const float* gamma0, float* dgamma0, float* dbeta0, float* dbias0, DropCfg drop0,
-              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s, FinDefer* defer) {
+              int M1, const float* gamma1, float* dgamma1, float* dbeta1, float* dbias1, DropCfg drop1, hipStream_t s, FinDefer* defer, int z_split) {
     RGQA_REQUIRE(N % 4 == 0 && N <= LN_MAXV * 256 && part != nullptr && M0 > 0 && M1 > 0, "layernorm bwd2: bad arguments (N=%d)", N);
     const DropCfg nodrop = make_drop(0.f, 0, 0);
     int nb0 = ln_bwd_blocks_t<T>(M0, N), nb1 = ln_bwd_blocks_t<T>(M1, N);
@@ -553,7 +564,8 @@ int k_ln_bwd2(const T* dy, int lddy, const T* z, int ldz, const float* mean, con
     }
     LnBwdSeg<T> a, b;
     a.dy = dy; a.z = z; a.gamma = gamma0; a.mean = mean; a.rstd = rstd; a.dz = dz; a.dzd = drop0.thresh ? dzd : nullptr; a.M = M0; a.drop = drop0; a.drop_in = nodrop;
-    b.dy = dy + (size_t)M0 * lddy; b.z = z + (size_t)M0 * ldz; b.gamma = gamma1; b.mean = mean + M0; b.rstd = rstd + M0;
+    a.z_split = b.z_split = z_split;
+    b.dy = dy + (size_t)M0 * lddy; b.z = z + (size_t)M0 * ldz * (z_split ? 4 / sizeof(T) : 1); b.gamma = gamma1; b.mean = mean + M0; b.rstd = rstd + M0;
     b.dz = dz + (size_t)M0 * lddz; b.dzd = drop1.thresh ? dzd + (size_t)M0 * lddz : nullptr; b.M = M1; b.drop = drop1; b.drop_in = nodrop;
     if (defer && !defer->room(nb0 + nb1, 6, N)) defer = nullptr;
     const int blk0 = defer ? defer->blk : 0;
@@ -588,12 +600,12 @@ template int k_ln_fwd2<sf32>(const sf32*, int, const float*, const float*, const
 template int k_ln_fwd<float>(const float*, int, const float*, const float*, float*, int, float*, float*, int, int, float, hipStream_t, bf16_t*);
 template int k_ln_fwd<bf16_t>(const bf16_t*, int, const float*, const float*, bf16_t*, int, float*, float*, int, int, float, hipStream_t, bf16_t*);
 template int k_ln_fwd<sf32>(const sf32*, int, const float*, const float*, sf32*, int, float*, float*, int, int, float, hipStream_t, bf16_t*);
-template int k_ln_bwd2<float>(const float*, int, const float*, int, const float*, const float*, float*, float*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
-template int k_ln_bwd2<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, bf16_t*, bf16_t*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
-template int k_ln_bwd2<sf32>(const sf32*, int, const sf32*, int, const float*, const float*, sf32*, sf32*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*);
-template int k_ln_bwd<float>(const float*, int, const float*, int, const float*, const float*, const float*, float*, float*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*);
-template int k_ln_bwd<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, bf16_t*, bf16_t*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*);
-template int k_ln_bwd<sf32>(const sf32*, int, const sf32*, int, const float*, const float*, const float*, sf32*, sf32*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*);
+template int k_ln_bwd2<float>(const float*, int, const float*, int, const float*, const float*, float*, float*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*, int);
+template int k_ln_bwd2<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, bf16_t*, bf16_t*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*, int);
+template int k_ln_bwd2<sf32>(const sf32*, int, const sf32*, int, const float*, const float*, sf32*, sf32*, int, float*, int, int, int, const float*, float*, float*, float*, DropCfg, int, const float*, float*, float*, float*, DropCfg, hipStream_t, FinDefer*, int);
+template int k_ln_bwd<float>(const float*, int, const float*, int, const float*, const float*, const float*, float*, float*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*, int);
+template int k_ln_bwd<bf16_t>(const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, bf16_t*, bf16_t*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*, int);
+template int k_ln_bwd<sf32>(const sf32*, int, const sf32*, int, const float*, const float*, const float*, sf32*, sf32*, int, float*, float*, float*, float*, int, int, int, DropCfg, DropCfg, float, hipStream_t, FinDefer*, int);
 template int k_colsum<float>(const float*, int, float*, float*, int, int, int, hipStream_t);
 template int k_colsum<bf16_t>(const bf16_t*, int, float*, float*, int, int, int, hipStream_t);
 template int k_colsum<sf32>(const sf32*, int, float*, float*, int, int, int, hipStream_t);

@@ -765,6 +765,37 @@ def test_train_steps_are_bit_reproducible(prec):
         assert torch.equal(a, c), i
 
 
+def test_layernorm_backward_reads_the_split_sums_in_place():
+    """Round 6, bf16x3_fwd: the pre-LayerNorm sums no longer get a bf16 image from the projections' epilogues - the LayerNorm backward kernel reads the hi
+    parts of the split-f32 tensor in place (norm.hip ln_bwd16_kernel<.., ZSF>; rgqa_debug_set key 21 = 0 restores the image).  hi = bf16(x) is exactly what
+    the image held: logits and every gradient are bit-identical, packed and padded rows, the [CLS]-row tail included."""
+    from rgqa_amd import _lib
+    L = _lib.load()
+    B, T, O = 24, 20, 36
+    raw = synth.synth_batch(B, T, O=O, F=FULL["feat_dim"], NA=FULL["num_answers"], vocab=FULL["vocab_size"], seed=23, min_len=3)
+    b = dev(raw)
+    lens = np.ascontiguousarray(raw["lengths"], dtype=np.int32)
+    res = {}
+    try:
+        for inplace in (0, 1):
+            assert L.rgqa_debug_set(21, inplace) == 0
+            e = make_engine(FULL, "bf16x3_fwd", dropout=0.1)
+            e.ensure_shape(B, T, O)
+            e.sync_weights()
+            out = []
+            for packed in (True, False):
+                lg = e.forward(b["feats"], b["boxes"], b["input_ids"], b["input_mask"], b["segment_ids"], train=True, seed=7, lengths=lens if packed else None)[0].clone()
+                e.loss_backward(b["target"])
+                out += [lg, e.grads.clone()]
+            torch.cuda.synchronize()
+            res[inplace] = out
+    finally:
+        L.rgqa_debug_set(21, 1)
+    assert float(res[1][1].abs().max()) > 0
+    for a, c in zip(res[0], res[1]):
+        assert torch.equal(a, c)
+
+
 def test_rebind_right_after_an_overlapped_update(prec="bf16"):
     """ensure_shape() re-plans (or frees) the workspace, which holds the transpose descriptor table the LAST kernel of an optimizer pass
     still running on the update stream reads.  adam_step(overlap) -> ensure_shape(bigger) -> forward / backward must give what the serial order gives:
