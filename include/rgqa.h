@@ -70,7 +70,9 @@ int rgqa_version(void);
  * key 20: cap on the grid of the (grid-stride) BertAdam kernel, default 2048 workgroups (with the update beside the forward pass a smaller grid
  * only delays the weights the forward waits for: 2048 10.98, 512 11.15, 128 11.61 ms per step);
  * key 21: bf16x3_fwd precision, 1 (default) = the LayerNorm backward reads the hi parts of the split-f32 pre-LayerNorm sums in place, 0 = a bf16 image of them is
- * stored by the projections' epilogues (round 5); bit-identical gradients. */
+ * stored by the projections' epilogues (round 5); bit-identical gradients;
+ * key 22: persistent NT GEMM launches: the blocks that walk one tile fewer than the busiest ones start late by value / 16 x K-steps x ~2 us (inside their slack), so that
+ * their K loops run beside the other blocks' tile stores; 0 = every block starts at once (rounds 1-5); default 8; same results. */
 int rgqa_debug_set(int key, int value);
 /* The library runs the deferred weight-gradient GEMMs on ONE side stream per device, shared by every engine of the process.  By default it makes
  * that stream itself when the first engine is bound; a caller that knows better hands one in BEFORE that (the Python binding does: HIP maps streams

@@ -30,6 +30,7 @@ extern int g_rgqa_butd_gru_persist;
 extern int g_rgqa_ln_fuse;
 extern int g_rgqa_adam_blocks;
 extern int g_rgqa_z_in_place;
+extern int g_rgqa_nt_stagger;
 int rgqa_set_side_stream(int device, void* stream) {
     RGQA_REQUIRE(device >= 0 && stream != nullptr, "set_side_stream: bad argument");
     std::lock_guard<std::mutex> lk(rgqa_side_stream_mutex());
@@ -56,6 +57,7 @@ int rgqa_debug_set(int key, int value) {
     if (key == 19) { g_rgqa_ln_fuse = value; return RGQA_OK; }
     if (key == 20) { g_rgqa_adam_blocks = value; return RGQA_OK; }
     if (key == 21) { g_rgqa_z_in_place = value; return RGQA_OK; }
+    if (key == 22) { g_rgqa_nt_stagger = value; return RGQA_OK; }
     rgqa_set_error("debug_set: unknown key %d", key);
     return RGQA_ERR_ARG;
 }

@@ -56,6 +56,8 @@ struct GemmGroupT {
     int a_f32;          // NT only: A operand is f32 in memory (converted to bf16 while staging)
     int b_kn;           // bf16 NT LDS-DMA kernels only: EVERY problem's B operand is stored [K, N] row-major (ldb = row pitch) instead of [N, K]: C = A B.
                         // The dgrad GEMMs on the weight as it lies ([out, in]: the contraction runs over its rows) - no transposed copy.  K % 64 == 0
+    int stagger;        // persistent NT kernels (round 6, rgqa_debug_set key 22; 0 = off): a block that walks one tile FEWER than the busiest blocks starts late by
+                        // stagger / 16 x (its K-step count) x ~2 us - inside the slack it has anyway - so that its K loops run while the others store their tiles
     const void* zeros;  // TN LDS-DMA kernel: >= 16 zero bytes on the device (source of the contraction tail's A rows)
     unsigned long long* stamps;   // clock probe only (rgqa_probe_gemm: separately instantiated, stamped kernels): 8 words per block
     float* splitk_ws;   // bf16 NT launches: scratch for the split-K path of skinny problems (gemm_mfma256.hip), splitk_floats floats, or null

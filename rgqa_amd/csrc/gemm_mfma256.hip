@@ -7,6 +7,8 @@
 #include "gemm_nt256.h"
 
 int g_rgqa_force_mt = 0;      // rgqa_debug_set key 1
+int g_rgqa_nt_stagger = 8;    // rgqa_debug_set key 22 (gemm_nt256.h): blocks of a persistent NT launch that walk one tile fewer start ~0.5 x K-steps x 2 us late; 0 = off.
+                              // A/B on one box (profiles/r06_ab_records.txt): bf16x3_fwd 15.346 -> 15.288 ms per step (FFN1-class launches -6 %), bf16 11.023 -> 10.985; 20: worse
 int g_rgqa_nt_panel = -1;     // rgqa_debug_set key 9
 
 // true when every problem of the group can run on the LDS-DMA kernel

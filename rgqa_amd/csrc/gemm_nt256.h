@@ -182,6 +182,17 @@ __global__ __launch_bounds__(T256_THREADS) void gemm_nt256_kernel(const GemmGrou
     const int fr = lane & 15, fq = lane >> 4;
     int vt = blockIdx.x;
     locate(vt);
+    if (PERSIST && g.stagger > 0) {
+        // All blocks of a launch move in lock-step: K loop (matrix pipe busy, HBM idle: the operands come out of the L2s), then the epilogue (every CU stores
+        // its tile at once: HBM-bound, matrix pipe idle).  In a launch of 2.67 tile rounds a third of the blocks walk one tile fewer: they can afford to
+        // start late, and then their K loops run beside the others' stores
+        const int total = g.total_tiles, grid = (int)gridDim.x;
+        const int mine = (total - (int)blockIdx.x + grid - 1) / grid, mx = (total + grid - 1) / grid;
+        if (mine < mx) {
+            const int loops = (nkt * g.stagger) >> 4;
+            for (int i = 0; i < loops; ++i) __builtin_amdgcn_s_sleep(64);          // 64 x 64 clocks ~ 2 us
+        }
+    }
     issue(0, 0);
     bool pre1 = false;      // K-step 1 of the current tile was already issued (behind the previous tile's epilogue)
     for (;;) {
@@ -366,6 +377,7 @@ static inline int pick_mt(const GemmGroup& g, long& tiles_out) {
 }
 
 extern int g_rgqa_force_mt;      // rgqa_debug_set key 1 (kernel parity tests: every tile height)
+extern int g_rgqa_nt_stagger;    // rgqa_debug_set key 22: late start of the persistent NT blocks that walk one tile fewer (GemmGroupT::stagger); 0 = off
 extern int g_rgqa_nt_panel;      // rgqa_debug_set key 9: 0 = row-major tile numbering everywhere, -1 = default, n > 0 = panel width n
 
 // panel width per problem (see nt_tile_coords): the widest panel whose weight rows fit ~1.6 MB (split f32: 2.4 MB - three tiles at K = 768,
@@ -417,6 +429,7 @@ static int launch256(GemmGroup& g, hipStream_t s) {
         }
         int grid = g.total_tiles;
         if (grid > rgqa_num_cus()) grid = rgqa_num_cus();     // one persistent block per CU
+        g.stagger = g_rgqa_nt_stagger;
         hipLaunchKernelGGL((gemm_nt256_kernel<OutT, EPI, MT, X3, false, NN, LNF>), dim3(grid), dim3(T256_THREADS), LDS_BYTES, s, nt_prefix(g));
         RGQA_LAUNCH_CHECK("gemm_nt256_kernel");
         return RGQA_OK;
