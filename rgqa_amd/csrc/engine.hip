@@ -817,7 +817,7 @@ public:
         double f, b; gemm_work(g, f, b);
         char tg[48];
         prof_begin(PC_GEMM_NT, f, b, s, profiling ? gemm_tag(g, tg) : "", last_obytes);
-        if constexpr (std::is_same<T, bf16_t>::value) { if (cls_rows) { g.splitk_ws = part; g.splitk_floats = part_floats; } }
+        if constexpr (LP) { if (cls_rows) { g.splitk_ws = part; g.splitk_floats = part_floats; } }      // (split f32 since round 6: gemm_x3.hip)
         int r = nt_gemm(g, out_f32, 0, s);
         prof_end(s);
         return r;
@@ -828,7 +828,7 @@ public:
         double f, b; gemm_work_t<TB>(g, f, b);
         char tg[48];
         prof_begin(PC_GEMM_NT_D, f, b, s, profiling ? gemm_tag(g, tg) : "", last_obytes);
-        if constexpr (std::is_same<TB, bf16_t>::value) { if (cls_rows) { g.splitk_ws = part; g.splitk_floats = part_floats; } }
+        if constexpr (LP) { if (cls_rows) { g.splitk_ws = part; g.splitk_floats = part_floats; } }
         int r = nt_gemm_b(g, 0, 1, s);
         prof_end(s);
         return r;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue4_e(const GemmProblem& P, const int
         const AuxT* arow = reinterpret_cast<const AuxT*>(P.aux) + (size_t)m * P.ldaux + n0;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         if (nvalid == 4) load4(arow, a);
-        else for (int i = 0; i < nvalid; ++i) a[i] = to_f32(arow[i]);
+        else for (int i = 0; i < nvalid; ++i) a[i] = ld_elem(arow + i);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (epi == EPI_RESID_DROP) {
@@ -126,11 +126,15 @@ __device__ __forceinline__ void gemm_epilogue4_e(const GemmProblem& P, const int
     }
     if (nvalid == 4) {
         store4(crow, v);
-        if (epi == EPI_GELU && P.C2 != nullptr) store4(reinterpret_cast<OutT*>(P.C2) + (size_t)m * P.ldc + n0, pre);
+        if (P.Cb != nullptr) store4(reinterpret_cast<bf16_t*>(P.Cb) + (size_t)m * P.ldc + n0, v);      // split-f32 results (bf16x3_fwd): the bf16 image beside them
+        if (epi == EPI_GELU && P.C2 != nullptr) {
+            if (P.c2_lp) store4(reinterpret_cast<bf16_t*>(P.C2) + (size_t)m * P.ldc + n0, pre);
+            else store4(reinterpret_cast<OutT*>(P.C2) + (size_t)m * P.ldc + n0, pre);
+        }
     } else {
         for (int i = 0; i < nvalid; ++i) {
-            crow[i] = from_f32<OutT>(v[i]);
-            if (epi == EPI_GELU && P.C2 != nullptr) (reinterpret_cast<OutT*>(P.C2) + (size_t)m * P.ldc + n0)[i] = from_f32<OutT>(pre[i]);
+            st_elem(crow + i, v[i]);
+            if (epi == EPI_GELU && P.C2 != nullptr) st_elem(reinterpret_cast<OutT*>(P.C2) + (size_t)m * P.ldc + n0 + i, pre[i]);
         }
     }
 }

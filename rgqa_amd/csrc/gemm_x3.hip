@@ -13,6 +13,69 @@
 // every problem: K % 32 == 0, rows of A / W / C / aux whole 128-byte lines (ld % 32 == 0, bases 128-byte aligned), N % 8 == 0
 static bool x3_aligned(const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 127) == 0 && (ld % 32) == 0); }
 
+// ---------------------------------------------------------------------------------------------------------------- split-K for skinny problems (round 6)
+// The [CLS]-row GEMMs of the LXMERT engines (tail FFN, pooler, answer head: M = B rows) and the BUTD engine's per-sample GEMMs - above all the GRU's
+// per-token h W_hh^T (M = B, K = 1024) and its dgrad (K = 3072) - are 3-12 tiles on a 256-CU chip, each walking a long contraction alone: 46 us for the
+// GRU's forward product, 78 us for the tail FFN2, in split f32 twice the K-steps of the bf16 kernels.  As the bf16 launcher does since round 4
+// (gemm_mfma256.hip): the contraction is cut into S = K / 256 <= 12 slices that run as the S problems of ONE grouped launch of the f32-result kernel,
+// and one pass folds the slices in slice order (bit-reproducible) and applies the epilogue - bias, activation, dropout, residual, the second output and the
+// bf16 images.  Chosen by call site (the caller hands scratch over), never by M; more than 256 rows run as row groups of 256.
+#define X3_SPLITK_ROWS 256
+extern int g_rgqa_nt_splitk;     // rgqa_debug_set key 7
+template <typename OutT>
+__global__ __launch_bounds__(256) void splitk_finish_x3_kernel(const GemmProblem P, const DropCfg drop, const float* __restrict__ part, int S, int ldp, size_t slice_stride,
+                                                               int m_base, int rows) {
+    const int nq = P.N >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * nq) return;
+    const int ml = (int)(i / nq), n0 = (int)(i % nq) << 2;
+    const float* src = part + (size_t)ml * ldp + n0;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        float t[4]; load4(src + (size_t)s * slice_stride, t);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    gemm_epilogue4_e<OutT, sf32>(P, P.epi, drop, m_base + ml, n0, v);
+}
+static int x3_splitk_slices(const GemmGroup& g, int out_f32) {
+    if (!g_rgqa_nt_splitk || g.count != 1 || g.splitk_ws == nullptr || g.stamps != nullptr) return 0;
+    const GemmProblem& p = g.p[0];
+    if (p.K < 768 || (p.K % 32) != 0 || (p.N % 8) != 0) return 0;
+    if (out_f32 && p.epi != EPI_BIAS) return 0;
+    if (p.epi == EPI_ACCUM || (epi_needs_aux(p.epi) && p.aux == nullptr)) return 0;
+    int S = p.K / 256;
+    if (S > GEMM_NT_MAX_PROBLEMS) S = GEMM_NT_MAX_PROBLEMS;
+    const int rows = p.M < X3_SPLITK_ROWS ? p.M : X3_SPLITK_ROWS;
+    if (S < 2 || (size_t)S * rows * p.N > g.splitk_floats) return 0;
+    return S;
+}
+static int launch_gemm_nt_x3_splitk(GemmGroup& g, int S, int out_f32, hipStream_t s) {
+    const GemmProblem P = g.p[0];
+    const int steps = P.K / 32, ldp = P.N;              // K-steps of 32 contraction elements (64 staged bf16 columns)
+    for (int m0 = 0; m0 < P.M; m0 += X3_SPLITK_ROWS) {
+        const int rows = P.M - m0 < X3_SPLITK_ROWS ? P.M - m0 : X3_SPLITK_ROWS;
+        const size_t stride = (size_t)rows * ldp;
+        GemmGroup g2; memset(&g2, 0, sizeof g2);
+        g2.count = S; g2.drop = g.drop;
+        for (int i = 0, k0 = 0; i < S; ++i) {
+            const int ks = (steps / S + (i < steps % S ? 1 : 0)) * 32;
+            GemmProblem& q = g2.p[i];
+            q.A = reinterpret_cast<const sf32*>(P.A) + (size_t)m0 * P.lda + k0; q.lda = P.lda;      // 32-aligned columns: whole 128-byte lines
+            q.B = reinterpret_cast<const sf32*>(P.B) + k0; q.ldb = P.ldb;
+            q.C = g.splitk_ws + (size_t)i * stride; q.ldc = ldp;
+            q.M = rows; q.N = P.N; q.K = ks; q.epi = EPI_BIAS;
+            k0 += ks;
+        }
+        if (int r = launch256<float, EPI_BIAS, 2, true>(g2, s)) return r;
+        const long n4 = (long)rows * (P.N >> 2);
+        const int blocks = (int)((n4 + 255) / 256);
+        if (out_f32) hipLaunchKernelGGL((splitk_finish_x3_kernel<float>), dim3(blocks), dim3(256), 0, s, P, g.drop, g.splitk_ws, S, ldp, stride, m0, rows);
+        else hipLaunchKernelGGL((splitk_finish_x3_kernel<sf32>), dim3(blocks), dim3(256), 0, s, P, g.drop, g.splitk_ws, S, ldp, stride, m0, rows);
+        RGQA_LAUNCH_CHECK("splitk_finish_x3_kernel");
+    }
+    return RGQA_OK;
+}
+
 int launch_gemm_nt_x3(GemmGroup& g, int out_f32, hipStream_t s) {
     RGQA_REQUIRE(g.count >= 1 && g.count <= GEMM_NT_MAX_PROBLEMS, "gemm_x3: bad problem count %d", g.count);
     const int epi = g.p[0].epi;
@@ -30,6 +93,7 @@ int launch_gemm_nt_x3(GemmGroup& g, int out_f32, hipStream_t s) {
         }
         if (epi_needs_aux(epi)) RGQA_REQUIRE(p.aux != nullptr && x3_aligned(p.aux, p.ldaux), "gemm_x3[%d]: epilogue %d needs a split-f32 aux operand (ldaux=%d)", i, epi, p.ldaux);
     }
+    if (const int S = x3_splitk_slices(g, out_f32)) return launch_gemm_nt_x3_splitk(g, S, out_f32, s);
     long tiles = 0;
     int mt = pick_mt(g, tiles);
     if (g_rgqa_force_mt) mt = g_rgqa_force_mt;
