@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 //                de rows in that order (loads of eight rows in flight), and the four partial rows are folded in wave order: dword[id] (+)= sum.
 //   pos / type   few keys with many rows each (position t: one row per sample; token type: up to every row): partial sums per (key, chunk of 256 rows) - a wave per 64
 //                rows, folded in wave order - then one workgroup per key folds the chunks in chunk order.
-// 5,120 rows at B = 256: 33 us for the three launches where the atomic kernel took 24 (and 129 when many rows shared one id).
+// (timings: profiles/r06_*kernel_stats*; the atomic kernel took 24 us at 3,140 packed rows, and 129 us when thousands of rows shared one id)
 __global__ void embed_keys_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const int* __restrict__ row_src, int rows, int Tn,
                                   int* __restrict__ kw, int* __restrict__ kp, int* __restrict__ kt) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,16 +134,25 @@ __device__ __forceinline__ void embed_fold_waves(float* fold, int H, int wave, i
     }
 }
 
-template <typename T, int NV>
+// KLDS: the keys of all rows are staged in LDS once per workgroup (coalesced, every load in flight at once) and both scans run out of LDS; without it
+// (more than 16,384 rows) the scans read the keys from global memory - one dependent L2 round trip per 256 / 64 keys: 68 us at 3,140 rows, first version
+template <typename T, int NV, bool KLDS>
 __global__ __launch_bounds__(256) void embed_word_grad_kernel(const T* __restrict__ de, int ldde, const int* __restrict__ kw, float* __restrict__ dword, int rows, int H, int q_cap, int pad_key, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
     float* fold = reinterpret_cast<float*>(emb_lds);                                      // [3][H]
     unsigned short* lists = reinterpret_cast<unsigned short*>(emb_lds + (size_t)3 * H * 4);   // [4][q_cap]
+    const int* keys = kw;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int key = kw[r];
     if (key == pad_key) return;                                 // padding_idx
+    if constexpr (KLDS) {
+        int* kl = reinterpret_cast<int*>(emb_lds + (((size_t)3 * H * 4 + (size_t)4 * q_cap * 2 + 15) & ~(size_t)15));
+        for (int j = tid; j < rows; j += 256) kl[j] = kw[j];
+        __syncthreads();
+        keys = kl;
+    }
     int found = 0;
-    for (int j = tid; j < r; j += 256) found |= (kw[j] == key);
+    for (int j = tid; j < r; j += 256) found |= (keys[j] == key);
     if (__syncthreads_or(found)) return;                        // an earlier row owns this id
     const int span = rows - r, q = (span + 3) >> 2;
     const int lo = r + wave * q, hi = (lo + q < rows) ? lo + q : rows;
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256) void embed_word_grad_kernel(const T* __restric
     int cnt = 0;
     for (int base = lo; base < hi; base += 64) {
         const int j = base + lane;
-        const bool m = j < hi && kw[j] == key;
+        const bool m = j < hi && keys[j] == key;
         const unsigned long long mask = __ballot(m);
         if (m) lst[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(j - lo);
         cnt += __popcll(mask);
@@ -219,7 +228,13 @@ __global__ __launch_bounds__(256) void embed_small_fold_kernel(const float* __re
     float* dst = (is_pos ? dpos : dtype) + (size_t)k * H;
     for (int n = threadIdx.x; n < H; n += 256) {
         float s = 0.f;
-        for (int c = 0; c < nchunk; ++c) s += partial[((size_t)ky * nchunk + c) * H + n];
+        for (int c0 = 0; c0 < nchunk; c0 += 8) {             // eight chunk partials in flight, added in chunk order
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = c0 + k < nchunk ? partial[((size_t)ky * nchunk + c0 + k) * H + n] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (c0 + k < nchunk) s += t[k];
+        }
         dst[n] = accumulate ? dst[n] + s : s;
     }
 }
@@ -250,12 +265,16 @@ int k_embed_word_grad(const T* de, int ldde, const int* keys, int rows, float* d
     RGQA_REQUIRE(H % 4 == 0 && H <= 2048 && ldde % 4 == 0 && ldde >= H, "embed word grad: hidden %d / pitch %d unsupported", H, ldde);
     const int q_cap = (rows + 3) / 4 + 1;
     RGQA_REQUIRE(q_cap <= 65536, "embed word grad: %d rows exceed the 16-bit row lists", rows);
-    const size_t lds_w = (size_t)3 * H * 4 + (size_t)4 * q_cap * 2;
+    const size_t lds_base = (((size_t)3 * H * 4 + (size_t)4 * q_cap * 2 + 15) & ~(size_t)15);
+    const bool klds = rows <= 16384 && lds_base + (size_t)rows * 4 <= 64 * 1024;      // the keys beside the lists: five or more workgroups per CU at 5,120 rows
+    const size_t lds_w = klds ? lds_base + (size_t)rows * 4 : lds_base;
     RGQA_REQUIRE(lds_w <= 160 * 1024, "embed word grad: %d rows need %zu bytes of LDS", rows, lds_w);
     const int nvl = cdiv(H / 4, 64);
 #define EMBW(NVV) do { \
-        if (lds_w > 64 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_word_grad_kernel<T, NVV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); \
-        hipLaunchKernelGGL((embed_word_grad_kernel<T, NVV>), dim3(rows), dim3(256), lds_w, s, de, ldde, keys, dtable, rows, H, q_cap, pad_key, accumulate); } while (0)
+        if (klds) hipLaunchKernelGGL((embed_word_grad_kernel<T, NVV, true>), dim3(rows), dim3(256), lds_w, s, de, ldde, keys, dtable, rows, H, q_cap, pad_key, accumulate); \
+        else { \
+            if (lds_w > 64 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_word_grad_kernel<T, NVV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); \
+            hipLaunchKernelGGL((embed_word_grad_kernel<T, NVV, false>), dim3(rows), dim3(256), lds_w, s, de, ldde, keys, dtable, rows, H, q_cap, pad_key, accumulate); } } while (0)
     if (nvl <= 1) EMBW(1); else if (nvl == 2) EMBW(2); else if (nvl == 3) EMBW(3); else if (nvl == 4) EMBW(4); else EMBW(8);
 #undef EMBW
     RGQA_LAUNCH_CHECK("embed_word_grad_kernel");

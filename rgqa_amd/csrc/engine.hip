@@ -247,8 +247,8 @@ public:
         else return RGQA_OK;
     }
     // f32 -> the activation type of the LDS-DMA GEMM operands (the RoI features)
-    static int cast_lp(const float* src, T* dst, size_t n, hipStream_t s) {
-        if constexpr (X3) return k_cast_split(src, dst, n, s);
+    static int cast_lp(const float* src, T* dst, size_t n, hipStream_t s, bf16_t* image = nullptr) {
+        if constexpr (X3) return k_cast_split(src, dst, n, s, image);
         else return k_cast_bf16(src, dst, n, s);
     }
     ModelParams mp;
@@ -996,8 +996,7 @@ public:
         CK(image_of(emb_z, H, n_text, H, s));
         // image: LN(img_linear(feat)) + LN(pos_linear(pos)) + type_emb[1] -> LayerNorm -> dropout
         GemmGroup g; gg_init(g);
-        if (LP) CKP(PC_OTHER, cast_lp(feats, feats_lp, (size_t)ni * cfg.feat_dim, s));
-        if (MIXED) CKP(PC_OTHER, k_cast_bf16(feats, img(feats_lp), (size_t)ni * cfg.feat_dim, s));
+        if (LP) CKP(PC_OTHER, cast_lp(feats, feats_lp, (size_t)ni * cfg.feat_dim, s, img(feats_lp)));
         add_fwd(g, LP ? (const void*)feats_lp : (const void*)feats, cfg.feat_dim, mp.visn_fc, 0, H, u_zf, H, ni, EPI_BIAS, nullptr, 0, nullptr, 0);
         CK(run_fwd(g, s));
         CKP(PC_LN, k_ln_fwd<T>(u_zf, H, P + mp.visn_ln.w, P + mp.visn_ln.b, u_a1, H, u_st, u_st + ni, ni, H, cfg.ln_eps, s));
@@ -1074,8 +1073,7 @@ public:
         {   // VisualFeatEncoder: GEMM on the RoI features (one f32->bf16 cast pass in bf16 precision, so that this GEMM and
             // its weight-gradient GEMM run on the LDS-DMA kernels), then the fused LN/LN/avg tail
             GemmGroup g; gg_init(g);
-            if (LP) CKP(PC_OTHER, cast_lp(feats, feats_lp, (size_t)Rv * cfg.feat_dim, s));
-            if (MIXED) CKP(PC_OTHER, k_cast_bf16(feats, img(feats_lp), (size_t)Rv * cfg.feat_dim, s));      // the bf16 wgrad's operand
+            if (LP) CKP(PC_OTHER, cast_lp(feats, feats_lp, (size_t)Rv * cfg.feat_dim, s, img(feats_lp)));      // (MIXED: + the bf16 wgrad's operand, same pass)
             add_fwd(g, LP ? (const void*)feats_lp : (const void*)feats, cfg.feat_dim, mp.visn_fc, 0, H, zf, H, Rv, EPI_BIAS, nullptr, 0, nullptr, 0);
             CK(run_fwd(g, s));
             CKP(PC_OTHER, k_visn_combine_fwd<T>(zf, H, boxes, P + mp.box_fc.w, P + mp.box_fc.b, P + mp.visn_ln.w, P + mp.visn_ln.b, P + mp.box_ln.w, P + mp.box_ln.b,

@@ -148,7 +148,7 @@ int k_clip_scale(float* g, size_t n, const float* sumsq, float max_norm, hipStre
 struct TransDesc { long src_off, dst_off; int N, K, ld_dst, tile_start; };
 int k_cast_transpose(const void* src, int src_is_bf16, void* dst, int dst_split, const TransDesc* desc_dev, int ndesc, int total_tiles, hipStream_t s);
 int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s);
-int k_cast_split(const float* src, void* dst_split, size_t n, hipStream_t s);
+int k_cast_split(const float* src, void* dst_split, size_t n, hipStream_t s, bf16_t* img = nullptr /* also dst's bf16 image (= its hi parts) at the same element offsets */);
 int k_sum_bf16_parts(const void* parts, size_t stride, int nparts, float* dst, size_t n, hipStream_t s);
 int k_sum_parts(const void* parts, int parts_f32, size_t stride, int nparts, float* dst, size_t n, float* sq_ws /* >= 1025 floats or null */, float* sq_out /* += sum(dst^2), or null */, hipStream_t s);
 

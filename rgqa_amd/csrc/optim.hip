@@ -282,21 +282,26 @@ int k_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
 }
 
 // f32 -> split f32 (bf16x3 precision), element i of src -> slot i of dst: the weight arena's operand copy, the RoI features
-__global__ __launch_bounds__(256) void cast_split_kernel(const float* __restrict__ src, sf32* __restrict__ dst, size_t n) {
+// img (bf16x3_fwd precision, the RoI features): the bf16 image the backward pass reads, from the same registers (round 5: a second pass over the f32 source)
+__global__ __launch_bounds__(256) void cast_split_kernel(const float* __restrict__ src, sf32* __restrict__ dst, size_t n, bf16_t* __restrict__ img) {
     const size_t nv = n >> 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
         float v[4];
         load4(src + i * 4, v);
         store4(dst + i * 4, v);
+        if (img) store4(img + i * 4, v);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) sf_store1(dst + (nv << 2) + threadIdx.x, src[(nv << 2) + threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        sf_store1(dst + (nv << 2) + threadIdx.x, src[(nv << 2) + threadIdx.x]);
+        if (img) img[(nv << 2) + threadIdx.x] = (bf16_t)src[(nv << 2) + threadIdx.x];
+    }
 }
-int k_cast_split(const float* src, void* dst, size_t n, hipStream_t s) {
+int k_cast_split(const float* src, void* dst, size_t n, hipStream_t s, bf16_t* img) {
     if (n == 0) return RGQA_OK;
-    RGQA_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "cast_split: 16-byte alignment required");
+    RGQA_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)img % 8) == 0, "cast_split: 16-byte alignment required");
     size_t nb = (n / 4 + 255) / 256;
     int nblk = nb > 2048 ? 2048 : (nb < 1 ? 1 : (int)nb);
-    hipLaunchKernelGGL(cast_split_kernel, dim3(nblk), dim3(256), 0, s, src, reinterpret_cast<sf32*>(dst), n);
+    hipLaunchKernelGGL(cast_split_kernel, dim3(nblk), dim3(256), 0, s, src, reinterpret_cast<sf32*>(dst), n, img);
     RGQA_LAUNCH_CHECK("cast_split_kernel");
     return RGQA_OK;
 }
