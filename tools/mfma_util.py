@@ -5,8 +5,8 @@ import collections, csv, json, sys
 
 
 def family(k):
-    if "gemm_nt" in k:
-        return "gemm_nt"
+    if "gemm_nt" in k:      # (round 6: the split-f32 forward launches apart from the bf16 launches - under bf16x3_fwd they are different kernel families)
+        return "gemm_nt_x3" if ("sf32" in k or ("<float" in k and ", true," in k)) else "gemm_nt_bf16"
     if "gemm_tn" in k:
         return "gemm_tn"
     if "attn_fwd" in k:
