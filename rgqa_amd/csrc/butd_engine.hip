@@ -137,7 +137,7 @@ public:
         size_t mw = 0;
         for (BLin* l : lins) { size_t n = (size_t)l->out * l->kp; if (n > mw) mw = n; }
         dwscr = take<float>(mw); dw_part = take<float>((size_t)B * H); db_part = take<float>(B);
-        gru_cnt = take<int>(gru_persist_counter_ints(B, L)); emb_keys = take<int>((size_t)B * L);
+        gru_cnt = take<int>(gru_persist_counter_ints(B, L)); emb_keys = take<int>(2 * ((size_t)B * L + 4));
         // the three long contractions of the pass - W_hh and W_ih over L * B rows, image_proj over B * O rows - are cut into 4 row slices each: as whole
         // problems their 108 output tiles walked 144-160 K-steps on an otherwise idle chip (one launch of 280 us: as long as its longest chain)
         for (BLin* l : lins) {
@@ -401,7 +401,7 @@ public:
         // dense gradient of the word table (nn.Embedding(padding_idx = ntoken): that row gets none, butd.py:36), every table row summed by one workgroup
         // in a fixed order (csrc/embed.hip; until round 6 a float-atomic scatter-add: the last bits changed from run to run)
         CKB(k_embed_keys(in_toks, B * L, emb_keys, s));
-        CKB(k_embed_word_grad<T>(dX, Ep, emb_keys, B * L, G + emb, E, cfg.vocab_size - 1, accumulate, s));
+        CKB(k_embed_word_grad<T>(dX, Ep, emb_keys, emb_keys + (((size_t)B * L + 3) & ~(size_t)3), B * L, G + emb, E, cfg.vocab_size - 1, accumulate, s));
         if (wg_collect) {
             CKB(tn_gemm(wg, s));
             CKB(kb_wn_backward_group(wn_dev, (int)wn_host.size(), wn_blocks, wn_partial, s));

@@ -89,10 +89,11 @@ __global__ void embed_keys_kernel(const int64_t* __restrict__ ids, const int64_t
 template <typename T, int NV>
 __device__ __forceinline__ void embed_sum_rows(const T* __restrict__ de, int ldde, int H, int row0, const unsigned short* lst, int cnt, int lane, float (&acc)[NV][4]) {
     const int nv = H >> 2;
-    for (int i0 = 0; i0 < cnt; i0 += 8) {
-        float v[8][NV][4];
+    constexpr int RPG = 8;
+    for (int i0 = 0; i0 < cnt; i0 += RPG) {
+        float v[RPG][NV][4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < RPG; ++k) {
             const bool on = i0 + k < cnt;
             const size_t row = (size_t)(row0 + (on ? (int)lst[i0 + k] : (int)lst[i0]));
 #pragma unroll
@@ -103,7 +104,7 @@ __device__ __forceinline__ void embed_sum_rows(const T* __restrict__ de, int ldd
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < RPG; ++k)
             if (i0 + k < cnt) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
@@ -134,46 +135,75 @@ __device__ __forceinline__ void embed_fold_waves(float* fold, int H, int wave, i
     }
 }
 
-// KLDS: the keys of all rows are staged in LDS once per workgroup (coalesced, every load in flight at once) and both scans run out of LDS; without it
-// (more than 16,384 rows) the scans read the keys from global memory - one dependent L2 round trip per 256 / 64 keys: 68 us at 3,140 rows, first version
-template <typename T, int NV, bool KLDS>
-__global__ __launch_bounds__(256) void embed_word_grad_kernel(const T* __restrict__ de, int ldde, const int* __restrict__ kw, float* __restrict__ dword, int rows, int H, int q_cap, int pad_key, int accumulate) {
+// plan[r] = number of rows that name row r's key if r is the key's FIRST occurrence (and the key is not pad_key), else 0.  One thread per row; the keys
+// of ALL rows are staged in LDS by every workgroup (16-byte loads, all in flight) and scanned as broadcasts: 3,140 LDS reads per thread, ~6 us.
+__global__ __launch_bounds__(256) void embed_word_plan_kernel(const int* __restrict__ kw, int rows, int rows4, int pad_key, int* __restrict__ plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
+    int* kl = reinterpret_cast<int*>(emb_lds);
+    for (int j = threadIdx.x; j < rows4; j += 256) reinterpret_cast<int4*>(kl)[j] = reinterpret_cast<const int4*>(kw)[j];      // (the key array is padded to whole int4s)
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const int key = kl[r];
+    int before = 0, cnt = 0;
+    for (int j = 0; j < r; ++j) before |= (kl[j] == key);
+    for (int j = r; j < rows; ++j) cnt += (kl[j] == key);
+    plan[r] = (before || key == pad_key) ? 0 : cnt;
+}
+
+// One workgroup per packed row r with plan[r] > 0.  plan[r] == 1 (the usual case: a word that occurs once in the batch): the row is copied (added) into its table
+// row by wave 0.  Otherwise (a word many questions share - [CLS], [SEP], '?'): the four waves scan one contiguous quarter each of the rows r .. rows-1 for the key
+// (ballot: a wave's matches come out in row order), sum their rows in that order, RPG rows' loads in flight, and the four partial rows are folded in wave order.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void embed_word_grad_kernel(const T* __restrict__ de, int ldde, const int* __restrict__ kw, const int* __restrict__ plan, float* __restrict__ dword,
+                                                              int rows, int H, int q_cap, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = plan[r];
+    if (n == 0) return;                                         // padding_idx, or an earlier row owns this id
+    const int nv = H >> 2;
+    const int key = kw[r];
+    float* dst = dword + (size_t)key * H;
+    float acc[NV][4];
+    if (n == 1) {
+        if (wave != 0) return;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                load4(de + (size_t)r * ldde + c * 4, acc[i]);
+                if (accumulate) { float t[4]; load4(dst + c * 4, t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += t[j]; }
+                store4(dst + c * 4, acc[i]);
+            }
+        }
+        return;
+    }
     float* fold = reinterpret_cast<float*>(emb_lds);                                      // [3][H]
     unsigned short* lists = reinterpret_cast<unsigned short*>(emb_lds + (size_t)3 * H * 4);   // [4][q_cap]
-    const int* keys = kw;
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int key = kw[r];
-    if (key == pad_key) return;                                 // padding_idx
-    if constexpr (KLDS) {
-        int* kl = reinterpret_cast<int*>(emb_lds + (((size_t)3 * H * 4 + (size_t)4 * q_cap * 2 + 15) & ~(size_t)15));
-        for (int j = tid; j < rows; j += 256) kl[j] = kw[j];
-        __syncthreads();
-        keys = kl;
-    }
-    int found = 0;
-    for (int j = tid; j < r; j += 256) found |= (keys[j] == key);
-    if (__syncthreads_or(found)) return;                        // an earlier row owns this id
     const int span = rows - r, q = (span + 3) >> 2;
     const int lo = r + wave * q, hi = (lo + q < rows) ? lo + q : rows;
     unsigned short* lst = lists + (size_t)wave * q_cap;
     int cnt = 0;
-    for (int base = lo; base < hi; base += 64) {
-        const int j = base + lane;
-        const bool m = j < hi && keys[j] == key;
-        const unsigned long long mask = __ballot(m);
-        if (m) lst[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(j - lo);
-        cnt += __popcll(mask);
+    for (int base = lo; base < hi; base += 256) {               // four 64-key groups per trip: their loads are in flight together
+        int kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int j = base + u * 64 + lane; kk[u] = j < hi ? kw[j] : key - 1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool m = kk[u] == key;
+            const unsigned long long mask = __ballot(m);
+            if (m) lst[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(base + u * 64 + lane - lo);
+            cnt += __popcll(mask);
+        }
     }
     __syncthreads();
-    float acc[NV][4];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
     if (lo < hi) embed_sum_rows<T, NV>(de, ldde, H, lo, lst, cnt, lane, acc);
     embed_fold_waves<NV>(fold, H, wave, lane, acc);
     if (wave == 0) {
-        const int nv = H >> 2;
-        float* dst = dword + (size_t)key * H;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
@@ -258,23 +288,26 @@ int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, cons
     return RGQA_OK;
 }
 
-// One table: dtable[key[r]] (+)= sum of the de rows that name it (rows of key pad_key: none).  keys: rows ints (device).  de row pitch ldde, table rows of H floats.
+// One table: dtable[key[r]] (+)= sum of the de rows that name it (rows of key pad_key: none).  keys: rows ints (device; readable up to the next multiple of
+// 4), plan: rows ints of scratch.  de row pitch ldde, table rows of H floats.
 template <typename T>
-int k_embed_word_grad(const T* de, int ldde, const int* keys, int rows, float* dtable, int H, int pad_key, int accumulate, hipStream_t s) {
+int k_embed_word_grad(const T* de, int ldde, const int* keys, int* plan, int rows, float* dtable, int H, int pad_key, int accumulate, hipStream_t s) {
     if (rows <= 0) return RGQA_OK;
     RGQA_REQUIRE(H % 4 == 0 && H <= 2048 && ldde % 4 == 0 && ldde >= H, "embed word grad: hidden %d / pitch %d unsupported", H, ldde);
+    RGQA_REQUIRE(keys != nullptr && plan != nullptr && ((uintptr_t)keys % 16) == 0, "embed word grad: null or misaligned key / plan scratch");
     const int q_cap = (rows + 3) / 4 + 1;
-    RGQA_REQUIRE(q_cap <= 65536, "embed word grad: %d rows exceed the 16-bit row lists", rows);
-    const size_t lds_base = (((size_t)3 * H * 4 + (size_t)4 * q_cap * 2 + 15) & ~(size_t)15);
-    const bool klds = rows <= 16384 && lds_base + (size_t)rows * 4 <= 64 * 1024;      // the keys beside the lists: five or more workgroups per CU at 5,120 rows
-    const size_t lds_w = klds ? lds_base + (size_t)rows * 4 : lds_base;
+    RGQA_REQUIRE(q_cap <= 65536 && rows <= 36864, "embed word grad: %d rows exceed the 16-bit row lists / the 144-KiB key image", rows);
+    const int rows4 = (rows + 3) / 4;
+    const size_t lds_plan = (size_t)rows4 * 16;
+    if (lds_plan > 64 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_word_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plan));
+    hipLaunchKernelGGL(embed_word_plan_kernel, dim3(cdiv(rows, 256)), dim3(256), lds_plan, s, keys, rows, rows4, pad_key, plan);
+    RGQA_LAUNCH_CHECK("embed_word_plan_kernel");
+    const size_t lds_w = (size_t)3 * H * 4 + (size_t)4 * q_cap * 2;
     RGQA_REQUIRE(lds_w <= 160 * 1024, "embed word grad: %d rows need %zu bytes of LDS", rows, lds_w);
     const int nvl = cdiv(H / 4, 64);
 #define EMBW(NVV) do { \
-        if (klds) hipLaunchKernelGGL((embed_word_grad_kernel<T, NVV, true>), dim3(rows), dim3(256), lds_w, s, de, ldde, keys, dtable, rows, H, q_cap, pad_key, accumulate); \
-        else { \
-            if (lds_w > 64 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_word_grad_kernel<T, NVV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); \
-            hipLaunchKernelGGL((embed_word_grad_kernel<T, NVV, false>), dim3(rows), dim3(256), lds_w, s, de, ldde, keys, dtable, rows, H, q_cap, pad_key, accumulate); } } while (0)
+        if (lds_w > 64 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_word_grad_kernel<T, NVV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); \
+        hipLaunchKernelGGL((embed_word_grad_kernel<T, NVV>), dim3(rows), dim3(256), lds_w, s, de, ldde, keys, plan, dtable, rows, H, q_cap, accumulate); } while (0)
     if (nvl <= 1) EMBW(1); else if (nvl == 2) EMBW(2); else if (nvl == 3) EMBW(3); else if (nvl == 4) EMBW(4); else EMBW(8);
 #undef EMBW
     RGQA_LAUNCH_CHECK("embed_word_grad_kernel");
@@ -292,7 +325,7 @@ int k_embed_keys(const int64_t* ids, int rows, int* keys, hipStream_t s) {
     return RGQA_OK;
 }
 
-// keys: 3 * rows ints of scratch; scratch: f32 scratch for the position / token-type partial sums ((Tn + type_vocab) * ceil(rows / 256) * H floats).
+// keys: 4 * (rows + 3) ints of scratch, 16-byte aligned; scratch: f32 scratch for the position / token-type partial sums ((Tn + type_vocab) * ceil(rows / 256) * H floats).
 // accumulate = 0: the tables were zeroed by the caller (rows no token names keep the zeros); 1: the sums are added to what the tables hold.
 template <typename T>
 int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, int type_vocab,
@@ -304,10 +337,11 @@ int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const i
     RGQA_REQUIRE(keys != nullptr && scratch != nullptr && (size_t)nkeys * nchunk * H <= scratch_floats, "embed scatter: scratch too small (%zu floats for %d keys x %d chunks x %d)",
                  scratch_floats, nkeys, nchunk, H);
     const size_t lds_p = (size_t)3 * H * 4 + 4 * 64 * 2;
-    int *kw = keys, *kp = keys + rows, *kt = keys + 2 * (size_t)rows;
+    const size_t rp = ((size_t)rows + 3) & ~(size_t)3;           // every array padded to whole int4s (the plan kernel stages the keys 16 bytes at a time)
+    int *kw = keys, *kp = keys + rp, *kt = keys + 2 * rp, *plan = keys + 3 * rp;
     hipLaunchKernelGGL(embed_keys_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, ids, seg, row_src, rows, Tn, kw, kp, kt);
     RGQA_LAUNCH_CHECK("embed_keys_kernel");
-    if (int r = k_embed_word_grad<T>(de, H, kw, rows, dword, H, 0, accumulate, s)) return r;
+    if (int r = k_embed_word_grad<T>(de, H, kw, plan, rows, dword, H, 0, accumulate, s)) return r;
     const int nvl = cdiv(H / 4, 64);
 #define EMBP(NVV) hipLaunchKernelGGL((embed_small_partial_kernel<T, NVV>), dim3(nchunk, nkeys), dim3(256), lds_p, s, de, kp, kt, scratch, rows, Tn, H, pad0_all)
     if (nvl <= 1) EMBP(1); else if (nvl == 2) EMBP(2); else if (nvl == 3) EMBP(3); else if (nvl == 4) EMBP(4); else EMBP(8);
@@ -331,6 +365,6 @@ template int k_embed_fwd<sf32>(const int64_t*, const int64_t*, const int*, const
 template int k_embed_scatter<sf32>(const sf32*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
 template int k_embed_scatter<float>(const float*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
 template int k_embed_scatter<bf16_t>(const bf16_t*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
-template int k_embed_word_grad<sf32>(const sf32*, int, const int*, int, float*, int, int, int, hipStream_t);
-template int k_embed_word_grad<float>(const float*, int, const int*, int, float*, int, int, int, hipStream_t);
-template int k_embed_word_grad<bf16_t>(const bf16_t*, int, const int*, int, float*, int, int, int, hipStream_t);
+template int k_embed_word_grad<sf32>(const sf32*, int, const int*, int*, int, float*, int, int, int, hipStream_t);
+template int k_embed_word_grad<float>(const float*, int, const int*, int*, int, float*, int, int, int, hipStream_t);
+template int k_embed_word_grad<bf16_t>(const bf16_t*, int, const int*, int*, int, float*, int, int, int, hipStream_t);

@@ -93,7 +93,8 @@ int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const i
                     int pad0_all, int accumulate, int* keys, float* scratch, size_t scratch_floats, hipStream_t s);
 // one embedding table's dense gradient without float atomics: dtable[keys[r]] (+)= sum over the rows r that name the key, in a fixed order (embed.hip)
 template <typename T>
-int k_embed_word_grad(const T* de, int ldde, const int* keys, int rows, float* dtable, int H, int pad_key, int accumulate, hipStream_t s);
+int k_embed_word_grad(const T* de, int ldde, const int* keys /* rows ints, 16-byte aligned, readable up to the next multiple of 4 */, int* plan /* rows ints of scratch */, int rows,
+                      float* dtable, int H, int pad_key, int accumulate, hipStream_t s);
 int k_embed_keys(const int64_t* ids, int rows, int* keys, hipStream_t s);
 // additive key mask (1 - m) * -10000 from the 0/1 int64 attention mask (modeling.py:857-865)
 int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s);
