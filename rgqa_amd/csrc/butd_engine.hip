@@ -118,7 +118,8 @@ public:
         B = B_; L = L_; O = O_;
         ws_used = 0;
         sumsq = take<float>(64); loss_dev = take<float>(64); sumsq_scr = take<float>(1088);      // k_sumsq's partials + ticket: not shared with the column-sum scratch
-        { size_t pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp; partial = take<float>(256 * pw); }
+        { size_t pw = 3 * (size_t)H; if ((size_t)NAp > pw) pw = NAp; partial_floats = 256 * pw; const size_t eg = (size_t)64 * cdiv(B * L, 256) * E; if (eg > partial_floats) partial_floats = eg;
+          partial = take<float>(partial_floats); }      // (column-sum scratch; also the hot words' partial sums of the embedding gradient: csrc/embed.hip)
         for (BLin* l : lins) {
             l->eff = ws_used; take<T>((size_t)l->op * l->kp);          // op >= out rows: the rows past `out` stay zero (bf16x3: the logits GEMM runs over op columns)
             l->efft = ws_used; take<T>((size_t)l->kp * l->op);
@@ -137,7 +138,7 @@ public:
         size_t mw = 0;
         for (BLin* l : lins) { size_t n = (size_t)l->out * l->kp; if (n > mw) mw = n; }
         dwscr = take<float>(mw); dw_part = take<float>((size_t)B * H); db_part = take<float>(B);
-        gru_cnt = take<int>(gru_persist_counter_ints(B, L)); emb_keys = take<int>(2 * ((size_t)B * L + 4));
+        gru_cnt = take<int>(gru_persist_counter_ints(B, L)); emb_keys = take<int>(2 * ((size_t)B * L + 4) + 128);
         // the three long contractions of the pass - W_hh and W_ih over L * B rows, image_proj over B * O rows - are cut into 4 row slices each: as whole
         // problems their 108 output tiles walked 144-160 K-steps on an otherwise idle chip (one launch of 280 us: as long as its longest chain)
         for (BLin* l : lins) {
@@ -177,7 +178,7 @@ public:
         }
         wn_uploaded = false;
     }
-    int* gru_cnt = nullptr; int* emb_keys = nullptr;
+    int* gru_cnt = nullptr; int* emb_keys = nullptr; size_t partial_floats = 0;
     bool gru_persist() const { if constexpr (LP && !X3) return gru_persist_ok(B, H); else return false; }
     size_t workspace_bytes(int B_, int L_, int O_) override { dry = true; plan(B_, L_, O_); dry = false; return ws_used + 256; }
     int bind(float* p, float* g, void*, void*, void* w, size_t wb, int B_, int L_, int O_) override {
@@ -401,7 +402,12 @@ public:
         // dense gradient of the word table (nn.Embedding(padding_idx = ntoken): that row gets none, butd.py:36), every table row summed by one workgroup
         // in a fixed order (csrc/embed.hip; until round 6 a float-atomic scatter-add: the last bits changed from run to run)
         CKB(k_embed_keys(in_toks, B * L, emb_keys, s));
-        CKB(k_embed_word_grad<T>(dX, Ep, emb_keys, emb_keys + (((size_t)B * L + 3) & ~(size_t)3), B * L, G + emb, E, cfg.vocab_size - 1, accumulate, s));
+        {
+            const size_t need = (size_t)64 * cdiv(B * L, 256) * E;      // the hot words' partial sums
+            RGQA_REQUIRE(need <= partial_floats, "embedding gradients: %zu floats of scratch needed", need);
+            CKB(k_embed_table_grads<T>(dX, Ep, emb_keys, nullptr, nullptr, B * L, G + emb, nullptr, nullptr, E, 0, 0, cfg.vocab_size - 1, 0, accumulate,
+                                       emb_keys + (((size_t)B * L + 3) & ~(size_t)3), partial, need, s));
+        }
         if (wg_collect) {
             CKB(tn_gemm(wg, s));
             CKB(kb_wn_backward_group(wn_dev, (int)wn_host.size(), wn_blocks, wn_partial, s));

@@ -63,18 +63,20 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------- embedding gradients
-// de [rows, H] -> the dense f32 gradients of the three tables (what the reference's nn.Embedding produces, lxrt/modeling.py:264-292; rows with index 0 are
-// skipped: padding_idx = 0 on all three tables in LXMERT (pad0_all), on the word table only in UNITER, uniter/modeling.py:563-568).
-// Round 6: DETERMINISTIC - no float atomics.  Until round 5 every row was scatter-added with atomicAdd; the order in which the 256 [CLS] rows of a batch
-// met in table row 101 changed from run to run, the last bits of the sums with it, and BertAdam's normalised update amplified that over a few steps
-// (every "equal to one rank" / "equal to the serial step" test inherited the noise).  Now every table row is summed by ONE workgroup in an order that depends on
-// the batch alone:
-//   word table   one workgroup per packed row r; it goes on only if no earlier row holds the same word id (the id's FIRST occurrence).  Its four waves
-//                scan one contiguous quarter each of the rows r .. rows-1 for the same id (ballot; the matches of a wave are in row order), sum their
-//                de rows in that order (loads of eight rows in flight), and the four partial rows are folded in wave order: dword[id] (+)= sum.
-//   pos / type   few keys with many rows each (position t: one row per sample; token type: up to every row): partial sums per (key, chunk of 256 rows) - a wave per 64
-//                rows, folded in wave order - then one workgroup per key folds the chunks in chunk order.
-// (timings: profiles/r06_*kernel_stats*; the atomic kernel took 24 us at 3,140 packed rows, and 129 us when thousands of rows shared one id)
+// de [rows, H] -> the dense f32 gradients of the embedding tables (what the reference's nn.Embedding produces, lxrt/modeling.py:264-292; rows with index 0 are
+// skipped: padding_idx = 0 on all three tables in LXMERT (pad0_all), on the word table only in UNITER, uniter/modeling.py:563-568; BUTD: nn.Embedding(padding_idx =
+// ntoken), butd.py:36).
+// Round 6: DETERMINISTIC - no float atomics.  Until round 5 every row was scatter-added with atomicAdd; the order in which the 256 [CLS] rows of a batch met in
+// table row 101 changed from run to run, the last bits of the sums with it, and BertAdam's normalised update amplified that over a few steps (every "equal to one
+// rank" / "equal to the serial step" test inherited the noise).  Now every table row is summed in an order that depends on the batch alone:
+//   plan         one thread per packed row (the keys of all rows staged in LDS, scanned 16 bytes at a time): is this the FIRST row that names its word, and how many
+//                rows name it?  Words named by more than HOT_MIN rows ([CLS], [SEP], '?': one row per sample) go on a short hot list.
+//   word table   one workgroup per first-occurrence row: a word that occurs once is copied into its table row; a word of <= HOT_MIN rows is summed by one wave in
+//                row order.
+//   keyed sums   few keys with many rows each - position t (one row per sample), token type, the hot words: partial sums per (key, chunk of 256 rows), a wave per
+//                64 rows folded in wave order, then one workgroup per key folds the chunks in chunk order into the table row.
+#define EMB_HOT_MIN 8
+#define EMB_HOT_MAX 64
 __global__ void embed_keys_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const int* __restrict__ row_src, int rows, int Tn,
                                   int* __restrict__ kw, int* __restrict__ kp, int* __restrict__ kt) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,6 +85,36 @@ __global__ void embed_keys_kernel(const int64_t* __restrict__ ids, const int64_t
     kw[r] = (int)ids[src];
     kp[r] = src % Tn;
     kt[r] = seg ? (int)seg[src] : 0;
+}
+__global__ void embed_keys_i64_kernel(const int64_t* __restrict__ ids, int rows, int* __restrict__ keys) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) keys[r] = (int)ids[r];
+}
+
+// plan[r] = number of rows that name row r's word if r is the word's first row, the word is not pad_key and is not hot; else 0.  hot[0] (zeroed by the launcher)
+// counts the hot words, hot[1 + slot] = first row of one (slots are handed out in arrival order: which slot a word gets changes nothing in its sum).
+__global__ __launch_bounds__(256) void embed_word_plan_kernel(const int* __restrict__ kw, int rows, int rows4, int pad_key, int* __restrict__ plan, int* __restrict__ hot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
+    int* kl = reinterpret_cast<int*>(emb_lds);
+    for (int j = threadIdx.x; j < rows4; j += 256) reinterpret_cast<int4*>(kl)[j] = reinterpret_cast<const int4*>(kw)[j];      // (the key array is padded to whole int4s)
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const int key = kl[r];
+    int before = 0, cnt = 0;
+    for (int j4 = 0; j4 < rows4; ++j4) {                        // every lane reads the same 16 bytes: an LDS broadcast
+        const int4 v = reinterpret_cast<const int4*>(kl)[j4];
+        const int j = j4 * 4;
+        const int m0 = v.x == key, m1 = v.y == key, m2 = v.z == key, m3 = v.w == key;
+        before |= (m0 & (j < r)) | (m1 & (j + 1 < r)) | (m2 & (j + 2 < r)) | (m3 & (j + 3 < r));
+        cnt += (m0 & (j >= r) & (j < rows)) + (m1 & (j + 1 >= r) & (j + 1 < rows)) + (m2 & (j + 2 >= r) & (j + 2 < rows)) + (m3 & (j + 3 >= r) & (j + 3 < rows));
+    }
+    int n = (before || key == pad_key) ? 0 : cnt;
+    if (n > EMB_HOT_MIN) {
+        const int slot = atomicAdd(hot, 1);                     // (an integer counter: which slot is immaterial)
+        if (slot < EMB_HOT_MAX) { hot[1 + slot] = r; n = 0; }   // summed by the keyed partial / fold launches
+    }
+    plan[r] = n;
 }
 
 // the de rows lst[0 .. cnt) (offsets from row0) added in list order to acc, eight rows' loads in flight; one wave, lane = 4-column groups lane + 64 i
@@ -135,49 +167,63 @@ __device__ __forceinline__ void embed_fold_waves(float* fold, int H, int wave, i
     }
 }
 
-// plan[r] = number of rows that name row r's key if r is the key's FIRST occurrence (and the key is not pad_key), else 0.  One thread per row; the keys
-// of ALL rows are staged in LDS by every workgroup (16-byte loads, all in flight) and scanned as broadcasts: 3,140 LDS reads per thread, ~6 us.
-__global__ __launch_bounds__(256) void embed_word_plan_kernel(const int* __restrict__ kw, int rows, int rows4, int pad_key, int* __restrict__ plan) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
-    int* kl = reinterpret_cast<int*>(emb_lds);
-    for (int j = threadIdx.x; j < rows4; j += 256) reinterpret_cast<int4*>(kl)[j] = reinterpret_cast<const int4*>(kw)[j];      // (the key array is padded to whole int4s)
-    __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const int key = kl[r];
-    int before = 0, cnt = 0;
-    for (int j = 0; j < r; ++j) before |= (kl[j] == key);
-    for (int j = r; j < rows; ++j) cnt += (kl[j] == key);
-    plan[r] = (before || key == pad_key) ? 0 : cnt;
+template <int NV>
+__device__ __forceinline__ void embed_store_row(float* dst, int H, int lane, int accumulate, float (&acc)[NV][4]) {
+    const int nv = H >> 2;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            if (accumulate) { float t[4]; load4(dst + c * 4, t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += t[j]; }
+            store4(dst + c * 4, acc[i]);
+        }
+    }
 }
 
-// One workgroup per packed row r with plan[r] > 0.  plan[r] == 1 (the usual case: a word that occurs once in the batch): the row is copied (added) into its table
-// row by wave 0.  Otherwise (a word many questions share - [CLS], [SEP], '?'): the four waves scan one contiguous quarter each of the rows r .. rows-1 for the key
-// (ballot: a wave's matches come out in row order), sum their rows in that order, RPG rows' loads in flight, and the four partial rows are folded in wave order.
+// One workgroup per packed row r with plan[r] > 0 (the others leave at once).  n == 1: the row is copied (added) into its table row.  n <= HOT_MIN: wave 0 collects the
+// word's rows r .. in row order (256 keys per trip) and sums them.  n > HOT_MIN (the hot list was full): four waves, a contiguous quarter of r .. rows-1 each, partial
+// rows folded in wave order.
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void embed_word_grad_kernel(const T* __restrict__ de, int ldde, const int* __restrict__ kw, const int* __restrict__ plan, float* __restrict__ dword,
                                                               int rows, int H, int q_cap, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = plan[r];
-    if (n == 0) return;                                         // padding_idx, or an earlier row owns this id
+    if (n == 0) return;
     const int nv = H >> 2;
     const int key = kw[r];
     float* dst = dword + (size_t)key * H;
     float acc[NV][4];
-    if (n == 1) {
+    if (n <= EMB_HOT_MIN) {
         if (wave != 0) return;
+        if (n == 1) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
-                load4(de + (size_t)r * ldde + c * 4, acc[i]);
-                if (accumulate) { float t[4]; load4(dst + c * 4, t);
+            for (int i = 0; i < NV; ++i) { const int c = lane + 64 * i; if (c < nv) load4(de + (size_t)r * ldde + c * 4, acc[i]); }
+            embed_store_row<NV>(dst, H, lane, accumulate, acc);
+            return;
+        }
+        unsigned short* lst = reinterpret_cast<unsigned short*>(emb_lds);            // <= HOT_MIN entries, offsets from row r... in 16 bits: rows <= 65535 (launcher)
+        int cnt = 0;
+        for (int base = r; base < rows && cnt < n; base += 256) {
+            int kk[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] += t[j]; }
-                store4(dst + c * 4, acc[i]);
+            for (int u = 0; u < 4; ++u) { const int j = base + u * 64 + lane; kk[u] = j < rows ? kw[j] : key - 1; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool m = kk[u] == key;
+                const unsigned long long mask = __ballot(m);
+                if (m) lst[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(base + u * 64 + lane - r);
+                cnt += __popcll(mask);
             }
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS writes have landed before other lanes read them
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+        embed_sum_rows<T, NV>(de, ldde, H, r, lst, cnt, lane, acc);
+        embed_store_row<NV>(dst, H, lane, accumulate, acc);
         return;
     }
     float* fold = reinterpret_cast<float*>(emb_lds);                                      // [3][H]
@@ -186,7 +232,7 @@ __global__ __launch_bounds__(256) void embed_word_grad_kernel(const T* __restric
     const int lo = r + wave * q, hi = (lo + q < rows) ? lo + q : rows;
     unsigned short* lst = lists + (size_t)wave * q_cap;
     int cnt = 0;
-    for (int base = lo; base < hi; base += 256) {               // four 64-key groups per trip: their loads are in flight together
+    for (int base = lo; base < hi; base += 256) {
         int kk[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int j = base + u * 64 + lane; kk[u] = j < hi ? kw[j] : key - 1; }
@@ -203,32 +249,26 @@ __global__ __launch_bounds__(256) void embed_word_grad_kernel(const T* __restric
     for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
     if (lo < hi) embed_sum_rows<T, NV>(de, ldde, H, lo, lst, cnt, lane, acc);
     embed_fold_waves<NV>(fold, H, wave, lane, acc);
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
-                if (accumulate) { float t[4]; load4(dst + c * 4, t);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] += t[j]; }
-                store4(dst + c * 4, acc[i]);
-            }
-        }
-    }
+    if (wave == 0) embed_store_row<NV>(dst, H, lane, accumulate, acc);
 }
 
-// partial[(ky * nchunk + chunk)][H] = sum of the de rows of this 256-row chunk whose key is ky (ky < Tn: position ky; else token type ky - Tn)
+// partial[(ky * nchunk + chunk)][H] = sum of the de rows of this 256-row chunk whose key is ky: ky < np: position ky; < np + nt: token type ky - np; else hot word
+// number ky - np - nt (the word of row hot[1 + that])
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void embed_small_partial_kernel(const T* __restrict__ de, const int* __restrict__ kp, const int* __restrict__ kt, float* __restrict__ partial,
-                                                                  int rows, int Tn, int H, int pad0_all) {
+__global__ __launch_bounds__(256) void embed_partial_kernel(const T* __restrict__ de, int ldde, const int* __restrict__ kw, const int* __restrict__ kp, const int* __restrict__ kt,
+                                                            const int* __restrict__ hot, float* __restrict__ partial, int rows, int np, int nt, int H, int pad0_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
     float* fold = reinterpret_cast<float*>(emb_lds);
     unsigned short* lists = reinterpret_cast<unsigned short*>(emb_lds + (size_t)3 * H * 4);   // [4][64]
     const int chunk = blockIdx.x, ky = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool is_pos = ky < Tn;
-    const int k = is_pos ? ky : ky - Tn;
-    if (k == 0 && pad0_all) return;                             // never folded either
-    const int* keys = is_pos ? kp : kt;
+    const int* keys; int k;
+    if (ky < np) { keys = kp; k = ky; if (k == 0 && pad0_all) return; }
+    else if (ky < np + nt) { keys = kt; k = ky - np; if (k == 0 && pad0_all) return; }
+    else {
+        const int h = ky - np - nt, nh = hot[0] < EMB_HOT_MAX ? hot[0] : EMB_HOT_MAX;
+        if (h >= nh) return;                                    // block-uniform
+        keys = kw; k = kw[hot[1 + h]];
+    }
     const int lo = chunk * 256 + wave * 64, j = lo + lane;
     const bool m = j < rows && keys[j] == k;
     const unsigned long long mask = __ballot(m);
@@ -239,7 +279,7 @@ __global__ __launch_bounds__(256) void embed_small_partial_kernel(const T* __res
     float acc[NV][4];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
-    if (cnt) embed_sum_rows<T, NV>(de, H, H, lo, lst, cnt, lane, acc);
+    if (cnt) embed_sum_rows<T, NV>(de, ldde, H, lo, lst, cnt, lane, acc);
     embed_fold_waves<NV>(fold, H, wave, lane, acc);
     if (wave == 0) {
         const int nv = H >> 2;
@@ -249,13 +289,17 @@ __global__ __launch_bounds__(256) void embed_small_partial_kernel(const T* __res
     }
 }
 
-__global__ __launch_bounds__(256) void embed_small_fold_kernel(const float* __restrict__ partial, int nchunk, float* __restrict__ dpos, float* __restrict__ dtype, int Tn, int H,
-                                                               int pad0_all, int accumulate) {
+__global__ __launch_bounds__(256) void embed_fold_kernel(const float* __restrict__ partial, int nchunk, const int* __restrict__ kw, const int* __restrict__ hot, float* __restrict__ dword,
+                                                         float* __restrict__ dpos, float* __restrict__ dtype, int np, int nt, int H, int pad0_all, int accumulate) {
     const int ky = blockIdx.x;
-    const bool is_pos = ky < Tn;
-    const int k = is_pos ? ky : ky - Tn;
-    if (k == 0 && pad0_all) return;
-    float* dst = (is_pos ? dpos : dtype) + (size_t)k * H;
+    float* dst;
+    if (ky < np) { if (ky == 0 && pad0_all) return; dst = dpos + (size_t)ky * H; }
+    else if (ky < np + nt) { if (ky == np && pad0_all) return; dst = dtype + (size_t)(ky - np) * H; }
+    else {
+        const int h = ky - np - nt, nh = hot[0] < EMB_HOT_MAX ? hot[0] : EMB_HOT_MAX;
+        if (h >= nh) return;
+        dst = dword + (size_t)kw[hot[1 + h]] * H;
+    }
     for (int n = threadIdx.x; n < H; n += 256) {
         float s = 0.f;
         for (int c0 = 0; c0 < nchunk; c0 += 8) {             // eight chunk partials in flight, added in chunk order
@@ -288,36 +332,43 @@ int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, cons
     return RGQA_OK;
 }
 
-// One table: dtable[key[r]] (+)= sum of the de rows that name it (rows of key pad_key: none).  keys: rows ints (device; readable up to the next multiple of
-// 4), plan: rows ints of scratch.  de row pitch ldde, table rows of H floats.
+// The tables' gradients from the keys of the rows.  kw: word key per row (16-byte aligned, readable up to the next multiple of 4 ints); kp / kt: position / token-type key
+// per row, or both null (a lone word table: BUTD).  iscratch: rows + 4 + 128 ints; fscratch: (np + nt + EMB_HOT_MAX) * ceil(rows / 256) * H floats.
+// accumulate = 0: the tables were zeroed by the caller (rows no token names keep the zeros); 1: the sums are added to what the tables hold.
 template <typename T>
-int k_embed_word_grad(const T* de, int ldde, const int* keys, int* plan, int rows, float* dtable, int H, int pad_key, int accumulate, hipStream_t s) {
+int k_embed_table_grads(const T* de, int ldde, const int* kw, const int* kp, const int* kt, int rows, float* dword, float* dpos, float* dtype, int H, int np, int nt,
+                        int pad_key, int pad0_all, int accumulate, int* iscratch, float* fscratch, size_t fscratch_floats, hipStream_t s) {
     if (rows <= 0) return RGQA_OK;
-    RGQA_REQUIRE(H % 4 == 0 && H <= 2048 && ldde % 4 == 0 && ldde >= H, "embed word grad: hidden %d / pitch %d unsupported", H, ldde);
-    RGQA_REQUIRE(keys != nullptr && plan != nullptr && ((uintptr_t)keys % 16) == 0, "embed word grad: null or misaligned key / plan scratch");
-    const int q_cap = (rows + 3) / 4 + 1;
-    RGQA_REQUIRE(q_cap <= 65536 && rows <= 36864, "embed word grad: %d rows exceed the 16-bit row lists / the 144-KiB key image", rows);
+    if (kp == nullptr || kt == nullptr) { np = 0; nt = 0; }
+    RGQA_REQUIRE(H % 4 == 0 && H <= 2048 && ldde % 4 == 0 && ldde >= H, "embedding gradients: hidden %d / pitch %d unsupported", H, ldde);
+    RGQA_REQUIRE(kw != nullptr && iscratch != nullptr && fscratch != nullptr && ((uintptr_t)kw % 16) == 0, "embedding gradients: null or misaligned scratch");
+    RGQA_REQUIRE(rows <= 36864, "embedding gradients: %d rows exceed the 144-KiB key image", rows);
+    const int nchunk = cdiv(rows, 256), nkeys = np + nt + EMB_HOT_MAX;
+    RGQA_REQUIRE((size_t)nkeys * nchunk * H <= fscratch_floats, "embedding gradients: scratch too small (%zu floats for %d keys x %d chunks x %d)", fscratch_floats, nkeys, nchunk, H);
+    const size_t rp = ((size_t)rows + 3) & ~(size_t)3;
+    int *plan = iscratch, *hot = iscratch + rp;
+    RGQA_HIP(hipMemsetAsync(hot, 0, sizeof(int), s));
     const int rows4 = (rows + 3) / 4;
     const size_t lds_plan = (size_t)rows4 * 16;
     if (lds_plan > 64 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_word_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plan));
-    hipLaunchKernelGGL(embed_word_plan_kernel, dim3(cdiv(rows, 256)), dim3(256), lds_plan, s, keys, rows, rows4, pad_key, plan);
+    hipLaunchKernelGGL(embed_word_plan_kernel, dim3(cdiv(rows, 256)), dim3(256), lds_plan, s, kw, rows, rows4, pad_key, plan, hot);
     RGQA_LAUNCH_CHECK("embed_word_plan_kernel");
-    const size_t lds_w = (size_t)3 * H * 4 + (size_t)4 * q_cap * 2;
-    RGQA_REQUIRE(lds_w <= 160 * 1024, "embed word grad: %d rows need %zu bytes of LDS", rows, lds_w);
+    const int q_cap = (rows + 3) / 4 + 1;
+    const size_t lds_w = (size_t)3 * H * 4 + (size_t)4 * q_cap * 2, lds_p = (size_t)3 * H * 4 + 4 * 64 * 2;
+    RGQA_REQUIRE(lds_w <= 160 * 1024, "embedding gradients: %d rows need %zu bytes of LDS", rows, lds_w);
     const int nvl = cdiv(H / 4, 64);
 #define EMBW(NVV) do { \
         if (lds_w > 64 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_word_grad_kernel<T, NVV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); \
-        hipLaunchKernelGGL((embed_word_grad_kernel<T, NVV>), dim3(rows), dim3(256), lds_w, s, de, ldde, keys, plan, dtable, rows, H, q_cap, accumulate); } while (0)
+        hipLaunchKernelGGL((embed_word_grad_kernel<T, NVV>), dim3(rows), dim3(256), lds_w, s, de, ldde, kw, plan, dword, rows, H, q_cap, accumulate); \
+        hipLaunchKernelGGL((embed_partial_kernel<T, NVV>), dim3(nchunk, nkeys), dim3(256), lds_p, s, de, ldde, kw, kp, kt, hot, fscratch, rows, np, nt, H, pad0_all); } while (0)
     if (nvl <= 1) EMBW(1); else if (nvl == 2) EMBW(2); else if (nvl == 3) EMBW(3); else if (nvl == 4) EMBW(4); else EMBW(8);
 #undef EMBW
-    RGQA_LAUNCH_CHECK("embed_word_grad_kernel");
+    RGQA_LAUNCH_CHECK("embed_word_grad_kernel / embed_partial_kernel");
+    hipLaunchKernelGGL(embed_fold_kernel, dim3(nkeys), dim3(256), 0, s, fscratch, nchunk, kw, hot, dword, dpos, dtype, np, nt, H, pad0_all, accumulate);
+    RGQA_LAUNCH_CHECK("embed_fold_kernel");
     return RGQA_OK;
 }
 
-__global__ void embed_keys_i64_kernel(const int64_t* __restrict__ ids, int rows, int* __restrict__ keys) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < rows) keys[r] = (int)ids[r];
-}
 int k_embed_keys(const int64_t* ids, int rows, int* keys, hipStream_t s) {
     if (rows <= 0) return RGQA_OK;
     hipLaunchKernelGGL(embed_keys_i64_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, ids, rows, keys);
@@ -325,31 +376,18 @@ int k_embed_keys(const int64_t* ids, int rows, int* keys, hipStream_t s) {
     return RGQA_OK;
 }
 
-// keys: 4 * (rows + 3) ints of scratch, 16-byte aligned; scratch: f32 scratch for the position / token-type partial sums ((Tn + type_vocab) * ceil(rows / 256) * H floats).
-// accumulate = 0: the tables were zeroed by the caller (rows no token names keep the zeros); 1: the sums are added to what the tables hold.
+// LXMERT / UNITER: keys: 4 * (rows + 4) + 128 ints of scratch, 16-byte aligned; scratch: (Tn + type_vocab + 64) * ceil(rows / 256) * H floats
 template <typename T>
 int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, int type_vocab,
                     int pad0_all, int accumulate, int* keys, float* scratch, size_t scratch_floats, hipStream_t s) {
     RGQA_REQUIRE(rows <= B * Tn, "embed scatter: %d rows exceed B*T = %d", rows, B * Tn);
     if (rows <= 0) return RGQA_OK;
-    const int nchunk = cdiv(rows, 256), nkeys = Tn + type_vocab;
-    RGQA_REQUIRE(H % 4 == 0 && H <= 2048, "embed scatter: hidden %d unsupported", H);
-    RGQA_REQUIRE(keys != nullptr && scratch != nullptr && (size_t)nkeys * nchunk * H <= scratch_floats, "embed scatter: scratch too small (%zu floats for %d keys x %d chunks x %d)",
-                 scratch_floats, nkeys, nchunk, H);
-    const size_t lds_p = (size_t)3 * H * 4 + 4 * 64 * 2;
+    RGQA_REQUIRE(keys != nullptr, "embed scatter: null key scratch");
     const size_t rp = ((size_t)rows + 3) & ~(size_t)3;           // every array padded to whole int4s (the plan kernel stages the keys 16 bytes at a time)
-    int *kw = keys, *kp = keys + rp, *kt = keys + 2 * rp, *plan = keys + 3 * rp;
+    int *kw = keys, *kp = keys + rp, *kt = keys + 2 * rp, *isc = keys + 3 * rp;
     hipLaunchKernelGGL(embed_keys_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, ids, seg, row_src, rows, Tn, kw, kp, kt);
     RGQA_LAUNCH_CHECK("embed_keys_kernel");
-    if (int r = k_embed_word_grad<T>(de, H, kw, plan, rows, dword, H, 0, accumulate, s)) return r;
-    const int nvl = cdiv(H / 4, 64);
-#define EMBP(NVV) hipLaunchKernelGGL((embed_small_partial_kernel<T, NVV>), dim3(nchunk, nkeys), dim3(256), lds_p, s, de, kp, kt, scratch, rows, Tn, H, pad0_all)
-    if (nvl <= 1) EMBP(1); else if (nvl == 2) EMBP(2); else if (nvl == 3) EMBP(3); else if (nvl == 4) EMBP(4); else EMBP(8);
-#undef EMBP
-    RGQA_LAUNCH_CHECK("embed_small_partial_kernel");
-    hipLaunchKernelGGL(embed_small_fold_kernel, dim3(nkeys), dim3(256), 0, s, scratch, nchunk, dpos, dtype, Tn, H, pad0_all, accumulate);
-    RGQA_LAUNCH_CHECK("embed_small_fold_kernel");
-    return RGQA_OK;
+    return k_embed_table_grads<T>(de, H, kw, kp, kt, rows, dword, dpos, dtype, H, Tn, type_vocab, 0, pad0_all, accumulate, isc, scratch, scratch_floats, s);
 }
 
 int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s) {
@@ -365,6 +403,6 @@ template int k_embed_fwd<sf32>(const int64_t*, const int64_t*, const int*, const
 template int k_embed_scatter<sf32>(const sf32*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
 template int k_embed_scatter<float>(const float*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
 template int k_embed_scatter<bf16_t>(const bf16_t*, const int64_t*, const int64_t*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
-template int k_embed_word_grad<sf32>(const sf32*, int, const int*, int*, int, float*, int, int, int, hipStream_t);
-template int k_embed_word_grad<float>(const float*, int, const int*, int*, int, float*, int, int, int, hipStream_t);
-template int k_embed_word_grad<bf16_t>(const bf16_t*, int, const int*, int*, int, float*, int, int, int, hipStream_t);
+template int k_embed_table_grads<sf32>(const sf32*, int, const int*, const int*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
+template int k_embed_table_grads<float>(const float*, int, const int*, const int*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);
+template int k_embed_table_grads<bf16_t>(const bf16_t*, int, const int*, const int*, const int*, int, float*, float*, float*, int, int, int, int, int, int, int*, float*, size_t, hipStream_t);

@@ -513,7 +513,7 @@ public:
         ws_used = 0;
         stages.clear();
         maskf = take<float>(RlC);
-        lens_dev = take<int>(B); cu_dev = take<int>(B + 1); row_src_dev = take<int>(RlC); emb_keys = take<int>(4 * ((size_t)RlC + 4)); cls_rows = take<T>((size_t)B * H); tail_x = take<T>((size_t)B * H); tail_dx = take<TB>((size_t)B * H);
+        lens_dev = take<int>(B); cu_dev = take<int>(B + 1); row_src_dev = take<int>(RlC); emb_keys = take<int>(4 * ((size_t)RlC + 4) + 128); cls_rows = take<T>((size_t)B * H); tail_x = take<T>((size_t)B * H); tail_dx = take<TB>((size_t)B * H);
         emb_out = take<T>((size_t)RC * H); emb_z = take<T>((size_t)RlC * H); emb_mean = take<float>(RlC); emb_rstd = take<float>(RlC);
         zf = take<T>((size_t)Rv * H); visn_stats = take<float>((size_t)Rv * 4);
         feats_lp = LP ? take<T>((size_t)Rv * cfg.feat_dim) : nullptr;   // bf16 copy of the RoI features: read by visn_fc forward AND its wgrad

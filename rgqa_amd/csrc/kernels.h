@@ -91,10 +91,11 @@ int k_embed_fwd(const int64_t* ids, const int64_t* seg, const int* row_src, cons
 template <typename T>
 int k_embed_scatter(const T* de, const int64_t* ids, const int64_t* seg, const int* row_src, int rows, float* dword, float* dpos, float* dtype, int B, int Tn, int H, int type_vocab,
                     int pad0_all, int accumulate, int* keys, float* scratch, size_t scratch_floats, hipStream_t s);
-// one embedding table's dense gradient without float atomics: dtable[keys[r]] (+)= sum over the rows r that name the key, in a fixed order (embed.hip)
+// the embedding tables' dense gradients without float atomics: every table row summed in an order the batch alone fixes (embed.hip).  kw / kp / kt: word / position /
+// token-type key per row (kp, kt null: a lone word table); iscratch: rows + 132 ints; fscratch: (np + nt + 64) * ceil(rows / 256) * H floats
 template <typename T>
-int k_embed_word_grad(const T* de, int ldde, const int* keys /* rows ints, 16-byte aligned, readable up to the next multiple of 4 */, int* plan /* rows ints of scratch */, int rows,
-                      float* dtable, int H, int pad_key, int accumulate, hipStream_t s);
+int k_embed_table_grads(const T* de, int ldde, const int* kw, const int* kp, const int* kt, int rows, float* dword, float* dpos, float* dtype, int H, int np, int nt,
+                        int pad_key, int pad0_all, int accumulate, int* iscratch, float* fscratch, size_t fscratch_floats, hipStream_t s);
 int k_embed_keys(const int64_t* ids, int rows, int* keys, hipStream_t s);
 // additive key mask (1 - m) * -10000 from the 0/1 int64 attention mask (modeling.py:857-865)
 int k_make_mask(const int64_t* input_mask, float* out, int n, hipStream_t s);
