@@ -93,22 +93,34 @@ __global__ void embed_keys_i64_kernel(const int64_t* __restrict__ ids, int rows,
 
 // plan[r] = number of rows that name row r's word if r is the word's first row, the word is not pad_key and is not hot; else 0.  hot[0] (zeroed by the launcher)
 // counts the hot words, hot[1 + slot] = first row of one (slots are handed out in arrival order: which slot a word gets changes nothing in its sum).
+// One WAVE per row: 64 lanes x 4 keys per trip straight from the key array (L2-resident, four trips' loads in flight), lane-local counts folded at the end.
+// (First forms: one workgroup staging all keys in LDS per row - 68 us, bound by the [CLS] / [SEP] rows' 256-row sums; one thread per row scanning LDS - 88-112 us.)
 __global__ __launch_bounds__(256) void embed_word_plan_kernel(const int* __restrict__ kw, int rows, int rows4, int pad_key, int* __restrict__ plan, int* __restrict__ hot) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char emb_lds[];
-    int* kl = reinterpret_cast<int*>(emb_lds);
-    for (int j = threadIdx.x; j < rows4; j += 256) reinterpret_cast<int4*>(kl)[j] = reinterpret_cast<const int4*>(kw)[j];      // (the key array is padded to whole int4s)
-    __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const int key = kl[r];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;                                      // wave-uniform
+    const int key = kw[r];
     int before = 0, cnt = 0;
-    for (int j4 = 0; j4 < rows4; ++j4) {                        // every lane reads the same 16 bytes: an LDS broadcast
-        const int4 v = reinterpret_cast<const int4*>(kl)[j4];
-        const int j = j4 * 4;
-        const int m0 = v.x == key, m1 = v.y == key, m2 = v.z == key, m3 = v.w == key;
-        before |= (m0 & (j < r)) | (m1 & (j + 1 < r)) | (m2 & (j + 2 < r)) | (m3 & (j + 3 < r));
-        cnt += (m0 & (j >= r) & (j < rows)) + (m1 & (j + 1 >= r) & (j + 1 < rows)) + (m2 & (j + 2 >= r) & (j + 2 < rows)) + (m3 & (j + 3 >= r) & (j + 3 < rows));
+    const int4* k4 = reinterpret_cast<const int4*>(kw);         // (the key array is padded to whole int4s)
+    for (int base = 0; base < rows4; base += 256) {             // 4 x 64 int4 per trip
+        int4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i4 = base + u * 64 + lane; v[u] = i4 < rows4 ? k4[i4] : make_int4(key - 1, key - 1, key - 1, key - 1); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = (base + u * 64 + lane) * 4;
+            const int e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = (e[t] == key) & (j + t < rows);
+                before |= m & (j + t < r);
+                cnt += m & (j + t >= r);
+            }
+        }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); before |= __shfl_xor(before, o, 64); }
+    if (lane != 0) return;
     int n = (before || key == pad_key) ? 0 : cnt;
     if (n > EMB_HOT_MIN) {
         const int slot = atomicAdd(hot, 1);                     // (an integer counter: which slot is immaterial)
@@ -342,16 +354,14 @@ int k_embed_table_grads(const T* de, int ldde, const int* kw, const int* kp, con
     if (kp == nullptr || kt == nullptr) { np = 0; nt = 0; }
     RGQA_REQUIRE(H % 4 == 0 && H <= 2048 && ldde % 4 == 0 && ldde >= H, "embedding gradients: hidden %d / pitch %d unsupported", H, ldde);
     RGQA_REQUIRE(kw != nullptr && iscratch != nullptr && fscratch != nullptr && ((uintptr_t)kw % 16) == 0, "embedding gradients: null or misaligned scratch");
-    RGQA_REQUIRE(rows <= 36864, "embedding gradients: %d rows exceed the 144-KiB key image", rows);
+    RGQA_REQUIRE(rows <= 65535, "embedding gradients: %d rows exceed the 16-bit row lists", rows);
     const int nchunk = cdiv(rows, 256), nkeys = np + nt + EMB_HOT_MAX;
     RGQA_REQUIRE((size_t)nkeys * nchunk * H <= fscratch_floats, "embedding gradients: scratch too small (%zu floats for %d keys x %d chunks x %d)", fscratch_floats, nkeys, nchunk, H);
     const size_t rp = ((size_t)rows + 3) & ~(size_t)3;
     int *plan = iscratch, *hot = iscratch + rp;
     RGQA_HIP(hipMemsetAsync(hot, 0, sizeof(int), s));
     const int rows4 = (rows + 3) / 4;
-    const size_t lds_plan = (size_t)rows4 * 16;
-    if (lds_plan > 64 * 1024) RGQA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_word_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plan));
-    hipLaunchKernelGGL(embed_word_plan_kernel, dim3(cdiv(rows, 256)), dim3(256), lds_plan, s, kw, rows, rows4, pad_key, plan, hot);
+    hipLaunchKernelGGL(embed_word_plan_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, kw, rows, rows4, pad_key, plan, hot);
     RGQA_LAUNCH_CHECK("embed_word_plan_kernel");
     const int q_cap = (rows + 3) / 4 + 1;
     const size_t lds_w = (size_t)3 * H * 4 + (size_t)4 * q_cap * 2, lds_p = (size_t)3 * H * 4 + 4 * 64 * 2;
