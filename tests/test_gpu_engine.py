@@ -168,6 +168,45 @@ def test_medium_config_vs_oracle(precision, tol, gtol):
     _report("medium config %s vs oracle" % precision, logits_max=lerr, worst_tensor_rel=gworst)
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_embedding_gradients_with_many_repeated_words(packed):
+    """The deterministic embedding backward (csrc/embed.hip, round 6) on a batch built to take every one of its paths: 90 distinct words over 64 x 16 tokens, so that
+    more than 64 words are named by more than 8 rows (the hot list overflows: the four-wave path of embed_word_grad_kernel), others by 2..8 rows (the one-wave
+    path), a few once (the copy path), [CLS] / [SEP] by every sample (the keyed partial sums), and token-type 1 rows.  f32 engine against the oracle, every
+    embedding table; two passes must agree bit for bit."""
+    B, T, O = 64, 16, 10
+    b = synth.synth_batch(B, T, O=O, F=MED["feat_dim"], NA=MED["num_answers"], vocab=MED["vocab_size"], seed=77, min_len=6)
+    rng = np.random.RandomState(3)
+    ids = b["input_ids"]
+    for r in range(B):
+        L = int(b["lengths"][r])
+        ids[r, 1:L - 1] = 110 + rng.randint(0, 88, size=L - 2)        # 88 frequent words ...
+    ids[0, 1], ids[1, 1], ids[2, 1] = 300, 301, 302                       # ... three that occur once
+    ids[3, 2] = ids[4, 2] = ids[5, 2] = 303                               # ... one that occurs three times
+    b["segment_ids"][:, 3] = 1
+    b["segment_ids"] = b["segment_ids"] * (ids != 0)
+    lg_r, pl_r, loss_r, Pr = oracle_run(MED, b)
+    e = make_engine(MED, "f32")
+    d = dev(b)
+    e.ensure_shape(B, T, O)
+    e.sync_weights()
+    lens = np.ascontiguousarray(b["lengths"], dtype=np.int32) if packed else None
+    outs = []
+    for _ in range(2):
+        e.forward(d["feats"], d["boxes"], d["input_ids"], d["input_mask"], d["segment_ids"], lengths=lens)
+        e.loss_backward(d["target"])
+        outs.append(e.grads.clone())
+    assert torch.equal(outs[0], outs[1])
+    counts = np.bincount(ids[ids != 0].reshape(-1))
+    assert (counts > 8).sum() > 64 and (counts == 1).sum() >= 3 and counts[101] == B
+    for sp in e.specs:
+        if "embeddings" in sp.name and "LayerNorm" not in sp.name:
+            got, ref = e.view(e.grads, sp).cpu(), Pr[sp.name].grad
+            rel = float((got - ref).norm()) / max(1e-12, float(ref.norm()))
+            assert rel < 2e-3, (sp.name, rel)
+            assert float(got[0].abs().max()) == 0.0, sp.name             # padding_idx = 0 on all three tables
+
+
 def _report(tag, **kv):
     """observed errors go to stdout (pytest -s) and to gpurun_out/parity_observed.txt: every bf16 tolerance below is <= 2x what is printed"""
     line = tag + ": " + ", ".join("%s %.3e" % (k, v) for k, v in kv.items())
