@@ -174,7 +174,7 @@ def test_embedding_gradients_with_many_repeated_words(packed):
     more than 64 words are named by more than 8 rows (the hot list overflows: the four-wave path of embed_word_grad_kernel), others by 2..8 rows (the one-wave
     path), a few once (the copy path), [CLS] / [SEP] by every sample (the keyed partial sums), and token-type 1 rows.  f32 engine against the oracle, every
     embedding table; two passes must agree bit for bit."""
-    B, T, O = 64, 16, 10
+    B, T, O = 160, 16, 10
     b = synth.synth_batch(B, T, O=O, F=MED["feat_dim"], NA=MED["num_answers"], vocab=MED["vocab_size"], seed=77, min_len=6)
     rng = np.random.RandomState(3)
     ids = b["input_ids"]
