@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 // table row 101 changed from run to run, the last bits of the sums with it, and BertAdam's normalised update amplified that over a few steps (every "equal to one
 // rank" / "equal to the serial step" test inherited the noise).  Now every table row is summed in an order that depends on the batch alone:
 //   plan         one thread per packed row (the keys of all rows staged in LDS, scanned 16 bytes at a time): is this the FIRST row that names its word, and how many
-//                rows name it?  Words named by more than HOT_MIN rows ([CLS], [SEP], '?': one row per sample) go on a short hot list.
+//                rows name it?  Words named by more than HOT_MIN rows ([CLS], [SEP], '?': one row per sample) go on a short hot list, filled in row order by a one-workgroup launch.
 //   word table   one workgroup per first-occurrence row: a word that occurs once is copied into its table row; a word of <= HOT_MIN rows is summed by one wave in
 //                row order.
 //   keyed sums   few keys with many rows each - position t (one row per sample), token type, the hot words: partial sums per (key, chunk of 256 rows), a wave per
@@ -91,11 +91,10 @@ __global__ void embed_keys_i64_kernel(const int64_t* __restrict__ ids, int rows,
     if (r < rows) keys[r] = (int)ids[r];
 }
 
-// plan[r] = number of rows that name row r's word if r is the word's first row, the word is not pad_key and is not hot; else 0.  hot[0] (zeroed by the launcher)
-// counts the hot words, hot[1 + slot] = first row of one (slots are handed out in arrival order: which slot a word gets changes nothing in its sum).
+// plan[r] = number of rows that name row r's word if r is the word's first row and the word is not pad_key; else 0.
 // One WAVE per row: 64 lanes x 4 keys per trip straight from the key array (L2-resident, four trips' loads in flight), lane-local counts folded at the end.
 // (First forms: one workgroup staging all keys in LDS per row - 68 us, bound by the [CLS] / [SEP] rows' 256-row sums; one thread per row scanning LDS - 88-112 us.)
-__global__ __launch_bounds__(256) void embed_word_plan_kernel(const int* __restrict__ kw, int rows, int rows4, int pad_key, int* __restrict__ plan, int* __restrict__ hot) {
+__global__ __launch_bounds__(256) void embed_word_plan_kernel(const int* __restrict__ kw, int rows, int rows4, int pad_key, int* __restrict__ plan) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;                                      // wave-uniform
@@ -121,12 +120,28 @@ __global__ __launch_bounds__(256) void embed_word_plan_kernel(const int* __restr
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); before |= __shfl_xor(before, o, 64); }
     if (lane != 0) return;
-    int n = (before || key == pad_key) ? 0 : cnt;
-    if (n > EMB_HOT_MIN) {
-        const int slot = atomicAdd(hot, 1);                     // (an integer counter: which slot is immaterial)
-        if (slot < EMB_HOT_MAX) { hot[1 + slot] = r; n = 0; }   // summed by the keyed partial / fold launches
-    }
-    plan[r] = n;
+    plan[r] = (before || key == pad_key) ? 0 : cnt;
+}
+
+// The hot list: the first EMB_HOT_MAX first-occurrence rows (in ROW order - which words are hot must not depend on arrival order, or a word's sum would be folded
+// one way in one run and another way in the next) whose word is named by more than EMB_HOT_MIN rows: hot[0] = their number, hot[1 ..] = the rows; their plan
+// entries become 0 (the keyed partial / fold launches sum them).  One workgroup: every thread counts its contiguous range of rows, an exclusive scan over the 256
+// counts, a second walk hands out the slots.
+__global__ __launch_bounds__(256) void embed_hot_select_kernel(int* __restrict__ plan, int rows, int* __restrict__ hot) {
+    __shared__ int cnts[256];
+    const int tid = threadIdx.x, per = (rows + 255) / 256, lo = tid * per, hi = (lo + per < rows) ? lo + per : rows;
+    int c = 0;
+    for (int r = lo; r < hi; ++r) c += plan[r] > EMB_HOT_MIN;
+    cnts[tid] = c;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < tid; ++i) base += cnts[i];
+    for (int r = lo; r < hi; ++r)
+        if (plan[r] > EMB_HOT_MIN) {
+            if (base < EMB_HOT_MAX) { hot[1 + base] = r; plan[r] = 0; }
+            ++base;
+        }
+    if (tid == 255) hot[0] = base < EMB_HOT_MAX ? base : EMB_HOT_MAX;
 }
 
 // the de rows lst[0 .. cnt) (offsets from row0) added in list order to acc, eight rows' loads in flight; one wave, lane = 4-column groups lane + 64 i
@@ -277,8 +292,8 @@ __global__ __launch_bounds__(256) void embed_partial_kernel(const T* __restrict_
     if (ky < np) { keys = kp; k = ky; if (k == 0 && pad0_all) return; }
     else if (ky < np + nt) { keys = kt; k = ky - np; if (k == 0 && pad0_all) return; }
     else {
-        const int h = ky - np - nt, nh = hot[0] < EMB_HOT_MAX ? hot[0] : EMB_HOT_MAX;
-        if (h >= nh) return;                                    // block-uniform
+        const int h = ky - np - nt;
+        if (h >= hot[0]) return;                                // block-uniform
         keys = kw; k = kw[hot[1 + h]];
     }
     const int lo = chunk * 256 + wave * 64, j = lo + lane;
@@ -308,8 +323,8 @@ __global__ __launch_bounds__(256) void embed_fold_kernel(const float* __restrict
     if (ky < np) { if (ky == 0 && pad0_all) return; dst = dpos + (size_t)ky * H; }
     else if (ky < np + nt) { if (ky == np && pad0_all) return; dst = dtype + (size_t)(ky - np) * H; }
     else {
-        const int h = ky - np - nt, nh = hot[0] < EMB_HOT_MAX ? hot[0] : EMB_HOT_MAX;
-        if (h >= nh) return;
+        const int h = ky - np - nt;
+        if (h >= hot[0]) return;
         dst = dword + (size_t)kw[hot[1 + h]] * H;
     }
     for (int n = threadIdx.x; n < H; n += 256) {
@@ -359,10 +374,10 @@ int k_embed_table_grads(const T* de, int ldde, const int* kw, const int* kp, con
     RGQA_REQUIRE((size_t)nkeys * nchunk * H <= fscratch_floats, "embedding gradients: scratch too small (%zu floats for %d keys x %d chunks x %d)", fscratch_floats, nkeys, nchunk, H);
     const size_t rp = ((size_t)rows + 3) & ~(size_t)3;
     int *plan = iscratch, *hot = iscratch + rp;
-    RGQA_HIP(hipMemsetAsync(hot, 0, sizeof(int), s));
     const int rows4 = (rows + 3) / 4;
-    hipLaunchKernelGGL(embed_word_plan_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, kw, rows, rows4, pad_key, plan, hot);
-    RGQA_LAUNCH_CHECK("embed_word_plan_kernel");
+    hipLaunchKernelGGL(embed_word_plan_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, kw, rows, rows4, pad_key, plan);
+    hipLaunchKernelGGL(embed_hot_select_kernel, dim3(1), dim3(256), 0, s, plan, rows, hot);
+    RGQA_LAUNCH_CHECK("embed_word_plan_kernel / embed_hot_select_kernel");
     const int q_cap = (rows + 3) / 4 + 1;
     const size_t lds_w = (size_t)3 * H * 4 + (size_t)4 * q_cap * 2, lds_p = (size_t)3 * H * 4 + 4 * 64 * 2;
     RGQA_REQUIRE(lds_w <= 160 * 1024, "embedding gradients: %d rows need %zu bytes of LDS", rows, lds_w);
