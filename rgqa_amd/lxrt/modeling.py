@@ -158,12 +158,15 @@ class ArenaParameter(nn.Parameter):
         ref = self.__dict__.get("_rgqa_binding")
         if ref is not None:
             b = ref()
-            if b is not None and b.engine is not None:
-                if getattr(b.engine, "_pending_clip", None) is not None:
-                    b.engine.flush_deferred_clip()
+            e = b.engine if b is not None else None
+            if e is not None:
+                if e._pending_clip is not None:
+                    e.flush_deferred_clip()
                 # whoever takes the gradient view may write it in place (nn.Module.zero_grad(set_to_none=False), a foreign optimizer): the caller's
-                # stream first joins an optimizer pass still reading the arena beside the forward pass (a stream-side wait; free when none is)
-                b.engine.join_update()
+                # stream first joins an optimizer pass still reading the arena beside the forward pass (a stream-side wait; two attribute reads when none is:
+                # the trainer's zero_grad() comes through here once per parameter)
+                if e._upd_done is not None:
+                    e.join_update()
         return _RAW_GRAD.__get__(self, type(self))
 
     @grad.setter
