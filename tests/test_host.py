@@ -465,7 +465,14 @@ def test_committed_bench_line_keeps_the_contract():
               "roofline", "cpu_baseline"):
         assert k in d, k
     assert base["metric"].startswith(d["metric"]) and d["unit"] == "QA-pairs/s"      # BASELINE's name without its ", 1/2/4/8 MI355X" tail (n_gpus says which)
-    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "bf16" and d["vs_baseline"] is None
+    # (round 6: the headline is the precision whose logits are inside the north star's bound - the bf16 step is the named leg `config3_bf16`)
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "bf16x3_fwd" and d["vs_baseline"] is None
+    p = d["parity_in_run"]
+    assert p["precision"] == d["dtype"] and p["within_bound"] is True and p["logits_max_err"] <= p["bound"] == 1e-3
+    assert d["config3_bf16"]["precision"] == "bf16" and d["config3_bf16"]["within_bound"] is False
+    assert d["seq30"]["seq_len"] == 30 and d["seq30"]["ms_per_step"] > d["ms_per_step"]
+    assert all(d["other_workloads"][k]["within_logits_bound"] for k in ("roi_mixup_b256", "butd_b256"))
+    assert abs(d["roofline"]["mfma_issued"]["achieved"] - 3 * d["roofline"]["achieved"]) < 0.05
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-3
     r = d["roofline"]
