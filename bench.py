@@ -251,12 +251,13 @@ def supervise(n_self_launch):
                          MASTER_PORT=str(port)) for r in range(n_self_launch)]
         return [dict(common, MASTER_PORT=str(base_port + 1 + attempt))]
 
-    first_deadline = total if mode != "sharded" else min(total, max(120.0, 0.6 * total))
+    retry = mode.partition("_")[0] in ("sharded", "peer")          # the modes with a fallback: the plain all-reduce, the most trodden RCCL path
+    first_deadline = total if not retry else min(total, max(120.0, 0.6 * total))
     t0 = time.time()
     rc, reason = _run_children(envs_for(0, mode, ""), first_deadline)
-    if rc != 0 and mode == "sharded":
-        sys.stderr.write("bench.py: %s under RGQA_DP_MODE=sharded; starting a fresh set of rank processes with RGQA_DP_MODE=allreduce\n" % reason)
-        rc, reason = _run_children(envs_for(1, "allreduce", "sharded exchange failed (%s); re-run with allreduce" % reason),
+    if rc != 0 and retry:
+        sys.stderr.write("bench.py: %s under RGQA_DP_MODE=%s; starting a fresh set of rank processes with RGQA_DP_MODE=allreduce\n" % (reason, mode))
+        rc, reason = _run_children(envs_for(1, "allreduce", "%s exchange failed (%s); re-run with allreduce" % (mode, reason)),
                                    max(120.0, total - (time.time() - t0)))
     if rc != 0:
         sys.stderr.write("bench.py: %s\n" % reason)
@@ -684,7 +685,7 @@ def main():
     if dist is not None and dist.get_backend() == "nccl" and not args.lean:
         note("dp_wire: collectives of the exchange on the real chunk sizes")
         dp_wire = dp_wire_probe(dist, comm, torch.device("cuda", local))
-    if (dp_wire is not None and world > 1 and dp_mode.partition("_")[0] == "sharded" and "all_to_all" in dp_wire and os.environ.get("RGQA_DP_PEER_PROBE", "1") != "0"
+    if (dp_wire is not None and (world > 1 or os.environ.get("RGQA_BENCH_RCCL_REHEARSAL") == "1") and dp_mode.partition("_")[0] == "sharded" and "all_to_all" in dp_wire and os.environ.get("RGQA_DP_PEER_PROBE", "1") != "0"
             and dp_wire["all_to_all"]["frac_of_all_links"] < float(os.environ.get("RGQA_DP_PEER_THRESHOLD", "0.7"))):
         # RCCL's all-to-all runs below 70 % of what seven links carry (a ring-shaped schedule shows 1/7): measure the hand-written peer-to-peer exchange
         # (hipIpc buffers, every rank pulling from all of its peers at once: rgqa_amd.parallel.PeerShardedExchange) on the same chunk and take it if it
@@ -694,6 +695,8 @@ def main():
         try:
             from rgqa_amd.parallel import PeerShardedExchange
             peer = PeerShardedExchange(e, dist, payload=(dp_mode.partition("_")[2] or None))
+            if not peer.selfcheck():
+                raise RuntimeError("peer exchange self-check: the pulled data is not what the peers staged")
         except Exception as exn:
             ok.zero_()
             dp_wire["peer_error"] = repr(exn)

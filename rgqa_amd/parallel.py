@@ -659,6 +659,24 @@ class PeerShardedExchange(ShardedExchange):
         self._pull(off, nbytes, out, nbytes)
         self._barrier()
 
+    def selfcheck(self):
+        """One all-to-all and one all-gather by peer pulls on a small range, checked numerically: rank q stages the value q * W + r + 1 for rank r, so after
+        the exchange part q of this rank's buffer must read q * W + rank + 1 (exact in bf16 up to W = 16).  -> bool.  bench.py's wire probe runs it before it
+        times (and possibly selects) this exchange: a mapping that returns stale or foreign bytes must veto, not win on speed."""
+        W, s = self.world, int(min(self.smax, 1 << 16))
+        send, recv = self._stage[0][0][:W * s], self._stage[0][1][:W * s]
+        for r in range(W):
+            send[r * s:(r + 1) * s] = float(self.rank * W + r + 1)
+        recv.zero_()
+        self._a2a(recv, send)
+        want = torch.tensor([q * W + self.rank + 1 for q in range(W)], dtype=torch.float32, device=recv.device)
+        ok = bool((recv.view(W, s).float() == want[:, None]).all())
+        part = torch.full((s,), float(100 + self.rank), dtype=recv.dtype, device=recv.device)
+        recv.zero_()
+        self._ag(recv, part)
+        want = torch.arange(100, 100 + W, dtype=torch.float32, device=recv.device)
+        return ok and bool((recv.view(W, s).float() == want[:, None]).all())
+
     def close(self):
         c, self._comm = getattr(self, "_comm", None), None
         if c is not None:

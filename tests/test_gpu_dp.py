@@ -195,6 +195,7 @@ def _peer_worker(rank, world, port, backend, precision, overlap, q):
         comm = make_exchange(e, dist, mode, chunk_mb=1, bucket_mb=1, overlap=overlap, f32_chunk_elems=1 << 14)
         if mode == "peer":
             assert type(comm).__name__ == "PeerShardedExchange" and len(comm.chunks) >= 3
+            assert comm.selfcheck()          # what bench.py's wire probe runs before it times this exchange
         for _ in range(3):
             _step(e, d, comm, world)
         lp = None if e.params_lp is None else e.params_lp.clone()
