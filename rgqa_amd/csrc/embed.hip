@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 // Round 6: DETERMINISTIC - no float atomics.  Until round 5 every row was scatter-added with atomicAdd; the order in which the 256 [CLS] rows of a batch met in
 // table row 101 changed from run to run, the last bits of the sums with it, and BertAdam's normalised update amplified that over a few steps (every "equal to one
 // rank" / "equal to the serial step" test inherited the noise).  Now every table row is summed in an order that depends on the batch alone:
-//   plan         one thread per packed row (the keys of all rows staged in LDS, scanned 16 bytes at a time): is this the FIRST row that names its word, and how many
+//   plan         one wave per packed row (the keys of all rows straight from L2, 16 bytes per lane): is this the FIRST row that names its word, and how many
 //                rows name it?  Words named by more than HOT_MIN rows ([CLS], [SEP], '?': one row per sample) go on a short hot list, filled in row order by a one-workgroup launch.
 //   word table   one workgroup per first-occurrence row: a word that occurs once is copied into its table row; a word of <= HOT_MIN rows is summed by one wave in
 //                row order.
