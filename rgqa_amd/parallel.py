@@ -592,19 +592,33 @@ class PeerShardedExchange(ShardedExchange):
         self._ag_bytes = -(-self.smax * 4 // 256) * 256                  # one owned part, f32 at worst
         self._set_bytes = self._send_bytes + self._ag_bytes
         nsets = 2
-        h = C.c_void_p()
-        check(lib.rgqa_peer_comm_create(self.rank, W, nsets * self._set_bytes, C.byref(h)))
-        self._comm = h
-        p, nb = C.c_void_p(), C.c_size_t()
-        check(lib.rgqa_peer_comm_stage(self._comm, C.byref(p), C.byref(nb)))
+        # Set-up is collective: a rank that cannot create, export or map a buffer still takes part in both object gathers below and every rank
+        # raises together - a rank that left early would leave its peers inside a collective it never joins
+        self._comm = None
         dev = engine.grads.device
-        self._stage_raw = torch.as_tensor(_RawDeviceBytes(p.value, nb.value), device=dev)
-        self._stage_raw.zero_()
         hb = C.create_string_buffer(64)
-        check(lib.rgqa_peer_comm_export(self._comm, hb))
+        err = None
+        try:
+            h = C.c_void_p()
+            check(lib.rgqa_peer_comm_create(self.rank, W, nsets * self._set_bytes, C.byref(h)))
+            self._comm = h
+            p, nb = C.c_void_p(), C.c_size_t()
+            check(lib.rgqa_peer_comm_stage(self._comm, C.byref(p), C.byref(nb)))
+            self._stage_raw = torch.as_tensor(_RawDeviceBytes(p.value, nb.value), device=dev)
+            self._stage_raw.zero_()
+            check(lib.rgqa_peer_comm_export(self._comm, hb))
+        except Exception as exn:
+            err = repr(exn)
         handles = [None] * W
-        dist.all_gather_object(handles, bytes(hb.raw))
-        check(lib.rgqa_peer_comm_connect(self._comm, C.create_string_buffer(b"".join(handles), 64 * W)))
+        dist.all_gather_object(handles, (err, bytes(hb.raw)))
+        self._raise_together([h_[0] for h_ in handles], "create / export its staging buffer")
+        try:
+            check(lib.rgqa_peer_comm_connect(self._comm, C.create_string_buffer(b"".join(h_[1] for h_ in handles), 64 * W)))
+        except Exception as exn:
+            err = repr(exn)
+        mapped = [None] * W
+        dist.all_gather_object(mapped, err)
+        self._raise_together(mapped, "map its peers' staging buffers")
         # the parent's staging sets, their send halves now inside the exported buffer
         sets = []
         for k in range(nsets):
@@ -618,6 +632,15 @@ class PeerShardedExchange(ShardedExchange):
             self._alloc_ready = torch.cuda.Event()
             self._alloc_ready.record(torch.cuda.current_stream(dev))
         self._barrier()            # every rank has mapped every buffer before anyone pulls
+
+    def _raise_together(self, errors, what):
+        bad = [(r, e_) for r, e_ in enumerate(errors) if e_ is not None]
+        if bad:
+            comm, self._comm = self._comm, None
+            self._stage_raw = None
+            if comm is not None:
+                self.e.lib.rgqa_peer_comm_destroy(comm)
+            raise RuntimeError("peer exchange: rank %d could not %s: %s" % (bad[0][0], what, bad[0][1]))
 
     def describe(self):
         return "peer: " + super().describe()[len("sharded: "):].replace("all-to-all reduce-scatter", "reduce-scatter by hipIpc peer pulls").replace("weight all-gather", "weight all-gather by peer pulls")

@@ -242,6 +242,68 @@ def test_peer_exchange_equals_the_collective_exchange(backend, world, precision,
         assert np.array_equal(res[0][1], res[r][1])          # replicas identical (four ranks: every rank pulls from three peers)
 
 
+def _peer_fail_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from rgqa_amd.parallel import PeerShardedExchange, make_exchange
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    full = _full_batch()
+    n = 2 * B // world
+    shard = {k: v[rank * n:(rank + 1) * n] for k, v in full.items()}
+    e, d = _make(shard, "bf16")
+    if rank == 1:          # this rank cannot create its staging buffer
+        class _Lib:
+            def __init__(self, lib):
+                self._lib = lib
+
+            def __getattr__(self, k):
+                if k == "rgqa_peer_comm_create":
+                    return lambda *a: 1
+                return getattr(self._lib, k)
+        e.lib = _Lib(e.lib)
+    msg = None
+    try:
+        PeerShardedExchange(e, dist, chunk_mb=1, bucket_mb=1, f32_chunk_elems=1 << 14)
+    except RuntimeError as exn:
+        msg = str(exn)
+    if rank == 1:
+        e.lib = e.lib._lib
+    # the process group is still in step: the collective exchange works right after
+    comm = make_exchange(e, dist, "sharded", chunk_mb=1, bucket_mb=1, f32_chunk_elems=1 << 14)
+    _step(e, d, comm, world)
+    comm.gather_master()
+    torch.cuda.synchronize()
+    q.put((rank, msg, bool(torch.isfinite(e.params).all())))
+    dist.destroy_process_group()
+
+
+def test_peer_exchange_setup_fails_on_every_rank_together():
+    """A rank that cannot create (or map) its staging buffer must not leave its peers inside a collective it never joins: set-up gathers every rank's
+    status with the handles and every rank raises the same error (bench.py's probe then falls back to the collective exchange on all ranks)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 400) + 97
+    procs = [ctx.Process(target=_peer_fail_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r, msg, finite = q.get(timeout=300)
+            res[r] = (msg, finite)
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    for r in (0, 1):
+        assert res[r][0] is not None and "rank 1 could not create" in res[r][0], res[r][0]
+        assert res[r][1]
+
+
 # ---------------------------------------------------------------------------------------------- BASELINE config 5 under the exchange
 BUTD = dict(arch=1, vocab_size=201, hidden=1024, emb_dim=300, feat_dim=2048, pos_dim=4, num_answers=70, heads=1, inter=8, l_layers=0, x_layers=0, r_layers=0)
 BB, BL, BO = 6, 14, 36
